@@ -1,0 +1,329 @@
+"""Synthetic DAB Mode-I transmit chain (the inverse of the receiver hot path).
+
+The reference contains no modulator; this follows ETSI EN 300 401 as mirrored by the receiver code
+(SURVEY.md Appendix B): FIB CRC (MathHelper.h:53-80), energy dispersal PRBS (fic-handler.cpp:62-71),
+K=7 rate-1/4 mother code with the generator bit order of viterbi.cpp:36, puncturing vectors
+(protTables.cpp:25-51; FIC fic-handler.cpp:158-191; EEP eep-protection.cpp:32-113), 16-CIF time
+interleaving (dab-audio.cpp:113-143), CIF layout (msc-handler.cpp:129-158), QPSK mapping + frequency
+interleaving (ofdm-decoder.cpp:198-214, freq-interleaver.cpp:35-59), differential modulation against
+the phase reference symbol (phasereference.cpp:45-51) and OFDM symbol generation.
+
+Used by tests/ and bench.py to make input; it is not part of the receive product path.
+"""
+import numpy as np
+
+T_U, T_S, T_G, T_NULL, T_F, L_SYM, K_CARR = 2048, 2552, 504, 2656, 196608, 76, 1536
+CIF_BITS = 55296
+POLYS = (0o155, 0o117, 0o123, 0o155)
+TI_MAP = np.array([0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15])
+
+
+def prbs(n):
+    """x^9 + x^5 + 1, all-ones start; bit i = s[8]^s[4] before the shift."""
+    out = np.zeros(n, np.uint8)
+    sr = [1] * 9
+    for i in range(n):
+        b = sr[8] ^ sr[4]
+        sr = [b] + sr[:8]
+        out[i] = b
+    return out
+
+
+_PRBS_CACHE = {}
+
+
+def prbs_cached(n):
+    if n not in _PRBS_CACHE:
+        _PRBS_CACHE[n] = prbs(n)
+    return _PRBS_CACHE[n]
+
+
+def pi_vector(p):
+    """Puncturing vector PI_p (p = 1..24), EN 300 401 table 29: 8+p ones in 32."""
+    v = np.zeros(32, np.uint8)
+    v[0::4] = 1
+    order = [0, 4, 2, 6, 1, 5, 3, 7]
+    for r in range(p):
+        col = 1 + r // 8
+        grp = order[r % 8]
+        v[4 * grp + col] = 1
+    return v
+
+
+PI_X = np.array([1, 1, 0, 0] * 6, np.uint8)
+
+
+def conv_encode(bits):
+    """Mother code: returns 4*(n+6) bits, order (x0,x1,x2,x3) per input bit, 6 zero tail bits."""
+    n = len(bits)
+    padded = np.concatenate([np.zeros(6, np.uint8), bits.astype(np.uint8), np.zeros(6, np.uint8)])
+    out = np.zeros((n + 6, 4), np.uint8)
+    for k, poly in enumerate(POLYS):
+        acc = np.zeros(n + 6, np.uint8)
+        for j in range(7):
+            if (poly >> j) & 1:
+                acc ^= padded[6 - j: 6 - j + n + 6]
+        out[:, k] = acc
+    return out.reshape(-1)
+
+
+def puncture_mask(segments, nbits):
+    """segments: list of (n_blocks_of_128, PI index); returns bool mask of length 4*nbits+24."""
+    parts = []
+    for nblk, p in segments:
+        if nblk > 0:
+            parts.append(np.tile(pi_vector(p), 4 * nblk))
+    m = np.concatenate(parts + [PI_X])
+    assert len(m) == 4 * nbits + 24, (len(m), nbits)
+    return m.astype(bool)
+
+
+FIC_MASK = puncture_mask([(21, 16), (3, 15)], 768)
+
+
+def eep_segments(bitrate, profile_b, level):
+    """(L1,PI1),(L2,PI2) as eep-protection.cpp:32-113."""
+    n = bitrate // 8
+    if not profile_b:
+        if level == 1:
+            return [(6 * n - 3, 24), (3, 23)]
+        if level == 2:
+            if bitrate == 8:
+                return [(5, 13), (1, 12)]
+            return [(2 * n - 3, 14), (4 * n + 3, 13)]
+        if level == 3:
+            return [(6 * n - 3, 8), (3, 7)]
+        if level == 4:
+            return [(4 * n - 3, 3), (2 * n + 3, 2)]
+    else:
+        n32 = 24 * bitrate // 32 - 3
+        pi = {4: (2, 1), 3: (4, 3), 2: (6, 5), 1: (10, 9)}[level]
+        return [(n32, pi[0]), (3, pi[1])]
+    raise ValueError("bad EEP level")
+
+
+def crc16_ccitt(data):
+    crc = 0xFFFF
+    for b in data:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc ^ 0xFFFF
+
+
+def make_fib(payload):
+    """30 data bytes (padded with 0xFF) + inverted CRC-16-CCITT."""
+    body = bytes(payload) + b"\xff" * (30 - len(payload))
+    assert len(body) == 30
+    c = crc16_ccitt(body)
+    return body + bytes([c >> 8, c & 0xFF])
+
+
+def bytes_to_bits(b):
+    return np.unpackbits(np.frombuffer(bytes(b), np.uint8))
+
+
+def fic_encode(fibs3):
+    """3 FIBs (96 bytes) -> 2304 punctured bits."""
+    bits = bytes_to_bits(b"".join(fibs3)) ^ prbs_cached(768)
+    return conv_encode(bits)[FIC_MASK]
+
+
+def msc_encode(frame_bytes, segments):
+    """one logical frame (3*bitrate bytes) -> punctured bits (length*64)."""
+    bits = bytes_to_bits(frame_bytes)
+    n = len(bits)
+    bits = bits ^ prbs_cached(n)
+    return conv_encode(bits)[puncture_mask(segments, n)]
+
+
+def freq_perm():
+    t = np.zeros(T_U, np.int64)
+    for i in range(1, T_U):
+        t[i] = (13 * t[i - 1] + 511) % T_U
+    keep = t[(t >= 256) & (t <= 256 + K_CARR) & (t != T_U // 2)]
+    return keep - T_U // 2
+
+
+_H = np.array([
+    [0, 2, 0, 0, 0, 0, 1, 1, 2, 0, 0, 0, 2, 2, 1, 1] * 2,
+    [0, 3, 2, 3, 0, 1, 3, 0, 2, 1, 2, 3, 2, 3, 3, 0] * 2,
+    [0, 0, 0, 2, 0, 2, 1, 3, 2, 2, 0, 2, 2, 0, 1, 3] * 2,
+    [0, 1, 2, 1, 0, 3, 3, 2, 2, 3, 2, 1, 2, 1, 3, 2] * 2])
+# EN 300 401 table 39 (Mode I): for the 48 blocks of 32 carriers from k=-768 upward, (i, n)
+_PRS_I = [0, 1, 2, 3] * 6 + [0, 3, 2, 1] * 6
+_PRS_N = [1, 2, 0, 1, 3, 2, 2, 3, 2, 1, 2, 3, 1, 2, 3, 3, 2, 2, 2, 1, 1, 3, 1, 2,
+          3, 1, 1, 1, 2, 2, 1, 0, 2, 2, 3, 3, 0, 2, 1, 3, 3, 3, 3, 0, 3, 0, 1, 1]
+
+
+def prs_quadrant():
+    """integer phase index q[bin] (phi = q*pi/2) for the 1536 active bins, -1 elsewhere."""
+    q = -np.ones(T_U, np.int64)
+    for blk in range(48):
+        kmin = -768 + 32 * blk if blk < 24 else 1 + 32 * (blk - 24)
+        for j in range(32):
+            k = kmin + j
+            q[k % T_U] = (_H[_PRS_I[blk]][j] + _PRS_N[blk]) % 4
+    return q
+
+
+def prs_freq():
+    q = prs_quadrant()
+    z = np.zeros(T_U, np.complex128)
+    act = q >= 0
+    z[act] = np.exp(1j * np.pi / 2 * q[act])
+    return z
+
+
+class SubchannelCfg:
+    """EEP sub-channel (long form).  size in CUs derived like Subchannel::bitrate (dab-constants.cpp:404)."""
+
+    def __init__(self, subch_id, start_cu, bitrate, profile_b=False, level=3, dabplus=True):
+        self.subch_id, self.start_cu, self.bitrate = subch_id, start_cu, bitrate
+        self.profile_b, self.level, self.dabplus = profile_b, level, dabplus
+        self.segments = eep_segments(bitrate, profile_b, level)
+        nb = 24 * bitrate
+        self.n_coded = int(puncture_mask(self.segments, nb).sum())
+        assert self.n_coded % 64 == 0
+        self.size_cu = self.n_coded // 64
+        self.frame_bytes = 3 * bitrate
+
+    def fig0_1(self):
+        opt = 1 if self.profile_b else 0
+        prot = self.level - 1
+        return bytes([(self.subch_id << 2) | (self.start_cu >> 8), self.start_cu & 0xFF,
+                      0x80 | (opt << 4) | (prot << 2) | (self.size_cu >> 8), self.size_cu & 0xFF])
+
+
+def default_subchannels(n=18, bitrate=64):
+    """canonical ensemble of SURVEY.md 8(d): n x 64 kbit/s DAB+ EEP-3A of 48 CU each."""
+    out = []
+    cu = 0
+    for i in range(n):
+        s = SubchannelCfg(i + 1, cu, bitrate)
+        out.append(s)
+        cu += s.size_cu
+    assert cu <= 864
+    return out
+
+
+def build_fibs(eid, subchs, cif_count):
+    """12 FIBs for one frame: FIG0/0, FIG0/1 (all sub-channels), FIG0/2, FIG1/0, FIG1/1, rest padding."""
+    figs = []
+    figs.append(bytes([0x05, 0x00, eid >> 8, eid & 0xFF, (cif_count // 250) % 20, cif_count % 250]))
+    for i in range(0, len(subchs), 6):
+        body = b"".join(s.fig0_1() for s in subchs[i:i + 6])
+        figs.append(bytes([len(body) + 1, 0x01]) + body)
+    for i in range(0, len(subchs), 5):
+        body = b""
+        for s in subchs[i:i + 5]:
+            sid = 0x1000 + s.subch_id
+            body += bytes([sid >> 8, sid & 0xFF, 0x01, 0x3F if s.dabplus else 0x00, (s.subch_id << 2) | 0x02])
+        figs.append(bytes([len(body) + 1, 0x02]) + body)
+    label = ("MI355X ENS %04X" % eid).ljust(16)[:16].encode()
+    figs.append(bytes([0x35, 0x00, eid >> 8, eid & 0xFF]) + label + b"\xff\x00")
+    for s in subchs[:2]:
+        sid = 0x1000 + s.subch_id
+        figs.append(bytes([0x35, 0x01, sid >> 8, sid & 0xFF]) + ("SERVICE %02d" % s.subch_id).ljust(16).encode() + b"\xff\x00")
+    fibs = []
+    for f in figs:          # first-fit packing
+        for i in range(len(fibs)):
+            if len(fibs[i]) + len(f) <= 30:
+                fibs[i] += f
+                break
+        else:
+            fibs.append(f)
+    assert len(fibs) <= 12, len(fibs)
+    while len(fibs) < 12:
+        fibs.append(b"")
+    return [make_fib(f) for f in fibs]
+
+
+class EnsembleTx:
+    """Generates consecutive Mode-I transmission frames (cf64 numpy arrays of T_F samples)."""
+
+    def __init__(self, eid=0x1000, subchs=None, seed=0, payload_fn=None, amplitude=0.25):
+        self.eid = eid
+        self.subchs = default_subchannels() if subchs is None else subchs
+        self.rng = np.random.RandomState(seed)
+        self.payload_fn = payload_fn
+        self.perm = freq_perm()
+        self.bins = np.where(self.perm < 0, self.perm + T_U, self.perm)
+        self.prs = prs_freq()
+        self.cif_no = 0
+        self.amplitude = amplitude
+        # time interleaver memory: coded bits of the last 16 logical frames per sub-channel
+        self.hist = {s.subch_id: np.zeros((16, s.n_coded), np.uint8) for s in self.subchs}
+        self.fib_log = []       # list of 12x32-byte frames
+        self.payload_log = {s.subch_id: [] for s in self.subchs}
+
+    def _next_cif(self):
+        cif = np.zeros(CIF_BITS, np.uint8)
+        r = self.cif_no
+        for s in self.subchs:
+            if self.payload_fn is not None:
+                data = self.payload_fn(s, r)
+            else:
+                data = self.rng.randint(0, 256, s.frame_bytes).astype(np.uint8).tobytes()
+            self.payload_log[s.subch_id].append(bytes(data))
+            coded = msc_encode(data, s.segments)
+            h = self.hist[s.subch_id]
+            h[r % 16] = coded
+            # bit i of logical frame r' is sent in CIF r' + map[i%16]  ->  CIF r carries frame r - map[i%16]
+            idx = np.arange(s.n_coded)
+            src = (r - TI_MAP[idx % 16]) % 16
+            tx = h[src, idx]
+            tx[(r - TI_MAP[idx % 16]) < 0] = 0
+            cif[s.start_cu * 64: s.start_cu * 64 + s.n_coded] = tx
+        self.cif_no += 1
+        return cif
+
+    def next_frame_bits(self):
+        fibs = build_fibs(self.eid, self.subchs, self.cif_no)
+        self.fib_log.append(fibs)
+        fic = np.concatenate([fic_encode(fibs[3 * i:3 * i + 3]) for i in range(4)])
+        msc = np.concatenate([self._next_cif() for _ in range(4)])
+        return np.concatenate([fic, msc]).reshape(75, 3072)
+
+    def next_frame(self):
+        bits = self.next_frame_bits()
+        z = self.prs.copy()
+        syms = np.zeros((L_SYM, T_U), np.complex128)
+        syms[0] = z
+        for l in range(75):
+            b = bits[l].astype(np.float64)
+            y = ((1 - 2 * b[:K_CARR]) + 1j * (1 - 2 * b[K_CARR:])) / np.sqrt(2)
+            z = z.copy()
+            z[self.bins] = z[self.bins] * y
+            syms[l + 1] = z
+        t = np.fft.ifft(syms, axis=1) * T_U     # unnormalised inverse DFT
+        t = np.concatenate([t[:, -T_G:], t], axis=1).reshape(-1)
+        frame = np.concatenate([np.zeros(T_NULL, np.complex128), t])
+        rms = np.sqrt(np.mean(np.abs(t) ** 2))
+        return frame * (self.amplitude / rms)
+
+
+def make_stream(n_frames, eid=0x1000, subchs=None, seed=0, snr_db=None, cfo_hz=0.0, delay=0,
+                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False):
+    """cf32 interleaved stream of n_frames frames (+ `delay` leading noise/zero samples)."""
+    tx = EnsembleTx(eid, subchs, seed, payload_fn, amplitude)
+    x = np.concatenate([tx.next_frame() for _ in range(n_frames)])
+    if delay:
+        x = np.concatenate([np.zeros(delay, np.complex128), x])
+    if cfo_hz:
+        n = np.arange(len(x))
+        x = x * np.exp(2j * np.pi * cfo_hz * n / 2048000.0)
+    if snr_db is not None:
+        rng = np.random.RandomState(noise_seed)
+        sig_p = amplitude ** 2
+        sigma = np.sqrt(sig_p / (10 ** (snr_db / 10)) / 2)
+        x = x + sigma * (rng.randn(len(x)) + 1j * rng.randn(len(x)))
+    out = x.astype(np.complex64)
+    return (out, tx) if return_tx else out
+
+
+def to_u8(x):
+    """RAW u8 IQ as read by raw_file.cpp:324-366: (b-128)/128."""
+    v = np.empty(2 * len(x), np.float32)
+    v[0::2], v[1::2] = x.real, x.imag
+    return np.clip(np.round(v * 127.0) + 128, 0, 255).astype(np.uint8)
