@@ -1,0 +1,117 @@
+/* include/dabphy.h -- C ABI of libdabphy_hip.so, the MI355X (gfx950) DAB Mode-I PHY backend for welle.io.
+ *
+ * The reference (welle.io v2.7) has no FFI: its backend boundary is the C++ facade RadioReceiver
+ * (src/backend/radio-receiver.h:52-116) over InputInterface / RadioControllerInterface
+ * (src/backend/radio-controller.h:83-215).  This header is the thin C boundary placed UNDER that facade:
+ * each entry point replaces one internal seam of the reference's hot path (cited per function) and is
+ * what a maintainer binds from the existing C++ host code (see INTEGRATION.md for the 1:1 call sites).
+ *
+ * Conventions: extern "C"; opaque handle; int status (0 = ok, negative = dabphy_status); no exceptions and
+ * no C++/torch types cross the boundary; the caller owns every host buffer, the library owns all device
+ * memory; one handle = one HIP device + one stream; a handle is not thread-safe, distinct handles are.
+ * Unless a parameter is documented as a DEVICE pointer it is a HOST pointer.
+ * The library has no CPU fallback: dabphy_create fails with DABPHY_ERR_NO_DEVICE when no gfx950 GPU is visible.
+ */
+#ifndef DABPHY_H
+#define DABPHY_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dabphy_handle dabphy_handle;
+
+typedef enum {
+    DABPHY_OK = 0,
+    DABPHY_ERR_NO_DEVICE = -1,      /* no HIP device / not gfx950 */
+    DABPHY_ERR_INVALID = -2,        /* bad argument */
+    DABPHY_ERR_NOMEM = -3,
+    DABPHY_ERR_HIP = -4,            /* a HIP call failed; see dabphy_last_error */
+    DABPHY_ERR_STATE = -5           /* call sequence error (e.g. process before bind) */
+} dabphy_status;
+
+/* RadioReceiverOptions (src/backend/radio-receiver-options.h:66-84) + batch geometry */
+typedef struct {
+    uint32_t n_ensembles;           /* independent ensembles (streams) decoded in lock step; >= 1 */
+    uint32_t max_frames;            /* transmission frames per dabphy_process call and ensemble; >= 1 */
+    int32_t device;                 /* HIP device ordinal */
+    int32_t fft_placement;          /* FFTPlacementMethod: 2 = ThresholdBeforePeak (default), 0 = StrongestPeak */
+    int32_t disable_coarse;         /* RadioReceiverOptions::disableCoarseCorrector */
+    int32_t want_constellation;     /* keep the 1200 constellation points per frame (onConstellationPoints) */
+    int32_t want_impulse_response;  /* keep the 2048-float CIR per frame (onNewImpulseResponse) */
+    int32_t demod_chunk;            /* data symbols per work-group of the demod kernel; 0 = default */
+} dabphy_config;
+
+/* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)
+ * tuples followed by the 24-bit tail (PI_X).  Replaces the constructor tables of EEPProtection
+ * (eep-protection.cpp:32-113), UEPProtection (uep-protection.cpp:27-167) and the fixed FIC scheme
+ * (fic-handler.cpp:158-191). */
+typedef struct {
+    int32_t nbits;                  /* decoded bits: 768 (FIC) or 24 * bitrate */
+    int32_t L[4];
+    int32_t PI[4];                  /* 1..24, 0 = tuple unused */
+} dabphy_protection;
+
+/* One MSC sub-channel to decode: Subchannel (src/backend/dab-constants.h:164-198) after bitrate()/protection lookup */
+typedef struct {
+    int32_t subch_id;
+    int32_t start_cu;               /* Subchannel::startAddr */
+    int32_t size_cu;                /* Subchannel::length */
+    dabphy_protection prot;
+} dabphy_subchannel;
+
+int dabphy_create(const dabphy_config* cfg, dabphy_handle** out);      /* RadioReceiver::RadioReceiver, radio-receiver.cpp:66-80 */
+void dabphy_destroy(dabphy_handle* h);
+const char* dabphy_last_error(const dabphy_handle* h);
+const char* dabphy_device_name(const dabphy_handle* h);
+
+/* protection helpers (pure host) */
+int dabphy_protection_fic(dabphy_protection* p);
+int dabphy_protection_eep(dabphy_protection* p, int bitrate, int profile_b, int level);     /* eep-protection.cpp:32-113 */
+int dabphy_protection_uep(dabphy_protection* p, int bitrate, int level);                    /* uep-protection.cpp:120-167 */
+int dabphy_protection_input_bits(const dabphy_protection* p);                               /* punctured soft bits consumed */
+
+/* ---- seam 1: OfdmDecoder::pushAllSymbols (ofdm-decoder.cpp:132-139) -> processPRS + 75 x decodeDataSymbol --------
+ * frames: n_frames x (2048 + 75*2552) complex floats, [PRS useful part][75 symbols incl. cyclic prefix], already
+ *         frequency-corrected (as OFDMProcessor hands them over).
+ * soft:   n_frames x 75 x 3072 int8 (layout of ofdm-decoder.cpp:211-212: [0,1536) real bits, [1536,3072) imaginary)
+ * constellation (may be NULL): n_frames x 1200 complex floats (every 96th carrier, :214-216)
+ * snr (may be NULL): n_frames floats; the value OfdmDecoder would pass to onSNR after that frame, NaN when it
+ *         would not report (it reports every 11th frame, :155-158).  The IIR state persists in the handle. */
+int dabphy_demod_frames(dabphy_handle* h, const float* frames, uint32_t n_frames,
+                        int8_t* soft, float* constellation, float* snr);
+
+/* ---- seam 2: Viterbi::deconvolve (viterbi.cpp:227-245), batched -------------------------------------------
+ * in:  n_codewords x 4*(nbits+6) soft values (depunctured, erasures = 0)
+ * out: n_codewords x nbits/8 bytes, bit i of a codeword at byte i/8, MSB first (the packing of
+ *      decoder_adapter.cpp:61-67; the reference returns one bit per byte) */
+int dabphy_viterbi_batch(dabphy_handle* h, const int8_t* in, uint32_t nbits, uint32_t n_codewords, uint8_t* out);
+
+/* ---- FicHandler::processFicBlock x3 (fic-handler.cpp:111-230), batched over frames -------------------------
+ * soft: n_frames x 9216 soft bits (symbols 1..3).  fib: n_frames x 12 x 32 bytes (energy dispersal removed).
+ * crc_ok: n_frames x 12 flags.  Returns the FIC success ratio in percent (getFicDecodeRatioPercent, :234-237)
+ * through *ratio_percent when not NULL; the counter persists in the handle (ensemble 0). */
+int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, uint8_t* fib, uint8_t* crc_ok,
+                      int32_t* ratio_percent);
+
+/* ---- Protection::deconvolve (protection.h:32-37) + EnergyDispersal + bit packing, batched ------------------
+ * in:  n_codewords x dabphy_protection_input_bits(prot) punctured soft bits (time de-interleaved)
+ * out: n_codewords x nbits/8 bytes (as written to the reference's .msc dump, decoder_adapter.cpp:71-73) */
+int dabphy_msc_deconvolve(dabphy_handle* h, const dabphy_protection* prot, const int8_t* in, uint32_t n_codewords,
+                          uint8_t* out);
+
+/* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
+ * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
+ *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.
+ * dabphy_time_viterbi: decodes n_codewords random-content codewords of nbits `iters` times; *ms_gather / *ms_decode. */
+int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
+                      int32_t mix, int32_t f_hz, uint32_t iters, float* ms);
+int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
+                        float* ms_decode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""pytest configuration: the `gpu` marker, package loading (the package directory is named `welle.io_amd`,
+which is not an importable identifier, so it is loaded by path as `welle_io_amd`) and library fixtures."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "welle.io_amd")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_package():
+    if "welle_io_amd" in sys.modules:
+        return sys.modules["welle_io_amd"]
+    spec = importlib.util.spec_from_file_location("welle_io_amd", os.path.join(PKG_DIR, "__init__.py"),
+                                                  submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["welle_io_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+load_package()
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "libdabphy_emu.so")
+GPU_LIB = os.path.join(PKG_DIR, "libdabphy_hip.so")
+ORC_LIB = os.path.join(ROOT, "oracle", "libdabphy_oracle.so")
+
+
+def _make(args, cwd):
+    subprocess.run(["make"] + args, cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def oracle_built():
+    """the C restatement (checker) -- built from source when missing"""
+    if not os.path.exists(ORC_LIB):
+        _make(["oracle"], os.path.join(ROOT, "oracle"))
+    return ORC_LIB
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """kernel sources compiled for the CPU execution model of tests/hipemu (logic check only, never timed)"""
+    _make(["emu"], os.path.join(PKG_DIR, "csrc"))
+    from welle_io_amd import capi
+    d = capi.DabPhy(lib_path=EMU_LIB)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """the product library on a real device; fails loudly if it is missing"""
+    from welle_io_amd import capi
+    assert os.path.exists(GPU_LIB), "libdabphy_hip.so not built: run __graft_entry__.build()"
+    d = capi.DabPhy(lib_path=GPU_LIB)
+    assert "gfx950" in d.device_name
+    yield d
+    d.close()

@@ -1,0 +1,38 @@
+"""The C-ABI library exports every symbol include/dabphy.h declares (no compute calls: no GPU here), and the
+product refuses to start without a gfx950 device instead of falling back to anything."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GPU_LIB, ROOT
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "dabphy.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dabphy_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    if not os.path.exists(GPU_LIB):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); m.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", GPU_LIB], capture_output=True, text=True, check=True).stdout
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
+    fns = declared_functions()
+    assert len(fns) >= 10
+    missing = [f for f in fns if f not in exported]
+    assert not missing, "declared in include/dabphy.h but not exported: %s" % missing
+
+
+def test_no_cpu_fallback():
+    """on a machine without a GPU, creating a handle on the product library must fail loudly"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from welle_io_amd import capi
+    with pytest.raises(capi.DabPhyError):
+        capi.DabPhy(lib_path=GPU_LIB)

@@ -1,0 +1,31 @@
+"""CPU suite: the kernel SOURCES, compiled unchanged for the tests/hipemu execution model, against the oracle.
+Checks indexing / barrier / packing logic without a GPU; the GPU suite repeats these on the device."""
+import numpy as np
+import pytest
+
+import parity_cases as P
+
+
+@pytest.mark.parametrize("nbits,kind", [(768, "uniform"), (1536, "coded"), (192, "extreme"), (768, "zeros"), (2304, "coded")])
+def test_viterbi(emu, nbits, kind):
+    P.check_viterbi(emu, nbits, 70 if nbits < 2000 else 5, seed=nbits, kind=kind)
+
+
+@pytest.mark.parametrize("args", [("eep", 64, 0, 3), ("eep", 8, 0, 2), ("eep", 32, 1, 1), ("eep", 128, 0, 4), ("uep", 80, 1, 0), ("uep", 32, 5, 0)])
+def test_msc_deconvolve(emu, args):
+    P.check_msc_deconvolve(emu, *args, n=3, seed=7)
+
+
+def test_fic(emu):
+    assert P.check_fic(emu, 3, snr_db=9, seed=4) > 0
+
+
+def test_demod(emu):
+    P.check_demod(emu, 2, snr_db=14, seed=2)
+
+
+def test_demod_zero_carriers(emu):
+    """r1 == 0 (the reference's inf*0 -> NaN -> int8 case, SURVEY C-3): all-zero symbols give soft bit 0"""
+    frames = np.zeros((1, 2048 + 75 * 2552), np.complex64)
+    soft, con, _ = emu.demod_frames(frames)
+    assert not soft.any()

@@ -1,0 +1,135 @@
+"""ctypes binding of the C ABI in include/dabphy.h (libdabphy_hip.so).
+
+This is harness plumbing for tests/ and bench.py -- the product boundary is the C ABI itself, bound from the
+reference's C++ host code as shown in INTEGRATION.md.  There is no CPU fallback: without the HIP library
+(or without a gfx950 device) construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libdabphy_hip.so")
+
+T_U, T_S, FRAME_SYMS_LEN = 2048, 2552, 2048 + 75 * 2552
+
+
+class Config(C.Structure):
+    _fields_ = [("n_ensembles", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
+                ("fft_placement", C.c_int32), ("disable_coarse", C.c_int32), ("want_constellation", C.c_int32),
+                ("want_impulse_response", C.c_int32), ("demod_chunk", C.c_int32)]
+
+
+class Protection(C.Structure):
+    _fields_ = [("nbits", C.c_int32), ("L", C.c_int32 * 4), ("PI", C.c_int32 * 4)]
+
+
+class Subchannel(C.Structure):
+    _fields_ = [("subch_id", C.c_int32), ("start_cu", C.c_int32), ("size_cu", C.c_int32), ("prot", Protection)]
+
+
+class DabPhyError(RuntimeError):
+    pass
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_library(path=None):
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise DabPhyError("HIP library not built: %s (run __graft_entry__.build())" % path)
+    lib = C.CDLL(path)
+    lib.dabphy_last_error.restype = C.c_char_p
+    lib.dabphy_device_name.restype = C.c_char_p
+    return lib
+
+
+class DabPhy:
+    def __init__(self, n_ensembles=1, max_frames=1, device=0, lib_path=None, fft_placement=2, disable_coarse=False,
+                 want_constellation=True, want_impulse_response=True, demod_chunk=0):
+        self.lib = load_library(lib_path)
+        cfg = Config(n_ensembles, max_frames, device, fft_placement, int(disable_coarse), int(want_constellation),
+                     int(want_impulse_response), demod_chunk)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        r = self.lib.dabphy_create(C.byref(cfg), C.byref(self.h))
+        if r != 0:
+            raise DabPhyError("dabphy_create failed with status %d (no gfx950 device?)" % r)
+
+    def close(self):
+        if self.h:
+            self.lib.dabphy_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise DabPhyError("status %d: %s" % (r, self.lib.dabphy_last_error(self.h).decode()))
+
+    @property
+    def device_name(self):
+        return self.lib.dabphy_device_name(self.h).decode()
+
+    # ---- protection helpers
+    def protection_fic(self):
+        p = Protection(); self._chk(self.lib.dabphy_protection_fic(C.byref(p))); return p
+
+    def protection_eep(self, bitrate, profile_b, level):
+        p = Protection(); self._chk(self.lib.dabphy_protection_eep(C.byref(p), bitrate, int(profile_b), level)); return p
+
+    def protection_uep(self, bitrate, level):
+        p = Protection(); self._chk(self.lib.dabphy_protection_uep(C.byref(p), bitrate, level)); return p
+
+    def protection_input_bits(self, p):
+        return self.lib.dabphy_protection_input_bits(C.byref(p))
+
+    # ---- unit-level seams
+    def demod_frames(self, frames, want_con=True):
+        frames = np.ascontiguousarray(frames, np.complex64).reshape(-1, FRAME_SYMS_LEN)
+        n = frames.shape[0]
+        soft = np.zeros((n, 75, 3072), np.int8)
+        con = np.zeros((n, 1200), np.complex64) if want_con else None
+        snr = np.zeros(n, np.float32)
+        self._chk(self.lib.dabphy_demod_frames(self.h, _p(frames), n, _p(soft), _p(con) if want_con else None, _p(snr)))
+        return soft, con, snr
+
+    def viterbi_batch(self, soft, nbits):
+        soft = np.ascontiguousarray(soft, np.int8).reshape(-1, 4 * (nbits + 6))
+        n = soft.shape[0]
+        out = np.zeros((n, nbits // 8), np.uint8)
+        self._chk(self.lib.dabphy_viterbi_batch(self.h, _p(soft), nbits, n, _p(out)))
+        return out
+
+    def msc_deconvolve(self, prot, soft):
+        nin = self.protection_input_bits(prot)
+        soft = np.ascontiguousarray(soft, np.int8).reshape(-1, nin)
+        n = soft.shape[0]
+        out = np.zeros((n, prot.nbits // 8), np.uint8)
+        self._chk(self.lib.dabphy_msc_deconvolve(self.h, C.byref(prot), _p(soft), n, _p(out)))
+        return out
+
+    def fic_decode(self, soft):
+        soft = np.ascontiguousarray(soft, np.int8).reshape(-1, 9216)
+        n = soft.shape[0]
+        fib = np.zeros((n, 12, 32), np.uint8); ok = np.zeros((n, 12), np.uint8); ratio = C.c_int32(0)
+        self._chk(self.lib.dabphy_fic_decode(self.h, _p(soft), n, _p(fib), _p(ok), C.byref(ratio)))
+        return fib, ok, ratio.value
+
+    # ---- diagnostics
+    def time_demod(self, frames, n_ens, n_frames, mix=0, f_hz=0, iters=5):
+        frames = np.ascontiguousarray(frames, np.complex64).reshape(-1, FRAME_SYMS_LEN)
+        ms = C.c_float(0)
+        self._chk(self.lib.dabphy_time_demod(self.h, _p(frames), frames.shape[0], n_ens, n_frames, mix, f_hz, iters, C.byref(ms)))
+        return ms.value
+
+    def time_viterbi(self, nbits, n_codewords, iters=3):
+        a = C.c_float(0); b = C.c_float(0)
+        self._chk(self.lib.dabphy_time_viterbi(self.h, nbits, n_codewords, iters, C.byref(a), C.byref(b)))
+        return a.value, b.value

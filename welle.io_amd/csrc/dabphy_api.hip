@@ -1,0 +1,313 @@
+// welle.io_amd/csrc/dabphy_api.hip -- C ABI of libdabphy_hip.so (include/dabphy.h): handle, device tables,
+// buffer management and kernel sequencing.  No arithmetic of the hot path happens on the host.
+#include "dabphy_kernels.h"
+#include "dabphy_host.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+using namespace dabphy;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+} // namespace
+
+struct dabphy_handle {
+    dabphy_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    char devname[256] = {0};
+    // constant tables in HBM
+    cf32 *d_tw = nullptr, *d_ref = nullptr, *d_nco = nullptr;
+    int16_t* d_bin2soft = nullptr; uint32_t* d_prbs_words = nullptr; int16_t* d_fic_map = nullptr;
+    Tables tab{};
+    // grow-only scratch
+    DevBuf iq, soft, con, prs_mag, snr, desc, in8, map, vsym, vdec, vout, ok;
+    RxState* d_state = nullptr;       // [n_ensembles]
+    std::vector<void*> owned;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                                   \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return DABPHY_ERR_HIP; } } while (0)
+
+int ensure(dabphy_handle* h, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (hipMalloc(&b.p, bytes) != hipSuccess) { h->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; b.p = nullptr; return DABPHY_ERR_NOMEM; }
+    b.cap = bytes;
+    return 0;
+}
+
+template <typename T> int upload_const(dabphy_handle* h, T** dst, const std::vector<T>& src)
+{
+    void* p = nullptr;
+    if (hipMalloc(&p, src.size() * sizeof(T)) != hipSuccess) { h->err = "hipMalloc(table) failed"; return DABPHY_ERR_NOMEM; }
+    h->owned.push_back(p);
+    HIPCHK(h, hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<T*>(p);
+    return 0;
+}
+
+int sync(dabphy_handle* h)
+{
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// Fill a VitClass for n_cw codewords of nbits and make sure its device buffers exist.
+int prepare_class(dabphy_handle* h, VitClass& c, int nbits, int n_cw, int dedisperse)
+{
+    c.nbits = nbits; c.nsteps = nbits + 6; c.n_cw = n_cw; c.n_groups = (n_cw + 63) / 64; c.dedisperse = dedisperse;
+    const size_t cells = (size_t)c.n_groups * c.nsteps * 64;
+    int r;
+    if ((r = ensure(h, h->vsym, cells * sizeof(uint32_t)))) return r;
+    if ((r = ensure(h, h->vdec, cells * sizeof(uint2)))) return r;
+    if ((r = ensure(h, h->vout, (size_t)c.n_groups * 64 * (nbits / 8)))) return r;
+    c.sym = h->vsym.as<uint32_t>(); c.dec = h->vdec.as<uint2>(); c.out = h->vout.as<uint8_t>();
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
+{
+    if (!cfg || !out || cfg->n_ensembles < 1 || cfg->max_frames < 1) return DABPHY_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return DABPHY_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return DABPHY_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DABPHY_ERR_NO_DEVICE;     // kernels are built for gfx950 only
+    if (hipSetDevice(cfg->device) != hipSuccess) return DABPHY_ERR_NO_DEVICE;
+    dabphy_handle* h = new dabphy_handle();
+    h->cfg = *cfg;
+    if (h->cfg.demod_chunk <= 0) h->cfg.demod_chunk = 15;
+    if (h->cfg.demod_chunk > 75) h->cfg.demod_chunk = 75;
+    snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
+    int r = 0;
+    auto fail = [&](int code) { dabphy_destroy(h); return code; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    const HostTables& T = host_tables();
+    if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
+    if ((r = upload_const(h, &h->d_ref, T.ref))) return fail(r);
+    if ((r = upload_const(h, &h->d_nco, T.nco))) return fail(r);
+    if ((r = upload_const(h, &h->d_bin2soft, T.bin2soft))) return fail(r);
+    if ((r = upload_const(h, &h->d_prbs_words, T.prbs_words))) return fail(r);
+    dabphy_protection pf; protection_fic(&pf);
+    if ((r = upload_const(h, &h->d_fic_map, depuncture_map(&pf)))) return fail(r);
+    h->tab.tw = h->d_tw; h->tab.ref = h->d_ref; h->tab.nco = h->d_nco; h->tab.bin2soft = h->d_bin2soft; h->tab.prbs_bytes = nullptr;
+    void* st = nullptr;
+    if (hipMalloc(&st, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+    h->owned.push_back(st); h->d_state = reinterpret_cast<RxState*>(st);
+    if (hipMemset(st, 0, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    *out = h;
+    return DABPHY_OK;
+}
+
+void dabphy_destroy(dabphy_handle* h)
+{
+    if (!h) return;
+    hipError_t e;
+    if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
+    for (void* p : h->owned) e = hipFree(p);
+    DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok};
+    for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
+    (void)e;
+    delete h;
+}
+
+const char* dabphy_last_error(const dabphy_handle* h) { return h ? h->err.c_str() : "null handle"; }
+const char* dabphy_device_name(const dabphy_handle* h) { return h ? h->devname : ""; }
+
+int dabphy_protection_fic(dabphy_protection* p) { return p ? protection_fic(p) : DABPHY_ERR_INVALID; }
+int dabphy_protection_eep(dabphy_protection* p, int bitrate, int profile_b, int level)
+{
+    if (!p) return DABPHY_ERR_INVALID;
+    return protection_eep(p, bitrate, profile_b, level) ? DABPHY_ERR_INVALID : DABPHY_OK;
+}
+int dabphy_protection_uep(dabphy_protection* p, int bitrate, int level) { return p ? protection_uep(p, bitrate, level) : DABPHY_ERR_INVALID; }
+int dabphy_protection_input_bits(const dabphy_protection* p) { return p ? protection_input_bits(p) : DABPHY_ERR_INVALID; }
+
+int dabphy_demod_frames(dabphy_handle* h, const float* frames, uint32_t n_frames, int8_t* soft, float* constellation, float* snr)
+{
+    if (!h || !frames || !soft || n_frames == 0) return DABPHY_ERR_INVALID;
+    const size_t per = (size_t)T_U + 75 * (size_t)T_S;
+    int r;
+    if ((r = ensure(h, h->iq, per * n_frames * sizeof(cf32)))) return r;
+    if ((r = ensure(h, h->soft, (size_t)n_frames * SOFT_PER_FRAME))) return r;
+    if ((r = ensure(h, h->desc, n_frames * sizeof(FrameDesc)))) return r;
+    if ((r = ensure(h, h->prs_mag, (size_t)n_frames * T_U * sizeof(float)))) return r;
+    if ((r = ensure(h, h->snr, n_frames * sizeof(float)))) return r;
+    if (constellation && (r = ensure(h, h->con, (size_t)n_frames * 1200 * sizeof(cf32)))) return r;
+    std::vector<FrameDesc> d(n_frames);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        memset(&d[f], 0, sizeof(FrameDesc));
+        d[f].pos = (int64_t)(per * f); d[f].frame_no = f; d[f].valid = 1;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->iq.p, frames, per * n_frames * sizeof(cf32), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->desc.p, d.data(), n_frames * sizeof(FrameDesc), hipMemcpyHostToDevice, h->stream));
+    DemodArgs a{};
+    a.tab = h->tab; a.iq = h->iq.as<cf32>(); a.iq_stride = 0; a.ring = (int64_t)(per * n_frames);
+    a.desc = h->desc.as<FrameDesc>(); a.n_frames = (int)n_frames; a.chunk_len = h->cfg.demod_chunk; a.mix = 0;
+    a.soft = h->soft.as<int8_t>(); a.soft_ring = (int)n_frames;
+    a.con = constellation ? h->con.as<cf32>() : nullptr; a.prs_mag = h->prs_mag.as<float>();
+    launch_demod(a, 1, h->stream);
+    SnrArgs s{}; s.state = h->d_state; s.desc = a.desc; s.n_ens = 1; s.n_frames = (int)n_frames; s.prs_mag = a.prs_mag; s.snr_out = h->snr.as<float>();
+    launch_snr(s, h->stream);
+    HIPCHK(h, hipMemcpyAsync(soft, h->soft.p, (size_t)n_frames * SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
+    if (constellation) HIPCHK(h, hipMemcpyAsync(constellation, h->con.p, (size_t)n_frames * 1200 * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
+    if (snr) HIPCHK(h, hipMemcpyAsync(snr, h->snr.p, n_frames * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+static int run_lin_decode(dabphy_handle* h, const int8_t* in, size_t in_stride, const int16_t* d_map, int nbits, uint32_t n_cw,
+                          int dedisperse, uint8_t* out)
+{
+    int r;
+    if ((r = ensure(h, h->in8, in_stride * n_cw))) return r;
+    VitClass c{};
+    if ((r = prepare_class(h, c, nbits, (int)n_cw, dedisperse))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->in8.p, in, in_stride * n_cw, hipMemcpyHostToDevice, h->stream));
+    LinGatherArgs g{}; g.in = h->in8.as<int8_t>(); g.in_stride = in_stride; g.map = d_map; g.c = c;
+    launch_lin_gather(g, h->stream);
+    VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+    launch_viterbi(v, h->stream);
+    HIPCHK(h, hipMemcpyAsync(out, c.out, (size_t)n_cw * (nbits / 8), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_viterbi_batch(dabphy_handle* h, const int8_t* in, uint32_t nbits, uint32_t n_codewords, uint8_t* out)
+{
+    if (!h || !in || !out || n_codewords == 0 || nbits == 0 || nbits % 32 || nbits > PRBS_MAX_BITS) return DABPHY_ERR_INVALID;
+    return run_lin_decode(h, in, (size_t)4 * (nbits + 6), nullptr, (int)nbits, n_codewords, 0, out);
+}
+
+int dabphy_msc_deconvolve(dabphy_handle* h, const dabphy_protection* prot, const int8_t* in, uint32_t n_codewords, uint8_t* out)
+{
+    if (!h || !prot || !in || !out || n_codewords == 0 || !protection_valid(prot) || prot->nbits > PRBS_MAX_BITS) return DABPHY_ERR_INVALID;
+    const std::vector<int16_t> m = depuncture_map(prot);
+    int r;
+    if ((r = ensure(h, h->map, m.size() * sizeof(int16_t)))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->map.p, m.data(), m.size() * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));     // m goes out of scope on return paths below only after the copy
+    return run_lin_decode(h, in, (size_t)protection_input_bits(prot), h->map.as<int16_t>(), prot->nbits, n_codewords, 1, out);
+}
+
+int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, uint8_t* fib, uint8_t* crc_ok, int32_t* ratio_percent)
+{
+    if (!h || !soft || !fib || !crc_ok || n_frames == 0) return DABPHY_ERR_INVALID;
+    int r;
+    if ((r = ensure(h, h->in8, (size_t)n_frames * 9216))) return r;
+    if ((r = ensure(h, h->desc, n_frames * sizeof(FrameDesc)))) return r;
+    if ((r = ensure(h, h->ok, (size_t)n_frames * 12))) return r;
+    VitClass c{};
+    if ((r = prepare_class(h, c, 768, (int)n_frames * 4, 1))) return r;
+    std::vector<FrameDesc> d(n_frames);
+    for (uint32_t f = 0; f < n_frames; f++) { memset(&d[f], 0, sizeof(FrameDesc)); d[f].frame_no = f; d[f].valid = 1; }
+    HIPCHK(h, hipMemcpyAsync(h->in8.p, soft, (size_t)n_frames * 9216, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->desc.p, d.data(), n_frames * sizeof(FrameDesc), hipMemcpyHostToDevice, h->stream));
+    FicGatherArgs g{}; g.soft = h->in8.as<int8_t>(); g.soft_ring = (int)n_frames; g.frame_stride = 9216; g.desc = h->desc.as<FrameDesc>();
+    g.n_ens = 1; g.n_frames = (int)n_frames; g.map = h->d_fic_map; g.c = c;
+    launch_fic_gather(g, h->stream);
+    VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+    launch_viterbi(v, h->stream);
+    CrcArgs k{}; k.fib = c.out; k.ok = h->ok.as<uint8_t>(); k.state = h->d_state; k.desc = g.desc; k.n_ens = 1; k.n_frames = (int)n_frames;
+    launch_fib_crc(k, h->stream);
+    launch_fic_ratio(k, h->stream);
+    HIPCHK(h, hipMemcpyAsync(fib, c.out, (size_t)n_frames * 384, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(crc_ok, h->ok.p, (size_t)n_frames * 12, hipMemcpyDeviceToHost, h->stream));
+    RxState st;
+    HIPCHK(h, hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    if ((r = sync(h))) return r;
+    if (ratio_percent) *ratio_percent = st.fic_ratio * 10;
+    return DABPHY_OK;
+}
+
+int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
+                      int32_t mix, int32_t f_hz, uint32_t iters, float* ms)
+{
+    if (!h || !frames || !ms || n_src == 0 || n_ens == 0 || n_frames == 0 || iters == 0) return DABPHY_ERR_INVALID;
+    const size_t per = (size_t)T_U + 75 * (size_t)T_S;
+    const size_t total = (size_t)n_ens * n_frames;
+    int r;
+    if ((r = ensure(h, h->iq, per * total * sizeof(cf32)))) return r;
+    if ((r = ensure(h, h->soft, total * SOFT_PER_FRAME))) return r;
+    if ((r = ensure(h, h->desc, total * sizeof(FrameDesc)))) return r;
+    for (size_t i = 0; i < total; i++)
+        HIPCHK(h, hipMemcpyAsync(h->iq.as<cf32>() + per * i, frames + 2 * per * (i % n_src), per * sizeof(cf32), hipMemcpyHostToDevice, h->stream));
+    std::vector<FrameDesc> d(total);
+    for (uint32_t b = 0; b < n_ens; b++)
+        for (uint32_t f = 0; f < n_frames; f++) {
+            FrameDesc& x = d[(size_t)b * n_frames + f];
+            memset(&x, 0, sizeof x);
+            x.pos = (int64_t)(per * f); x.frame_no = f; x.valid = 1; x.f_prs = x.f_sym = f_hz; x.L0 = 12345; x.L1 = 54321;
+        }
+    HIPCHK(h, hipMemcpyAsync(h->desc.p, d.data(), total * sizeof(FrameDesc), hipMemcpyHostToDevice, h->stream));
+    DemodArgs a{};
+    a.tab = h->tab; a.iq = h->iq.as<cf32>(); a.iq_stride = per * n_frames; a.ring = (int64_t)(per * n_frames);
+    a.desc = h->desc.as<FrameDesc>(); a.n_frames = (int)n_frames; a.chunk_len = h->cfg.demod_chunk; a.mix = mix;
+    a.soft = h->soft.as<int8_t>(); a.soft_ring = (int)n_frames; a.con = nullptr; a.prs_mag = nullptr;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    launch_demod(a, (int)n_ens, h->stream);                       // warm-up
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (uint32_t i = 0; i < iters; i++) launch_demod(a, (int)n_ens, h->stream);
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float t = 0; HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    HIPCHK(h, hipEventDestroy(e0)); HIPCHK(h, hipEventDestroy(e1));
+    return sync(h);
+}
+
+int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather, float* ms_decode)
+{
+    if (!h || !ms_gather || !ms_decode || nbits == 0 || nbits % 32 || nbits > PRBS_MAX_BITS || n_codewords == 0 || iters == 0) return DABPHY_ERR_INVALID;
+    const size_t stride = (size_t)4 * (nbits + 6);
+    int r;
+    if ((r = ensure(h, h->in8, stride * n_codewords))) return r;
+    VitClass c{};
+    if ((r = prepare_class(h, c, (int)nbits, (int)n_codewords, 1))) return r;
+    {   // pseudo-random soft bits (content only drives the data-dependent clock, not the instruction count)
+        std::vector<int8_t> host(stride * n_codewords);
+        uint32_t x = 12345u;
+        for (auto& v : host) { x = x * 1664525u + 1013904223u; v = (int8_t)(x >> 24); }
+        HIPCHK(h, hipMemcpyAsync(h->in8.p, host.data(), host.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    LinGatherArgs g{}; g.in = h->in8.as<int8_t>(); g.in_stride = stride; g.map = nullptr; g.c = c;
+    VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+    hipEvent_t e0, e1, e2;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1)); HIPCHK(h, hipEventCreate(&e2));
+    launch_lin_gather(g, h->stream); launch_viterbi(v, h->stream);
+    float tg = 0, tv = 0;
+    for (uint32_t i = 0; i < iters; i++) {
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+        launch_lin_gather(g, h->stream);
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        launch_viterbi(v, h->stream);
+        HIPCHK(h, hipEventRecord(e2, h->stream));
+        HIPCHK(h, hipEventSynchronize(e2));
+        float a = 0, b = 0; HIPCHK(h, hipEventElapsedTime(&a, e0, e1)); HIPCHK(h, hipEventElapsedTime(&b, e1, e2));
+        tg += a; tv += b;
+    }
+    *ms_gather = tg / iters; *ms_decode = tv / iters;
+    HIPCHK(h, hipEventDestroy(e0)); HIPCHK(h, hipEventDestroy(e1)); HIPCHK(h, hipEventDestroy(e2));
+    return sync(h);
+}
+
+} // extern "C"

@@ -1,0 +1,113 @@
+// welle.io_amd/csrc/dabphy_kernels.h -- device-side data structures and kernel argument blocks.
+#pragma once
+#include "dabphy_common.h"
+
+namespace dabphy {
+
+// Receiver state of one ensemble (the members of OFDMProcessor / OfdmDecoder / FicHandler that survive from
+// frame to frame: ofdm-processor.h:95-110, ofdm-decoder.h:75-77, fic-handler.h:64).  Lives in HBM.
+struct RxState {
+    int64_t pos;            // absolute index of the next unread sample (ring index = pos % ring)
+    int64_t frame_no;       // frames demodulated so far (selects the soft-bit ring slot; CIF count = 4*frame_no)
+    int32_t local_phase;    // OFDMProcessor::localPhase, 0..INPUT_RATE-1
+    int32_t coarse;         // coarseCorrector [Hz]
+    int32_t fine;           // fineCorrector [Hz], int16 range
+    int32_t synced;         // 0: acquisition needed (notSynced), 1: tracking (SyncOnPhase loop)
+    int32_t fic_ratio;      // saturating 0..10 FIB CRC success counter
+    int32_t snr_count;      // OfdmDecoder::snrCount
+    float snr;              // OfdmDecoder::snr
+    float s_level;          // OFDMProcessor::sLevel (maintained by the acquisition kernel only)
+    int32_t lost;           // number of findIndex failures seen
+    int32_t pad;
+};
+
+// Where one transmission frame sits in the sample stream and which oscillator settings were in force while
+// its samples were pulled (written by the sync kernel, read by the demod kernel).
+struct FrameDesc {
+    int64_t pos;            // absolute sample index of the T_u-sample sync buffer (ofdm-processor.cpp:337)
+    int64_t frame_no;
+    int32_t start_index;    // PhaseReference::findIndex result; the PRS useful part starts at pos + start_index
+    int32_t L0;             // localPhase before the first sample at pos
+    int32_t f_prs;          // coarse+fine while the PRS was pulled
+    int32_t L1;             // localPhase after the PRS (before the first sample of symbol 1)
+    int32_t f_sym;          // coarse+fine while symbols 1..75 were pulled
+    int32_t valid;
+    int32_t fine_after, coarse_after;   // correctors after the frame (reported like onFrequencyCorrectorChange)
+};
+
+struct DemodArgs {
+    Tables tab;
+    const cf32* iq; size_t iq_stride; int64_t ring;     // per-ensemble sample ring: iq + b*iq_stride, `ring` samples long
+    const FrameDesc* desc; int n_frames;
+    int chunk_len;                                        // data symbols per work-group
+    int mix;                                              // 1: apply the NCO (streaming path); 0: input already mixed
+    int8_t* soft; int soft_ring;                          // [B][soft_ring][75][3072]
+    cf32* con;                                            // optional [B][n_frames][1200]
+    float* prs_mag;                                       // optional [B][n_frames][2048]
+};
+
+struct SnrArgs {
+    RxState* state; const FrameDesc* desc; int n_ens, n_frames;
+    const float* prs_mag; float* snr_out;                 // [B][n_frames], NaN = no report
+};
+
+// ---------------------------------------------------------------------------------------------- Viterbi
+// A "class" is a set of codewords with identical length and puncturing, decoded 64 per wavefront
+// (lane = codeword).  Symbols are stored step-major so that each trellis step is one coalesced dword
+// load per lane: sym[(group*nsteps + step)*64 + lane] = 4 x uint8 (viterbi.cpp:233-238 mapping applied).
+struct VitClass {
+    int nbits;              // decoded bits per codeword (768 FIC, 24*bitrate MSC)
+    int nsteps;             // nbits + 6
+    int n_cw;               // codewords in the class
+    int n_groups;           // ceil(n_cw / 64)
+    uint32_t* sym;          // [n_groups][nsteps][64]
+    uint2* dec;             // [n_groups][nsteps][64] decision words (scratch)
+    uint8_t* out;           // [n_cw][nbits/8] decoded bytes, energy dispersal removed when prbs != 0
+    int dedisperse;
+};
+
+struct VitArgs { VitClass c; const uint32_t* prbs_words; };
+
+// Gather for the FIC: soft bits of symbols 1..3 of frame (b,f) -> 4 codewords, depunctured (fic-handler.cpp:158-191)
+struct FicGatherArgs {
+    const int8_t* soft; int soft_ring; size_t frame_stride;   // bytes between frame slots (SOFT_PER_FRAME in the ring)
+    const FrameDesc* desc; int n_ens, n_frames;
+    const int16_t* map;     // [3096] mother-code index -> index into the 2304 punctured bits, -1 = erasure
+    VitClass c;
+};
+
+// Gather for one MSC sub-channel class: time de-interleave (dab-audio.cpp:138-143) + depuncture
+// (eep-protection.cpp:127-148) fused into one indexed read of the soft-bit ring.
+struct MscGatherArgs {
+    const int8_t* soft; int soft_ring; const RxState* state; int n_ens, n_frames;
+    const int16_t* map;     // [4*nbits+24] -> index into the sub-channel's length*64 soft bits, -1 = erasure
+    const int32_t* start_bit; // [n_subch_in_class] startAddr*64 per member sub-channel
+    int n_members;            // sub-channels in the class (per ensemble)
+    const FrameDesc* desc;    // [B][n_frames]; desc[b][0].frame_no is the first frame of this batch
+    VitClass c;
+};
+
+struct CrcArgs {
+    const uint8_t* fib;     // [B][F][12][32]
+    uint8_t* ok;            // [B][F][12]
+    RxState* state; const FrameDesc* desc; int n_ens, n_frames;
+};
+
+// Gather from a plain [n_cw][in_stride] array of soft bits (the Viterbi::deconvolve / Protection::deconvolve seams)
+struct LinGatherArgs {
+    const int8_t* in; size_t in_stride;
+    const int16_t* map;     // nullptr: input is already depunctured (index = 4*step + j)
+    VitClass c;
+};
+
+// host-callable launchers (defined next to their kernels)
+void launch_demod(const DemodArgs& a, int n_ens, hipStream_t s);
+void launch_snr(const SnrArgs& a, hipStream_t s);
+void launch_viterbi(const VitArgs& a, hipStream_t s);
+void launch_fic_gather(const FicGatherArgs& a, hipStream_t s);
+void launch_msc_gather(const MscGatherArgs& a, hipStream_t s);
+void launch_lin_gather(const LinGatherArgs& a, hipStream_t s);
+void launch_fib_crc(const CrcArgs& a, hipStream_t s);
+void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
+
+} // namespace dabphy

@@ -1,0 +1,141 @@
+// welle.io_amd/csrc/fft2048.h -- 2048-point complex FFT for one 128-thread work-group (two wave64).
+//
+// Replaces fft::Forward / fft::Backward (src/various/fft.cpp:98-164) for T_u = 2048.  The result is
+// bit-identical to the reference's KISS FFT build: same mixed-radix decomposition 2048 = 4.4.4.4.4.2
+// (kiss_fft.c:309-330), same butterfly arithmetic and operation order (kf_bfly2 :21-42, kf_bfly4 :44-90),
+// same float twiddles (double cos/sin rounded to float, :353-364), no FMA contraction.  What is NOT
+// taken from KISS is the schedule: the six passes run as three register-resident rounds of 16 points
+// per thread, with two exchanges through a 16 KiB LDS tile:
+//
+//   round A  (leaf copy + radix-2 m=1 + radix-4 m=2)   two blocks of 8 consecutive positions per thread,
+//            inputs x[b + 256 j] (b = t, t+128): 64 lanes read 512 contiguous bytes per load
+//   round B  (radix-4 m=8, m=32)                        positions 128c + k + 8a + 32b,  t = 8c + k
+//   round C  (radix-4 m=128, m=512)                     positions k + 128a + 512b,      t = k
+//
+// After round C thread t holds bins t + 128 j (j = 0..15) -- exactly the inputs x[b + 256 j'] that round A
+// of a following transform needs, so FFT -> multiply -> IFFT (phasereference.cpp:81-90) chains in
+// registers.  LDS addressing is XOR-swizzled so that every ds_write_b128 / ds_read_b64 / ds_write_b64 of
+// the two exchanges is bank-conflict free on gfx950 (MI355X_MICROARCH.md, LDS table):
+//   exchange 1: E1(p) = p ^ (((p>>7)&3)<<3) ^ (((p>>9)&3)<<1)
+//   exchange 2: E2(p) = p ^ (((p>>7)&1)<<3)
+#pragma once
+#include "dabphy_common.h"
+
+namespace dabphy {
+
+struct FftTwiddles {           // per-thread constants (forward values; the inverse conjugates them)
+    cf32 a1, a2, a3;           // round A, k = 1: tw[256], tw[512], tw[768]
+    cf32 t0;                   // tw[0]
+    cf32 b8[3];                // m=8:   tw[64k], tw[128k], tw[192k]
+    cf32 b32[4][3];            // m=32:  k' = k + 8a: tw[16k'], tw[32k'], tw[48k']
+    cf32 c128[3];              // m=128: tw[4k], tw[8k], tw[12k]
+    cf32 c512[4][3];           // m=512: k' = k + 128a: tw[k'], tw[2k'], tw[3k']
+};
+
+__device__ __forceinline__ void fft_load_twiddles(FftTwiddles& w, const cf32* __restrict__ tw, int t)
+{
+    w.t0 = tw[0]; w.a1 = tw[256]; w.a2 = tw[512]; w.a3 = tw[768];
+    const int kb = t & 7;
+    for (int i = 0; i < 3; i++) w.b8[i] = tw[64 * kb * (i + 1)];
+    for (int a = 0; a < 4; a++) for (int i = 0; i < 3; i++) w.b32[a][i] = tw[16 * (kb + 8 * a) * (i + 1)];
+    for (int i = 0; i < 3; i++) w.c128[i] = tw[4 * t * (i + 1)];
+    for (int a = 0; a < 4; a++) for (int i = 0; i < 3; i++) w.c512[a][i] = tw[(t + 128 * a) * (i + 1)];
+}
+
+template <bool INV> __device__ __forceinline__ cf32 twc(cf32 w) { if (INV) w.im = -w.im; return w; }
+
+// kf_bfly2 (kiss_fft.c:21-42), one butterfly
+__device__ __forceinline__ void bfly2(cf32& f0, cf32& f1, cf32 tw)
+{
+    const cf32 t = cmul(f1, tw);
+    f1 = csub(f0, t);
+    f0 = cadd(f0, t);
+}
+
+// kf_bfly4 (kiss_fft.c:44-90), one butterfly
+template <bool INV>
+__device__ __forceinline__ void bfly4(cf32& f0, cf32& f1, cf32& f2, cf32& f3, cf32 tw1, cf32 tw2, cf32 tw3)
+{
+    const cf32 s0 = cmul(f1, tw1);
+    const cf32 s1 = cmul(f2, tw2);
+    const cf32 s2 = cmul(f3, tw3);
+    const cf32 s5 = csub(f0, s1);
+    f0 = cadd(f0, s1);
+    const cf32 s3 = cadd(s0, s2);
+    const cf32 s4 = csub(s0, s2);
+    f2 = csub(f0, s3);
+    f0 = cadd(f0, s3);
+    if (INV) {
+        f1.re = s5.re - s4.im; f1.im = s5.im + s4.re;
+        f3.re = s5.re + s4.im; f3.im = s5.im - s4.re;
+    } else {
+        f1.re = s5.re + s4.im; f1.im = s5.im - s4.re;
+        f3.re = s5.re - s4.im; f3.im = s5.im + s4.re;
+    }
+}
+
+// In:  v[8h + j] = x[t + 128h + 256j]  (h = 0,1; j = 0..7)
+// Out: v[j] = X[t + 128 j]             (j = 0..15)
+// lds: 2048 cf32 owned by the work-group.  Contains 4 __syncthreads(); the tile may be reused right after.
+template <bool INV>
+__device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t)
+{
+    // ---------------------------------------------------------------- round A
+    __syncthreads();            // previous users of the tile are done
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        cf32 a[8];
+#pragma unroll
+        for (int j5 = 0; j5 < 4; j5++) { a[2 * j5] = v[8 * h + j5]; a[2 * j5 + 1] = v[8 * h + j5 + 4]; }
+#pragma unroll
+        for (int j5 = 0; j5 < 4; j5++) bfly2(a[2 * j5], a[2 * j5 + 1], twc<INV>(w.t0));
+        bfly4<INV>(a[0], a[2], a[4], a[6], twc<INV>(w.t0), twc<INV>(w.t0), twc<INV>(w.t0));
+        bfly4<INV>(a[1], a[3], a[5], a[7], twc<INV>(w.a1), twc<INV>(w.a2), twc<INV>(w.a3));
+        const int b = t + 128 * h;
+        const int j1 = b & 3, j2 = (b >> 2) & 3, j3 = (b >> 4) & 3, j4 = (b >> 6) & 3;
+        const int q = 64 * j1 + 16 * j2 + 4 * j3 + (j4 ^ j2);           // chunk index with the E1 row swizzle
+        float4* dst = reinterpret_cast<float4*>(lds + 8 * q);
+#pragma unroll
+        for (int s = 0; s < 4; s++)                                      // 16-byte slot s holds positions 2s, 2s+1
+            dst[s ^ j1] = make_float4(a[2 * s].re, a[2 * s].im, a[2 * s + 1].re, a[2 * s + 1].im);
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- round B
+    {
+        const int c = t >> 3, k = t & 7;
+        const int sw = (8 * (c & 3)) ^ (2 * (c >> 2));
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) v[4 * b + a] = lds[(128 * c + k + 8 * a + 32 * b) ^ sw];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], twc<INV>(w.b8[0]), twc<INV>(w.b8[1]), twc<INV>(w.b8[2]));
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.b32[a][0]), twc<INV>(w.b32[a][1]), twc<INV>(w.b32[a][2]));
+        __syncthreads();        // everyone has read exchange 1
+        const int sw2 = 8 * (c & 1);
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) lds[(128 * c + k + 8 * a + 32 * b) ^ sw2] = v[4 * b + a];
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- round C
+    {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) v[4 * b + a] = lds[(t + 128 * a + 512 * b) ^ (8 * (a & 1))];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], twc<INV>(w.c128[0]), twc<INV>(w.c128[1]), twc<INV>(w.c128[2]));
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.c512[a][0]), twc<INV>(w.c512[a][1]), twc<INV>(w.c512[a][2]));
+    }
+    // v[4b + a] = X[t + 128a + 512b] = X[t + 128 (a + 4b)]  -> already in j = a + 4b order
+}
+
+} // namespace dabphy

@@ -1,0 +1,285 @@
+// welle.io_amd/csrc/k_viterbi.hip -- K=7 rate-1/4 Viterbi decoder, depuncturing gathers, FIB CRC.
+//
+// Replaces (reference file:line, relative to src/backend):
+//   Viterbi::deconvolve / BFLY / chainback_viterbi    viterbi.cpp:227-339
+//   FicHandler::processFicInput (depuncture, PRBS)    fic-handler.cpp:144-204
+//   EEPProtection / UEPProtection::deconvolve         eep-protection.cpp:115-152, uep-protection.cpp:169-239
+//   DabAudio::run time de-interleaver                 dab-audio.cpp:113-149
+//   EnergyDispersal::dedisperse                       energy_dispersal.h:35-54
+//   DecoderAdapter::addtoFrame bit packing            decoder_adapter.cpp:55-67
+//   check_CRC_bits                                    various/MathHelper.h:53-80
+//
+// MI355X mapping.  The reference decodes one codeword at a time with 64 scalar states.  Here ONE LANE
+// decodes ONE CODEWORD: a wavefront carries 64 independent codewords, the 64 path metrics of each live in
+// 32 VGPRs as packed uint16 pairs (state j | state j+32 << 16) and a trellis step is 16 packed butterflies
+// (v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_i16) with no cross-lane traffic and no LDS.  Decisions (64 bit per
+// step and codeword) stream to HBM as one coalesced 8-byte store per lane and are read back by the same
+// lane during traceback.  Exact-integer equivalence with the reference: metrics are uint16 without
+// wrap-around (minimum subtracted every 16 steps; spread <= 6*1020, growth <= 16*1020), decisions are
+// "m0 > m1" evaluated on the true integers, ties keep the m0/m2 branch -- the reference's own
+// renormalisation schedule (viterbi.cpp:104-120) changes no decision, so none of it is mimicked.
+#include "dabphy_kernels.h"
+
+namespace dabphy {
+
+typedef unsigned short u16x2 __attribute__((vector_size(4)));
+__device__ __forceinline__ uint32_t asu(u16x2 a) { uint32_t r; __builtin_memcpy(&r, &a, 4); return r; }
+__device__ __forceinline__ u16x2 asv(uint32_t a) { u16x2 r; __builtin_memcpy(&r, &a, 4); return r; }
+__device__ __forceinline__ u16x2 pkmin(u16x2 a, u16x2 b) { return (a < b) ? a : b; }
+__device__ __forceinline__ u16x2 splat(uint32_t x) { return asv(x | (x << 16)); }
+
+// Branch pattern of butterfly i (0..15): bit j = parity((2i) & poly_j) for polys {0155, 0117, 0123}
+// (viterbi.cpp:36,170-177; the 4th output repeats poly 0155).  Butterfly i+16 has bit 0 flipped.
+__host__ __device__ constexpr int parity6(int x) { x ^= x >> 4; x ^= x >> 2; x ^= x >> 1; return x & 1; }
+__host__ __device__ constexpr int bf_pattern(int i)
+{
+    return parity6((2 * i) & 0155) | (parity6((2 * i) & 0117) << 1) | (parity6((2 * i) & 0123) << 2);
+}
+
+template <int I>
+__device__ __forceinline__ void bfly_pair(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&MV)[8], uint32_t& acc0, uint32_t& acc1)
+{
+    constexpr int p = bf_pattern(I);
+    const u16x2 A = asv(__builtin_amdgcn_perm(asu(R[I + 16]), asu(R[I]), 0x05040100u));   // (old[i],    old[i+16])
+    const u16x2 B = asv(__builtin_amdgcn_perm(asu(R[I + 16]), asu(R[I]), 0x07060302u));   // (old[i+32], old[i+48])
+    const u16x2 m0 = A + MV[p], m1 = B + MV[p ^ 7], m2 = A + MV[p ^ 7], m3 = B + MV[p];
+    N[2 * I] = pkmin(m0, m1);                  // (new[2i],   new[2i+32])
+    N[2 * I + 1] = pkmin(m2, m3);              // (new[2i+1], new[2i+33])
+    acc0 |= asu((m1 - m0) >> 15) << I;         // decision0 = m0 > m1   (viterbi.cpp:271)
+    acc1 |= asu((m3 - m2) >> 15) << I;         // decision1 = m2 > m3   (viterbi.cpp:272)
+}
+
+__device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out)
+{
+    // sy = 4 symbols 0..255 (byte j = output j of the mother code).  Branch metric of pattern p:
+    // sum_j (bit_j(p) ? 255 - s_j : s_j), outputs 0 and 3 share bit 0 (viterbi.cpp:259-261).
+    const uint32_t s0 = sy & 0xff, s1 = (sy >> 8) & 0xff, s2 = (sy >> 16) & 0xff, s3 = sy >> 24;
+    const uint32_t t0 = s0 + s3;
+    const u16x2 X0 = asv(t0 | ((510u - t0) << 16));        // (b0=0 | b0=1)
+    const u16x2 X1 = asv((510u - t0) | (t0 << 16));
+    const u16x2 Y0 = splat(s1), Y1 = splat(255u - s1), Z0 = splat(s2), Z1 = splat(255u - s2);
+    const u16x2 W00 = Y0 + Z0, W10 = Y1 + Z0, W01 = Y0 + Z1, W11 = Y1 + Z1;
+    u16x2 MV[8];   // MV[p] = (metric of pattern p, metric of pattern p^1)
+    MV[0] = X0 + W00; MV[1] = X1 + W00; MV[2] = X0 + W10; MV[3] = X1 + W10;
+    MV[4] = X0 + W01; MV[5] = X1 + W01; MV[6] = X0 + W11; MV[7] = X1 + W11;
+    uint32_t acc0 = 0, acc1 = 0;
+    bfly_pair<0>(R, N, MV, acc0, acc1);  bfly_pair<1>(R, N, MV, acc0, acc1);  bfly_pair<2>(R, N, MV, acc0, acc1);
+    bfly_pair<3>(R, N, MV, acc0, acc1);  bfly_pair<4>(R, N, MV, acc0, acc1);  bfly_pair<5>(R, N, MV, acc0, acc1);
+    bfly_pair<6>(R, N, MV, acc0, acc1);  bfly_pair<7>(R, N, MV, acc0, acc1);  bfly_pair<8>(R, N, MV, acc0, acc1);
+    bfly_pair<9>(R, N, MV, acc0, acc1);  bfly_pair<10>(R, N, MV, acc0, acc1); bfly_pair<11>(R, N, MV, acc0, acc1);
+    bfly_pair<12>(R, N, MV, acc0, acc1); bfly_pair<13>(R, N, MV, acc0, acc1); bfly_pair<14>(R, N, MV, acc0, acc1);
+    bfly_pair<15>(R, N, MV, acc0, acc1);
+    *dec_out = make_uint2(acc0, acc1);
+}
+
+__device__ __forceinline__ void renorm(u16x2 (&R)[32])
+{
+    u16x2 m = R[0];
+#pragma unroll
+    for (int j = 1; j < 32; j++) m = pkmin(m, R[j]);
+    const uint32_t mu = asu(m);
+    uint32_t lo = mu & 0xffffu, hi = mu >> 16;
+    const uint32_t mn = lo < hi ? lo : hi;
+    const u16x2 sub = splat(mn);
+#pragma unroll
+    for (int j = 0; j < 32; j++) R[j] = R[j] - sub;
+}
+
+__global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
+{
+    const int lane = threadIdx.x, g = blockIdx.x;
+    const int nsteps = A.c.nsteps, nbits = A.c.nbits;
+    const uint32_t* __restrict__ sym = A.c.sym + (size_t)g * nsteps * 64 + lane;
+    uint2* __restrict__ dec = A.c.dec + (size_t)g * nsteps * 64 + lane;
+
+    u16x2 R[32], N[32];
+    // init_viterbi (viterbi.cpp:342-354): all 63, start state 0 biased to 0
+#pragma unroll
+    for (int j = 0; j < 32; j++) R[j] = splat(63);
+    R[0] = asv(63u << 16);
+
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        const uint32_t y0 = sym[(size_t)s * 64], y1 = sym[(size_t)(s + 1) * 64];
+        trellis_step(R, N, y0, dec + (size_t)s * 64);
+        trellis_step(N, R, y1, dec + (size_t)(s + 1) * 64);
+        if ((s & 14) == 14) renorm(R);
+    }
+    if (s < nsteps) {
+        trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64);
+    }
+
+    // chainback_viterbi (viterbi.cpp:313-339) from state 0, skipping the 6 tail steps; bits are packed MSB
+    // first (decoder_adapter.cpp:61-67) into little-endian 32-bit words and XORed with the energy-dispersal
+    // sequence when asked to (fic-handler.cpp:206-208, energy_dispersal.h:51-53).
+    const int cw = g * 64 + lane;
+    uint32_t* out = reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32);
+    uint32_t T = 0, acc = 0;
+    for (int n = nbits - 1; n >= 0; n--) {
+        const uint2 d = dec[(size_t)(n + 6) * 64];
+        const uint32_t wsel = (T & 1) ? d.y : d.x;
+        const uint32_t k = (wsel >> (((T >> 1) & 15) | ((T >> 5) << 4))) & 1;
+        T = (T >> 1) | (k << 5);
+        acc |= k << (8 * ((n >> 3) & 3) + 7 - (n & 7));
+        if ((n & 31) == 0) {
+            if (cw < A.c.n_cw) out[n >> 5] = A.c.dedisperse ? acc ^ A.prbs_words[n >> 5] : acc;
+            acc = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ FIC gather
+// soft bits of symbols 1..3 (9216 = 4 x 2304) -> depunctured, offset (viterbi.cpp:233-238) symbols of the
+// 4 FIC codewords of each frame, written in the step-major layout k_viterbi reads.
+__global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x;
+    const int cw = g * 64 + lane;
+    const int nsteps = A.c.nsteps;
+    const bool live = cw < A.c.n_cw;
+    const int q = cw & 3, bf = cw >> 2;                    // bf = b * n_frames + f
+    const int b = live ? bf / A.n_frames : 0;
+    const FrameDesc d = A.desc[live ? bf : 0];
+    const int8_t* __restrict__ src = A.soft + ((size_t)b * A.soft_ring + (size_t)(d.frame_no % A.soft_ring)) * A.frame_stride + 2304 * q;
+    uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
+    for (int s = blockIdx.y * 4 + wave; s < nsteps; s += gridDim.y * 4) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int u = A.map[4 * s + j];
+            int v = (u >= 0 && live && d.valid) ? (int)src[u] : 0;
+            v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
+            word |= (uint32_t)v << (8 * j);
+        }
+        dst[(size_t)s * 64] = word;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ MSC gather
+// codeword (b, r, m): ensemble b, CIF r of this batch (0..4F-1), member sub-channel m of the class.
+// Soft bit u of the logical frame emitted at CIF c comes from CIF c - 16 + map16[u & 15]
+// (dab-audio.cpp:113,138-143: tempX[i] = hist[(idx + map[i&15]) & 15][i] read BEFORE the current CIF is
+// stored), i.e. the de-interleaver is an address computation on the soft-bit ring, no copy.
+__global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x;
+    const int cw = g * 64 + lane;
+    const int nsteps = A.c.nsteps;
+    const bool live = cw < A.c.n_cw;
+    const int m = live ? cw % A.n_members : 0;
+    const int br = live ? cw / A.n_members : 0;
+    const int r = br % (4 * A.n_frames), b = br / (4 * A.n_frames);
+    const int64_t c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;       // global CIF number of the CIF that triggers this output
+    const int8_t* __restrict__ base = A.soft + (size_t)b * A.soft_ring * SOFT_PER_FRAME + A.start_bit[m];
+    uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
+    const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+    for (int s = blockIdx.y * 4 + wave; s < nsteps; s += gridDim.y * 4) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int u = A.map[4 * s + j];
+            int v = 0;
+            if (u >= 0 && live) {
+                const int64_t c_src = c_glob - 16 + map16[u & 15];
+                if (c_src >= 0) {
+                    const int64_t fr = c_src >> 2; const int cif = (int)(c_src & 3);
+                    v = base[((size_t)(fr % A.soft_ring) * 75 + 3 + 18 * cif) * SOFT_PER_SYM + u];
+                }
+            }
+            v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
+            word |= (uint32_t)v << (8 * j);
+        }
+        dst[(size_t)s * 64] = word;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ linear gather
+// Input as the reference's seams hand it over: in[cw][...] int8, either already depunctured
+// (Viterbi::deconvolve, viterbi.cpp:227) or punctured with a depuncturing map (Protection::deconvolve).
+__global__ void __launch_bounds__(256) k_lin_gather(LinGatherArgs A)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x, cw = g * 64 + lane;
+    const bool live = cw < A.c.n_cw;
+    const int8_t* __restrict__ src = A.in + (size_t)(live ? cw : 0) * A.in_stride;
+    uint32_t* __restrict__ dst = A.c.sym + (size_t)g * A.c.nsteps * 64 + lane;
+    for (int s = blockIdx.y * 4 + wave; s < A.c.nsteps; s += gridDim.y * 4) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int u = A.map ? (int)A.map[4 * s + j] : 4 * s + j;
+            int v = (live && u >= 0) ? (int)src[u] : 0;
+            v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
+            word |= (uint32_t)v << (8 * j);
+        }
+        dst[(size_t)s * 64] = word;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ FIB CRC
+// CRC-16-CCITT (x^16+x^12+x^5+1, register preset to ones, transmitted inverted) over 30 data bytes,
+// compared with the 2 stored bytes: the byte-wise form of check_CRC_bits (MathHelper.h:53-80).
+__global__ void k_fib_crc(CrcArgs A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = A.n_ens * A.n_frames * 12;
+    if (i >= n) return;
+    const uint8_t* p = A.fib + (size_t)i * 32;
+    uint32_t crc = 0xFFFF;
+    for (int k = 0; k < 30; k++) {
+        crc ^= (uint32_t)p[k] << 8;
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
+    }
+    crc ^= 0xFFFF;
+    const bool valid = A.desc[i / 12].valid != 0;
+    A.ok[i] = (valid && crc == (((uint32_t)p[30] << 8) | p[31])) ? 1 : 0;
+}
+
+// saturating success counter (fic-handler.cpp:219-229), one thread per ensemble walks its FIBs in order
+__global__ void k_fic_ratio(CrcArgs A)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.n_ens) return;
+    int r = A.state[b].fic_ratio;
+    for (int f = 0; f < A.n_frames; f++) {
+        if (!A.desc[(size_t)b * A.n_frames + f].valid) continue;
+        for (int k = 0; k < 12; k++) {
+            if (A.ok[((size_t)b * A.n_frames + f) * 12 + k]) { if (r < 10) r++; }
+            else if (r > 0) r--;
+        }
+    }
+    A.state[b].fic_ratio = r;
+}
+
+static inline int gather_rows(int nsteps) { int y = (nsteps + 63) / 64; return y < 1 ? 1 : (y > 32 ? 32 : y); }
+
+void launch_viterbi(const VitArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_viterbi, dim3(a.c.n_groups), dim3(64), 0, s, a);
+}
+void launch_fic_gather(const FicGatherArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fic_gather, dim3(a.c.n_groups, gather_rows(a.c.nsteps)), dim3(256), 0, s, a);
+}
+void launch_msc_gather(const MscGatherArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_msc_gather, dim3(a.c.n_groups, gather_rows(a.c.nsteps)), dim3(256), 0, s, a);
+}
+void launch_lin_gather(const LinGatherArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lin_gather, dim3(a.c.n_groups, gather_rows(a.c.nsteps)), dim3(256), 0, s, a);
+}
+void launch_fib_crc(const CrcArgs& a, hipStream_t s)
+{
+    const int n = a.n_ens * a.n_frames * 12;
+    hipLaunchKernelGGL(k_fib_crc, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_fic_ratio(const CrcArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fic_ratio, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+}
+
+} // namespace dabphy
