@@ -102,6 +102,61 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
 int dabphy_msc_deconvolve(dabphy_handle* h, const dabphy_protection* prot, const int8_t* in, uint32_t n_codewords,
                           uint8_t* out);
 
+/* ======================================================================================================
+ * Streaming receiver: OFDMProcessor::run (ofdm-processor.cpp:235-501) for n_ensembles independent sample
+ * streams at once, followed by the whole decode chain.  This is what RadioReceiver::restart() starts in the
+ * reference; the per-frame callbacks of RadioControllerInterface become the getters below.
+ * ====================================================================================================== */
+
+/* InputInterface::getSamples (radio-controller.h:193-199) replaced by a sample ring in HBM.
+ * dabphy_stream_bind_device: d_iq is a DEVICE pointer to n_ensembles rows of `stride_samples` complex floats, of
+ *   which the first `ring_samples` are the ring; `n_valid` samples have been written (ignored when loop != 0:
+ *   the ring then repeats for ever like CRAWFile with rewind, raw_file.cpp:284-286).  Resets the receiver state.
+ * dabphy_stream_upload: convenience for host data: n_ensembles x n_samples complex floats are copied to HBM. */
+int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_samples, uint64_t stride_samples,
+                              uint64_t n_valid, int32_t loop);
+int dabphy_stream_upload(dabphy_handle* h, const float* iq, uint64_t n_samples, int32_t loop);
+
+/* OFDMProcessor::restart (ofdm-processor.cpp:115-132): correctors, phase, sync state, FIC counter, SNR filter cleared */
+int dabphy_reset(dabphy_handle* h);
+
+/* MscHandler::addSubchannel (msc-handler.cpp:61-103) for every ensemble of the handle; n = 0 clears the list
+ * (MscHandler::stopProcessing).  Must be called before the first dabphy_process of a stream for the time
+ * de-interleaver to see all CIFs, exactly as in the reference. */
+int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n);
+
+/* Decode the next n_frames (<= max_frames) transmission frames of every ensemble: acquisition (null-symbol
+ * search) where an ensemble is not synchronised, PRS time sync, coarse/fine frequency tracking, demodulation,
+ * FIC and MSC channel decoding.  Results stay in HBM until fetched with the getters.
+ * Note on the coarse corrector: the reference consults the FIB CRC success ratio of the PREVIOUS frame
+ * (ofdm-processor.cpp:397); that feedback is exact when n_frames == 1.  With n_frames > 1 the ratio of the
+ * last finished batch is used for the whole batch -- identical once the ratio is >= 50 (normal tracking) or
+ * with disable_coarse. */
+int dabphy_process(dabphy_handle* h, uint32_t n_frames);
+
+typedef struct {
+    int64_t sample_pos;             /* absolute index of the sync buffer start (ofdm-processor.cpp:337) */
+    int64_t frame_no;               /* running frame counter of the ensemble */
+    int32_t start_index;            /* PhaseReference::findIndex result (< 0: sync lost, onSyncChange(false)) */
+    int32_t valid;                  /* frame was demodulated */
+    int32_t fine_corrector;         /* as passed to onFrequencyCorrectorChange after the frame */
+    int32_t coarse_corrector;
+    float snr;                      /* onSNR value, NaN when the reference would not report on this frame */
+} dabphy_frame_info;
+
+int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out /* [n_ensembles][n_frames] */);
+/* onFIBDecodeSuccess: fib [n_ensembles][n_frames][12][32], crc_ok [n_ensembles][n_frames][12] */
+int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok);
+int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensembles] */);
+/* decoded logical frames of sub-channel `subch_index` (order of dabphy_set_subchannels):
+ * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file;
+ * first_valid[b] = number of leading CIF slots of this batch that carry no frame yet (the de-interleaver emits
+ * its first frame on the 17th CIF, dab-audio.cpp:146-149). */
+int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t* first_valid);
+int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_frames][2048] */);      /* onNewImpulseResponse */
+int dabphy_get_constellation(dabphy_handle* h, float* out /* [n_ensembles][n_frames][1200] cf32 */);   /* onConstellationPoints */
+int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, int8_t* out /* 75*3072 */);
+
 /* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
  * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
  *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.

@@ -78,3 +78,62 @@ def check_demod(d, n_frames, snr_db, seed, early=100):
     if len(sn):
         assert np.allclose(rep, sn, rtol=1e-5, atol=1e-5)      # north-star tolerance for SNR floats
     return soft
+
+
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1):
+    """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
+    from welle_io_amd import capi  # noqa: F401
+    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse)
+    try:
+        d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+        logs = [dict(fib=[], ok=[], info=[], con=[], soft=[], msc=[[] for _ in subs]) for _ in range(B)]
+        done = 0
+        while done < n_frames_total:
+            d.process(F)
+            info = d.frame_info(); fb, ok = d.fibs(); cn = d.constellation()
+            mscs = [d.msc(i) for i in range(len(subs))]
+            for b in range(B):
+                nv = 0
+                for f in range(F):
+                    if info[b, f]["valid"]:
+                        L = logs[b]
+                        L["fib"].append(fb[b, f]); L["ok"].append(ok[b, f]); L["info"].append(info[b, f]); L["con"].append(cn[b, f])
+                        if b == 0:
+                            L["soft"].append(d.soft_bits(b, f))
+                        nv += 1
+                for i in range(len(subs)):
+                    m, fv = mscs[i]
+                    logs[b]["msc"][i].append(m[b, fv[b]:4 * nv].tobytes())
+            if not info["valid"].any():
+                break
+            done += F
+        return logs
+    finally:
+        d.close()
+
+
+def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4):
+    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
+    subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
+    o = R.orc_receiver_run(x, subchs=subs, want_soft=True)
+    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B)
+    for b in range(B):
+        L = logs[b]
+        n = min(len(L["fib"]), len(o["fib"]) // 12)
+        assert n >= o["n_frames"] - (1 if lockstep else F), (n, o["n_frames"])
+        ofib = o["fib"][:12 * n].reshape(n, 12, 33)
+        assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]), "CRC flags differ"
+        assert np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:]), "FIB bytes differ"
+        inf = np.array(L["info"][:n])
+        assert np.array_equal(np.stack([inf["fine"], inf["coarse"]], 1), o["corr"][:n]), "correctors differ"
+        assert np.array_equal(np.array(L["con"][:n]).view(np.uint32), o["con"][:n].view(np.uint32)), "constellation differs"
+        if b == 0:
+            assert np.array_equal(np.array(L["soft"][:n]), o["soft"][:n]), "soft bits differ"
+        rep = inf["snr"][~np.isnan(inf["snr"])]
+        assert np.array_equal(rep, o["snr"][:len(rep)])      # same libm-free arithmetic up to log10: equal here, 1e-5 by contract
+        for i in range(len(subs)):
+            got = b"".join(L["msc"][i])
+            assert len(got) > 0 or n < 5
+            assert got == o["msc"][i][:len(got)], "MSC bytes of sub-channel %d differ" % i
+    return logs, o, tx

@@ -1,0 +1,21 @@
+"""CPU suite: the whole streaming receiver (acquisition, PRS sync, coarse/fine tracking, demod, FIC, MSC with time
+de-interleaving) compiled for tests/hipemu, against orc_receiver_run -- which tests/test_oracle_vs_ref.py pins to
+the real reference end to end."""
+import pytest
+
+import parity_cases as P
+from conftest import EMU_LIB
+from welle_io_amd import capi
+
+
+def factory(**kw):
+    return capi.DabPhy(lib_path=EMU_LIB, **kw)
+
+
+@pytest.mark.parametrize("snr,cfo,delay,nf,lockstep", [(25, 0, 0, 10, False), (13, 137, 1000, 8, True), (20, 2300, 0, 8, True), (20, -400, 333, 8, True)])
+def test_stream(emu, snr, cfo, delay, nf, lockstep):
+    P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, lockstep)
+
+
+def test_two_ensembles_in_lock_step(emu):
+    P.check_stream_vs_oracle(factory, 18, 0, 500, 7, False, B=2, F=2)

@@ -133,3 +133,78 @@ class DabPhy:
         a = C.c_float(0); b = C.c_float(0)
         self._chk(self.lib.dabphy_time_viterbi(self.h, nbits, n_codewords, iters, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    # ---- streaming receiver
+    def reset(self):
+        self._chk(self.lib.dabphy_reset(self.h))
+
+    def stream_upload(self, iq, loop=False):
+        """iq: (n_ensembles, n_samples) complex64 host array"""
+        iq = np.ascontiguousarray(iq, np.complex64).reshape(self.cfg.n_ensembles, -1)
+        self._chk(self.lib.dabphy_stream_upload(self.h, _p(iq), C.c_uint64(iq.shape[1]), int(loop)))
+
+    def stream_bind_device(self, dev_ptr, ring_samples, stride_samples, n_valid, loop=False):
+        self._chk(self.lib.dabphy_stream_bind_device(self.h, C.c_void_p(dev_ptr), C.c_uint64(ring_samples), C.c_uint64(stride_samples),
+                                                     C.c_uint64(n_valid), int(loop)))
+
+    def set_subchannels(self, subs):
+        """subs: list of (subch_id, start_cu, size_cu, Protection)"""
+        arr = (Subchannel * max(1, len(subs)))()
+        for i, (sid, start, size, prot) in enumerate(subs):
+            arr[i].subch_id = sid; arr[i].start_cu = start; arr[i].size_cu = size; arr[i].prot = prot
+        self._n_sub = len(subs); self._sub_bytes = [s[3].nbits // 8 for s in subs]
+        self._chk(self.lib.dabphy_set_subchannels(self.h, arr, len(subs)))
+
+    def process(self, n_frames):
+        self._chk(self.lib.dabphy_process(self.h, n_frames))
+        self._last = n_frames
+
+    def frame_info(self):
+        B, F = self.cfg.n_ensembles, self._last
+        arr = (FrameInfo * (B * F))()
+        self._chk(self.lib.dabphy_get_frame_info(self.h, arr))
+        out = np.zeros((B, F), dtype=[("pos", np.int64), ("frame_no", np.int64), ("start_index", np.int32), ("valid", np.int32),
+                                      ("fine", np.int32), ("coarse", np.int32), ("snr", np.float32)])
+        for i in range(B * F):
+            a = arr[i]
+            out.reshape(-1)[i] = (a.sample_pos, a.frame_no, a.start_index, a.valid, a.fine_corrector, a.coarse_corrector, a.snr)
+        return out
+
+    def fibs(self):
+        B, F = self.cfg.n_ensembles, self._last
+        fib = np.zeros((B, F, 12, 32), np.uint8); ok = np.zeros((B, F, 12), np.uint8)
+        self._chk(self.lib.dabphy_get_fibs(self.h, _p(fib), _p(ok)))
+        return fib, ok
+
+    def fic_ratio(self):
+        r = np.zeros(self.cfg.n_ensembles, np.int32)
+        self._chk(self.lib.dabphy_get_fic_ratio(self.h, _p(r)))
+        return r
+
+    def msc(self, idx):
+        B, F = self.cfg.n_ensembles, self._last
+        out = np.zeros((B, 4 * F, self._sub_bytes[idx]), np.uint8); fv = np.zeros(B, np.int32)
+        self._chk(self.lib.dabphy_get_msc(self.h, idx, _p(out), _p(fv)))
+        return out, fv
+
+    def impulse_response(self):
+        B, F = self.cfg.n_ensembles, self._last
+        out = np.zeros((B, F, 2048), np.float32)
+        self._chk(self.lib.dabphy_get_impulse_response(self.h, _p(out)))
+        return out
+
+    def constellation(self):
+        B, F = self.cfg.n_ensembles, self._last
+        out = np.zeros((B, F, 1200), np.complex64)
+        self._chk(self.lib.dabphy_get_constellation(self.h, _p(out)))
+        return out
+
+    def soft_bits(self, ens, frame):
+        out = np.zeros((75, 3072), np.int8)
+        self._chk(self.lib.dabphy_get_soft_bits(self.h, ens, frame, _p(out)))
+        return out
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("sample_pos", C.c_int64), ("frame_no", C.c_int64), ("start_index", C.c_int32), ("valid", C.c_int32),
+                ("fine_corrector", C.c_int32), ("coarse_corrector", C.c_int32), ("snr", C.c_float)]

@@ -32,6 +32,23 @@ struct dabphy_handle {
     DevBuf iq, soft, con, prs_mag, snr, desc, in8, map, vsym, vdec, vout, ok;
     RxState* d_state = nullptr;       // [n_ensembles]
     std::vector<void*> owned;
+
+    // ---- streaming receiver (dabphy_stream_* / dabphy_process)
+    struct MscClass {
+        dabphy_protection prot{};
+        std::vector<int> members;     // indices into subch
+        DevBuf map, start_bits, out;  // depuncture map, startAddr*64 per member, decoded bytes [B][4F][members][nbits/8]
+    };
+    const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
+    DevBuf s_iq_own;
+    uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
+    std::vector<dabphy_subchannel> subch;
+    std::vector<MscClass> classes;
+    DevBuf s_desc, s_soft, s_cir, s_con, s_mag, s_snr, s_fib, s_ok;
+    int soft_ring = 0;
+    uint32_t last_frames = 0;         // n_frames of the last dabphy_process
+    std::vector<FrameDesc> h_desc;    // host copy of the last batch's frame descriptors
+    std::vector<float> h_snr;
 };
 
 namespace {
@@ -235,6 +252,225 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
     if ((r = sync(h))) return r;
     if (ratio_percent) *ratio_percent = st.fic_ratio * 10;
     return DABPHY_OK;
+}
+
+// =================================================================================== streaming receiver
+
+int dabphy_reset(dabphy_handle* h)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    HIPCHK(h, hipMemsetAsync(h->d_state, 0, sizeof(RxState) * h->cfg.n_ensembles, h->stream));
+    h->last_frames = 0;
+    return sync(h);
+}
+
+int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_samples, uint64_t stride_samples,
+                              uint64_t n_valid, int32_t loop)
+{
+    if (!h || !d_iq || ring_samples < (uint64_t)T_F || stride_samples < ring_samples) return DABPHY_ERR_INVALID;
+    h->s_iq = reinterpret_cast<const cf32*>(d_iq); h->s_ring = ring_samples; h->s_stride = stride_samples;
+    h->s_valid = n_valid; h->s_loop = loop;
+    return dabphy_reset(h);
+}
+
+int dabphy_stream_upload(dabphy_handle* h, const float* iq, uint64_t n_samples, int32_t loop)
+{
+    if (!h || !iq || n_samples < (uint64_t)T_F) return DABPHY_ERR_INVALID;
+    const size_t bytes = (size_t)h->cfg.n_ensembles * n_samples * sizeof(cf32);
+    int r;
+    if ((r = ensure(h, h->s_iq_own, bytes))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->s_iq_own.p, iq, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return dabphy_stream_bind_device(h, h->s_iq_own.p, n_samples, n_samples, n_samples, loop);
+}
+
+int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n)
+{
+    if (!h || (n && !list)) return DABPHY_ERR_INVALID;
+    for (uint32_t i = 0; i < n; i++) {
+        const dabphy_subchannel& s = list[i];
+        if (!protection_valid(&s.prot) || s.prot.nbits > PRBS_MAX_BITS || s.start_cu < 0 || s.size_cu <= 0 || s.start_cu + s.size_cu > 864 ||
+            protection_input_bits(&s.prot) > s.size_cu * 64) { h->err = "invalid sub-channel " + std::to_string(i); return DABPHY_ERR_INVALID; }
+    }
+    for (auto& c : h->classes) {
+        hipError_t e;
+        if (c.map.p) e = hipFree(c.map.p);
+        if (c.start_bits.p) e = hipFree(c.start_bits.p);
+        if (c.out.p) e = hipFree(c.out.p);
+        (void)e;
+    }
+    h->classes.clear();
+    h->subch.assign(list, list + n);
+    for (uint32_t i = 0; i < n; i++) {
+        dabphy_handle::MscClass* cls = nullptr;
+        for (auto& c : h->classes) if (!memcmp(&c.prot, &list[i].prot, sizeof(dabphy_protection))) { cls = &c; break; }
+        if (!cls) { h->classes.emplace_back(); cls = &h->classes.back(); cls->prot = list[i].prot; }
+        cls->members.push_back((int)i);
+    }
+    for (auto& c : h->classes) {
+        const std::vector<int16_t> m = depuncture_map(&c.prot);
+        std::vector<int32_t> sb;
+        for (int i : c.members) sb.push_back(h->subch[i].start_cu * 64);
+        int r;
+        if ((r = ensure(h, c.map, m.size() * sizeof(int16_t)))) return r;
+        if ((r = ensure(h, c.start_bits, sb.size() * sizeof(int32_t)))) return r;
+        HIPCHK(h, hipMemcpy(c.map.p, m.data(), m.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(c.start_bits.p, sb.data(), sb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return DABPHY_OK;
+}
+
+// One batch: acquisition where needed, n_frames frame steps of the synchroniser, then the fully parallel stages.
+int dabphy_process(dabphy_handle* h, uint32_t n_frames)
+{
+    if (!h || n_frames == 0 || n_frames > h->cfg.max_frames) return DABPHY_ERR_INVALID;
+    if (!h->s_iq) { h->err = "no sample stream bound"; return DABPHY_ERR_STATE; }
+    const uint32_t B = h->cfg.n_ensembles, F = n_frames;
+    const int ring_frames = (int)h->cfg.max_frames + 5;
+    int r;
+    if ((r = ensure(h, h->s_desc, (size_t)B * F * sizeof(FrameDesc)))) return r;
+    if ((r = ensure(h, h->s_soft, (size_t)B * ring_frames * SOFT_PER_FRAME))) return r;
+    if ((r = ensure(h, h->s_mag, (size_t)B * F * T_U * sizeof(float)))) return r;
+    if ((r = ensure(h, h->s_snr, (size_t)B * F * sizeof(float)))) return r;
+    if ((r = ensure(h, h->s_fib, (size_t)B * F * 384))) return r;
+    if ((r = ensure(h, h->s_ok, (size_t)B * F * 12))) return r;
+    if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir, (size_t)B * F * T_U * sizeof(float)))) return r;
+    if (h->cfg.want_constellation && (r = ensure(h, h->s_con, (size_t)B * F * 1200 * sizeof(cf32)))) return r;
+    h->soft_ring = ring_frames;
+
+    SyncArgs sa{};
+    sa.tab = h->tab; sa.iq = h->s_iq; sa.iq_stride = h->s_stride; sa.ring = (int64_t)h->s_ring; sa.n_valid = (int64_t)h->s_valid;
+    sa.loop = h->s_loop; sa.state = h->d_state; sa.desc = h->s_desc.as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
+    sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse;
+    sa.cir = h->cfg.want_impulse_response ? h->s_cir.as<float>() : nullptr;
+    for (uint32_t f = 0; f < F; f++) {
+        launch_acquire(sa, h->stream);             // no-op for ensembles that are tracking
+        sa.frame = (int)f;
+        launch_sync_frame(sa, h->stream);
+    }
+
+    DemodArgs da{};
+    da.tab = h->tab; da.iq = h->s_iq; da.iq_stride = h->s_stride; da.ring = (int64_t)h->s_ring;
+    da.desc = sa.desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
+    da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames;
+    da.con = h->cfg.want_constellation ? h->s_con.as<cf32>() : nullptr; da.prs_mag = h->s_mag.as<float>();
+    launch_demod(da, (int)B, h->stream);
+    SnrArgs sn{}; sn.state = h->d_state; sn.desc = sa.desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
+    launch_snr(sn, h->stream);
+
+    // FIC: 4 codewords per frame
+    {
+        VitClass c{};
+        if ((r = prepare_class(h, c, 768, (int)(B * F * 4), 1))) return r;
+        c.out = h->s_fib.as<uint8_t>();
+        // the class output must hold whole groups of 64 codewords
+        if ((r = ensure(h, h->s_fib, (size_t)c.n_groups * 64 * 96))) return r;
+        c.out = h->s_fib.as<uint8_t>();
+        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = sa.desc;
+        g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
+        launch_fic_gather(g, h->stream);
+        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+        launch_viterbi(v, h->stream);
+        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_state; k.desc = sa.desc; k.n_ens = (int)B; k.n_frames = (int)F;
+        launch_fib_crc(k, h->stream);
+        launch_fic_ratio(k, h->stream);
+    }
+    // MSC: one launch pair per protection class
+    for (auto& cls : h->classes) {
+        VitClass c{};
+        const int n_cw = (int)(B * 4 * F * cls.members.size());
+        if ((r = prepare_class(h, c, cls.prot.nbits, n_cw, 1))) return r;
+        if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
+        c.out = cls.out.as<uint8_t>();
+        MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
+        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = sa.desc; g.c = c;
+        launch_msc_gather(g, h->stream);
+        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+        launch_viterbi(v, h->stream);
+    }
+    h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
+    HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), h->s_desc.p, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_snr.data(), h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->last_frames = F;
+    return sync(h);
+}
+
+int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out)
+{
+    if (!h || !out || !h->last_frames) return DABPHY_ERR_INVALID;
+    const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
+    for (size_t i = 0; i < n; i++) {
+        const FrameDesc& d = h->h_desc[i];
+        out[i].sample_pos = d.pos; out[i].frame_no = d.frame_no; out[i].start_index = d.start_index; out[i].valid = d.valid;
+        out[i].fine_corrector = d.fine_after; out[i].coarse_corrector = d.coarse_after; out[i].snr = h->h_snr[i];
+    }
+    return DABPHY_OK;
+}
+
+int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
+{
+    if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
+    const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
+    HIPCHK(h, hipMemcpyAsync(fib, h->s_fib.p, n * 384, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(crc_ok, h->s_ok.p, n * 12, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
+{
+    if (!h || !ratio_percent) return DABPHY_ERR_INVALID;
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) ratio_percent[i] = st[i].fic_ratio * 10;
+    return DABPHY_OK;
+}
+
+int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t* first_valid)
+{
+    if (!h || !out || subch_index >= h->subch.size() || !h->last_frames) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    for (auto& cls : h->classes) {
+        for (size_t m = 0; m < cls.members.size(); m++) {
+            if (cls.members[m] != (int)subch_index) continue;
+            const size_t bytes = cls.prot.nbits / 8, nm = cls.members.size();
+            std::vector<uint8_t> all((size_t)B * 4 * F * nm * bytes);
+            HIPCHK(h, hipMemcpyAsync(all.data(), cls.out.p, all.size(), hipMemcpyDeviceToHost, h->stream));
+            int r = sync(h); if (r) return r;
+            for (size_t br = 0; br < (size_t)B * 4 * F; br++) memcpy(out + br * bytes, all.data() + (br * nm + m) * bytes, bytes);
+            if (first_valid)
+                for (uint32_t b = 0; b < B; b++) {
+                    // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149)
+                    const int64_t c0 = 4 * h->h_desc[(size_t)b * F].frame_no;
+                    first_valid[b] = c0 >= 16 ? 0 : (int32_t)(16 - c0);
+                }
+            return DABPHY_OK;
+        }
+    }
+    return DABPHY_ERR_INVALID;
+}
+
+int dabphy_get_impulse_response(dabphy_handle* h, float* out)
+{
+    if (!h || !out || !h->last_frames || !h->cfg.want_impulse_response) return DABPHY_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(out, h->s_cir.p, (size_t)h->cfg.n_ensembles * h->last_frames * T_U * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_constellation(dabphy_handle* h, float* out)
+{
+    if (!h || !out || !h->last_frames || !h->cfg.want_constellation) return DABPHY_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(out, h->s_con.p, (size_t)h->cfg.n_ensembles * h->last_frames * 1200 * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, int8_t* out)
+{
+    if (!h || !out || ensemble >= h->cfg.n_ensembles || frame >= h->last_frames) return DABPHY_ERR_INVALID;
+    const FrameDesc& d = h->h_desc[(size_t)ensemble * h->last_frames + frame];
+    const size_t slot = (size_t)(d.frame_no % h->soft_ring);
+    HIPCHK(h, hipMemcpyAsync(out, h->s_soft.as<int8_t>() + ((size_t)ensemble * h->soft_ring + slot) * SOFT_PER_FRAME, SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
 }
 
 int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,

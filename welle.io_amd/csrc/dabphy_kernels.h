@@ -18,7 +18,11 @@ struct RxState {
     float snr;              // OfdmDecoder::snr
     float s_level;          // OFDMProcessor::sLevel (maintained by the acquisition kernel only)
     int32_t lost;           // number of findIndex failures seen
-    int32_t pad;
+    // acquisition state machine (survives a call that ran out of samples mid-search)
+    int32_t acq_phase;      // 0 priming sLevel, 1 first 50 samples, 2 looking for the dip, 3 looking for the end of the null
+    int32_t acq_counter, acq_idx, acq_left;
+    float acq_cs;           // currentStrength
+    float env[64];          // last 64 entries of envBuffer (only the 50 most recent are ever read)
 };
 
 // Where one transmission frame sits in the sample stream and which oscillator settings were in force while
@@ -33,6 +37,18 @@ struct FrameDesc {
     int32_t f_sym;          // coarse+fine while symbols 1..75 were pulled
     int32_t valid;
     int32_t fine_after, coarse_after;   // correctors after the frame (reported like onFrequencyCorrectorChange)
+    int32_t null_L, null_f;             // oscillator state while the trailing null symbol was pulled (onNewNullSymbol)
+};
+
+// Argument block of the synchronisation kernels (k_sync.hip)
+struct SyncArgs {
+    Tables tab;
+    const cf32* iq; size_t iq_stride; int64_t ring;     // sample ring of each ensemble
+    int64_t n_valid;                                     // samples written so far (absolute); ignored when loop != 0
+    int loop;                                            // the ring is a looping recording (CRAWFile with rewind, raw_file.cpp:284-286)
+    RxState* state; FrameDesc* desc; int n_ens, n_frames, frame;
+    int fft_placement, disable_coarse;
+    float* cir;                                          // optional [B][n_frames][2048] impulse responses
 };
 
 struct DemodArgs {
@@ -109,5 +125,7 @@ void launch_msc_gather(const MscGatherArgs& a, hipStream_t s);
 void launch_lin_gather(const LinGatherArgs& a, hipStream_t s);
 void launch_fib_crc(const CrcArgs& a, hipStream_t s);
 void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
+void launch_sync_frame(const SyncArgs& a, hipStream_t s);
+void launch_acquire(const SyncArgs& a, hipStream_t s);
 
 } // namespace dabphy

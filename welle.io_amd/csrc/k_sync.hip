@@ -1,0 +1,358 @@
+// welle.io_amd/csrc/k_sync.hip -- time/frequency synchronisation of OFDMProcessor::run, one work-group per ensemble.
+//
+// Replaces (reference file:line, relative to src/backend):
+//   OFDMProcessor::run, notSynced .. SyncOnEndNull      ofdm-processor.cpp:249-319     -> k_acquire
+//   OFDMProcessor::run, SyncOnPhase .. ReadyForNewFrame ofdm-processor.cpp:324-490     -> k_sync_frame
+//   OFDMProcessor::getSample(s) oscillator              ofdm-processor.cpp:145-224     (closed-form phase, table gather)
+//   PhaseReference::findIndex                           phasereference.cpp:73-256      (ThresholdBeforePeak, StrongestPeak)
+//   OFDMProcessor::processPRS (PatternOfZeros)          ofdm-processor.cpp:537-616
+//
+// The chain frame -> frame is inherently serial per ensemble (the window position and the fine corrector of
+// frame n+1 depend on frame n), so the batch dimension is the ensemble: B work-groups per launch, one launch
+// per frame step.  Everything that decides an integer (window index, int16 corrector) is computed in the
+// reference's operand order: the cyclic-prefix correlation is 37 800 float complex additions in sequence --
+// the products are formed in parallel, the additions are done by one lane in order.
+#include "fft2048.h"
+#include "dabphy_kernels.h"
+
+namespace dabphy {
+
+__device__ __forceinline__ int32_t mod_rate64(int64_t x)
+{
+    int64_t r = x % INPUT_RATE;
+    if (r < 0) r += INPUT_RATE;
+    return (int32_t)r;
+}
+
+// sample `off` (from absolute position pos) of ensemble stream, oscillator applied: phase (L - (rel+1) f) mod RATE
+__device__ __forceinline__ cf32 mixed_sample(const cf32* __restrict__ iq, int64_t ring, int64_t pos, int64_t off,
+                                             const cf32* __restrict__ nco, int32_t L, int32_t f, int64_t rel)
+{
+    const cf32 x = iq[(pos + off) % ring];
+    const int32_t ph = (f == 0) ? L : mod_rate64((int64_t)L - (rel + 1) * (int64_t)f);
+    return cmul(x, nco[ph]);
+}
+
+// 2048 samples starting `off` after pos, phase progression from (L, f) with the first sample at relative index rel0,
+// delivered in round-A order: v[8h + j] = x[t + 128h + 256j]
+__device__ __forceinline__ void load_mix2048(cf32 (&v)[16], const cf32* __restrict__ iq, int64_t ring, int64_t pos, int64_t off,
+                                             const cf32* __restrict__ nco, int32_t L, int32_t f, int64_t rel0, int t)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[(i & 1) * 8 + (i >> 1)] = mixed_sample(iq, ring, pos, off + t + 128 * i, nco, L, f, rel0 + t + 128 * i);
+}
+
+__device__ __forceinline__ float block_max(float x, float* red, int t)
+{
+    __syncthreads();
+    red[t] = x;
+    __syncthreads();
+    for (int s = FFT_THREADS / 2; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ int block_min_int(int x, int* red, int t)
+{
+    __syncthreads();
+    red[t] = x;
+    __syncthreads();
+    for (int s = FFT_THREADS / 2; s > 0; s >>= 1) {
+        if (t < s) red[t] = red[t] < red[t + s] ? red[t] : red[t + s];
+        __syncthreads();
+    }
+    const int r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
+{
+    __shared__ __attribute__((aligned(16))) cf32 tile[T_U];
+    __shared__ float lbuf[T_U + 128];
+    __shared__ float pa[T_U];
+    __shared__ __attribute__((aligned(16))) cf32 prod[2][512];
+    __shared__ float redf[FFT_THREADS];
+    __shared__ int redi[FFT_THREADS];
+    __shared__ float s_sum;
+    __shared__ cf32 s_corr;
+
+    const int t = threadIdx.x, b = blockIdx.x;
+    RxState st = A.state[b];
+    FrameDesc& dout = A.desc[(size_t)b * A.n_frames + A.frame];
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    const cf32* __restrict__ nco = A.tab.nco;
+
+    FrameDesc d;
+    d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
+    d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0;
+
+    // a whole frame (with the largest possible window index) must be available
+    const int64_t need = (int64_t)T_U + (T_U - 1) + 75 * (int64_t)T_S + T_NULL;
+    if (!st.synced || (!A.loop && st.pos + need > A.n_valid)) {
+        if (t == 0) dout = d;
+        return;
+    }
+
+    FftTwiddles w; fft_load_twiddles(w, A.tab.tw, t);
+    cf32 v[16], u[16];
+
+    // ---- PhaseReference::findIndex (phasereference.cpp:73-92): FFT, multiply by conj(refTable), IFFT (scaled by 1/N)
+    load_mix2048(v, iq, A.ring, st.pos, 0, nco, d.L0, d.f_prs, 0, t);
+    fft2048_wg<false>(v, tile, w, t);
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = cmul(v[j], cconj(A.tab.ref[t + 128 * j]));
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) u[8 * h + j] = v[h + 2 * j];          // bin t + 128 (h + 2j) = input t + 128h + 256j
+    fft2048_wg<true>(u, tile, w, t);
+    const float factor = 1.0f / (float)T_U;                                // fft.cpp:154
+    float* cir = A.cir ? A.cir + ((size_t)b * A.n_frames + A.frame) * T_U : nullptr;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float a = hypotf_exact(u[j].re * factor, u[j].im * factor);  // phasereference.cpp:214-215
+        lbuf[t + 128 * j] = a;
+        if (cir) cir[t + 128 * j] = a;
+    }
+    if (t < 128) lbuf[T_U + t] = 0.0f;
+    __syncthreads();
+
+    int startIndex = -1;
+    if (A.fft_placement == 0) {
+        // StrongestPeak (phasereference.cpp:99-129): sum in order, first maximum
+        if (t == 0) { float s = 0; for (int i = 0; i < T_U; i++) s += lbuf[i]; s_sum = s; }
+        float mx = -10000.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) mx = fmaxf(mx, lbuf[16 * t + j]);
+        const float gmax = block_max(mx, redf, t);
+        int cand = T_U;
+        for (int j = 15; j >= 0; j--) if (lbuf[16 * t + j] == gmax) cand = 16 * t + j;
+        const int first = block_min_int(cand, redi, t);
+        const float sum = s_sum;
+        if (sum == 0) startIndex = -1;
+        else if (gmax < 3 * sum / T_U) startIndex = (int)(-fabsf(gmax * T_U / sum) - 1);
+        else startIndex = first;
+    } else {
+        // ThresholdBeforePeak (phasereference.cpp:212-252)
+        if (t == 0) { float s = 0; for (int i = 0; i < T_U; i++) s += lbuf[i]; s_sum = s; }   // :214-218, in order
+        // peak_averages[i] = max(lbuf[i .. i+99]) for i < 1948; thread t owns i = 16t .. 16t+15
+        float mx = -10000.0f;
+        if (16 * t < T_U - 100) {
+            float common = -10000.0f;                                   // lbuf[16t+15 .. 16t+99]
+            for (int k = 16 * t + 15; k <= 16 * t + 99; k++) common = fmaxf(common, lbuf[k]);
+            float suf[16];                                              // suf[k] = max(lbuf[16t+k .. 16t+14])
+            float run = -10000.0f;
+            for (int k = 14; k >= 0; k--) { run = fmaxf(run, lbuf[16 * t + k]); suf[k] = run; }
+            suf[15] = -10000.0f;
+            run = -10000.0f;                                            // prefix over lbuf[16t+100 .. 16t+99+k]
+            for (int k = 0; k < 16; k++) {
+                const int i = 16 * t + k;
+                if (k > 0) run = fmaxf(run, lbuf[16 * t + 99 + k]);
+                float m = fmaxf(common, suf[k]);
+                if (k > 0) m = fmaxf(m, run);
+                if (i + 100 < T_U) { pa[i] = m; mx = fmaxf(mx, m); } else pa[i] = 0.0f;
+            }
+        } else {
+            for (int k = 0; k < 16; k++) pa[16 * t + k] = 0.0f;
+        }
+        const float gmax = block_max(mx, redf, t);                       // contains the barriers that publish pa / s_sum
+        const float sum = s_sum;
+        int cand = T_U;
+        if (gmax > 3 * sum / T_U) {                                      // :238-239
+            const float thresh = gmax / 2;
+            for (int k = 15; k >= 0; k--) {
+                const int i = 16 * t + k;
+                if (i + 100 < T_U && pa[i + 100] > thresh) cand = i;    // :241-245
+            }
+        }
+        const int first = block_min_int(cand, redi, t);
+        startIndex = first < T_U ? first : -1;
+    }
+
+    if (startIndex < 0) {
+        // ofdm-processor.cpp:347-350: SyncOnPhase failed -> notSynced (the 2048 samples are consumed)
+        if (t == 0) {
+            d.start_index = startIndex;
+            dout = d;
+            st.pos += T_U;
+            st.local_phase = mod_rate64((int64_t)d.L0 - (int64_t)T_U * d.f_prs);
+            st.synced = 0; st.lost++;
+            A.state[b] = st;
+        }
+        return;
+    }
+    d.start_index = startIndex;
+    const int32_t J0 = startIndex + T_U;
+    d.L1 = mod_rate64((int64_t)d.L0 - (int64_t)J0 * d.f_prs);
+
+    // ---- coarse frequency corrector (ofdm-processor.cpp:397-409, processPRS :537-616 PatternOfZeros)
+    int32_t coarse = st.coarse;
+    if (!A.disable_coarse && st.fic_ratio * 10 < 50) {
+        load_mix2048(v, iq, A.ring, st.pos, startIndex, nco, d.L0, d.f_prs, startIndex, t);
+        fft2048_wg<false>(v, tile, w, t);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) tile[t + 128 * j] = v[j];          // natural bin order
+        __syncthreads();
+        float sum = 3.0e38f; int idx = 1 << 20;
+        if (t < 72) {
+            const int i = T_U - 36 + t;
+#define FB(k) tile[(k) % T_U]
+#define ARG(a, c) ([&] { const cf32 z_ = cmul(FB(a), cconj(FB(c))); return fdlibm_atan2f(z_.im, z_.re); }())
+            // the reference's unqualified abs() binds to ::abs(int): arguments are truncated to int first
+            // (disassembly of the -O2 build: cvttsd2si / cvttss2si); oracle/dabphy_oracle.c pins this.
+            const float a1 = (float)abs(abs((int)((double)ARG(i + 1, i + 2) / M_PI)) - 1);
+            const float a2 = (float)abs(abs((int)((double)ARG(i + 2, i + 3) / M_PI)) - 1);
+            const float a3 = (float)abs((int)ARG(i + 3, i + 4));
+            const float a4 = (float)abs((int)ARG(i + 4, i + 5));
+            const float a5 = (float)abs((int)ARG(i + 5, i + 6));
+            const float b1 = (float)abs(abs((int)((double)ARG(i + 17, i + 19) / M_PI)) - 1);
+            const float b2 = (float)abs((int)ARG(i + 19, i + 20));
+            const float b3 = (float)abs((int)ARG(i + 20, i + 21));
+            const float b4 = (float)abs((int)ARG(i + 21, i + 22));
+#undef ARG
+#undef FB
+            sum = a1 + a2 + a3 + a4 + a5 + b1 + b2 + b3 + b4;
+            idx = i;
+        }
+        // first index with the smallest sum (strict '<' scan in ascending i, Mmin starts at 1000)
+        const float neg_min = block_max(-sum, redf, t);
+        const int first = block_min_int((-sum == neg_min) ? idx : (1 << 20), redi, t);
+        {
+            const int index = (-neg_min < 1000.0f) ? first : 100;       // "int16_t index = 100" when nothing beat Mmin = 1000
+            const int correction = index - T_U;
+            if (correction != 100) {                                     // :403 (always true, kept for fidelity)
+                coarse += correction * 1000;
+                if (abs(coarse) > 35000) coarse = 0;
+            }
+        }
+    }
+    d.f_sym = coarse + st.fine;
+
+    // ---- cyclic-prefix correlation over the 75 data symbols (ofdm-processor.cpp:435-442)
+    // products for symbol s: buf[2048+j] * conj(buf[j]), j < 504; threads form them, lane 0 adds them in order
+    cf32 acc; acc.re = 0.0f; acc.im = 0.0f;
+    auto products = [&](int s, int bufsel) {
+        const int64_t rel_sym = (int64_t)(s - 1) * T_S;                  // relative index of buf[0] after the PRS
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = t + 128 * k;
+            if (j < T_G) {
+                const cf32 lo = mixed_sample(iq, A.ring, st.pos, J0 + rel_sym + j, nco, d.L1, d.f_sym, rel_sym + j);
+                const cf32 hi = mixed_sample(iq, A.ring, st.pos, J0 + rel_sym + T_U + j, nco, d.L1, d.f_sym, rel_sym + T_U + j);
+                prod[bufsel][j] = cmul(hi, cconj(lo));
+            }
+        }
+    };
+    products(1, 1);
+    __syncthreads();
+    for (int s = 1; s < L_SYM; s++) {
+        if (s + 1 < L_SYM) products(s + 1, (s + 1) & 1);
+        if (t == 0) {
+            const cf32* p = prod[s & 1];
+            for (int j = 0; j < T_G; j++) { acc.re += p[j].re; acc.im += p[j].im; }
+        }
+        __syncthreads();
+    }
+
+    if (t == 0) {
+        // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
+        const float a = fdlibm_atan2f(acc.im, acc.re);
+        int32_t fine = (int32_t)(int16_t)((double)st.fine + 0.1 * (double)a / M_PI * (1000 / 2));
+        // null symbol (:462-463) is pulled with the new fine corrector
+        const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
+        const int32_t f_null = coarse + fine;
+        const int32_t L3 = mod_rate64((int64_t)L2 - (int64_t)T_NULL * f_null);
+        d.null_L = L2; d.null_f = f_null;
+        d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
+        if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
+        else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
+        d.valid = 1;
+        dout = d;
+        st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
+        st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
+        A.state[b] = st;
+    }
+}
+
+// ---- acquisition: OFDMProcessor::run from "Initing" / notSynced to SyncOnPhase (ofdm-processor.cpp:249-319).
+// A strictly per-sample recurrence (sLevel IIR evaluated in double, 50-sample moving sum); one work-group per
+// ensemble stages |re|+|im| of the oscillator-corrected samples in LDS, lane 0 walks the state machine.
+__global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
+{
+    constexpr int TILE = 1024;
+    __shared__ float l1[TILE];
+    __shared__ RxState s_st;
+    __shared__ int s_done;
+
+    const int t = threadIdx.x, b = blockIdx.x;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    const cf32* __restrict__ nco = A.tab.nco;
+    if (t == 0) { s_st = A.state[b]; s_done = s_st.synced ? 1 : 0; }
+    __syncthreads();
+    if (s_done) return;
+
+    for (;;) {
+        const int64_t pos = s_st.pos; const int32_t L = s_st.local_phase;
+        // getSample(0) while priming / taking the first 50 samples, getSample(coarse+fine) while searching (:254,:269,:286,:305)
+        const int32_t f = (s_st.acq_phase >= 2) ? s_st.coarse + s_st.fine : 0;
+        int64_t avail = A.loop ? TILE : A.n_valid - pos;
+        if (avail > TILE) avail = TILE;
+        if (avail <= 0) break;                                       // starved: state is kept for the next call
+        for (int i = t; i < (int)avail; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, pos, i, nco, L, f, i));
+        __syncthreads();
+        if (t == 0) {
+            RxState st = s_st;
+            float sLevel = st.s_level, cs = st.acq_cs;
+            int ph = st.acq_phase, idx = st.acq_idx, counter = st.acq_counter, left = st.acq_left;
+            int i = 0; bool done = false;
+            for (;;) {
+                // loop conditions are evaluated before a sample is pulled (:284, :303)
+                if (ph == 2 && !((double)(cs / 50) > 0.50 * (double)sLevel)) { ph = 3; counter = 0; }
+                if (ph == 3 && !((double)(cs / 50) < 0.75 * (double)sLevel)) { done = true; break; }
+                if (i >= (int)avail) break;
+                const float a = l1[i++];
+                sLevel = (float)(0.00001 * (double)a + (1 - 0.00001) * (double)sLevel);         // :174
+                if (ph == 0) {                                                                  // :252-255
+                    if (--left <= 0) { ph = 1; idx = 0; cs = 0.0f; }
+                } else if (ph == 1) {                                                           // :268-273
+                    st.env[idx & 63] = a; cs += a; idx++;
+                    if (idx == 50) { ph = 2; counter = 0; break; }                              // oscillator changes -> new tile
+                } else {                                                                        // :285-297 / :304-316
+                    st.env[idx & 63] = a;
+                    cs += a - st.env[(idx - 50) & 63];
+                    idx = (idx + 1) & 32767;
+                    counter++;
+                    if ((ph == 2 && counter > T_F) || (ph == 3 && counter > T_NULL + 50)) {     // hopeless -> notSynced
+                        ph = 1; idx = 0; cs = 0.0f; break;
+                    }
+                }
+            }
+            st.s_level = sLevel; st.acq_cs = cs; st.acq_phase = ph; st.acq_idx = idx; st.acq_counter = counter; st.acq_left = left;
+            st.pos = pos + i;
+            st.local_phase = (f == 0) ? L : mod_rate64((int64_t)L - (int64_t)i * f);
+            if (done) { st.synced = 1; st.acq_phase = 1; st.acq_idx = 0; st.acq_cs = 0.0f; st.acq_counter = 0; }
+            s_st = st; s_done = done ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (t == 0) A.state[b] = s_st;
+}
+
+void launch_sync_frame(const SyncArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sync_frame, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
+}
+void launch_acquire(const SyncArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_acquire, dim3(a.n_ens), dim3(256), 0, s, a);
+}
+
+} // namespace dabphy
