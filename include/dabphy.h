@@ -157,6 +157,23 @@ int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_
 int dabphy_get_constellation(dabphy_handle* h, float* out /* [n_ensembles][n_frames][1200] cf32 */);   /* onConstellationPoints */
 int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, int8_t* out /* 75*3072 */);
 
+/* ---- RSDecoder::DecodeSuperframe (dabplus_decoder.cpp:326-359), batched --------------------------------------
+ * sf: n_sf superframes of 120*s_per_sf bytes (s_per_sf = bitrate/8), corrected in place.  corrected[i] = number of
+ * corrected symbols in superframe i (total_corr_count), uncorrectable[i] != 0 when any of its codewords failed. */
+int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint32_t n_sf, int32_t* corrected,
+                          int32_t* uncorrectable);
+/* The same on the MSC output of the last dabphy_process, in HBM.  subch_index < 0: every sub-channel.
+ * first_cif[b]: CIF slot of this batch (0..4*n_frames-1, may be negative) where ensemble b's first superframe
+ * starts -- the alignment SuperframeFilter::CheckSync (dabplus_decoder.cpp:171-215) finds on the host.  Only
+ * superframes lying entirely inside the batch are decoded.  corrected / uncorrectable (may be NULL): per ensemble sums. */
+int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* first_cif, int32_t* corrected,
+                         int32_t* uncorrectable);
+
+/* ---- per-stage device time of the last dabphy_process (HIP events on the handle's stream) -------------------
+ * ms[0..6] = sync chain, demod kernel, SNR, FIC (gather+Viterbi+CRC), MSC gather, MSC Viterbi, Reed-Solomon */
+int dabphy_set_profiling(dabphy_handle* h, int32_t on);
+int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);
+
 /* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
  * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
  *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.

@@ -16,10 +16,8 @@ def declared_functions():
 
 
 def test_header_symbols_exported():
-    if not os.path.exists(GPU_LIB):
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
-        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); m.build()
+    # (re)build incrementally so the check always sees the current sources
+    subprocess.run(["make", "-j4"], cwd=os.path.join(ROOT, "welle.io_amd", "csrc"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     out = subprocess.run(["nm", "-D", "--defined-only", GPU_LIB], capture_output=True, text=True, check=True).stdout
     exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
     fns = declared_functions()

@@ -208,3 +208,34 @@ class DabPhy:
 class FrameInfo(C.Structure):
     _fields_ = [("sample_pos", C.c_int64), ("frame_no", C.c_int64), ("start_index", C.c_int32), ("valid", C.c_int32),
                 ("fine_corrector", C.c_int32), ("coarse_corrector", C.c_int32), ("snr", C.c_float)]
+
+
+def _rs_superframes(self, sf, s_per_sf):
+    sf = np.ascontiguousarray(sf, np.uint8).reshape(-1, 120 * s_per_sf).copy()
+    n = sf.shape[0]; corr = np.zeros(n, np.int32); unc = np.zeros(n, np.int32)
+    self._chk(self.lib.dabphy_rs_superframes(self.h, _p(sf), s_per_sf, n, _p(corr), _p(unc)))
+    return sf, corr, unc
+
+
+def _rs_decode_msc(self, subch_index, first_cif):
+    B = self.cfg.n_ensembles
+    fc = np.ascontiguousarray(first_cif, np.int32).reshape(B)
+    corr = np.zeros(B, np.int32); unc = np.zeros(B, np.int32)
+    self._chk(self.lib.dabphy_rs_decode_msc(self.h, int(subch_index), _p(fc), _p(corr), _p(unc)))
+    return corr, unc
+
+
+def _set_profiling(self, on=True):
+    self._chk(self.lib.dabphy_set_profiling(self.h, int(on)))
+
+
+def _stage_times(self):
+    ms = np.zeros(7, np.float32)
+    self._chk(self.lib.dabphy_get_stage_times(self.h, _p(ms)))
+    return dict(zip(["sync", "demod", "snr", "fic", "msc_gather", "msc_viterbi", "rs"], [float(v) for v in ms]))
+
+
+DabPhy.rs_superframes = _rs_superframes
+DabPhy.rs_decode_msc = _rs_decode_msc
+DabPhy.set_profiling = _set_profiling
+DabPhy.stage_times = _stage_times

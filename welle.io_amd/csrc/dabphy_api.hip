@@ -49,6 +49,12 @@ struct dabphy_handle {
     uint32_t last_frames = 0;         // n_frames of the last dabphy_process
     std::vector<FrameDesc> h_desc;    // host copy of the last batch's frame descriptors
     std::vector<float> h_snr;
+    // stage timing (HIP events on the handle's stream, recorded when profiling is on)
+    enum { ST_SYNC = 0, ST_DEMOD, ST_SNR, ST_FIC, ST_MSC_GATHER, ST_MSC_VITERBI, ST_RS, ST_COUNT };
+    bool profiling = false;
+    hipEvent_t ev_beg[ST_COUNT]{}, ev_end[ST_COUNT]{};
+    bool ev_used[ST_COUNT]{};
+    DevBuf rs_first, rs_result;
 };
 
 namespace {
@@ -131,6 +137,8 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipMalloc(&st, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
     h->owned.push_back(st); h->d_state = reinterpret_cast<RxState*>(st);
     if (hipMemset(st, 0, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
+        if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
     return DABPHY_OK;
 }
@@ -141,6 +149,10 @@ void dabphy_destroy(dabphy_handle* h)
     hipError_t e;
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
+    for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
+    DevBuf* more[] = {&h->s_iq_own, &h->s_desc, &h->s_soft, &h->s_cir, &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
+    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.out.p) e = hipFree(c.out.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
     (void)e;
@@ -343,20 +355,32 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     sa.loop = h->s_loop; sa.state = h->d_state; sa.desc = h->s_desc.as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
     sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse;
     sa.cir = h->cfg.want_impulse_response ? h->s_cir.as<float>() : nullptr;
+    for (int i = 0; i < dabphy_handle::ST_COUNT; i++) h->ev_used[i] = false;
+    auto mark = [&](int stage, bool end) {
+        if (!h->profiling) return;
+        hipError_t e = hipEventRecord(end ? h->ev_end[stage] : h->ev_beg[stage], h->stream); (void)e;
+        h->ev_used[stage] = true;
+    };
+    mark(dabphy_handle::ST_SYNC, false);
     for (uint32_t f = 0; f < F; f++) {
         launch_acquire(sa, h->stream);             // no-op for ensembles that are tracking
         sa.frame = (int)f;
         launch_sync_frame(sa, h->stream);
     }
+    mark(dabphy_handle::ST_SYNC, true);
 
     DemodArgs da{};
     da.tab = h->tab; da.iq = h->s_iq; da.iq_stride = h->s_stride; da.ring = (int64_t)h->s_ring;
     da.desc = sa.desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
     da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames;
     da.con = h->cfg.want_constellation ? h->s_con.as<cf32>() : nullptr; da.prs_mag = h->s_mag.as<float>();
+    mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
+    mark(dabphy_handle::ST_DEMOD, true);
     SnrArgs sn{}; sn.state = h->d_state; sn.desc = sa.desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
+    mark(dabphy_handle::ST_SNR, false);
     launch_snr(sn, h->stream);
+    mark(dabphy_handle::ST_SNR, true);
 
     // FIC: 4 codewords per frame
     {
@@ -368,14 +392,16 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         c.out = h->s_fib.as<uint8_t>();
         FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = sa.desc;
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
+        mark(dabphy_handle::ST_FIC, false);
         launch_fic_gather(g, h->stream);
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         launch_viterbi(v, h->stream);
         CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_state; k.desc = sa.desc; k.n_ens = (int)B; k.n_frames = (int)F;
         launch_fib_crc(k, h->stream);
         launch_fic_ratio(k, h->stream);
+        mark(dabphy_handle::ST_FIC, true);
     }
-    // MSC: one launch pair per protection class
+    // MSC: one launch pair per protection class (stage events bracket the first class only: one class in the canonical ensemble)
     for (auto& cls : h->classes) {
         VitClass c{};
         const int n_cw = (int)(B * 4 * F * cls.members.size());
@@ -384,9 +410,13 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         c.out = cls.out.as<uint8_t>();
         MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
         g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = sa.desc; g.c = c;
+        const bool first_cls = (&cls == &h->classes.front());
+        if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
         launch_msc_gather(g, h->stream);
+        if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         launch_viterbi(v, h->stream);
+        if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
     }
     h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
     HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), h->s_desc.p, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
@@ -470,6 +500,85 @@ int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, in
     const FrameDesc& d = h->h_desc[(size_t)ensemble * h->last_frames + frame];
     const size_t slot = (size_t)(d.frame_no % h->soft_ring);
     HIPCHK(h, hipMemcpyAsync(out, h->s_soft.as<int8_t>() + ((size_t)ensemble * h->soft_ring + slot) * SOFT_PER_FRAME, SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_set_profiling(dabphy_handle* h, int32_t on)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    h->profiling = on != 0;
+    return DABPHY_OK;
+}
+
+int dabphy_get_stage_times(dabphy_handle* h, float* ms)
+{
+    if (!h || !ms) return DABPHY_ERR_INVALID;
+    for (int i = 0; i < dabphy_handle::ST_COUNT; i++) {
+        ms[i] = 0.0f;
+        if (h->ev_used[i]) { float t = 0; if (hipEventElapsedTime(&t, h->ev_beg[i], h->ev_end[i]) == hipSuccess) ms[i] = t; }
+    }
+    return DABPHY_OK;
+}
+
+int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint32_t n_sf, int32_t* corrected, int32_t* uncorrectable)
+{
+    if (!h || !sf || !corrected || !uncorrectable || s_per_sf == 0 || n_sf == 0) return DABPHY_ERR_INVALID;
+    const size_t bytes = (size_t)120 * s_per_sf * n_sf;
+    int r;
+    if ((r = ensure(h, h->in8, bytes))) return r;
+    if ((r = ensure(h, h->rs_result, 2 * sizeof(int) * n_sf))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->in8.p, sf, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->rs_result.p, 0, 2 * sizeof(int) * n_sf, h->stream));
+    RsArgs a{}; a.data = h->in8.as<uint8_t>(); a.sf_stride = (size_t)120 * s_per_sf; a.n_sf = (int)n_sf; a.s = (int)s_per_sf;
+    a.corr = h->rs_result.as<int>(); a.uncorr = h->rs_result.as<int>() + n_sf;
+    launch_rs_superframes(a, h->stream);
+    HIPCHK(h, hipMemcpyAsync(sf, h->in8.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(corrected, a.corr, sizeof(int) * n_sf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(uncorrectable, a.uncorr, sizeof(int) * n_sf, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* first_cif, int32_t* corrected, int32_t* uncorrectable)
+{
+    if (!h || !first_cif || !h->last_frames || subch_index >= (int32_t)h->subch.size()) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    const int n_cif = (int)(4 * F), n_sf = n_cif / 5 + 1;
+    int r;
+    if ((r = ensure(h, h->rs_first, sizeof(int) * B))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->rs_first.p, first_cif, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    if (corrected) memset(corrected, 0, sizeof(int32_t) * B);
+    if (uncorrectable) memset(uncorrectable, 0, sizeof(int32_t) * B);
+    bool first_launch = true;
+    for (auto& cls : h->classes) {
+        int member = -1;
+        if (subch_index >= 0) {
+            for (size_t m = 0; m < cls.members.size(); m++) if (cls.members[m] == subch_index) member = (int)m;
+            if (member < 0) continue;
+        }
+        const int bitrate = cls.prot.nbits / 24;
+        if (bitrate % 8) continue;
+        const size_t nres = (size_t)B * n_sf * cls.members.size() * 2;
+        if ((r = ensure(h, h->rs_result, nres * sizeof(int)))) return r;
+        HIPCHK(h, hipMemsetAsync(h->rs_result.p, 0, nres * sizeof(int), h->stream));
+        RsMscArgs a{}; a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = (int)cls.members.size();
+        a.frame_bytes = cls.prot.nbits / 8; a.s = bitrate / 8; a.n_sf_per_ens = n_sf; a.member_only = member;
+        a.first_cif = h->rs_first.as<int>(); a.result = h->rs_result.as<int>();
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
+        launch_rs_msc(a, h->stream);
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
+        first_launch = false;
+        if (corrected || uncorrectable) {
+            std::vector<int> res(nres);
+            HIPCHK(h, hipMemcpyAsync(res.data(), h->rs_result.p, nres * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            if ((r = sync(h))) return r;
+            for (uint32_t b = 0; b < B; b++)
+                for (size_t k = 0; k < (size_t)n_sf * cls.members.size(); k++) {
+                    const size_t o = ((size_t)b * n_sf * cls.members.size() + k) * 2;
+                    if (corrected) corrected[b] += res[o];
+                    if (uncorrectable) uncorrectable[b] += res[o + 1];
+                }
+        }
+    }
     return sync(h);
 }
 

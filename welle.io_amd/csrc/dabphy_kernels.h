@@ -116,6 +116,20 @@ struct LinGatherArgs {
     VitClass c;
 };
 
+// Reed-Solomon (k_rs.hip)
+struct RsArgs {            // contiguous superframes [n_sf][sf_stride], s = bitrate/8 codewords each
+    uint8_t* data; size_t sf_stride; int n_sf, s;
+    int* corr; int* uncorr;                       // [n_sf]
+};
+struct RsMscArgs {         // superframes inside a class's MSC output [B][n_cif][n_members][frame_bytes]
+    uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s, n_sf_per_ens;
+    int member_only;                              // -1: every member, else only this member
+    const int* first_cif;                         // [B] logical-frame slot (in this batch) where the first superframe starts
+    int* result;                                  // [B][n_sf_per_ens][n_members][2] = corrected symbols, uncorrectable flag
+};
+void launch_rs_superframes(const RsArgs& a, hipStream_t s);
+void launch_rs_msc(const RsMscArgs& a, hipStream_t s);
+
 // host-callable launchers (defined next to their kernels)
 void launch_demod(const DemodArgs& a, int n_ens, hipStream_t s);
 void launch_snr(const SnrArgs& a, hipStream_t s);

@@ -327,3 +327,77 @@ def to_u8(x):
     v = np.empty(2 * len(x), np.float32)
     v[0::2], v[1::2] = x.real, x.imag
     return np.clip(np.round(v * 127.0) + 128, 0, 255).astype(np.uint8)
+
+
+# ---- DAB+ superframe payload with Reed-Solomon parity (EN 102 563 clause 6: RS(120,110) shortened from (255,245),
+# ---- GF(2^8) polynomial 0x11D, generator roots alpha^0..alpha^9) so that the receiver's RS stage sees valid codewords
+def _gf_tables():
+    exp = np.zeros(512, np.int64); log = np.zeros(256, np.int64)
+    x = 1
+    for i in range(255):
+        exp[i] = x; log[x] = i
+        x <<= 1
+        if x & 0x100:
+            x ^= 0x11D
+    exp[255:510] = exp[:255]
+    return exp, log
+
+
+_GF_EXP, _GF_LOG = _gf_tables()
+
+
+def _rs_genpoly():
+    g = [1]
+    for r in range(10):
+        ng = [0] * (len(g) + 1)
+        for i, c in enumerate(g):          # multiply by (x + alpha^r)
+            ng[i] ^= c
+            if c:
+                ng[i + 1] ^= int(_GF_EXP[_GF_LOG[c] + r])
+        g = ng
+    return g                               # highest degree first: g[0] = 1
+
+
+_RS_GEN = _rs_genpoly()
+
+
+def rs_parity(data110):
+    """systematic RS(120,110): 10 parity bytes for 110 data bytes"""
+    rem = [0] * 10
+    for d in data110:
+        fb = int(d) ^ rem[0]
+        rem = rem[1:] + [0]
+        if fb:
+            lf = _GF_LOG[fb]
+            for j in range(10):
+                c = _RS_GEN[j + 1]
+                if c:
+                    rem[j] ^= int(_GF_EXP[lf + _GF_LOG[c]])
+    return np.array(rem, np.uint8)
+
+
+def make_superframe(bitrate, rng):
+    """120*s random bytes (s = bitrate/8) whose s column-interleaved codewords (bytes pos*s+i) are valid RS words"""
+    s = bitrate // 8
+    sf = np.zeros(120 * s, np.uint8)
+    for i in range(s):
+        d = rng.randint(0, 256, 110).astype(np.uint8)
+        sf[i::s] = np.concatenate([d, rs_parity(d)])
+    return sf
+
+
+def dabplus_payload_fn(period_cifs=80, seed=0):
+    """payload_fn for EnsembleTx: RS-valid DAB+ superframes, periodic with period_cifs (a multiple of 5 and of 16) so a
+    recording of period_cifs/4 frames can be looped without breaking the time interleaver or the superframes"""
+    assert period_cifs % 5 == 0 and period_cifs % 16 == 0
+    cache = {}
+
+    def fn(s, r):
+        r = r % period_cifs
+        q = r // 5
+        key = (s.subch_id, q)
+        if key not in cache:
+            cache[key] = make_superframe(s.bitrate, np.random.RandomState(seed * 1000003 + s.subch_id * 1009 + q))
+        fb = s.frame_bytes
+        return cache[key][(r % 5) * fb:(r % 5 + 1) * fb].tobytes()
+    return fn
