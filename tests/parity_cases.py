@@ -69,6 +69,7 @@ def check_fic(d, n_frames, snr_db, seed):
 def check_demod(d, n_frames, snr_db, seed, early=100):
     x = synth.make_stream(n_frames + 1, snr_db=snr_db, seed=seed)
     frames = cut_frames(x, n_frames, early)
+    d.reset()                      # fresh OfdmDecoder state (SNR filter + report counter), like the oracle call below
     soft, con, snr = d.demod_frames(frames)
     so, co, sn = R.orc_demod_frames(frames)
     assert np.array_equal(soft, so), "%d of %d soft bits differ" % ((soft != so).sum(), soft.size)
