@@ -7,6 +7,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <algorithm>
 
 using namespace dabphy;
 
@@ -37,7 +38,7 @@ struct dabphy_handle {
     struct MscClass {
         dabphy_protection prot{};
         std::vector<int> members;     // indices into subch
-        DevBuf map, start_bits, out;  // depuncture map, startAddr*64 per member, decoded bytes [B][4F][members][nbits/8]
+        DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
     };
     const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
     DevBuf s_iq_own;
@@ -152,7 +153,7 @@ void dabphy_destroy(dabphy_handle* h)
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
     DevBuf* more[] = {&h->s_iq_own, &h->s_desc, &h->s_soft, &h->s_cir, &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
-    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.out.p) e = hipFree(c.out.p); }
+    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
     (void)e;
@@ -271,7 +272,11 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
 int dabphy_reset(dabphy_handle* h)
 {
     if (!h) return DABPHY_ERR_INVALID;
-    HIPCHK(h, hipMemsetAsync(h->d_state, 0, sizeof(RxState) * h->cfg.n_ensembles, h->stream));
+    // OFDMProcessor::restart + the start of run(): everything zero, sLevel primed over the first T_F/2 samples (:252-255)
+    std::vector<RxState> init(h->cfg.n_ensembles);
+    memset(init.data(), 0, init.size() * sizeof(RxState));
+    for (auto& s : init) { s.acq_phase = 0; s.acq_left = T_F / 2; }
+    HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
     h->last_frames = 0;
     return sync(h);
 }
@@ -308,6 +313,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         hipError_t e;
         if (c.map.p) e = hipFree(c.map.p);
         if (c.start_bits.p) e = hipFree(c.start_bits.p);
+        if (c.tiles.p) e = hipFree(c.tiles.p);
         if (c.out.p) e = hipFree(c.out.p);
         (void)e;
     }
@@ -328,6 +334,19 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         if ((r = ensure(h, c.start_bits, sb.size() * sizeof(int32_t)))) return r;
         HIPCHK(h, hipMemcpy(c.map.p, m.data(), m.size() * sizeof(int16_t), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(c.start_bits.p, sb.data(), sb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        // step tiles of the MSC gather kernel (56 trellis steps each): source byte range of every tile
+        std::vector<int32_t> tl;
+        const int nsteps = c.prot.nbits + 6;
+        for (int s0 = 0; s0 < nsteps; s0 += 56) {
+            const int s1 = std::min(nsteps, s0 + 56);
+            int lo = -1, hi = -1;
+            for (int v = 4 * s0; v < 4 * s1; v++) if (m[v] >= 0) { if (lo < 0) lo = m[v]; hi = m[v]; }
+            if (lo < 0) { tl.push_back(0); tl.push_back(0); continue; }
+            const int lo_al = lo & ~3;
+            tl.push_back(lo_al); tl.push_back((hi - lo_al) / 4 + 1);
+        }
+        if ((r = ensure(h, c.tiles, tl.size() * sizeof(int32_t)))) return r;
+        HIPCHK(h, hipMemcpy(c.tiles.p, tl.data(), tl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     return DABPHY_OK;
 }
@@ -409,7 +428,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
         c.out = cls.out.as<uint8_t>();
         MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
-        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = sa.desc; g.c = c;
+        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = sa.desc; g.c = c;
         const bool first_cls = (&cls == &h->classes.front());
         if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
         launch_msc_gather(g, h->stream);
@@ -467,7 +486,8 @@ int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t
             std::vector<uint8_t> all((size_t)B * 4 * F * nm * bytes);
             HIPCHK(h, hipMemcpyAsync(all.data(), cls.out.p, all.size(), hipMemcpyDeviceToHost, h->stream));
             int r = sync(h); if (r) return r;
-            for (size_t br = 0; br < (size_t)B * 4 * F; br++) memcpy(out + br * bytes, all.data() + (br * nm + m) * bytes, bytes);
+            const size_t Rn = (size_t)4 * F;
+            for (size_t b = 0; b < B; b++) memcpy(out + b * Rn * bytes, all.data() + ((b * nm + m) * Rn) * bytes, Rn * bytes);
             if (first_valid)
                 for (uint32_t b = 0; b < B; b++) {
                     // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149)
@@ -573,7 +593,7 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
             if ((r = sync(h))) return r;
             for (uint32_t b = 0; b < B; b++)
                 for (size_t k = 0; k < (size_t)n_sf * cls.members.size(); k++) {
-                    const size_t o = ((size_t)b * n_sf * cls.members.size() + k) * 2;
+                    const size_t o = ((size_t)b * n_sf * cls.members.size() + k) * 2;   // [b][superframe][member]
                     if (corrected) corrected[b] += res[o];
                     if (uncorrectable) uncorrectable[b] += res[o + 1];
                 }

@@ -98,6 +98,7 @@ struct MscGatherArgs {
     const int8_t* soft; int soft_ring; const RxState* state; int n_ens, n_frames;
     const int16_t* map;     // [4*nbits+24] -> index into the sub-channel's length*64 soft bits, -1 = erasure
     const int32_t* start_bit; // [n_subch_in_class] startAddr*64 per member sub-channel
+    const int32_t* tiles;     // [ceil(nsteps/56)][2]: first source byte (4-aligned) and dwords per row of each step tile
     int n_members;            // sub-channels in the class (per ensemble)
     const FrameDesc* desc;    // [B][n_frames]; desc[b][0].frame_no is the first frame of this batch
     VitClass c;
@@ -121,7 +122,7 @@ struct RsArgs {            // contiguous superframes [n_sf][sf_stride], s = bitr
     uint8_t* data; size_t sf_stride; int n_sf, s;
     int* corr; int* uncorr;                       // [n_sf]
 };
-struct RsMscArgs {         // superframes inside a class's MSC output [B][n_cif][n_members][frame_bytes]
+struct RsMscArgs {         // superframes inside a class's MSC output [B][n_members][n_cif][frame_bytes]
     uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s, n_sf_per_ens;
     int member_only;                              // -1: every member, else only this member
     const int* first_cif;                         // [B] logical-frame slot (in this batch) where the first superframe starts

@@ -18,28 +18,35 @@
 // the two exchanges is bank-conflict free on gfx950 (MI355X_MICROARCH.md, LDS table):
 //   exchange 1: E1(p) = p ^ (((p>>7)&3)<<3) ^ (((p>>9)&3)<<1)
 //   exchange 2: E2(p) = p ^ (((p>>7)&1)<<3)
+// Register budget: the 15 round-C twiddles are per-thread constants kept in VGPRs; the 15 round-B twiddles
+// come from a 1 KiB LDS copy of tw[16 i] (ds_read_b64, 60 LDS cycles per transform); round-A twiddles are
+// wave-uniform (SGPRs).
 #pragma once
 #include "dabphy_common.h"
 
 namespace dabphy {
 
-struct FftTwiddles {           // per-thread constants (forward values; the inverse conjugates them)
-    cf32 a1, a2, a3;           // round A, k = 1: tw[256], tw[512], tw[768]
-    cf32 t0;                   // tw[0]
-    cf32 b8[3];                // m=8:   tw[64k], tw[128k], tw[192k]
-    cf32 b32[4][3];            // m=32:  k' = k + 8a: tw[16k'], tw[32k'], tw[48k']
-    cf32 c128[3];              // m=128: tw[4k], tw[8k], tw[12k]
-    cf32 c512[4][3];           // m=512: k' = k + 128a: tw[k'], tw[2k'], tw[3k']
+constexpr int FFT_TWB_ENTRIES = 128;      // tw[16 i], i < 128
+
+struct FftTwiddles {           // forward values; the inverse conjugates them on use
+    cf32 t0, a1, a2, a3;       // round A: tw[0], tw[256], tw[512], tw[768]   (uniform)
+    cf32 c128[3];              // m=128: tw[4t], tw[8t], tw[12t]
+    cf32 c512[4][3];           // m=512: k' = t + 128a: tw[k'], tw[2k'], tw[3k']
+    const cf32* twB;           // LDS: tw[16 i]
 };
 
-__device__ __forceinline__ void fft_load_twiddles(FftTwiddles& w, const cf32* __restrict__ tw, int t)
+// fills the LDS sub-table (needs a __syncthreads() before first use: fft2048_wg starts with one) and the registers
+__device__ __forceinline__ void fft_load_twiddles(FftTwiddles& w, const cf32* __restrict__ tw, cf32* twB_lds, int t)
 {
+    if (t < FFT_TWB_ENTRIES) twB_lds[t] = tw[16 * t];
+    w.twB = twB_lds;
     w.t0 = tw[0]; w.a1 = tw[256]; w.a2 = tw[512]; w.a3 = tw[768];
-    const int kb = t & 7;
-    for (int i = 0; i < 3; i++) w.b8[i] = tw[64 * kb * (i + 1)];
-    for (int a = 0; a < 4; a++) for (int i = 0; i < 3; i++) w.b32[a][i] = tw[16 * (kb + 8 * a) * (i + 1)];
+#pragma unroll
     for (int i = 0; i < 3; i++) w.c128[i] = tw[4 * t * (i + 1)];
-    for (int a = 0; a < 4; a++) for (int i = 0; i < 3; i++) w.c512[a][i] = tw[(t + 128 * a) * (i + 1)];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) w.c512[a][i] = tw[(t + 128 * a) * (i + 1)];
 }
 
 template <bool INV> __device__ __forceinline__ cf32 twc(cf32 w) { if (INV) w.im = -w.im; return w; }
@@ -74,33 +81,32 @@ __device__ __forceinline__ void bfly4(cf32& f0, cf32& f1, cf32& f2, cf32& f3, cf
     }
 }
 
-// In:  v[8h + j] = x[t + 128h + 256j]  (h = 0,1; j = 0..7)
-// Out: v[j] = X[t + 128 j]             (j = 0..15)
-// lds: 2048 cf32 owned by the work-group.  Contains 4 __syncthreads(); the tile may be reused right after.
+// Round A for one half (h = 0: inputs x[t + 256 j], h = 1: inputs x[t + 128 + 256 j], j = 0..7 in x[]) and the
+// swizzled store of its 8 consecutive positions.  The caller must have passed a barrier since the tile was last read.
 template <bool INV>
-__device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t)
+__device__ __forceinline__ void fft_round_a(const cf32 (&x)[8], int h, cf32* lds, const FftTwiddles& w, int t)
 {
-    // ---------------------------------------------------------------- round A
-    __syncthreads();            // previous users of the tile are done
+    cf32 a[8];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        cf32 a[8];
+    for (int j5 = 0; j5 < 4; j5++) { a[2 * j5] = x[j5]; a[2 * j5 + 1] = x[j5 + 4]; }
 #pragma unroll
-        for (int j5 = 0; j5 < 4; j5++) { a[2 * j5] = v[8 * h + j5]; a[2 * j5 + 1] = v[8 * h + j5 + 4]; }
+    for (int j5 = 0; j5 < 4; j5++) bfly2(a[2 * j5], a[2 * j5 + 1], twc<INV>(w.t0));
+    bfly4<INV>(a[0], a[2], a[4], a[6], twc<INV>(w.t0), twc<INV>(w.t0), twc<INV>(w.t0));
+    bfly4<INV>(a[1], a[3], a[5], a[7], twc<INV>(w.a1), twc<INV>(w.a2), twc<INV>(w.a3));
+    const int b = t + 128 * h;
+    const int j1 = b & 3, j2 = (b >> 2) & 3, j3 = (b >> 4) & 3, j4 = (b >> 6) & 3;
+    const int q = 64 * j1 + 16 * j2 + 4 * j3 + (j4 ^ j2);           // chunk index with the E1 row swizzle
+    float4* dst = reinterpret_cast<float4*>(lds + 8 * q);
 #pragma unroll
-        for (int j5 = 0; j5 < 4; j5++) bfly2(a[2 * j5], a[2 * j5 + 1], twc<INV>(w.t0));
-        bfly4<INV>(a[0], a[2], a[4], a[6], twc<INV>(w.t0), twc<INV>(w.t0), twc<INV>(w.t0));
-        bfly4<INV>(a[1], a[3], a[5], a[7], twc<INV>(w.a1), twc<INV>(w.a2), twc<INV>(w.a3));
-        const int b = t + 128 * h;
-        const int j1 = b & 3, j2 = (b >> 2) & 3, j3 = (b >> 4) & 3, j4 = (b >> 6) & 3;
-        const int q = 64 * j1 + 16 * j2 + 4 * j3 + (j4 ^ j2);           // chunk index with the E1 row swizzle
-        float4* dst = reinterpret_cast<float4*>(lds + 8 * q);
-#pragma unroll
-        for (int s = 0; s < 4; s++)                                      // 16-byte slot s holds positions 2s, 2s+1
-            dst[s ^ j1] = make_float4(a[2 * s].re, a[2 * s].im, a[2 * s + 1].re, a[2 * s + 1].im);
-    }
+    for (int s = 0; s < 4; s++)                                      // 16-byte slot s holds positions 2s, 2s+1
+        dst[s ^ j1] = make_float4(a[2 * s].re, a[2 * s].im, a[2 * s + 1].re, a[2 * s + 1].im);
+}
+
+// Rounds B and C.  Out: v[j] = X[t + 128 j].  Starts with the barrier that publishes round A's stores.
+template <bool INV>
+__device__ __forceinline__ void fft_rounds_bc(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t)
+{
     __syncthreads();
-    // ---------------------------------------------------------------- round B
     {
         const int c = t >> 3, k = t & 7;
         const int sw = (8 * (c & 3)) ^ (2 * (c >> 2));
@@ -108,12 +114,16 @@ __device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTw
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int a = 0; a < 4; a++) v[4 * b + a] = lds[(128 * c + k + 8 * a + 32 * b) ^ sw];
+        {
+            const cf32 w1 = twc<INV>(w.twB[4 * k]), w2 = twc<INV>(w.twB[8 * k]), w3 = twc<INV>(w.twB[12 * k]);   // tw[64k(i+1)]
 #pragma unroll
-        for (int b = 0; b < 4; b++)
-            bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], twc<INV>(w.b8[0]), twc<INV>(w.b8[1]), twc<INV>(w.b8[2]));
+            for (int b = 0; b < 4; b++) bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], w1, w2, w3);
+        }
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.b32[a][0]), twc<INV>(w.b32[a][1]), twc<INV>(w.b32[a][2]));
+        for (int a = 0; a < 4; a++) {
+            const int kp = k + 8 * a;                                                                              // tw[16 k'(i+1)]
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.twB[kp]), twc<INV>(w.twB[2 * kp]), twc<INV>(w.twB[3 * kp]));
+        }
         __syncthreads();        // everyone has read exchange 1
         const int sw2 = 8 * (c & 1);
 #pragma unroll
@@ -122,7 +132,6 @@ __device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTw
             for (int a = 0; a < 4; a++) lds[(128 * c + k + 8 * a + 32 * b) ^ sw2] = v[4 * b + a];
     }
     __syncthreads();
-    // ---------------------------------------------------------------- round C
     {
 #pragma unroll
         for (int b = 0; b < 4; b++)
@@ -136,6 +145,21 @@ __device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTw
             bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.c512[a][0]), twc<INV>(w.c512[a][1]), twc<INV>(w.c512[a][2]));
     }
     // v[4b + a] = X[t + 128a + 512b] = X[t + 128 (a + 4b)]  -> already in j = a + 4b order
+}
+
+// Whole transform.  In: v[8h + j] = x[t + 128h + 256j].  Out: v[j] = X[t + 128 j].  4 barriers.
+template <bool INV>
+__device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t)
+{
+    __syncthreads();            // previous users of the tile are done
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        cf32 x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = v[8 * h + j];
+        fft_round_a<INV>(x, h, lds, w, t);
+    }
+    fft_rounds_bc<INV>(v, lds, w, t);
 }
 
 } // namespace dabphy

@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(256) k_rs_msc(RsMscArgs A)
     const int r0 = A.first_cif[b] + 5 * q;                       // first logical frame of superframe q
     if (r0 < 0 || r0 + 5 > A.n_cif) return;
     RsMscIo io;
-    io.frame_bytes = A.frame_bytes; io.s = A.s; io.i = i; io.frame_stride = (size_t)A.n_members * A.frame_bytes;
-    io.frames = A.out + (((size_t)b * A.n_cif + r0) * A.n_members + m) * A.frame_bytes;
+    io.frame_bytes = A.frame_bytes; io.s = A.s; io.i = i; io.frame_stride = (size_t)A.frame_bytes;
+    io.frames = A.out + (((size_t)b * A.n_members + m) * A.n_cif + r0) * A.frame_bytes;
     const int c = rs_decode120(io, alpha_to, index_of);
     int* cnt = A.result + 2 * (((size_t)b * A.n_sf_per_ens + q) * A.n_members + m);
     if (c < 0) atomicOr(cnt + 1, 1);

@@ -38,9 +38,15 @@ __device__ __forceinline__ cf32 mixed_sample(const cf32* __restrict__ iq, int64_
 __device__ __forceinline__ void load_mix2048(cf32 (&v)[16], const cf32* __restrict__ iq, int64_t ring, int64_t pos, int64_t off,
                                              const cf32* __restrict__ nco, int32_t L, int32_t f, int64_t rel0, int t)
 {
+    int64_t a = (pos + off + t) % ring;
+    int32_t ph = mod_rate64((int64_t)L - (rel0 + t + 1) * (int64_t)f);
+    const int32_t step = mod_rate64(128LL * f);
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        v[(i & 1) * 8 + (i >> 1)] = mixed_sample(iq, ring, pos, off + t + 128 * i, nco, L, f, rel0 + t + 128 * i);
+    for (int i = 0; i < 16; i++) {
+        v[(i & 1) * 8 + (i >> 1)] = cmul(iq[a], nco[ph]);
+        a += 128; if (a >= ring) a -= ring;
+        ph -= step; if (ph < 0) ph += INPUT_RATE;
+    }
 }
 
 __device__ __forceinline__ float block_max(float x, float* red, int t)
@@ -80,7 +86,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
     __shared__ float redf[FFT_THREADS];
     __shared__ int redi[FFT_THREADS];
     __shared__ float s_sum;
-    __shared__ cf32 s_corr;
+    __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
 
     const int t = threadIdx.x, b = blockIdx.x;
     RxState st = A.state[b];
@@ -99,7 +105,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
         return;
     }
 
-    FftTwiddles w; fft_load_twiddles(w, A.tab.tw, t);
+    FftTwiddles w; fft_load_twiddles(w, A.tab.tw, twB, t);
     cf32 v[16], u[16];
 
     // ---- PhaseReference::findIndex (phasereference.cpp:73-92): FFT, multiply by conj(refTable), IFFT (scaled by 1/N)
@@ -238,22 +244,32 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
     // ---- cyclic-prefix correlation over the 75 data symbols (ofdm-processor.cpp:435-442)
     // products for symbol s: buf[2048+j] * conj(buf[j]), j < 504; threads form them, lane 0 adds them in order
     cf32 acc; acc.re = 0.0f; acc.im = 0.0f;
-    auto products = [&](int s, int bufsel) {
-        const int64_t rel_sym = (int64_t)(s - 1) * T_S;                  // relative index of buf[0] after the PRS
+    // oscillator phase and ring position advance incrementally (one 64-bit modulo per thread, then add/compare)
+    const int32_t stepTS = mod_rate64((int64_t)T_S * d.f_sym), stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
+    int32_t ph_sym = mod_rate64((int64_t)d.L1 - (int64_t)(t + 1) * d.f_sym);     // phase of sample j = t of symbol 1
+    int64_t a_sym = (st.pos + J0 + t) % A.ring;                                  // its ring index
+    auto products = [&](int bufsel) {                                            // one call per symbol, in order
+        int32_t ph = ph_sym; int64_t a = a_sym;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = t + 128 * k;
             if (j < T_G) {
-                const cf32 lo = mixed_sample(iq, A.ring, st.pos, J0 + rel_sym + j, nco, d.L1, d.f_sym, rel_sym + j);
-                const cf32 hi = mixed_sample(iq, A.ring, st.pos, J0 + rel_sym + T_U + j, nco, d.L1, d.f_sym, rel_sym + T_U + j);
+                int64_t a_hi = a + T_U; if (a_hi >= A.ring) a_hi -= A.ring;
+                int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
+                const cf32 lo = cmul(iq[a], nco[ph]);
+                const cf32 hi = cmul(iq[a_hi], nco[ph_hi]);
                 prod[bufsel][j] = cmul(hi, cconj(lo));
             }
+            a += 128; if (a >= A.ring) a -= A.ring;
+            ph -= step128; if (ph < 0) ph += INPUT_RATE;
         }
+        ph_sym -= stepTS; if (ph_sym < 0) ph_sym += INPUT_RATE;
+        a_sym += T_S; if (a_sym >= A.ring) a_sym -= A.ring;
     };
-    products(1, 1);
+    products(1);
     __syncthreads();
     for (int s = 1; s < L_SYM; s++) {
-        if (s + 1 < L_SYM) products(s + 1, (s + 1) & 1);
+        if (s + 1 < L_SYM) products((s + 1) & 1);
         if (t == 0) {
             const cf32* p = prod[s & 1];
             for (int j = 0; j < T_G; j++) { acc.re += p[j].re; acc.im += p[j].im; }

@@ -157,41 +157,113 @@ __global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
 }
 
 // ------------------------------------------------------------------------------------------ MSC gather
-// codeword (b, r, m): ensemble b, CIF r of this batch (0..4F-1), member sub-channel m of the class.
-// Soft bit u of the logical frame emitted at CIF c comes from CIF c - 16 + map16[u & 15]
-// (dab-audio.cpp:113,138-143: tempX[i] = hist[(idx + map[i&15]) & 15][i] read BEFORE the current CIF is
-// stored), i.e. the de-interleaver is an address computation on the soft-bit ring, no copy.
+// Codeword order of an MSC class: cw = (b * n_members + m) * R + r  (ensemble b, member sub-channel m, CIF r of this
+// batch, R = 4 * n_frames), so the 64 lanes of a Viterbi wave are consecutive CIFs of one sub-channel (at most a
+// few (b, m) pairs per group).  Soft bit u of the logical frame emitted at CIF c comes from CIF
+// c - 16 + map16[u & 15] (dab-audio.cpp:113,138-143: tempX[i] = hist[(idx + map[i & 15]) & 15][i], read BEFORE the
+// current CIF is stored): the time de-interleaver is an address computation on the soft-bit ring, never a copy.
+//
+// Data movement: a work-group owns one group of 64 codewords and walks the trellis in tiles of GT_STEPS steps.
+// For a tile it stages the needed byte columns [u_lo, u_hi) of every source CIF row (<= 64 + 15 rows per (b, m)
+// segment) in LDS with coalesced dword loads, then every lane picks its 4 symbols per step from LDS and the wave
+// stores one coalesced 256-byte row of the step-major symbol array.  HBM traffic is ~1.25x the soft bits read
+// once plus the symbols written once; the per-byte global gather this replaces moved ~100x more through L2.
+constexpr int GT_STEPS = 56;                    // 224 mother-code bits -> at most 224 + 3 source bytes = 57 dwords per row
+constexpr int GT_PITCHW = 57;                   // odd number of dwords: consecutive rows start on consecutive banks
+constexpr int GT_MAXROWS = 112;                 // two (b, m) segments: 64 + 2 * 15 = 94 rows
+
 __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t tile[GT_MAXROWS * GT_PITCHW];
+    __shared__ long long s_rowsrc[GT_MAXROWS];
+    __shared__ int s_pair[64], s_rowbase[64];
+    __shared__ long long s_c[64];
+    __shared__ int s_nrows;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int g = blockIdx.x;
     const int cw = g * 64 + lane;
-    const int nsteps = A.c.nsteps;
+    const int nsteps = A.c.nsteps, R = 4 * A.n_frames;
     const bool live = cw < A.c.n_cw;
-    const int m = live ? cw % A.n_members : 0;
-    const int br = live ? cw / A.n_members : 0;
-    const int r = br % (4 * A.n_frames), b = br / (4 * A.n_frames);
-    const int64_t c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;       // global CIF number of the CIF that triggers this output
-    const int8_t* __restrict__ base = A.soft + (size_t)b * A.soft_ring * SOFT_PER_FRAME + A.start_bit[m];
-    uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
+    const int pair = live ? cw / R : -1, r = live ? cw % R : 0;
+    const int b = live ? pair / A.n_members : 0, m = live ? pair % A.n_members : 0;
+    const long long c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;   // CIF whose arrival emits this logical frame
+    const size_t ens_base = (size_t)b * A.soft_ring * SOFT_PER_FRAME + A.start_bit[m];
     const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-    for (int s = blockIdx.y * 4 + wave; s < nsteps; s += gridDim.y * 4) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int u = A.map[4 * s + j];
-            int v = 0;
-            if (u >= 0 && live) {
-                const int64_t c_src = c_glob - 16 + map16[u & 15];
-                if (c_src >= 0) {
-                    const int64_t fr = c_src >> 2; const int cif = (int)(c_src & 3);
-                    v = base[((size_t)(fr % A.soft_ring) * 75 + 3 + 18 * cif) * SOFT_PER_SYM + u];
-                }
+    uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
+
+    if (wave == 0) { s_pair[lane] = pair; s_c[lane] = c_glob; }
+    __syncthreads();
+    if (t == 0) {
+        // segments = runs of lanes with the same (b, m) and consecutive CIFs; a segment [c_a .. c_b] needs the rows
+        // of CIFs c_a - 16 .. c_b - 1
+        int nrows = 0;
+        for (int l = 0; l < 64;) {
+            int e = l;
+            while (e + 1 < 64 && s_pair[e + 1] == s_pair[l] && s_c[e + 1] == s_c[e] + 1) e++;
+            const int need = (e - l) + 16;
+            if (s_pair[l] < 0) { for (int k = l; k <= e; k++) s_rowbase[k] = -1; l = e + 1; continue; }
+            if (nrows + need > GT_MAXROWS) { nrows = -1; break; }
+            const int pb = s_pair[l] / A.n_members, pm = s_pair[l] % A.n_members;
+            const long long pbase = (long long)pb * A.soft_ring * SOFT_PER_FRAME + A.start_bit[pm];
+            for (int k = 0; k < need; k++) {
+                const long long c_src = s_c[l] - 16 + k;
+                long long src = -1;
+                if (c_src >= 0) src = pbase + ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM;
+                s_rowsrc[nrows + k] = src;
             }
-            v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
-            word |= (uint32_t)v << (8 * j);
+            for (int k = l; k <= e; k++) s_rowbase[k] = nrows + (k - l);
+            nrows += need;
+            l = e + 1;
         }
-        dst[(size_t)s * 64] = word;
+        s_nrows = nrows;
+    }
+    __syncthreads();
+    const int nrows = s_nrows;
+    const int rowbase = s_rowbase[lane];
+
+    if (nrows < 0) {
+        // many short segments (tiny batches): plain per-byte gather
+        for (int s = wave; s < nsteps; s += 4) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = A.map[4 * s + j];
+                int v = 0;
+                if (u >= 0 && live) {
+                    const long long c_src = c_glob - 16 + map16[u & 15];
+                    if (c_src >= 0) v = A.soft[ens_base + ((size_t)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM + u];
+                }
+                v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
+                word |= (uint32_t)v << (8 * j);
+            }
+            dst[(size_t)s * 64] = word;
+        }
+        return;
+    }
+
+    const int8_t* tile8 = reinterpret_cast<const int8_t*>(tile);
+    for (int s0 = 0, ti = 0; s0 < nsteps; s0 += GT_STEPS, ti++) {
+        const int u_lo = A.tiles[2 * ti], ndw = A.tiles[2 * ti + 1];       // first source byte (4-aligned), dwords per row
+        for (int row = wave; row < nrows; row += 4) {
+            const long long src = s_rowsrc[row];
+            if (lane < ndw) tile[row * GT_PITCHW + lane] = (src >= 0) ? *reinterpret_cast<const uint32_t*>(A.soft + src + u_lo + 4 * lane) : 0u;
+        }
+        __syncthreads();
+        const int s1 = (s0 + GT_STEPS < nsteps) ? s0 + GT_STEPS : nsteps;
+        for (int s = s0 + wave; s < s1; s += 4) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = A.map[4 * s + j];
+                int v = 0;
+                if (u >= 0 && rowbase >= 0) v = tile8[(rowbase + map16[u & 15]) * (GT_PITCHW * 4) + (u - u_lo)];
+                v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
+                word |= (uint32_t)v << (8 * j);
+            }
+            dst[(size_t)s * 64] = word;
+        }
+        __syncthreads();
     }
 }
 
@@ -266,7 +338,7 @@ void launch_fic_gather(const FicGatherArgs& a, hipStream_t s)
 }
 void launch_msc_gather(const MscGatherArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_msc_gather, dim3(a.c.n_groups, gather_rows(a.c.nsteps)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_msc_gather, dim3(a.c.n_groups), dim3(256), 0, s, a);
 }
 void launch_lin_gather(const LinGatherArgs& a, hipStream_t s)
 {
