@@ -42,6 +42,9 @@ typedef struct {
     int32_t want_constellation;     /* keep the 1200 constellation points per frame (onConstellationPoints) */
     int32_t want_impulse_response;  /* keep the 2048-float CIR per frame (onNewImpulseResponse) */
     int32_t demod_chunk;            /* data symbols per work-group of the demod kernel; 0 = default */
+    int32_t pipeline_sync;          /* 1: synchronise batch k+1 on a second stream while batch k is decoded (throughput mode:
+                                       constant n_frames, samples of the next batch already in the ring; the coarse-corrector
+                                       feedback then lags one more batch) */
 } dabphy_config;
 
 /* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)

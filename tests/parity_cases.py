@@ -81,10 +81,10 @@ def check_demod(d, n_frames, snr_db, seed, early=100):
     return soft
 
 
-def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1):
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False):
     """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
     from welle_io_amd import capi  # noqa: F401
-    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse)
+    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
@@ -114,15 +114,15 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1)
         d.close()
 
 
-def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4):
+def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False):
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
-    o = R.orc_receiver_run(x, subchs=subs, want_soft=True)
-    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B)
+    o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse)
+    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse)
     for b in range(B):
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)
-        assert n >= o["n_frames"] - (1 if lockstep else F), (n, o["n_frames"])
+        assert n >= o["n_frames"] - (1 if lockstep else F) * (2 if pipeline_sync else 1), (n, o["n_frames"])
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
         assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]), "CRC flags differ"
         assert np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:]), "FIB bytes differ"

@@ -19,3 +19,13 @@ def test_stream(emu, snr, cfo, delay, nf, lockstep):
 
 def test_two_ensembles_in_lock_step(emu):
     P.check_stream_vs_oracle(factory, 18, 0, 500, 7, False, B=2, F=2)
+
+
+def test_big_batch_tiled_gather(emu):
+    """F = 20 (80 CIFs per sub-channel and batch): exercises the LDS-tiled MSC gather incl. groups straddling two sub-channels"""
+    P.check_stream_vs_oracle(factory, 14, 30, 200, 43, False, F=20)
+
+
+def test_pipelined_sync(emu):
+    """throughput mode: batch k+1 synchronised ahead of batch k's decode gives the same bytes (coarse corrector off)"""
+    P.check_stream_vs_oracle(factory, 16, -20, 50, 14, False, F=3, pipeline_sync=True, disable_coarse=True)

@@ -36,3 +36,12 @@ def test_full_ensemble_roundtrip(gpu):
         got = b"".join(L["msc"][i])
         pay = b"".join(tx.payload_log[s.subch_id])
         assert len(got) >= 24 * s.frame_bytes and got in pay
+
+
+def test_big_batch_tiled_gather(gpu):
+    P.check_stream_vs_oracle(factory, 14, 30, 200, 43, False, F=20)
+
+
+def test_pipelined_sync(gpu):
+    """batch k+1 is synchronised on a second stream while batch k is decoded: same bytes as the serial order"""
+    P.check_stream_vs_oracle(factory, 16, -20, 50, 26, False, F=4, pipeline_sync=True, disable_coarse=True, B=3)

@@ -31,7 +31,8 @@ struct dabphy_handle {
     Tables tab{};
     // grow-only scratch
     DevBuf iq, soft, con, prs_mag, snr, desc, in8, map, vsym, vdec, vout, ok;
-    RxState* d_state = nullptr;       // [n_ensembles]
+    RxState* d_state = nullptr;       // [n_ensembles] synchroniser state
+    DecState* d_dec = nullptr;        // [n_ensembles] decoder state
     std::vector<void*> owned;
 
     // ---- streaming receiver (dabphy_stream_* / dabphy_process)
@@ -45,9 +46,13 @@ struct dabphy_handle {
     uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
-    DevBuf s_desc, s_soft, s_cir, s_con, s_mag, s_snr, s_fib, s_ok;
+    DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
+    hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
+    int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
+    uint32_t presynced = 0;           // frames already synchronised ahead into s_desc2[desc_sel] (pipelined mode)
     int soft_ring = 0;
     uint32_t last_frames = 0;         // n_frames of the last dabphy_process
+    float* cur_cir = nullptr;
     std::vector<FrameDesc> h_desc;    // host copy of the last batch's frame descriptors
     std::vector<float> h_snr;
     // stage timing (HIP events on the handle's stream, recorded when profiling is on)
@@ -138,6 +143,12 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipMalloc(&st, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
     h->owned.push_back(st); h->d_state = reinterpret_cast<RxState*>(st);
     if (hipMemset(st, 0, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    void* ds = nullptr;
+    if (hipMalloc(&ds, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+    h->owned.push_back(ds); h->d_dec = reinterpret_cast<DecState*>(ds);
+    if (hipMemset(ds, 0, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->sync_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
@@ -148,10 +159,12 @@ void dabphy_destroy(dabphy_handle* h)
 {
     if (!h) return;
     hipError_t e;
+    if (h->sync_stream) { e = hipStreamSynchronize(h->sync_stream); e = hipStreamDestroy(h->sync_stream); }
+    if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_iq_own, &h->s_desc, &h->s_soft, &h->s_cir, &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok};
@@ -196,7 +209,7 @@ int dabphy_demod_frames(dabphy_handle* h, const float* frames, uint32_t n_frames
     a.soft = h->soft.as<int8_t>(); a.soft_ring = (int)n_frames;
     a.con = constellation ? h->con.as<cf32>() : nullptr; a.prs_mag = h->prs_mag.as<float>();
     launch_demod(a, 1, h->stream);
-    SnrArgs s{}; s.state = h->d_state; s.desc = a.desc; s.n_ens = 1; s.n_frames = (int)n_frames; s.prs_mag = a.prs_mag; s.snr_out = h->snr.as<float>();
+    SnrArgs s{}; s.state = h->d_dec; s.desc = a.desc; s.n_ens = 1; s.n_frames = (int)n_frames; s.prs_mag = a.prs_mag; s.snr_out = h->snr.as<float>();
     launch_snr(s, h->stream);
     HIPCHK(h, hipMemcpyAsync(soft, h->soft.p, (size_t)n_frames * SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
     if (constellation) HIPCHK(h, hipMemcpyAsync(constellation, h->con.p, (size_t)n_frames * 1200 * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
@@ -255,13 +268,13 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
     launch_fic_gather(g, h->stream);
     VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
     launch_viterbi(v, h->stream);
-    CrcArgs k{}; k.fib = c.out; k.ok = h->ok.as<uint8_t>(); k.state = h->d_state; k.desc = g.desc; k.n_ens = 1; k.n_frames = (int)n_frames;
+    CrcArgs k{}; k.fib = c.out; k.ok = h->ok.as<uint8_t>(); k.state = h->d_dec; k.desc = g.desc; k.n_ens = 1; k.n_frames = (int)n_frames;
     launch_fib_crc(k, h->stream);
     launch_fic_ratio(k, h->stream);
     HIPCHK(h, hipMemcpyAsync(fib, c.out, (size_t)n_frames * 384, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(crc_ok, h->ok.p, (size_t)n_frames * 12, hipMemcpyDeviceToHost, h->stream));
-    RxState st;
-    HIPCHK(h, hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    DecState st;
+    HIPCHK(h, hipMemcpyAsync(&st, h->d_dec, sizeof st, hipMemcpyDeviceToHost, h->stream));
     if ((r = sync(h))) return r;
     if (ratio_percent) *ratio_percent = st.fic_ratio * 10;
     return DABPHY_OK;
@@ -273,6 +286,9 @@ int dabphy_reset(dabphy_handle* h)
 {
     if (!h) return DABPHY_ERR_INVALID;
     // OFDMProcessor::restart + the start of run(): everything zero, sLevel primed over the first T_F/2 samples (:252-255)
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    h->presynced = 0; h->desc_sel = 0;
+    HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
     std::vector<RxState> init(h->cfg.n_ensembles);
     memset(init.data(), 0, init.size() * sizeof(RxState));
     for (auto& s : init) { s.acq_phase = 0; s.acq_left = T_F / 2; }
@@ -359,44 +375,64 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     const uint32_t B = h->cfg.n_ensembles, F = n_frames;
     const int ring_frames = (int)h->cfg.max_frames + 5;
     int r;
-    if ((r = ensure(h, h->s_desc, (size_t)B * F * sizeof(FrameDesc)))) return r;
+    for (int k = 0; k < 2; k++) {
+        if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
+        if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
+    }
     if ((r = ensure(h, h->s_soft, (size_t)B * ring_frames * SOFT_PER_FRAME))) return r;
     if ((r = ensure(h, h->s_mag, (size_t)B * F * T_U * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_snr, (size_t)B * F * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_fib, (size_t)B * F * 384))) return r;
     if ((r = ensure(h, h->s_ok, (size_t)B * F * 12))) return r;
-    if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir, (size_t)B * F * T_U * sizeof(float)))) return r;
     if (h->cfg.want_constellation && (r = ensure(h, h->s_con, (size_t)B * F * 1200 * sizeof(cf32)))) return r;
     h->soft_ring = ring_frames;
 
-    SyncArgs sa{};
-    sa.tab = h->tab; sa.iq = h->s_iq; sa.iq_stride = h->s_stride; sa.ring = (int64_t)h->s_ring; sa.n_valid = (int64_t)h->s_valid;
-    sa.loop = h->s_loop; sa.state = h->d_state; sa.desc = h->s_desc.as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
-    sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse;
-    sa.cir = h->cfg.want_impulse_response ? h->s_cir.as<float>() : nullptr;
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) h->ev_used[i] = false;
     auto mark = [&](int stage, bool end) {
         if (!h->profiling) return;
         hipError_t e = hipEventRecord(end ? h->ev_end[stage] : h->ev_beg[stage], h->stream); (void)e;
         h->ev_used[stage] = true;
     };
-    mark(dabphy_handle::ST_SYNC, false);
-    for (uint32_t f = 0; f < F; f++) {
-        launch_acquire(sa, h->stream);             // no-op for ensembles that are tracking
-        sa.frame = (int)f;
-        launch_sync_frame(sa, h->stream);
+    // The synchroniser runs on its own stream.  Pipelined mode (cfg.pipeline_sync): while this batch is decoded on the
+    // main stream, the frame chain of the NEXT batch already runs on the sync stream (it needs only the samples and its
+    // own state), so its serial latency disappears behind the decode kernels.
+    auto launch_sync_chain = [&](int sel) {
+        SyncArgs sa{};
+        sa.tab = h->tab; sa.iq = h->s_iq; sa.iq_stride = h->s_stride; sa.ring = (int64_t)h->s_ring; sa.n_valid = (int64_t)h->s_valid;
+        sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
+        sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse;
+        sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
+        if (h->profiling) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_SYNC], h->sync_stream); (void)e; }
+        for (uint32_t f = 0; f < F; f++) {
+            launch_acquire(sa, h->sync_stream);            // no-op for ensembles that are tracking
+            sa.frame = (int)f;
+            launch_sync_frame(sa, h->sync_stream);
+        }
+        if (h->profiling) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_SYNC], h->sync_stream); (void)e; h->ev_used[dabphy_handle::ST_SYNC] = true; }
+    };
+    if (h->presynced != 0 && h->presynced != F) { h->err = "pipelined mode needs a constant n_frames"; return DABPHY_ERR_STATE; }
+    const int cur = h->desc_sel;
+    if (h->presynced == 0) {
+        // the previous batch's decoder results (FIC ratio) must be final before the chain consults them
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        launch_sync_chain(cur);
     }
-    mark(dabphy_handle::ST_SYNC, true);
+    HIPCHK(h, hipEventRecord(h->ev_sync_done, h->sync_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync_done, 0));
+    if (h->cfg.pipeline_sync) { launch_sync_chain(cur ^ 1); h->presynced = F; h->desc_sel = cur ^ 1; }
+    else h->presynced = 0;
+    FrameDesc* const d_desc = h->s_desc2[cur].as<FrameDesc>();
+    h->cur_cir = h->cfg.want_impulse_response ? h->s_cir2[cur].as<float>() : nullptr;
 
     DemodArgs da{};
     da.tab = h->tab; da.iq = h->s_iq; da.iq_stride = h->s_stride; da.ring = (int64_t)h->s_ring;
-    da.desc = sa.desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
+    da.desc = d_desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
     da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames;
     da.con = h->cfg.want_constellation ? h->s_con.as<cf32>() : nullptr; da.prs_mag = h->s_mag.as<float>();
     mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
     mark(dabphy_handle::ST_DEMOD, true);
-    SnrArgs sn{}; sn.state = h->d_state; sn.desc = sa.desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
+    SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
     mark(dabphy_handle::ST_SNR, false);
     launch_snr(sn, h->stream);
     mark(dabphy_handle::ST_SNR, true);
@@ -409,13 +445,13 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // the class output must hold whole groups of 64 codewords
         if ((r = ensure(h, h->s_fib, (size_t)c.n_groups * 64 * 96))) return r;
         c.out = h->s_fib.as<uint8_t>();
-        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = sa.desc;
+        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
         mark(dabphy_handle::ST_FIC, false);
         launch_fic_gather(g, h->stream);
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         launch_viterbi(v, h->stream);
-        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_state; k.desc = sa.desc; k.n_ens = (int)B; k.n_frames = (int)F;
+        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F;
         launch_fib_crc(k, h->stream);
         launch_fic_ratio(k, h->stream);
         mark(dabphy_handle::ST_FIC, true);
@@ -428,7 +464,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
         c.out = cls.out.as<uint8_t>();
         MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
-        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = sa.desc; g.c = c;
+        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = d_desc; g.c = c;
         const bool first_cls = (&cls == &h->classes.front());
         if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
         launch_msc_gather(g, h->stream);
@@ -438,7 +474,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
     }
     h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
-    HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), h->s_desc.p, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_snr.data(), h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->last_frames = F;
     return sync(h);
@@ -468,8 +504,8 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
 int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
 {
     if (!h || !ratio_percent) return DABPHY_ERR_INVALID;
-    std::vector<RxState> st(h->cfg.n_ensembles);
-    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    std::vector<DecState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
     int r = sync(h); if (r) return r;
     for (size_t i = 0; i < st.size(); i++) ratio_percent[i] = st[i].fic_ratio * 10;
     return DABPHY_OK;
@@ -503,7 +539,7 @@ int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t
 int dabphy_get_impulse_response(dabphy_handle* h, float* out)
 {
     if (!h || !out || !h->last_frames || !h->cfg.want_impulse_response) return DABPHY_ERR_INVALID;
-    HIPCHK(h, hipMemcpyAsync(out, h->s_cir.p, (size_t)h->cfg.n_ensembles * h->last_frames * T_U * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, h->cur_cir, (size_t)h->cfg.n_ensembles * h->last_frames * T_U * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
 

@@ -13,9 +13,6 @@ struct RxState {
     int32_t coarse;         // coarseCorrector [Hz]
     int32_t fine;           // fineCorrector [Hz], int16 range
     int32_t synced;         // 0: acquisition needed (notSynced), 1: tracking (SyncOnPhase loop)
-    int32_t fic_ratio;      // saturating 0..10 FIB CRC success counter
-    int32_t snr_count;      // OfdmDecoder::snrCount
-    float snr;              // OfdmDecoder::snr
     float s_level;          // OFDMProcessor::sLevel (maintained by the acquisition kernel only)
     int32_t lost;           // number of findIndex failures seen
     // acquisition state machine (survives a call that ran out of samples mid-search)
@@ -23,6 +20,16 @@ struct RxState {
     int32_t acq_counter, acq_idx, acq_left;
     float acq_cs;           // currentStrength
     float env[64];          // last 64 entries of envBuffer (only the 50 most recent are ever read)
+};
+
+// Decoder-side state (written by the decode kernels, which may run concurrently with the NEXT batch's
+// synchroniser on another stream -- hence not part of RxState): OfdmDecoder::snr/snrCount (ofdm-decoder.h:75-77)
+// and FicHandler::fic_decode_success_ratio (fic-handler.h:64).
+struct DecState {
+    int32_t fic_ratio;      // saturating 0..10 FIB CRC success counter
+    int32_t snr_count;      // OfdmDecoder::snrCount
+    float snr;              // OfdmDecoder::snr
+    int32_t pad;
 };
 
 // Where one transmission frame sits in the sample stream and which oscillator settings were in force while
@@ -46,7 +53,7 @@ struct SyncArgs {
     const cf32* iq; size_t iq_stride; int64_t ring;     // sample ring of each ensemble
     int64_t n_valid;                                     // samples written so far (absolute); ignored when loop != 0
     int loop;                                            // the ring is a looping recording (CRAWFile with rewind, raw_file.cpp:284-286)
-    RxState* state; FrameDesc* desc; int n_ens, n_frames, frame;
+    RxState* state; const DecState* dec; FrameDesc* desc; int n_ens, n_frames, frame;
     int fft_placement, disable_coarse;
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
 };
@@ -63,7 +70,7 @@ struct DemodArgs {
 };
 
 struct SnrArgs {
-    RxState* state; const FrameDesc* desc; int n_ens, n_frames;
+    DecState* state; const FrameDesc* desc; int n_ens, n_frames;
     const float* prs_mag; float* snr_out;                 // [B][n_frames], NaN = no report
 };
 
@@ -107,7 +114,7 @@ struct MscGatherArgs {
 struct CrcArgs {
     const uint8_t* fib;     // [B][F][12][32]
     uint8_t* ok;            // [B][F][12]
-    RxState* state; const FrameDesc* desc; int n_ens, n_frames;
+    DecState* state; const FrameDesc* desc; int n_ens, n_frames;
 };
 
 // Gather from a plain [n_cw][in_stride] array of soft bits (the Viterbi::deconvolve / Protection::deconvolve seams)

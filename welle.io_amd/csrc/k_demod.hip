@@ -175,7 +175,7 @@ __global__ void k_snr(SnrArgs A)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= A.n_ens) return;
-    RxState& st = A.state[b];
+    DecState& st = A.state[b];
     float snr = st.snr; int cnt = st.snr_count;
     for (int f = 0; f < A.n_frames; f++) {
         float* out = A.snr_out + (size_t)b * A.n_frames + f;

@@ -80,9 +80,9 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
 __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
 {
     __shared__ __attribute__((aligned(16))) cf32 tile[T_U];
-    __shared__ float lbuf[T_U + 128];
+    __shared__ __attribute__((aligned(16))) float lbuf[T_U + 128];
     __shared__ float pa[T_U];
-    __shared__ __attribute__((aligned(16))) cf32 prod[2][512];
+    __shared__ __attribute__((aligned(16))) cf32 prod[6][512];
     __shared__ float redf[FFT_THREADS];
     __shared__ int redi[FFT_THREADS];
     __shared__ float s_sum;
@@ -146,7 +146,15 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
         else startIndex = first;
     } else {
         // ThresholdBeforePeak (phasereference.cpp:212-252)
-        if (t == 0) { float s = 0; for (int i = 0; i < T_U; i++) s += lbuf[i]; s_sum = s; }   // :214-218, in order
+        if (t == 0) {                                                                          // :214-218, in order
+            float s = 0; const float4* l4 = reinterpret_cast<const float4*>(lbuf);
+            for (int i = 0; i < T_U / 4; i += 4) {
+                const float4 q0 = l4[i], q1 = l4[i + 1], q2 = l4[i + 2], q3 = l4[i + 3];
+                s += q0.x; s += q0.y; s += q0.z; s += q0.w; s += q1.x; s += q1.y; s += q1.z; s += q1.w;
+                s += q2.x; s += q2.y; s += q2.z; s += q2.w; s += q3.x; s += q3.y; s += q3.z; s += q3.w;
+            }
+            s_sum = s;
+        }
         // peak_averages[i] = max(lbuf[i .. i+99]) for i < 1948; thread t owns i = 16t .. 16t+15
         float mx = -10000.0f;
         if (16 * t < T_U - 100) {
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
 
     // ---- coarse frequency corrector (ofdm-processor.cpp:397-409, processPRS :537-616 PatternOfZeros)
     int32_t coarse = st.coarse;
-    if (!A.disable_coarse && st.fic_ratio * 10 < 50) {
+    if (!A.disable_coarse && A.dec[b].fic_ratio * 10 < 50) {
         load_mix2048(v, iq, A.ring, st.pos, startIndex, nco, d.L0, d.f_prs, startIndex, t);
         fft2048_wg<false>(v, tile, w, t);
         __syncthreads();
@@ -266,16 +274,41 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
         ph_sym -= stepTS; if (ph_sym < 0) ph_sym += INPUT_RATE;
         a_sym += T_S; if (a_sym >= A.ring) a_sym -= A.ring;
     };
-    products(1);
+    // 75 symbols in 25 groups of 3: while all threads fetch + multiply group g+1 (24 sample loads and 24 oscillator
+    // gathers in flight per thread), thread 0 adds the real parts and thread 64 (another SIMD) the imaginary parts of
+    // group g -- each a single chain of float additions in the reference's order.
+    constexpr int GRP = 3;
+    auto products3 = [&](int sel) {
+#pragma unroll
+        for (int q = 0; q < GRP; q++) products(sel * GRP + q);
+    };
+    products3(0);
     __syncthreads();
-    for (int s = 1; s < L_SYM; s++) {
-        if (s + 1 < L_SYM) products((s + 1) & 1);
-        if (t == 0) {
-            const cf32* p = prod[s & 1];
-            for (int j = 0; j < T_G; j++) { acc.re += p[j].re; acc.im += p[j].im; }
+    for (int g = 0; g < (L_SYM - 1) / GRP; g++) {
+        if (g + 1 < (L_SYM - 1) / GRP) products3((g + 1) & 1);
+        if (t == 0 || t == 64) {
+            float a = (t == 0) ? acc.re : acc.im;
+            for (int q = 0; q < GRP; q++) {
+                const float4* p4 = reinterpret_cast<const float4*>(prod[(g & 1) * GRP + q]);
+                if (t == 0) {
+                    for (int j = 0; j < T_G / 2; j += 4) {
+                        const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
+                        a += q0.x; a += q0.z; a += q1.x; a += q1.z; a += q2.x; a += q2.z; a += q3.x; a += q3.z;
+                    }
+                } else {
+                    for (int j = 0; j < T_G / 2; j += 4) {
+                        const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
+                        a += q0.y; a += q0.w; a += q1.y; a += q1.w; a += q2.y; a += q2.w; a += q3.y; a += q3.w;
+                    }
+                }
+            }
+            if (t == 0) acc.re = a; else acc.im = a;
         }
         __syncthreads();
     }
+    if (t == 64) s_sum = acc.im;
+    __syncthreads();
+    if (t == 0) acc.im = s_sum;
 
     if (t == 0) {
         // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)

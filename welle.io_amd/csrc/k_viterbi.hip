@@ -36,8 +36,13 @@ __host__ __device__ constexpr int bf_pattern(int i)
     return parity6((2 * i) & 0155) | (parity6((2 * i) & 0117) << 1) | (parity6((2 * i) & 0123) << 2);
 }
 
+// Decision words.  The sign bits of (m1 - m0) and (m3 - m2) are the decisions (viterbi.cpp:271-272: d = m0 > m1).
+// For butterfly pair i the four sign-carrying bytes are gathered with one v_perm_b32 into
+//   [ d(2i) | d(2i+32) | d(2i+1) | d(2i+33) ]  (bit 7 of bytes 0..3)
+// and shifted so that pair i lands on bit (i & 7) of each byte of word (i >> 3).  Decision of state s at a step:
+//   word (s >> 4) & 1,  byte 2 * (s & 1) + (s >> 5),  bit (s >> 1) & 7.
 template <int I>
-__device__ __forceinline__ void bfly_pair(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&MV)[8], uint32_t& acc0, uint32_t& acc1)
+__device__ __forceinline__ void bfly_pair(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&MV)[8], uint32_t& accA, uint32_t& accB)
 {
     constexpr int p = bf_pattern(I);
     const u16x2 A = asv(__builtin_amdgcn_perm(asu(R[I + 16]), asu(R[I]), 0x05040100u));   // (old[i],    old[i+16])
@@ -45,8 +50,9 @@ __device__ __forceinline__ void bfly_pair(const u16x2 (&R)[32], u16x2 (&N)[32], 
     const u16x2 m0 = A + MV[p], m1 = B + MV[p ^ 7], m2 = A + MV[p ^ 7], m3 = B + MV[p];
     N[2 * I] = pkmin(m0, m1);                  // (new[2i],   new[2i+32])
     N[2 * I + 1] = pkmin(m2, m3);              // (new[2i+1], new[2i+33])
-    acc0 |= asu((m1 - m0) >> 15) << I;         // decision0 = m0 > m1   (viterbi.cpp:271)
-    acc1 |= asu((m3 - m2) >> 15) << I;         // decision1 = m2 > m3   (viterbi.cpp:272)
+    const uint32_t signs = __builtin_amdgcn_perm(asu(m3 - m2), asu(m1 - m0), 0x07050301u);
+    if (I < 8) accA = ((signs >> (7 - (I & 7))) & 0x01010101u * (1u << (I & 7))) | accA;
+    else       accB = ((signs >> (7 - (I & 7))) & 0x01010101u * (1u << (I & 7))) | accB;
 }
 
 __device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out)
@@ -62,14 +68,14 @@ __device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32
     u16x2 MV[8];   // MV[p] = (metric of pattern p, metric of pattern p^1)
     MV[0] = X0 + W00; MV[1] = X1 + W00; MV[2] = X0 + W10; MV[3] = X1 + W10;
     MV[4] = X0 + W01; MV[5] = X1 + W01; MV[6] = X0 + W11; MV[7] = X1 + W11;
-    uint32_t acc0 = 0, acc1 = 0;
-    bfly_pair<0>(R, N, MV, acc0, acc1);  bfly_pair<1>(R, N, MV, acc0, acc1);  bfly_pair<2>(R, N, MV, acc0, acc1);
-    bfly_pair<3>(R, N, MV, acc0, acc1);  bfly_pair<4>(R, N, MV, acc0, acc1);  bfly_pair<5>(R, N, MV, acc0, acc1);
-    bfly_pair<6>(R, N, MV, acc0, acc1);  bfly_pair<7>(R, N, MV, acc0, acc1);  bfly_pair<8>(R, N, MV, acc0, acc1);
-    bfly_pair<9>(R, N, MV, acc0, acc1);  bfly_pair<10>(R, N, MV, acc0, acc1); bfly_pair<11>(R, N, MV, acc0, acc1);
-    bfly_pair<12>(R, N, MV, acc0, acc1); bfly_pair<13>(R, N, MV, acc0, acc1); bfly_pair<14>(R, N, MV, acc0, acc1);
-    bfly_pair<15>(R, N, MV, acc0, acc1);
-    *dec_out = make_uint2(acc0, acc1);
+    uint32_t accA = 0, accB = 0;
+    bfly_pair<0>(R, N, MV, accA, accB);  bfly_pair<1>(R, N, MV, accA, accB);  bfly_pair<2>(R, N, MV, accA, accB);
+    bfly_pair<3>(R, N, MV, accA, accB);  bfly_pair<4>(R, N, MV, accA, accB);  bfly_pair<5>(R, N, MV, accA, accB);
+    bfly_pair<6>(R, N, MV, accA, accB);  bfly_pair<7>(R, N, MV, accA, accB);  bfly_pair<8>(R, N, MV, accA, accB);
+    bfly_pair<9>(R, N, MV, accA, accB);  bfly_pair<10>(R, N, MV, accA, accB); bfly_pair<11>(R, N, MV, accA, accB);
+    bfly_pair<12>(R, N, MV, accA, accB); bfly_pair<13>(R, N, MV, accA, accB); bfly_pair<14>(R, N, MV, accA, accB);
+    bfly_pair<15>(R, N, MV, accA, accB);
+    *dec_out = make_uint2(accA, accB);
 }
 
 __device__ __forceinline__ void renorm(u16x2 (&R)[32])
@@ -98,12 +104,17 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
     for (int j = 0; j < 32; j++) R[j] = splat(63);
     R[0] = asv(63u << 16);
 
+    // two trellis steps per iteration (R -> N -> R); the symbols of the next iteration are requested before the
+    // current ones are consumed, so a wave never waits on its own load (nor on its decision stores)
     int s = 0;
+    uint32_t y0 = sym[0], y1 = nsteps > 1 ? sym[64] : 0u;
     for (; s + 1 < nsteps; s += 2) {
-        const uint32_t y0 = sym[(size_t)s * 64], y1 = sym[(size_t)(s + 1) * 64];
+        const int sn = (s + 3 < nsteps) ? s + 2 : s;             // clamp: the last iteration re-reads valid memory
+        const uint32_t n0 = sym[(size_t)sn * 64], n1 = sym[(size_t)(sn + 1) * 64];
         trellis_step(R, N, y0, dec + (size_t)s * 64);
         trellis_step(N, R, y1, dec + (size_t)(s + 1) * 64);
         if ((s & 14) == 14) renorm(R);
+        y0 = n0; y1 = n1;
     }
     if (s < nsteps) {
         trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64);
@@ -111,18 +122,27 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
 
     // chainback_viterbi (viterbi.cpp:313-339) from state 0, skipping the 6 tail steps; bits are packed MSB
     // first (decoder_adapter.cpp:61-67) into little-endian 32-bit words and XORed with the energy-dispersal
-    // sequence when asked to (fic-handler.cpp:206-208, energy_dispersal.h:51-53).
+    // sequence when asked to (fic-handler.cpp:206-208, energy_dispersal.h:51-53).  The decision words do not
+    // depend on the path, so 8 steps are fetched at a time and resolved from registers.
     const int cw = g * 64 + lane;
     uint32_t* out = reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32);
     uint32_t T = 0, acc = 0;
-    for (int n = nbits - 1; n >= 0; n--) {
-        const uint2 d = dec[(size_t)(n + 6) * 64];
-        const uint32_t wsel = (T & 1) ? d.y : d.x;
-        const uint32_t k = (wsel >> (((T >> 1) & 15) | ((T >> 5) << 4))) & 1;
-        T = (T >> 1) | (k << 5);
-        acc |= k << (8 * ((n >> 3) & 3) + 7 - (n & 7));
-        if ((n & 31) == 0) {
-            if (cw < A.c.n_cw) out[n >> 5] = A.c.dedisperse ? acc ^ A.prbs_words[n >> 5] : acc;
+    for (int n = nbits - 1; n >= 0; n -= 8) {
+        uint2 dq[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dq[k] = dec[(size_t)(n - k + 6) * 64];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int nn = n - k;                                 // n is 7 mod 8: nn & 7 = 7 - k
+            const uint32_t wsel = (T & 16) ? dq[k].y : dq[k].x;
+            const uint32_t bit = ((T >> 1) & 7) + 8 * (2 * (T & 1) + (T >> 5));
+            const uint32_t kk = (wsel >> bit) & 1;
+            T = (T >> 1) | (kk << 5);
+            acc |= kk << (8 * ((nn >> 3) & 3) + k);                // 7 - (nn & 7) = k
+        }
+        if (((n - 7) & 31) == 0) {
+            const int wi = (n - 7) >> 5;
+            if (cw < A.c.n_cw) out[wi] = A.c.dedisperse ? acc ^ A.prbs_words[wi] : acc;
             acc = 0;
         }
     }
