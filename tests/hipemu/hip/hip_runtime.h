@@ -15,7 +15,6 @@
 #include <cmath>
 #include <functional>
 #include <vector>
-#include <ucontext.h>
 #include <chrono>
 
 #define __global__
@@ -117,4 +116,13 @@ static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned 
     unsigned long long src = ((unsigned long long)s0 << 32) | s1; unsigned r = 0;
     for (int i = 0; i < 4; i++) { unsigned c = (sel >> (8 * i)) & 0xff; unsigned b = c < 8 ? (unsigned)((src >> (8 * c)) & 0xff) : (c == 0x0c ? 0u : 0xffu); r |= b << (8 * i); }
     return r;
+}
+static inline void __builtin_amdgcn_s_setprio(int) {}
+// v_mov_b32 dpp row_shl:k (dpp_ctrl 0x101..0x10f): lane i reads lane i+k of its row of 16, 0 beyond the row (bound_ctrl)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    const int k = dpp_ctrl & 0xf; const int lane = hipemu_lane();
+    const int srcl = ((lane & 15) + k < 16) ? lane + k : lane;
+    unsigned v = hipemu_wave_exchange((unsigned)src, srcl, true);
+    return ((lane & 15) + k < 16) ? (int)v : 0;
 }

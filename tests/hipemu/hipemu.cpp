@@ -6,24 +6,50 @@ hipemu_idx threadIdx, blockIdx, blockDim, gridDim;
 
 namespace {
 constexpr size_t STACK = 512 * 1024;
-struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; hipemu_idx tid; };
+// minimal x86-64 System V context switch (callee-saved registers + stack pointer); ucontext's swapcontext makes two
+// sigprocmask system calls per switch, which dominated the run time of barrier-heavy kernels
+struct Fiber { void* sp = nullptr; char* stack = nullptr; bool done = true; hipemu_idx tid; };
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
 struct Block {
     std::vector<Fiber> f; int cur = -1; int nlive = 0;
     int arrived = 0; unsigned gen = 0;
     // wave state
-    int w_arrived[16]; unsigned w_gen[16]; unsigned w_val[16][64]; bool w_pred[16][64]; int w_live[16];
+    int w_arrived[16]; unsigned w_gen[16]; unsigned w_val[2][16][64]; unsigned w_tog[16][64]; bool w_pred[16][64]; int w_live[16];
 };
 Block B;
-ucontext_t sched_ctx;
+void* sched_sp = nullptr;
 const std::function<void()>* g_body = nullptr;
 
 void fiber_main() {
     (*g_body)();
     Fiber& me = B.f[B.cur];
     me.done = true; B.nlive--; B.w_live[B.cur / 64]--;
-    swapcontext(&me.ctx, &sched_ctx);
+    hipemu_switch(&me.sp, sched_sp);
+    __builtin_unreachable();
 }
-void yield_() { Fiber& me = B.f[B.cur]; swapcontext(&me.ctx, &sched_ctx); }
+void yield_() { Fiber& me = B.f[B.cur]; hipemu_switch(&me.sp, sched_sp); }
 }
 
 void hipemu_syncthreads() {
@@ -39,12 +65,12 @@ static void wave_barrier(int w) {
 }
 
 unsigned hipemu_wave_exchange(unsigned v, int src_lane, bool) {
+    // double-buffered: a lane can only reach its second-next exchange after every lane has left this one
     int t = B.cur, w = t / 64, l = t & 63;
-    B.w_val[w][l] = v;
+    const unsigned tog = (B.w_tog[w][l]++) & 1;
+    B.w_val[tog][w][l] = v;
     wave_barrier(w);
-    unsigned r = B.w_val[w][src_lane & 63];
-    wave_barrier(w);
-    return r;
+    return B.w_val[tog][w][src_lane & 63];
 }
 
 unsigned long long hipemu_ballot(bool p) {
@@ -69,12 +95,17 @@ void hipemu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     gridDim = {grid.x, grid.y, grid.z}; blockDim = {block.x, block.y, block.z};
     for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
         B.nlive = nt; B.arrived = 0; B.gen = 0;
+        memset(B.w_tog, 0, sizeof B.w_tog);
         for (int w = 0; w < 16; w++) { B.w_arrived[w] = 0; B.w_gen[w] = 0; int n = nt - 64 * w; B.w_live[w] = n < 0 ? 0 : (n > 64 ? 64 : n); }
         for (int t = 0; t < nt; t++) {
             Fiber& f = B.f[t];
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &sched_ctx;
-            makecontext(&f.ctx, fiber_main, 0);
+            // initial frame: six zeroed callee-saved registers, then the entry address; rsp after the `ret` into
+            // fiber_main must be 8 mod 16 as after a call
+            uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+            void** sp = (void**)(top - 8);
+            *--sp = (void*)fiber_main;
+            for (int k = 0; k < 6; k++) *--sp = nullptr;
+            f.sp = sp;
             f.done = false;
             f.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
         }
@@ -82,7 +113,7 @@ void hipemu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             for (int t = 0; t < nt; t++) {
                 if (B.f[t].done) continue;
                 B.cur = t; threadIdx = B.f[t].tid; blockIdx = {bx, by, bz};
-                swapcontext(&sched_ctx, &B.f[t].ctx);
+                hipemu_switch(&sched_sp, B.f[t].sp);
             }
         }
     }

@@ -46,9 +46,11 @@ struct dabphy_handle {
     uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
-    DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
+    DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
+    hipEvent_t ev_chain_beg[2]{}, ev_chain_end[2]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
+    bool need_acquire = true;         // queue k_acquire in front of every frame step
     uint32_t presynced = 0;           // frames already synchronised ahead into s_desc2[desc_sel] (pipelined mode)
     int soft_ring = 0;
     uint32_t last_frames = 0;         // n_frames of the last dabphy_process
@@ -149,6 +151,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipMemset(ds, 0, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->sync_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < 2; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
@@ -161,10 +164,11 @@ void dabphy_destroy(dabphy_handle* h)
     hipError_t e;
     if (h->sync_stream) { e = hipStreamSynchronize(h->sync_stream); e = hipStreamDestroy(h->sync_stream); }
     if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
+    for (int i = 0; i < 2; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok};
@@ -287,7 +291,7 @@ int dabphy_reset(dabphy_handle* h)
     if (!h) return DABPHY_ERR_INVALID;
     // OFDMProcessor::restart + the start of run(): everything zero, sLevel primed over the first T_F/2 samples (:252-255)
     if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
-    h->presynced = 0; h->desc_sel = 0;
+    h->presynced = 0; h->desc_sel = 0; h->need_acquire = true;
     HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
     std::vector<RxState> init(h->cfg.n_ensembles);
     memset(init.data(), 0, init.size() * sizeof(RxState));
@@ -380,6 +384,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
     if ((r = ensure(h, h->s_soft, (size_t)B * ring_frames * SOFT_PER_FRAME))) return r;
+    if ((r = ensure(h, h->s_prods, (size_t)B * 75 * 512 * sizeof(cf32)))) return r;
     if ((r = ensure(h, h->s_mag, (size_t)B * F * T_U * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_snr, (size_t)B * F * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_fib, (size_t)B * F * 384))) return r;
@@ -402,13 +407,19 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
         sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse;
         sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
-        if (h->profiling) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_SYNC], h->sync_stream); (void)e; }
+        sa.prods = h->s_prods.as<cf32>();
+        { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
         for (uint32_t f = 0; f < F; f++) {
-            launch_acquire(sa, h->sync_stream);            // no-op for ensembles that are tracking
-            sa.frame = (int)f;
-            launch_sync_frame(sa, h->sync_stream);
+            // acquisition is only queued while some ensemble may be out of lock (start of a stream, or a failed
+            // window search seen in the last finished batch); tracking ensembles skip it inside the kernel anyway
+            if (h->need_acquire) launch_acquire(sa, h->sync_stream);
+            sa.frame = (int)f; sa.do_finish = f > 0; sa.do_find = 1;
+            launch_sync_frame(sa, h->sync_stream);      // finish frame f-1, window search of frame f
+            launch_cp_products(sa, h->sync_stream);     // cyclic-prefix products of frame f (B x 75 work-groups)
         }
-        if (h->profiling) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_SYNC], h->sync_stream); (void)e; h->ev_used[dabphy_handle::ST_SYNC] = true; }
+        sa.frame = (int)F; sa.do_finish = 1; sa.do_find = 0;
+        launch_sync_frame(sa, h->sync_stream);          // finish the last frame
+        { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
     };
     if (h->presynced != 0 && h->presynced != F) { h->err = "pipelined mode needs a constant n_frames"; return DABPHY_ERR_STATE; }
     const int cur = h->desc_sel;
@@ -477,7 +488,14 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_snr.data(), h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->last_frames = F;
-    return sync(h);
+    if ((r = sync(h))) return r;
+    { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }
+    {   // every ensemble locked through the whole batch -> no acquisition launches for the next chain
+        bool all_locked = true;
+        for (const FrameDesc& d : h->h_desc) if (!d.valid) { all_locked = false; break; }
+        h->need_acquire = !all_locked;
+    }
+    return DABPHY_OK;
 }
 
 int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out)
@@ -573,6 +591,7 @@ int dabphy_get_stage_times(dabphy_handle* h, float* ms)
         ms[i] = 0.0f;
         if (h->ev_used[i]) { float t = 0; if (hipEventElapsedTime(&t, h->ev_beg[i], h->ev_end[i]) == hipSuccess) ms[i] = t; }
     }
+    ms[dabphy_handle::ST_SYNC] = h->chain_ms;    // measured on the sync stream (overlaps the previous batch's decode in pipelined mode)
     return DABPHY_OK;
 }
 

@@ -56,6 +56,8 @@ struct SyncArgs {
     RxState* state; const DecState* dec; FrameDesc* desc; int n_ens, n_frames, frame;
     int fft_placement, disable_coarse;
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
+    cf32* prods;                                         // [B][75][512] cyclic-prefix products of the pending frame
+    int do_finish, do_find;                              // phases of k_sync_frame (finish frame-1 / find frame)
 };
 
 struct DemodArgs {
@@ -149,5 +151,6 @@ void launch_fib_crc(const CrcArgs& a, hipStream_t s);
 void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
 void launch_sync_frame(const SyncArgs& a, hipStream_t s);
 void launch_acquire(const SyncArgs& a, hipStream_t s);
+void launch_cp_products(const SyncArgs& a, hipStream_t s);
 
 } // namespace dabphy

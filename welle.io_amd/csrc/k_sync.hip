@@ -77,23 +77,121 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
     return r;
 }
 
+// acc(lane 0) += x(lane 0) + x(lane 1) + ... + x(lane nk-1), one float addition at a time in that order.  Lane 0 reads
+// lane k through a row_shl:k DPP operand, so every step of the dependent chain is a single VALU instruction.
+template <int K> __device__ __forceinline__ float dpp_row_shl(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 | K, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float chain16(float acc, float x, int nk)
+{
+    acc += x;
+    acc += dpp_row_shl<1>(x); acc += dpp_row_shl<2>(x); acc += dpp_row_shl<3>(x);
+    acc += dpp_row_shl<4>(x); acc += dpp_row_shl<5>(x); acc += dpp_row_shl<6>(x); acc += dpp_row_shl<7>(x);
+    if (nk > 8) {
+        acc += dpp_row_shl<8>(x); acc += dpp_row_shl<9>(x); acc += dpp_row_shl<10>(x); acc += dpp_row_shl<11>(x);
+        acc += dpp_row_shl<12>(x); acc += dpp_row_shl<13>(x); acc += dpp_row_shl<14>(x); acc += dpp_row_shl<15>(x);
+    }
+    return acc;
+}
+
+// One step of the frame chain, two phases in one launch (B work-groups):
+//   finish: frame A.frame-1 -- add up its cyclic-prefix products (written by k_cp_products) in the reference's
+//           order, update the fine/coarse correctors, consume the null symbol, commit the receiver state
+//   find:   frame A.frame   -- PRS window search (+ coarse corrector), leaves the descriptor "pending" (valid = 2)
+// k_cp_products runs between two such launches with B x 75 work-groups, so the memory-latency-bound part of the
+// chain is a throughput kernel and only the 2 x 37 800 dependent float additions stay serial.
 __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
 {
     __shared__ __attribute__((aligned(16))) cf32 tile[T_U];
     __shared__ __attribute__((aligned(16))) float lbuf[T_U + 128];
     __shared__ float pa[T_U];
-    __shared__ __attribute__((aligned(16))) cf32 prod[6][512];
     __shared__ float redf[FFT_THREADS];
     __shared__ int redi[FFT_THREADS];
     __shared__ float s_sum;
     __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
+    __shared__ RxState s_st;
 
+    // latency-bound serial work that may share CUs with the previous batch's decode kernels: issue these waves first
+    __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, b = blockIdx.x;
-    RxState st = A.state[b];
-    FrameDesc& dout = A.desc[(size_t)b * A.n_frames + A.frame];
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
+    if (t == 0) s_st = A.state[b];
+    __syncthreads();
 
+    // ------------------------------------------------------------------------------------------ finish frame-1
+    if (A.do_finish) {
+        FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + (A.frame - 1)];
+        const int pending = dfin.valid;
+        __syncthreads();
+        if (pending == 2) {
+            // ofdm-processor.cpp:435-442: FreqCorr += buf[i] * conj(buf[i - T_u]) over 75 x 504 products, one float chain
+            // for the real parts (thread 0) and one for the imaginary parts (thread 64, another SIMD); operands are
+            // fetched 8 products ahead so each chain is bounded by add latency only
+            // Staging: all threads copy the products two symbols ahead from HBM/L2 into a 3-slot LDS ring (coalesced
+            // 16-byte loads issued before the chains start on the current symbol, stored after), so the chains only
+            // ever read LDS.
+            float acc = 0.0f;
+            float4* pb4 = reinterpret_cast<float4*>(tile);                         // 3 x 256 float4 (the FFT tile is idle here)
+            const float4* g4 = reinterpret_cast<const float4*>(A.prods + (size_t)b * 75 * 512);
+            if (t < 126) { pb4[2 * t] = g4[2 * t]; pb4[2 * t + 1] = g4[2 * t + 1]; pb4[256 + 2 * t] = g4[256 + 2 * t]; pb4[256 + 2 * t + 1] = g4[256 + 2 * t + 1]; }
+            __syncthreads();
+            for (int sy = 0; sy < 75; sy++) {
+                float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+                const bool more = (sy + 2 < 75) && t < 126;
+                if (more) { r0 = g4[(sy + 2) * 256 + 2 * t]; r1 = g4[(sy + 2) * 256 + 2 * t + 1]; }
+                {
+                    // wave 0 adds the real parts, wave 1 the imaginary parts.  Lanes 0..15 each hold one product of a
+                    // block of 16; lane 0 folds them in order with row_shl DPP reads (one instruction per addition).
+                    const float* q = reinterpret_cast<const float*>(pb4 + (sy % 3) * 256) + (t >> 6);   // +0: re, +1: im
+                    const int l16 = t & 15;
+                    float xs[32];
+#pragma unroll
+                    for (int i = 0; i < 32; i++) xs[i] = (16 * i + l16 < T_G) ? q[2 * (16 * i + l16)] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const int nk = (i < 31) ? 16 : 8;                       // 504 = 31 * 16 + 8
+                        acc = chain16(acc, xs[i], nk);
+                    }
+                }
+                if (more) { pb4[((sy + 2) % 3) * 256 + 2 * t] = r0; pb4[((sy + 2) % 3) * 256 + 2 * t + 1] = r1; }
+                __syncthreads();
+            }
+            if (t == 64) s_sum = acc;
+            __syncthreads();
+            if (t == 0) {
+                RxState st = s_st;
+                FrameDesc d = dfin;
+                const float acc_im = s_sum;
+                int32_t coarse = d.coarse_after;                                  // after the coarse corrector of this frame
+                // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
+                const float a = fdlibm_atan2f(acc_im, acc);
+                int32_t fine = (int32_t)(int16_t)((double)st.fine + 0.1 * (double)a / M_PI * (1000 / 2));
+                // null symbol (:462-463) is pulled with the new fine corrector
+                const int32_t J0 = d.start_index + T_U;
+                const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
+                const int32_t f_null = coarse + fine;
+                const int32_t L3 = mod_rate64((int64_t)L2 - (int64_t)T_NULL * f_null);
+                d.null_L = L2; d.null_f = f_null;
+                d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
+                if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
+                else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
+                d.valid = 1;
+                dfin = d;
+                st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
+                st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
+                s_st = st;
+                A.state[b] = st;
+            }
+            __syncthreads();
+        }
+    }
+    if (!A.do_find) return;
+
+    // ------------------------------------------------------------------------------------------ find frame
+    RxState st = s_st;
+    FrameDesc& dout = A.desc[(size_t)b * A.n_frames + A.frame];
     FrameDesc d;
     d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
     d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0;
@@ -107,7 +205,6 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
 
     FftTwiddles w; fft_load_twiddles(w, A.tab.tw, twB, t);
     cf32 v[16], u[16];
-
     // ---- PhaseReference::findIndex (phasereference.cpp:73-92): FFT, multiply by conj(refTable), IFFT (scaled by 1/N)
     load_mix2048(v, iq, A.ring, st.pos, 0, nco, d.L0, d.f_prs, 0, t);
     fft2048_wg<false>(v, tile, w, t);
@@ -248,85 +345,38 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
         }
     }
     d.f_sym = coarse + st.fine;
+    d.coarse_after = coarse;
+    d.valid = 2;                                   // pending: k_cp_products + the finish phase of the next launch complete it
+    if (t == 0) dout = d;
+}
 
-    // ---- cyclic-prefix correlation over the 75 data symbols (ofdm-processor.cpp:435-442)
-    // products for symbol s: buf[2048+j] * conj(buf[j]), j < 504; threads form them, lane 0 adds them in order
-    cf32 acc; acc.re = 0.0f; acc.im = 0.0f;
-    // oscillator phase and ring position advance incrementally (one 64-bit modulo per thread, then add/compare)
-    const int32_t stepTS = mod_rate64((int64_t)T_S * d.f_sym), stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
-    int32_t ph_sym = mod_rate64((int64_t)d.L1 - (int64_t)(t + 1) * d.f_sym);     // phase of sample j = t of symbol 1
-    int64_t a_sym = (st.pos + J0 + t) % A.ring;                                  // its ring index
-    auto products = [&](int bufsel) {                                            // one call per symbol, in order
-        int32_t ph = ph_sym; int64_t a = a_sym;
+// Cyclic-prefix products of one pending frame: grid (75 symbols, B ensembles).  prods[b][sym][j] =
+// buf[2048 + j] * conj(buf[j]), j < 504, both samples oscillator-corrected (ofdm-processor.cpp:211-214,440-441).
+__global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
+{
+    const int t = threadIdx.x, sy = blockIdx.x, b = blockIdx.y;
+    const FrameDesc d = A.desc[(size_t)b * A.n_frames + A.frame];
+    if (d.valid != 2) return;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    const cf32* __restrict__ nco = A.tab.nco;
+    const int32_t J0 = d.start_index + T_U;
+    const int64_t rel = (int64_t)sy * T_S + t;                                   // index of buf[t] after the PRS
+    const int32_t stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
+    int32_t ph = mod_rate64((int64_t)d.L1 - (rel + 1) * (int64_t)d.f_sym);
+    int64_t a = (d.pos + J0 + rel) % A.ring;
+    cf32* out = A.prods + ((size_t)b * 75 + sy) * 512;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = t + 128 * k;
-            if (j < T_G) {
-                int64_t a_hi = a + T_U; if (a_hi >= A.ring) a_hi -= A.ring;
-                int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
-                const cf32 lo = cmul(iq[a], nco[ph]);
-                const cf32 hi = cmul(iq[a_hi], nco[ph_hi]);
-                prod[bufsel][j] = cmul(hi, cconj(lo));
-            }
-            a += 128; if (a >= A.ring) a -= A.ring;
-            ph -= step128; if (ph < 0) ph += INPUT_RATE;
+    for (int k = 0; k < 4; k++) {
+        const int j = t + 128 * k;
+        if (j < T_G) {
+            int64_t a_hi = a + T_U; if (a_hi >= A.ring) a_hi -= A.ring;
+            int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
+            const cf32 lo = cmul(iq[a], nco[ph]);
+            const cf32 hi = cmul(iq[a_hi], nco[ph_hi]);
+            out[j] = cmul(hi, cconj(lo));
         }
-        ph_sym -= stepTS; if (ph_sym < 0) ph_sym += INPUT_RATE;
-        a_sym += T_S; if (a_sym >= A.ring) a_sym -= A.ring;
-    };
-    // 75 symbols in 25 groups of 3: while all threads fetch + multiply group g+1 (24 sample loads and 24 oscillator
-    // gathers in flight per thread), thread 0 adds the real parts and thread 64 (another SIMD) the imaginary parts of
-    // group g -- each a single chain of float additions in the reference's order.
-    constexpr int GRP = 3;
-    auto products3 = [&](int sel) {
-#pragma unroll
-        for (int q = 0; q < GRP; q++) products(sel * GRP + q);
-    };
-    products3(0);
-    __syncthreads();
-    for (int g = 0; g < (L_SYM - 1) / GRP; g++) {
-        if (g + 1 < (L_SYM - 1) / GRP) products3((g + 1) & 1);
-        if (t == 0 || t == 64) {
-            float a = (t == 0) ? acc.re : acc.im;
-            for (int q = 0; q < GRP; q++) {
-                const float4* p4 = reinterpret_cast<const float4*>(prod[(g & 1) * GRP + q]);
-                if (t == 0) {
-                    for (int j = 0; j < T_G / 2; j += 4) {
-                        const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
-                        a += q0.x; a += q0.z; a += q1.x; a += q1.z; a += q2.x; a += q2.z; a += q3.x; a += q3.z;
-                    }
-                } else {
-                    for (int j = 0; j < T_G / 2; j += 4) {
-                        const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
-                        a += q0.y; a += q0.w; a += q1.y; a += q1.w; a += q2.y; a += q2.w; a += q3.y; a += q3.w;
-                    }
-                }
-            }
-            if (t == 0) acc.re = a; else acc.im = a;
-        }
-        __syncthreads();
-    }
-    if (t == 64) s_sum = acc.im;
-    __syncthreads();
-    if (t == 0) acc.im = s_sum;
-
-    if (t == 0) {
-        // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
-        const float a = fdlibm_atan2f(acc.im, acc.re);
-        int32_t fine = (int32_t)(int16_t)((double)st.fine + 0.1 * (double)a / M_PI * (1000 / 2));
-        // null symbol (:462-463) is pulled with the new fine corrector
-        const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
-        const int32_t f_null = coarse + fine;
-        const int32_t L3 = mod_rate64((int64_t)L2 - (int64_t)T_NULL * f_null);
-        d.null_L = L2; d.null_f = f_null;
-        d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
-        if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
-        else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
-        d.valid = 1;
-        dout = d;
-        st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
-        st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
-        A.state[b] = st;
+        a += 128; if (a >= A.ring) a -= A.ring;
+        ph -= step128; if (ph < 0) ph += INPUT_RATE;
     }
 }
 
@@ -398,6 +448,10 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
 void launch_sync_frame(const SyncArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sync_frame, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
+}
+void launch_cp_products(const SyncArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cp_products, dim3(75, a.n_ens), dim3(128), 0, s, a);
 }
 void launch_acquire(const SyncArgs& a, hipStream_t s)
 {
