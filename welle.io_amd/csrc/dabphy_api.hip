@@ -149,7 +149,11 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipMalloc(&ds, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
     h->owned.push_back(ds); h->d_dec = reinterpret_cast<DecState*>(ds);
     if (hipMemset(ds, 0, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
-    if (hipStreamCreateWithFlags(&h->sync_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    {   // the frame chain is short serial work: give its queue the highest dispatch priority
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        if (hipStreamCreateWithPriority(&h->sync_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    }
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
@@ -413,12 +417,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             // acquisition is only queued while some ensemble may be out of lock (start of a stream, or a failed
             // window search seen in the last finished batch); tracking ensembles skip it inside the kernel anyway
             if (h->need_acquire) launch_acquire(sa, h->sync_stream);
-            sa.frame = (int)f; sa.do_finish = f > 0; sa.do_find = 1;
-            launch_sync_frame(sa, h->sync_stream);      // finish frame f-1, window search of frame f
-            launch_cp_products(sa, h->sync_stream);     // cyclic-prefix products of frame f (B x 75 work-groups)
+            sa.frame = (int)f;
+            launch_sync_find(sa, h->sync_stream);       // PRS window search of frame f
+            launch_cp_products(sa, h->sync_stream);     // its cyclic-prefix products (B x 75 work-groups)
+            launch_sync_finish(sa, h->sync_stream);     // ordered sums -> correctors -> state
         }
-        sa.frame = (int)F; sa.do_finish = 1; sa.do_find = 0;
-        launch_sync_frame(sa, h->sync_stream);          // finish the last frame
         { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
     };
     if (h->presynced != 0 && h->presynced != F) { h->err = "pipelined mode needs a constant n_frames"; return DABPHY_ERR_STATE; }

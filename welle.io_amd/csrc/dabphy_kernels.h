@@ -57,7 +57,6 @@ struct SyncArgs {
     int fft_placement, disable_coarse;
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
     cf32* prods;                                         // [B][75][512] cyclic-prefix products of the pending frame
-    int do_finish, do_find;                              // phases of k_sync_frame (finish frame-1 / find frame)
 };
 
 struct DemodArgs {
@@ -149,7 +148,8 @@ void launch_msc_gather(const MscGatherArgs& a, hipStream_t s);
 void launch_lin_gather(const LinGatherArgs& a, hipStream_t s);
 void launch_fib_crc(const CrcArgs& a, hipStream_t s);
 void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
-void launch_sync_frame(const SyncArgs& a, hipStream_t s);
+void launch_sync_find(const SyncArgs& a, hipStream_t s);
+void launch_sync_finish(const SyncArgs& a, hipStream_t s);
 void launch_acquire(const SyncArgs& a, hipStream_t s);
 void launch_cp_products(const SyncArgs& a, hipStream_t s);
 

@@ -14,6 +14,7 @@
 // the products are formed in parallel, the additions are done by one lane in order.
 #include "fft2048.h"
 #include "dabphy_kernels.h"
+#include <dabphy_wave_ops.h>
 
 namespace dabphy {
 
@@ -77,52 +78,22 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
     return r;
 }
 
-// acc(lane 0) += x(lane 0) + x(lane 1) + ... + x(lane nk-1), one float addition at a time in that order.  Lane 0 reads
-// lane k through a row_shl:k DPP operand, so every step of the dependent chain is a single VALU instruction.
-template <int K> __device__ __forceinline__ float dpp_row_shl(float x)
+// The frame chain, three launches per frame on the sync stream:
+//   k_sync_find(frame)      B work-groups: PRS window search (+ coarse corrector); leaves the descriptor "pending" (valid = 2)
+//   k_cp_products(frame)    B x 75 work-groups: cyclic-prefix products of the pending frame (throughput kernel)
+//   k_sync_finish(frame)    B work-groups: adds the products in the reference's order (two chains of 37 800 dependent
+//                           float additions), updates the fine/coarse correctors, consumes the null symbol, commits the state
+// Both serial kernels are kept small (<= 17 KiB LDS) so that they find room next to the decode kernels of the
+// previous batch that run concurrently on the main stream.
+__global__ void __launch_bounds__(FFT_THREADS) k_sync_finish(SyncArgs A)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 | K, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float chain16(float acc, float x, int nk)
-{
-    acc += x;
-    acc += dpp_row_shl<1>(x); acc += dpp_row_shl<2>(x); acc += dpp_row_shl<3>(x);
-    acc += dpp_row_shl<4>(x); acc += dpp_row_shl<5>(x); acc += dpp_row_shl<6>(x); acc += dpp_row_shl<7>(x);
-    if (nk > 8) {
-        acc += dpp_row_shl<8>(x); acc += dpp_row_shl<9>(x); acc += dpp_row_shl<10>(x); acc += dpp_row_shl<11>(x);
-        acc += dpp_row_shl<12>(x); acc += dpp_row_shl<13>(x); acc += dpp_row_shl<14>(x); acc += dpp_row_shl<15>(x);
-    }
-    return acc;
-}
-
-// One step of the frame chain, two phases in one launch (B work-groups):
-//   finish: frame A.frame-1 -- add up its cyclic-prefix products (written by k_cp_products) in the reference's
-//           order, update the fine/coarse correctors, consume the null symbol, commit the receiver state
-//   find:   frame A.frame   -- PRS window search (+ coarse corrector), leaves the descriptor "pending" (valid = 2)
-// k_cp_products runs between two such launches with B x 75 work-groups, so the memory-latency-bound part of the
-// chain is a throughput kernel and only the 2 x 37 800 dependent float additions stay serial.
-__global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
-{
-    __shared__ __attribute__((aligned(16))) cf32 tile[T_U];
-    __shared__ __attribute__((aligned(16))) float lbuf[T_U + 128];
-    __shared__ float pa[T_U];
-    __shared__ float redf[FFT_THREADS];
-    __shared__ int redi[FFT_THREADS];
+    __shared__ __attribute__((aligned(16))) cf32 tile[3 * 256 * 2];      // 3-slot ring of 504 (+8 pad) products
     __shared__ float s_sum;
-    __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
-    __shared__ RxState s_st;
-
-    // latency-bound serial work that may share CUs with the previous batch's decode kernels: issue these waves first
     __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, b = blockIdx.x;
-    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
-    const cf32* __restrict__ nco = A.tab.nco;
-    if (t == 0) s_st = A.state[b];
-    __syncthreads();
-
     // ------------------------------------------------------------------------------------------ finish frame-1
-    if (A.do_finish) {
-        FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + (A.frame - 1)];
+    {
+        FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + A.frame];
         const int pending = dfin.valid;
         __syncthreads();
         if (pending == 2) {
@@ -137,6 +108,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
             const float4* g4 = reinterpret_cast<const float4*>(A.prods + (size_t)b * 75 * 512);
             if (t < 126) { pb4[2 * t] = g4[2 * t]; pb4[2 * t + 1] = g4[2 * t + 1]; pb4[256 + 2 * t] = g4[256 + 2 * t]; pb4[256 + 2 * t + 1] = g4[256 + 2 * t + 1]; }
             __syncthreads();
+#pragma unroll 1
             for (int sy = 0; sy < 75; sy++) {
                 float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
                 const bool more = (sy + 2 < 75) && t < 126;
@@ -161,7 +133,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
             if (t == 64) s_sum = acc;
             __syncthreads();
             if (t == 0) {
-                RxState st = s_st;
+                RxState& st = A.state[b];              // updated field by field (the struct carries the 64-entry envelope history)
                 FrameDesc d = dfin;
                 const float acc_im = s_sum;
                 int32_t coarse = d.coarse_after;                                  // after the coarse corrector of this frame
@@ -181,16 +153,31 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
                 dfin = d;
                 st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
                 st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
-                s_st = st;
-                A.state[b] = st;
             }
             __syncthreads();
         }
     }
-    if (!A.do_find) return;
+}
 
-    // ------------------------------------------------------------------------------------------ find frame
-    RxState st = s_st;
+__global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
+{
+    // 17 KiB of LDS, reused phase by phase (FFT tile -> |IFFT| + window maxima)
+    __shared__ __attribute__((aligned(16))) cf32 tile[T_U + 96];
+    float* const lbuf = reinterpret_cast<float*>(tile);              // [T_U + 128], valid after the inverse transform
+    float* const pa = lbuf + (T_U + 128);                            // [T_U]
+    __shared__ float redf[FFT_THREADS];
+    __shared__ int redi[FFT_THREADS];
+    __shared__ float s_sum;
+    __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
+    __builtin_amdgcn_s_setprio(3);
+    const int t = threadIdx.x, b = blockIdx.x;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    const cf32* __restrict__ nco = A.tab.nco;
+    struct { int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced; } st;
+    {
+        const RxState& g = A.state[b];
+        st.pos = g.pos; st.frame_no = g.frame_no; st.local_phase = g.local_phase; st.coarse = g.coarse; st.fine = g.fine; st.synced = g.synced;
+    }
     FrameDesc& dout = A.desc[(size_t)b * A.n_frames + A.frame];
     FrameDesc d;
     d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
@@ -215,6 +202,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
 #pragma unroll
         for (int j = 0; j < 8; j++) u[8 * h + j] = v[h + 2 * j];          // bin t + 128 (h + 2j) = input t + 128h + 256j
     fft2048_wg<true>(u, tile, w, t);
+    __syncthreads();                                                       // all round-C reads of the tile are done: it becomes lbuf / pa
     const float factor = 1.0f / (float)T_U;                                // fft.cpp:154
     float* cir = A.cir ? A.cir + ((size_t)b * A.n_frames + A.frame) * T_U : nullptr;
 #pragma unroll
@@ -291,10 +279,10 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_frame(SyncArgs A)
         if (t == 0) {
             d.start_index = startIndex;
             dout = d;
-            st.pos += T_U;
-            st.local_phase = mod_rate64((int64_t)d.L0 - (int64_t)T_U * d.f_prs);
-            st.synced = 0; st.lost++;
-            A.state[b] = st;
+            RxState& g = A.state[b];
+            g.pos = st.pos + T_U;
+            g.local_phase = mod_rate64((int64_t)d.L0 - (int64_t)T_U * d.f_prs);
+            g.synced = 0; g.lost = g.lost + 1;
         }
         return;
     }
@@ -407,7 +395,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
         for (int i = t; i < (int)avail; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, pos, i, nco, L, f, i));
         __syncthreads();
         if (t == 0) {
-            RxState st = s_st;
+            RxState& st = s_st;
             float sLevel = st.s_level, cs = st.acq_cs;
             int ph = st.acq_phase, idx = st.acq_idx, counter = st.acq_counter, left = st.acq_left;
             int i = 0; bool done = false;
@@ -437,7 +425,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
             st.pos = pos + i;
             st.local_phase = (f == 0) ? L : mod_rate64((int64_t)L - (int64_t)i * f);
             if (done) { st.synced = 1; st.acq_phase = 1; st.acq_idx = 0; st.acq_cs = 0.0f; st.acq_counter = 0; }
-            s_st = st; s_done = done ? 1 : 0;
+            s_done = done ? 1 : 0;
         }
         __syncthreads();
         if (s_done) break;
@@ -445,9 +433,13 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
     if (t == 0) A.state[b] = s_st;
 }
 
-void launch_sync_frame(const SyncArgs& a, hipStream_t s)
+void launch_sync_find(const SyncArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sync_frame, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_sync_find, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
+}
+void launch_sync_finish(const SyncArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sync_finish, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
 }
 void launch_cp_products(const SyncArgs& a, hipStream_t s)
 {

@@ -194,7 +194,7 @@ constexpr int GT_MAXROWS = 112;                 // two (b, m) segments: 64 + 2 *
 
 __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
 {
-    __shared__ uint32_t tile[GT_MAXROWS * GT_PITCHW];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[GT_MAXROWS * GT_PITCHW];
     __shared__ long long s_rowsrc[GT_MAXROWS];
     __shared__ int s_pair[64], s_rowbase[64];
     __shared__ long long s_c[64];
@@ -263,25 +263,32 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
     }
 
     const int8_t* tile8 = reinterpret_cast<const int8_t*>(tile);
+    __shared__ __attribute__((aligned(16))) int s_map[4 * GT_STEPS];          // this tile's slice of the depuncturing map, pre-resolved to tile offsets
     for (int s0 = 0, ti = 0; s0 < nsteps; s0 += GT_STEPS, ti++) {
         const int u_lo = A.tiles[2 * ti], ndw = A.tiles[2 * ti + 1];       // first source byte (4-aligned), dwords per row
+        const int s1 = (s0 + GT_STEPS < nsteps) ? s0 + GT_STEPS : nsteps;
+        // map entry -> byte offset inside a tile row plus the row shift of the time de-interleaver; -1 = erasure
+        if (t < 4 * (s1 - s0)) {
+            const int u = A.map[4 * s0 + t];
+            s_map[t] = (u >= 0) ? (map16[u & 15] * (GT_PITCHW * 4) + (u - u_lo)) : -1;
+        }
         for (int row = wave; row < nrows; row += 4) {
             const long long src = s_rowsrc[row];
             if (lane < ndw) tile[row * GT_PITCHW + lane] = (src >= 0) ? *reinterpret_cast<const uint32_t*>(A.soft + src + u_lo + 4 * lane) : 0u;
         }
         __syncthreads();
-        const int s1 = (s0 + GT_STEPS < nsteps) ? s0 + GT_STEPS : nsteps;
+        const int rb = rowbase * (GT_PITCHW * 4);
         for (int s = s0 + wave; s < s1; s += 4) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int u = A.map[4 * s + j];
-                int v = 0;
-                if (u >= 0 && rowbase >= 0) v = tile8[(rowbase + map16[u & 15]) * (GT_PITCHW * 4) + (u - u_lo)];
-                v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
-                word |= (uint32_t)v << (8 * j);
-            }
-            dst[(size_t)s * 64] = word;
+            const int4 mo = *reinterpret_cast<const int4*>(&s_map[4 * (s - s0)]);
+            int v0 = (mo.x >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.x] : 0;
+            int v1 = (mo.y >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.y] : 0;
+            int v2 = (mo.z >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.z] : 0;
+            int v3 = (mo.w >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.w] : 0;
+            v0 += 127; v0 = v0 < 0 ? 0 : v0;            // viterbi.cpp:233-236 (an int8 + 127 never exceeds 254)
+            v1 += 127; v1 = v1 < 0 ? 0 : v1;
+            v2 += 127; v2 = v2 < 0 ? 0 : v2;
+            v3 += 127; v3 = v3 < 0 ? 0 : v3;
+            dst[(size_t)s * 64] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
         }
         __syncthreads();
     }
@@ -318,8 +325,15 @@ __global__ void k_fib_crc(CrcArgs A)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = A.n_ens * A.n_frames * 12;
     if (i >= n) return;
-    const uint8_t* p = A.fib + (size_t)i * 32;
+    // the 32 bytes of a FIB as two 16-byte loads; bytes are consumed in transmission order (little-endian words)
+    const uint4* p4 = reinterpret_cast<const uint4*>(A.fib + (size_t)i * 32);
+    const uint4 qa = p4[0], qb = p4[1];
+    const uint32_t w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    uint8_t p[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) p[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
     uint32_t crc = 0xFFFF;
+#pragma unroll
     for (int k = 0; k < 30; k++) {
         crc ^= (uint32_t)p[k] << 8;
 #pragma unroll
