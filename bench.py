@@ -86,6 +86,7 @@ def main():
         dist.init_process_group("nccl")          # RCCL
     load_package()
     from welle_io_amd import capi, synth
+    from welle_io_amd.distributed import gather_fibs
 
     B, F = args.ensembles, args.frames
     assert F % 5 == 0 and F % 4 == 0, "frames per step must keep superframes and the interleaver period aligned (multiple of 20)"
@@ -115,9 +116,7 @@ def main():
             corr, unc = dev.rs_decode_msc(-1, first_cif)
         fib, ok = dev.fibs()                               # decoded FIBs + CRC flags to the host of this rank
         if dist is not None:                               # final FIC gather to rank 0 over RCCL/xGMI
-            t = torch.from_numpy(np.concatenate([fib.reshape(-1), ok.reshape(-1)])).cuda()
-            gl = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-            dist.gather(t, gl, dst=0)
+            gather_fibs(dist, fib, ok, rank, world, device="cuda")
         return fib, ok, corr, unc
 
     # warm-up: acquisition + interleaver fill, then find the superframe alignment like SuperframeFilter does (try all 5)

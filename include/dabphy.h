@@ -120,6 +120,15 @@ int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_
                               uint64_t n_valid, int32_t loop);
 int dabphy_stream_upload(dabphy_handle* h, const float* iq, uint64_t n_samples, int32_t loop);
 
+/* Live input: a library-owned ring of ring_samples per ensemble (>= 4 frames) that the host appends to, the way
+ * CVirtualInput implementations fill their ring buffers (input/raw_file.cpp:244-290).  dabphy_stream_write copies
+ * n_ensembles x n_samples complex floats ([ensemble][sample]) behind the samples written so far; the caller must not
+ * overwrite unread samples: at most ring_samples - (written - dabphy_stream_consumed()) may be appended.
+ * dabphy_stream_consumed = samples the synchroniser no longer needs (minimum over ensembles). */
+int dabphy_stream_open(dabphy_handle* h, uint64_t ring_samples);
+int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples);
+uint64_t dabphy_stream_consumed(dabphy_handle* h);
+
 /* OFDMProcessor::restart (ofdm-processor.cpp:115-132): correctors, phase, sync state, FIC counter, SNR filter cleared */
 int dabphy_reset(dabphy_handle* h);
 
@@ -141,7 +150,8 @@ typedef struct {
     int64_t sample_pos;             /* absolute index of the sync buffer start (ofdm-processor.cpp:337) */
     int64_t frame_no;               /* running frame counter of the ensemble */
     int32_t start_index;            /* PhaseReference::findIndex result (< 0: sync lost, onSyncChange(false)) */
-    int32_t valid;                  /* frame was demodulated */
+    int32_t valid;                  /* 1: frame was demodulated; 0: no frame this slot (acquiring / not enough samples);
+                                       3: the PRS window search failed on this slot (SyncOnPhase failed, onSyncChange(false)) */
     int32_t fine_corrector;         /* as passed to onFrequencyCorrectorChange after the frame */
     int32_t coarse_corrector;
     float snr;                      /* onSNR value, NaN when the reference would not report on this frame */

@@ -1,0 +1,119 @@
+// oracle/ref_gpu_harness.cpp -- TEST INFRASTRUCTURE: drives welle.io_amd/host/GpuRadioReceiver (our drop-in for the
+// reference's RadioReceiver facade) through the SAME public surface and the same recording callbacks as
+// oracle/ref_harness.cpp drives the reference's RadioReceiver, so the two runs can be compared callback by callback.
+// Linked against the reference's unmodified FIBProcessor / DecoderAdapter objects and either the CPU execution model
+// of the kernels (libdabphy_emu.so) or the real libdabphy_hip.so.
+#include <cstring>
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <vector>
+#include "gpu_radio_receiver.h"
+
+namespace {
+struct NullProgrammeHandler : ProgrammeHandlerInterface {
+    std::atomic<int> rs_calls{0}, rs_uncorr{0}, rs_corr{0};
+    void onFrameErrors(int) override {}
+    void onNewAudio(std::vector<int16_t>&&, int, const std::string&) override {}
+    void onRsErrors(bool u, int n) override { rs_calls++; if (u) rs_uncorr++; rs_corr += n; }
+    void onAacErrors(int) override {}
+    void onNewDynamicLabel(const std::string&) override {}
+    void onMOT(const mot_file_t&) override {}
+    void onPADLengthError(size_t, size_t) override {}
+};
+
+struct Rec : RadioControllerInterface {
+    uint8_t* fib = nullptr; int fib_cap = 0; std::atomic<int> n_fib{0};
+    float* cir = nullptr; int cir_cap = 0; std::atomic<int> n_cir{0};
+    float* con = nullptr; int con_cap = 0; std::atomic<int> n_con{0};
+    float* snr = nullptr; int snr_cap = 0; std::atomic<int> n_snr{0};
+    int32_t* corr = nullptr; int corr_cap = 0; std::atomic<int> n_corr{0};
+    std::atomic<int> n_sync_true{0}, n_sync_false{0}, n_services{0};
+    std::atomic<bool> failed{false};
+    void onSNR(float s) override { int k = n_snr++; if (k < snr_cap) snr[k] = s; }
+    void onFrequencyCorrectorChange(int f, int c) override { int k = n_corr++; if (k < corr_cap) { corr[2 * k] = f; corr[2 * k + 1] = c; } }
+    void onSyncChange(char s) override { if (s) n_sync_true++; else n_sync_false++; }
+    void onSignalPresence(bool) override {}
+    void onServiceDetected(uint32_t) override { n_services++; }
+    void onNewEnsemble(uint16_t) override {}
+    void onSetEnsembleLabel(DabLabel&) override {}
+    void onDateTimeUpdate(const dab_date_time_t&) override {}
+    void onFIBDecodeSuccess(bool ok, const uint8_t* bits) override {
+        int k = n_fib++;
+        if (k < fib_cap) {
+            uint8_t* o = fib + 33 * (size_t)k; o[0] = ok;
+            for (int i = 0; i < 32; i++) { uint8_t b = 0; for (int j = 0; j < 8; j++) b = (b << 1) | (bits[8 * i + j] & 1); o[1 + i] = b; }
+        }
+    }
+    void onNewImpulseResponse(std::vector<float>&& d) override { int k = n_cir++; if (k < cir_cap && d.size() == 2048) memcpy(cir + 2048 * (size_t)k, d.data(), 8192); }
+    void onConstellationPoints(std::vector<DSPCOMPLEX>&& d) override { int k = n_con++; if (k < con_cap && d.size() == 1200) memcpy(con + 2400 * (size_t)k, d.data(), 9600); }
+    void onNewNullSymbol(std::vector<DSPCOMPLEX>&&) override {}
+    void onTIIMeasurement(tii_measurement_t&&) override {}
+    void onMessage(message_level_t, const std::string&, const std::string&) override {}
+    void onInputFailure() override { failed = true; }
+};
+
+struct MemInput : InputInterface {
+    const DSPCOMPLEX* data; int64_t n; int64_t pos = 0;
+    MemInput(const float* iq, int64_t n_) : data((const DSPCOMPLEX*)iq), n(n_) {}
+    void setFrequency(int) override {}
+    int getFrequency() const override { return 0; }
+    bool is_ok() override { return pos < n; }
+    bool restart() override { pos = 0; return true; }
+    void stop() override {}
+    void reset() override {}
+    int32_t getSamples(DSPCOMPLEX* b, int32_t size) override { int64_t k = size; if (k > n - pos) k = n - pos; memcpy(b, data + pos, k * sizeof(DSPCOMPLEX)); pos += k; return (int32_t)k; }
+    std::vector<DSPCOMPLEX> getSpectrumSamples(int) override { return {}; }
+    int32_t getSamplesToRead() override { int64_t k = n - pos; return (int32_t)(k > (1 << 20) ? (1 << 20) : k); }
+    float setGain(int) override { return 0; }
+    float getGain() const override { return 0; }
+    int getGainCount() override { return 0; }
+    void setAgc(bool) override {}
+    std::string getDescription() override { return "mem"; }
+};
+}
+
+extern "C" {
+struct gpu_subch { int32_t subChId, startAddr, length, shortForm, uepTableIndex, uepLevel, eepProfileB, eepLevel, dabplus; char dump_path[256]; };
+struct gpu_run_io {
+    const float* iq; int64_t n_samples; int32_t disable_coarse, fft_placement;
+    int32_t n_subch; const gpu_subch* subch;
+    uint8_t* fib; int32_t fib_cap; float* cir; int32_t cir_cap; float* con; int32_t con_cap; float* snr; int32_t snr_cap; int32_t* corr; int32_t corr_cap;
+    int32_t n_fib, n_cir, n_con, n_snr, n_corr, n_sync_true, n_sync_false, n_services;
+    int32_t rs_calls[16], rs_uncorr[16], rs_corr[16];
+};
+
+int gpu_receiver_run(gpu_run_io* io)
+{
+    Rec rec;
+    rec.fib = io->fib; rec.fib_cap = io->fib_cap; rec.cir = io->cir; rec.cir_cap = io->cir_cap; rec.con = io->con; rec.con_cap = io->con_cap;
+    rec.snr = io->snr; rec.snr_cap = io->snr_cap; rec.corr = io->corr; rec.corr_cap = io->corr_cap;
+    MemInput in(io->iq, io->n_samples);
+    RadioReceiverOptions rro;
+    rro.decodeTII = false; rro.disableCoarseCorrector = io->disable_coarse != 0;
+    rro.fftPlacementMethod = io->fft_placement == 0 ? FFTPlacementMethod::StrongestPeak : FFTPlacementMethod::ThresholdBeforePeak;
+    std::vector<NullProgrammeHandler> handlers(io->n_subch > 0 ? io->n_subch : 1);
+    try {
+        GpuRadioReceiver rx(rec, in, rro);
+        rx.restart(false);
+        for (int i = 0; i < io->n_subch; i++) {
+            const gpu_subch& s = io->subch[i];
+            Subchannel sub;
+            sub.subChId = s.subChId; sub.startAddr = s.startAddr; sub.length = s.length;
+            sub.protectionSettings.shortForm = s.shortForm != 0; sub.protectionSettings.uepTableIndex = s.uepTableIndex; sub.protectionSettings.uepLevel = s.uepLevel;
+            sub.protectionSettings.eepProfile = s.eepProfileB ? EEPProtectionProfile::EEP_B : EEPProtectionProfile::EEP_A;
+            sub.protectionSettings.eepLevel = (EEPProtectionLevel)s.eepLevel;
+            rx.addSubchannel(handlers[i], s.dabplus ? AudioServiceComponentType::DABPlus : AudioServiceComponentType::DAB, std::string(s.dump_path), sub);
+        }
+        while (!rec.failed) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        rx.stop();
+    } catch (const std::exception& e) {
+        fprintf(stderr, "gpu_receiver_run: %s\n", e.what());
+        return -1;
+    }
+    io->n_fib = rec.n_fib; io->n_cir = rec.n_cir; io->n_con = rec.n_con; io->n_snr = rec.n_snr; io->n_corr = rec.n_corr;
+    io->n_sync_true = rec.n_sync_true; io->n_sync_false = rec.n_sync_false; io->n_services = rec.n_services;
+    for (int i = 0; i < io->n_subch && i < 16; i++) { io->rs_calls[i] = handlers[i].rs_calls; io->rs_uncorr[i] = handlers[i].rs_uncorr; io->rs_corr[i] = handlers[i].rs_corr; }
+    return 0;
+}
+}

@@ -97,7 +97,7 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
             for b in range(B):
                 nv = 0
                 for f in range(F):
-                    if info[b, f]["valid"]:
+                    if info[b, f]["valid"] == 1:
                         L = logs[b]
                         L["fib"].append(fb[b, f]); L["ok"].append(ok[b, f]); L["info"].append(info[b, f]); L["con"].append(cn[b, f])
                         if b == 0:
@@ -106,7 +106,7 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
                 for i in range(len(subs)):
                     m, fv = mscs[i]
                     logs[b]["msc"][i].append(m[b, fv[b]:4 * nv].tobytes())
-            if not info["valid"].any():
+            if not (info["valid"] == 1).any():
                 break
             done += F
         return logs

@@ -319,3 +319,52 @@ def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_
                 start_index=sidx[:k], frame_pos=fpos[:k], soft=soft[:k] if want_soft else None,
                 msc=[bufs[i][:lens[i]].tobytes() for i in range(len(subchs))],
                 n_sync_true=io.n_sync_true, n_sync_false=io.n_sync_false, n_frames=k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# our RadioReceiver drop-in (welle.io_amd/host) linked with the reference's FIBProcessor / DecoderAdapter objects
+GPU_EMU_SO = os.path.join(ROOT, "oracle", "_ref", "libwelle_gpu_emu.so")
+GPU_HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libwelle_gpu_hip.so")
+
+
+class GpuRunIO(C.Structure):
+    _fields_ = [("iq", C.c_void_p), ("n_samples", C.c_int64), ("disable_coarse", C.c_int32), ("fft_placement", C.c_int32),
+                ("n_subch", C.c_int32), ("subch", C.POINTER(RefSubch)),
+                ("fib", C.c_void_p), ("fib_cap", C.c_int32), ("cir", C.c_void_p), ("cir_cap", C.c_int32),
+                ("con", C.c_void_p), ("con_cap", C.c_int32), ("snr", C.c_void_p), ("snr_cap", C.c_int32),
+                ("corr", C.c_void_p), ("corr_cap", C.c_int32),
+                ("n_fib", C.c_int32), ("n_cir", C.c_int32), ("n_con", C.c_int32), ("n_snr", C.c_int32), ("n_corr", C.c_int32),
+                ("n_sync_true", C.c_int32), ("n_sync_false", C.c_int32), ("n_services", C.c_int32),
+                ("rs_calls", C.c_int32 * 16), ("rs_uncorr", C.c_int32 * 16), ("rs_corr", C.c_int32 * 16)]
+
+
+def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, lib=GPU_EMU_SO):
+    """Run GpuRadioReceiver (the facade mirror) over a cf32 stream; same outputs as receiver_run()."""
+    L = C.CDLL(lib)
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    nf = len(iq) // 196608 + 2
+    io = GpuRunIO(); io.iq = _p(iq); io.n_samples = len(iq); io.disable_coarse = int(disable_coarse); io.fft_placement = fft_placement
+    arr = (RefSubch * max(1, len(subchs)))(); paths = []
+    for i, s in enumerate(subchs):
+        arr[i].subChId = s.subch_id; arr[i].startAddr = s.start_cu; arr[i].length = s.size_cu
+        arr[i].shortForm = 0; arr[i].eepProfileB = int(s.profile_b); arr[i].eepLevel = s.level; arr[i].dabplus = int(s.dabplus)
+        path = os.path.join(dump_dir, "gpudump_%d_%d.msc" % (os.getpid(), s.subch_id))
+        if os.path.exists(path):
+            os.remove(path)
+        arr[i].dump_path = path.encode(); paths.append(path)
+    io.n_subch = len(subchs); io.subch = arr
+    fib = np.zeros((nf * 12, 33), np.uint8); io.fib = _p(fib); io.fib_cap = nf * 12
+    cir = np.zeros((nf * 2, 2048), np.float32); io.cir = _p(cir); io.cir_cap = nf * 2
+    con = np.zeros((nf, 1200), np.complex64); io.con = _p(con); io.con_cap = nf
+    snr = np.zeros(nf, np.float32); io.snr = _p(snr); io.snr_cap = nf
+    corr = np.zeros((nf, 2), np.int32); io.corr = _p(corr); io.corr_cap = nf
+    r = L.gpu_receiver_run(C.byref(io))
+    assert r == 0, "GpuRadioReceiver run failed"
+    msc = []
+    for pth in paths:
+        msc.append(open(pth, "rb").read() if os.path.exists(pth) else b"")
+        if os.path.exists(pth):
+            os.remove(pth)
+    return dict(fib=fib[:io.n_fib], cir=cir[:io.n_cir], con=con[:io.n_con], snr=snr[:io.n_snr], corr=corr[:io.n_corr], msc=msc,
+                n_sync_true=io.n_sync_true, n_sync_false=io.n_sync_false, n_services=io.n_services,
+                rs_calls=list(io.rs_calls), rs_uncorr=list(io.rs_uncorr), rs_corr=list(io.rs_corr))

@@ -325,6 +325,44 @@ int dabphy_stream_upload(dabphy_handle* h, const float* iq, uint64_t n_samples, 
     return dabphy_stream_bind_device(h, h->s_iq_own.p, n_samples, n_samples, n_samples, loop);
 }
 
+int dabphy_stream_open(dabphy_handle* h, uint64_t ring_samples)
+{
+    if (!h || ring_samples < 4 * (uint64_t)T_F) return DABPHY_ERR_INVALID;
+    const size_t bytes = (size_t)h->cfg.n_ensembles * ring_samples * sizeof(cf32);
+    int r;
+    if ((r = ensure(h, h->s_iq_own, bytes))) return r;
+    HIPCHK(h, hipMemsetAsync(h->s_iq_own.p, 0, bytes, h->stream));
+    return dabphy_stream_bind_device(h, h->s_iq_own.p, ring_samples, ring_samples, 0, 0);
+}
+
+int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples)
+{
+    if (!h || !iq || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring) return DABPHY_ERR_INVALID;
+    // the chain that may be running ahead must not race with the copy
+    HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    const uint64_t w = h->s_valid % h->s_ring;
+    const uint64_t first = std::min<uint64_t>(n_samples, h->s_ring - w);
+    for (uint32_t b = 0; b < h->cfg.n_ensembles; b++) {
+        cf32* dst = h->s_iq_own.as<cf32>() + (size_t)b * h->s_stride;
+        const cf32* src = reinterpret_cast<const cf32*>(iq) + (size_t)b * n_samples;
+        HIPCHK(h, hipMemcpyAsync(dst + w, src, first * sizeof(cf32), hipMemcpyHostToDevice, h->stream));
+        if (first < n_samples) HIPCHK(h, hipMemcpyAsync(dst, src + first, (n_samples - first) * sizeof(cf32), hipMemcpyHostToDevice, h->stream));
+    }
+    h->s_valid += n_samples;
+    return sync(h);
+}
+
+uint64_t dabphy_stream_consumed(dabphy_handle* h)
+{
+    if (!h) return 0;
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    if (hipStreamSynchronize(h->sync_stream) != hipSuccess) return 0;
+    if (hipMemcpy(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    uint64_t m = ~0ull;
+    for (auto& s : st) m = std::min<uint64_t>(m, (uint64_t)s.pos);
+    return m;
+}
+
 int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n)
 {
     if (!h || (n && !list)) return DABPHY_ERR_INVALID;
@@ -495,7 +533,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }
     {   // every ensemble locked through the whole batch -> no acquisition launches for the next chain
         bool all_locked = true;
-        for (const FrameDesc& d : h->h_desc) if (!d.valid) { all_locked = false; break; }
+        for (const FrameDesc& d : h->h_desc) if (d.valid != 1) { all_locked = false; break; }
         h->need_acquire = !all_locked;
     }
     return DABPHY_OK;

@@ -42,7 +42,7 @@ struct FrameDesc {
     int32_t f_prs;          // coarse+fine while the PRS was pulled
     int32_t L1;             // localPhase after the PRS (before the first sample of symbol 1)
     int32_t f_sym;          // coarse+fine while symbols 1..75 were pulled
-    int32_t valid;
+    int32_t valid;          // 0: no frame (not synchronised / not enough samples), 1: demodulated, 2: pending (inside the chain), 3: window search failed
     int32_t fine_after, coarse_after;   // correctors after the frame (reported like onFrequencyCorrectorChange)
     int32_t null_L, null_f;             // oscillator state while the trailing null symbol was pulled (onNewNullSymbol)
 };

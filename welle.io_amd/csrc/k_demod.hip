@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     const int t = threadIdx.x;
     const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
     const FrameDesc d = A.desc[(size_t)b * A.n_frames + f];
-    if (!d.valid) return;
+    if (d.valid != 1) return;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
     const uint32_t ring = (uint32_t)A.ring;
@@ -181,7 +181,7 @@ __global__ void k_snr(SnrArgs A)
         float* out = A.snr_out + (size_t)b * A.n_frames + f;
         const float snr_new = *out;
         *out = __int_as_float(0x7fc00000);                     // NaN = "no report for this frame"
-        if (!A.desc[(size_t)b * A.n_frames + f].valid) continue;
+        if (A.desc[(size_t)b * A.n_frames + f].valid != 1) continue;
         snr = (float)(0.7 * snr + 0.3 * (double)(int16_t)snr_new);
         if (++cnt > 10) { *out = snr; cnt = 0; }
     }

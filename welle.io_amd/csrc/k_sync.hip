@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
     if (startIndex < 0) {
         // ofdm-processor.cpp:347-350: SyncOnPhase failed -> notSynced (the 2048 samples are consumed)
         if (t == 0) {
-            d.start_index = startIndex;
+            d.start_index = startIndex; d.valid = 3;   // window search failed: SyncOnPhase -> notSynced
             dout = d;
             RxState& g = A.state[b];
             g.pos = st.pos + T_U;

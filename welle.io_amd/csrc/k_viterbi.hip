@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int u = A.map[4 * s + j];
-            int v = (u >= 0 && live && d.valid) ? (int)src[u] : 0;
+            int v = (u >= 0 && live && d.valid == 1) ? (int)src[u] : 0;
             v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
             word |= (uint32_t)v << (8 * j);
         }
@@ -340,7 +340,7 @@ __global__ void k_fib_crc(CrcArgs A)
         for (int bit = 0; bit < 8; bit++) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
     }
     crc ^= 0xFFFF;
-    const bool valid = A.desc[i / 12].valid != 0;
+    const bool valid = A.desc[i / 12].valid == 1;
     A.ok[i] = (valid && crc == (((uint32_t)p[30] << 8) | p[31])) ? 1 : 0;
 }
 
@@ -351,7 +351,7 @@ __global__ void k_fic_ratio(CrcArgs A)
     if (b >= A.n_ens) return;
     int r = A.state[b].fic_ratio;
     for (int f = 0; f < A.n_frames; f++) {
-        if (!A.desc[(size_t)b * A.n_frames + f].valid) continue;
+        if (A.desc[(size_t)b * A.n_frames + f].valid != 1) continue;
         for (int k = 0; k < 12; k++) {
             if (A.ok[((size_t)b * A.n_frames + f) * 12 + k]) { if (r < 10) r++; }
             else if (r > 0) r--;
