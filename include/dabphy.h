@@ -196,6 +196,11 @@ int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uin
 int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
                         float* ms_decode);
 
+/* Device self-test of the reciprocal-based 127/x the demapper uses in place of the IEEE division sequence
+ * (ofdm-decoder.cpp:208 computes 127.0f / l1_norm): every float x in [2^-100, 2^100] is divided both ways on the device.
+ * counts[0] = mismatches of the 4-instruction variant, counts[1] = of the 6-instruction variant, counts[2] = values tried. */
+int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ def pytest_configure(config):
 
 
 EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "libdabphy_emu.so")
-GPU_LIB = os.path.join(PKG_DIR, "libdabphy_hip.so")
+GPU_LIB = os.environ.get("DABPHY_LIB") or os.path.join(PKG_DIR, "libdabphy_hip.so")
 ORC_LIB = os.path.join(ROOT, "oracle", "libdabphy_oracle.so")
 
 

@@ -2,6 +2,7 @@
 // CPU execution model (same results, lane exchange through the emulated wave instead of DPP instructions).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "dabphy_common.h"
 
 namespace dabphy {
 
@@ -18,5 +19,29 @@ static inline float chain16(float acc, float x, int nk)
     }
     return acc;
 }
+
+// packed complex arithmetic: the same IEEE operations, spelled out
+static inline cf32 pk_add(cf32 a, cf32 b) { return cadd(a, b); }
+static inline cf32 pk_sub(cf32 a, cf32 b) { return csub(a, b); }
+static inline cf32 pk_cmul(cf32 a, cf32 b) { return cmul(a, b); }
+static inline cf32 pk_cmulc(cf32 a, cf32 b) { return cmul(a, cconj(b)); }
+static inline cf32 pk_sub_ib(cf32 a, cf32 b) { cf32 r; r.re = a.re + b.im; r.im = a.im - b.re; return r; }
+static inline cf32 pk_add_ib(cf32 a, cf32 b) { cf32 r; r.re = a.re - b.im; r.im = a.im + b.re; return r; }
+static inline int cvt_i32_trunc(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 0x7fffffff;
+    if (x <= -2147483648.0f) return (int)0x80000000;
+    return (int)x;
+}
+
+template <int VARIANT> static inline float div127_fast(float x) { return 127.0f / x; }
+constexpr float DIV127_LO = 0x1p-100f, DIV127_HI = 0x1p100f;
+// the model decides per lane: both sides of a wave_all() branch must compute the same result wherever the fast side is legal
+static inline bool wave_all(bool p) { return p; }
+
+// LDS-DMA model: the copy happens at issue time
+template <int OFF> static inline void lds_dma16(const void* gptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + OFF + 16 * hipemu_lane(), (const char*)gptr + OFF, 16); }
+static inline void lds_dma_wait() {}
 
 } // namespace dabphy

@@ -81,10 +81,30 @@ def check_demod(d, n_frames, snr_db, seed, early=100):
     return soft
 
 
-def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False):
+def check_demod_degenerate(d, seed=21):
+    """magnitudes outside the range where the demapper's fast 127/x applies, zeroed symbols, and NaN / inf samples: the
+    float -> int8 corner cases of ofdm-decoder.cpp:208-212 as an x86-64 build of the reference resolves them"""
+    x = synth.make_stream(3, snr_db=20, seed=seed)
+    base = cut_frames(x, 2, 100)
+    cases = []
+    for scale in (1e-30, 1e-22, 1e-12, 1e14, 3e18):
+        cases.append((base * np.complex64(scale)).astype(np.complex64))
+    z = base.copy(); z[0, 2048 + 5 * 2552:2048 + 7 * 2552] = 0; z[1, :4000] = 0
+    cases.append(z)
+    w = base.copy(); w[0, 2048 + 9 * 2552 + 700] = np.nan; w[1, 2048 + 30 * 2552 + 900] = np.inf
+    cases.append(w)
+    for frames in cases:
+        d.reset()
+        soft, con, snr = d.demod_frames(frames)
+        with np.errstate(all="ignore"):
+            so, co, sn = R.orc_demod_frames(frames)
+        assert np.array_equal(soft, so), "%d of %d soft bits differ" % ((soft != so).sum(), soft.size)
+
+
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True):
     """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
     from welle_io_amd import capi  # noqa: F401
-    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync)
+    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
@@ -92,7 +112,7 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
         done = 0
         while done < n_frames_total:
             d.process(F)
-            info = d.frame_info(); fb, ok = d.fibs(); cn = d.constellation()
+            info = d.frame_info(); fb, ok = d.fibs(); cn = d.constellation() if con else np.zeros((B, F, 1200), np.complex64)
             mscs = [d.msc(i) for i in range(len(subs))]
             for b in range(B):
                 nv = 0
@@ -114,11 +134,11 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
         d.close()
 
 
-def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False):
+def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True):
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
     o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse)
-    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse)
+    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con)
     for b in range(B):
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)
@@ -128,7 +148,8 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
         assert np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:]), "FIB bytes differ"
         inf = np.array(L["info"][:n])
         assert np.array_equal(np.stack([inf["fine"], inf["coarse"]], 1), o["corr"][:n]), "correctors differ"
-        assert np.array_equal(np.array(L["con"][:n]).view(np.uint32), o["con"][:n].view(np.uint32)), "constellation differs"
+        if con:
+            assert np.array_equal(np.array(L["con"][:n]).view(np.uint32), o["con"][:n].view(np.uint32)), "constellation differs"
         if b == 0:
             assert np.array_equal(np.array(L["soft"][:n]), o["soft"][:n]), "soft bits differ"
         rep = inf["snr"][~np.isnan(inf["snr"])]

@@ -24,6 +24,10 @@ def test_demod(emu):
     P.check_demod(emu, 2, snr_db=14, seed=2)
 
 
+def test_demod_degenerate_magnitudes(emu):
+    P.check_demod_degenerate(emu)
+
+
 def test_demod_zero_carriers(emu):
     """r1 == 0 (the reference's inf*0 -> NaN -> int8 case, SURVEY C-3): all-zero symbols give soft bit 0"""
     frames = np.zeros((1, 2048 + 75 * 2552), np.complex64)

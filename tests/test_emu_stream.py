@@ -29,3 +29,7 @@ def test_big_batch_tiled_gather(emu):
 def test_pipelined_sync(emu):
     """throughput mode: batch k+1 synchronised ahead of batch k's decode gives the same bytes (coarse corrector off)"""
     P.check_stream_vs_oracle(factory, 16, -20, 50, 14, False, F=3, pipeline_sync=True, disable_coarse=True)
+
+
+def test_stream_without_constellation(emu):
+    P.check_stream_vs_oracle(factory, 12, 75, 10, 7, False, con=False)

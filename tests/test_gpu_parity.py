@@ -50,6 +50,18 @@ def test_demod_snr_report(gpu):
     assert soft.shape[0] == 12
 
 
+def test_demod_degenerate_magnitudes(gpu):
+    P.check_demod_degenerate(gpu)
+
+
+def test_div127_exhaustive(gpu):
+    """the reciprocal-based 127/x of the demapper equals the IEEE quotient for every float in [2^-100, 2^100]"""
+    bad4, bad6, tried = gpu.selftest_div127()
+    assert tried == 200 * 2 ** 23 + 1
+    assert bad6 == 0, "6-instruction variant: %d mismatches" % bad6
+    assert bad4 == 0, "4-instruction variant (the one k_demod is built with): %d mismatches" % bad4
+
+
 def test_demod_zero_carriers(gpu):
     frames = np.zeros((1, 2048 + 75 * 2552), np.complex64)
     soft, con, _ = gpu.demod_frames(frames)

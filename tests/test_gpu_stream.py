@@ -45,3 +45,8 @@ def test_big_batch_tiled_gather(gpu):
 def test_pipelined_sync(gpu):
     """batch k+1 is synchronised on a second stream while batch k is decoded: same bytes as the serial order"""
     P.check_stream_vs_oracle(factory, 16, -20, 50, 26, False, F=4, pipeline_sync=True, disable_coarse=True, B=3)
+
+
+def test_stream_without_constellation(gpu):
+    """the demod kernel variant without the constellation tap (what the throughput path runs)"""
+    P.check_stream_vs_oracle(factory, 12, 75, 10, 10, False, con=False)

@@ -129,6 +129,11 @@ class DabPhy:
         self._chk(self.lib.dabphy_time_demod(self.h, _p(frames), frames.shape[0], n_ens, n_frames, mix, f_hz, iters, C.byref(ms)))
         return ms.value
 
+    def selftest_div127(self):
+        c = (C.c_uint64 * 3)()
+        self._chk(self.lib.dabphy_selftest_div127(self.h, c))
+        return [int(x) for x in c]
+
     def time_viterbi(self, nbits, n_codewords, iters=3):
         a = C.c_float(0); b = C.c_float(0)
         self._chk(self.lib.dabphy_time_viterbi(self.h, nbits, n_codewords, iters, C.byref(a), C.byref(b)))

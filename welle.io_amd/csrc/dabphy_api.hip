@@ -698,6 +698,21 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
     return sync(h);
 }
 
+int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)
+{
+    if (!h || !counts) return DABPHY_ERR_INVALID;
+    unsigned long long* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, 3 * sizeof *d));
+    HIPCHK(h, hipMemsetAsync(d, 0, 3 * sizeof *d, h->stream));
+    launch_selftest_div127(d, h->stream);
+    unsigned long long host[3];
+    HIPCHK(h, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    const int r = sync(h);
+    (void)hipFree(d);
+    for (int i = 0; i < 3; i++) counts[i] = host[i];
+    return r;
+}
+
 int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
                       int32_t mix, int32_t f_hz, uint32_t iters, float* ms)
 {

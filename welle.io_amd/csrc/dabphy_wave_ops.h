@@ -3,6 +3,7 @@
 // angle brackets so the include path decides.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "dabphy_common.h"
 
 namespace dabphy {
 
@@ -25,5 +26,80 @@ __device__ __forceinline__ float chain16(float acc, float x, int nk)
     return acc;
 }
 #undef DABPHY_DPP_ADD
+
+// ---- packed complex arithmetic: one cf32 = one even-aligned VGPR pair, every operation one v_pk_*_f32 whose op_sel /
+// neg modifiers do the real/imaginary swizzles (the compiler's own packing of scalar complex code spends one v_mov per
+// swizzle).  Same IEEE operations in the same order as cmul/cadd/csub of dabphy_common.h: results are bit-identical.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f c2v(cf32 c) { v2f v; v.x = c.re; v.y = c.im; return v; }
+__device__ __forceinline__ cf32 v2c(v2f v) { cf32 c; c.re = v.x; c.im = v.y; return c; }
+
+__device__ __forceinline__ cf32 pk_add(cf32 a, cf32 b) { return v2c(c2v(a) + c2v(b)); }
+__device__ __forceinline__ cf32 pk_sub(cf32 a, cf32 b) { return v2c(c2v(a) - c2v(b)); }
+// a * b = (a.re b.re - a.im b.im, a.re b.im + a.im b.re).  The multiplies are vector C (the compiler folds the swizzles
+// into op_sel); only the add with one negated half needs asm -- back-to-back dependent asm statements would cost an s_nop.
+__device__ __forceinline__ cf32 pk_cmul(cf32 a, cf32 b)
+{
+    const v2f av = c2v(a), bv = c2v(b);
+    const v2f p = av.xx * bv;                   // (a.re b.re, a.re b.im)
+    const v2f q = av.yy * bv.yx;                // (a.im b.im, a.im b.re)
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));
+    return v2c(r);
+}
+// a * conj(b) = (a.re b.re - a.im (-b.im), a.re (-b.im) + a.im b.re) = (p.x + q.x, q.y - p.y): negations are exact
+__device__ __forceinline__ cf32 pk_cmulc(cf32 a, cf32 b)
+{
+    const v2f av = c2v(a), bv = c2v(b);
+    const v2f p = av.xx * bv;
+    const v2f q = av.yy * bv.yx;
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    return v2c(r);
+}
+// a - i b = (a.re + b.im, a.im - b.re)   and   a + i b = (a.re - b.im, a.im + b.re)
+__device__ __forceinline__ cf32 pk_sub_ib(cf32 a, cf32 b)
+{
+    v2f r; const v2f av = c2v(a), bv = c2v(b);
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return v2c(r);
+}
+__device__ __forceinline__ cf32 pk_add_ib(cf32 a, cf32 b)
+{
+    v2f r; const v2f av = c2v(a), bv = c2v(b);
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return v2c(r);
+}
+// float -> int32 as v_cvt_i32_f32 does it (truncate, NaN -> 0, saturate)
+__device__ __forceinline__ int cvt_i32_trunc(float x) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+
+// 127 / x for x in [2^-100, 2^100]: v_rcp_f32 (1 ulp) + one residual correction, 4 instructions instead of the 11 of the
+// IEEE division sequence.  DIV127_VARIANT 1 adds a second correction.  dabphy_selftest_div127 compares every variant
+// with the correctly rounded quotient for ALL floats of that range on the device it runs on; k_demod only uses the
+// variant that test proves exact (tests/test_gpu_parity.py::test_div127_exhaustive).
+template <int VARIANT>
+__device__ __forceinline__ float div127_fast(float x)
+{
+    const float y = __builtin_amdgcn_rcpf(x);
+    float q = 127.0f * y;
+    float r = __builtin_fmaf(-q, x, 127.0f);
+    q = __builtin_fmaf(r, y, q);
+    if (VARIANT >= 1) { r = __builtin_fmaf(-q, x, 127.0f); q = __builtin_fmaf(r, y, q); }
+    return q;
+}
+constexpr float DIV127_LO = 0x1p-100f, DIV127_HI = 0x1p100f;
+// true when every lane of the wave passes
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+
+// LDS-DMA: each of the 64 lanes fetches 16 bytes from its own global address + OFF; the wave's 1 KiB lands contiguously at
+// lds_wave_base + OFF + 16 * lane without passing through VGPRs (global_load_lds_dwordx4, gfx950).  lds_wave_base must be
+// wave-uniform (it travels in M0); OFF is the instruction's immediate offset (< 4096), applied to both addresses, so four
+// consecutive KiB share one address computation and one M0 write.  Completion is tracked by vmcnt: lds_dma_wait() + a
+// barrier before any lane reads the data.
+template <int OFF>
+__device__ __forceinline__ void lds_dma16(const void* gptr, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 } // namespace dabphy

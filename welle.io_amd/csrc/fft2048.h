@@ -23,6 +23,7 @@
 // wave-uniform (SGPRs).
 #pragma once
 #include "dabphy_common.h"
+#include <dabphy_wave_ops.h>
 
 namespace dabphy {
 
@@ -49,36 +50,33 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles& w, const cf32* __
         for (int i = 0; i < 3; i++) w.c512[a][i] = tw[(t + 128 * a) * (i + 1)];
 }
 
-template <bool INV> __device__ __forceinline__ cf32 twc(cf32 w) { if (INV) w.im = -w.im; return w; }
+// x * w (forward) or x * conj(w) (inverse): three packed instructions either way
+template <bool INV> __device__ __forceinline__ cf32 twmul(cf32 x, cf32 w) { return INV ? pk_cmulc(x, w) : pk_cmul(x, w); }
 
 // kf_bfly2 (kiss_fft.c:21-42), one butterfly
+template <bool INV>
 __device__ __forceinline__ void bfly2(cf32& f0, cf32& f1, cf32 tw)
 {
-    const cf32 t = cmul(f1, tw);
-    f1 = csub(f0, t);
-    f0 = cadd(f0, t);
+    const cf32 t = twmul<INV>(f1, tw);
+    f1 = pk_sub(f0, t);
+    f0 = pk_add(f0, t);
 }
 
-// kf_bfly4 (kiss_fft.c:44-90), one butterfly
+// kf_bfly4 (kiss_fft.c:44-90), one butterfly: 17 packed instructions
 template <bool INV>
 __device__ __forceinline__ void bfly4(cf32& f0, cf32& f1, cf32& f2, cf32& f3, cf32 tw1, cf32 tw2, cf32 tw3)
 {
-    const cf32 s0 = cmul(f1, tw1);
-    const cf32 s1 = cmul(f2, tw2);
-    const cf32 s2 = cmul(f3, tw3);
-    const cf32 s5 = csub(f0, s1);
-    f0 = cadd(f0, s1);
-    const cf32 s3 = cadd(s0, s2);
-    const cf32 s4 = csub(s0, s2);
-    f2 = csub(f0, s3);
-    f0 = cadd(f0, s3);
-    if (INV) {
-        f1.re = s5.re - s4.im; f1.im = s5.im + s4.re;
-        f3.re = s5.re + s4.im; f3.im = s5.im - s4.re;
-    } else {
-        f1.re = s5.re + s4.im; f1.im = s5.im - s4.re;
-        f3.re = s5.re - s4.im; f3.im = s5.im + s4.re;
-    }
+    const cf32 s0 = twmul<INV>(f1, tw1);
+    const cf32 s1 = twmul<INV>(f2, tw2);
+    const cf32 s2 = twmul<INV>(f3, tw3);
+    const cf32 s5 = pk_sub(f0, s1);
+    f0 = pk_add(f0, s1);
+    const cf32 s3 = pk_add(s0, s2);
+    const cf32 s4 = pk_sub(s0, s2);
+    f2 = pk_sub(f0, s3);
+    f0 = pk_add(f0, s3);
+    if (INV) { f1 = pk_add_ib(s5, s4); f3 = pk_sub_ib(s5, s4); }     // f1 = s5 + i s4, f3 = s5 - i s4
+    else     { f1 = pk_sub_ib(s5, s4); f3 = pk_add_ib(s5, s4); }
 }
 
 // Round A for one half (h = 0: inputs x[t + 256 j], h = 1: inputs x[t + 128 + 256 j], j = 0..7 in x[]) and the
@@ -90,9 +88,9 @@ __device__ __forceinline__ void fft_round_a(const cf32 (&x)[8], int h, cf32* lds
 #pragma unroll
     for (int j5 = 0; j5 < 4; j5++) { a[2 * j5] = x[j5]; a[2 * j5 + 1] = x[j5 + 4]; }
 #pragma unroll
-    for (int j5 = 0; j5 < 4; j5++) bfly2(a[2 * j5], a[2 * j5 + 1], twc<INV>(w.t0));
-    bfly4<INV>(a[0], a[2], a[4], a[6], twc<INV>(w.t0), twc<INV>(w.t0), twc<INV>(w.t0));
-    bfly4<INV>(a[1], a[3], a[5], a[7], twc<INV>(w.a1), twc<INV>(w.a2), twc<INV>(w.a3));
+    for (int j5 = 0; j5 < 4; j5++) bfly2<INV>(a[2 * j5], a[2 * j5 + 1], w.t0);
+    bfly4<INV>(a[0], a[2], a[4], a[6], w.t0, w.t0, w.t0);
+    bfly4<INV>(a[1], a[3], a[5], a[7], w.a1, w.a2, w.a3);
     const int b = t + 128 * h;
     const int j1 = b & 3, j2 = (b >> 2) & 3, j3 = (b >> 4) & 3, j4 = (b >> 6) & 3;
     const int q = 64 * j1 + 16 * j2 + 4 * j3 + (j4 ^ j2);           // chunk index with the E1 row swizzle
@@ -102,11 +100,14 @@ __device__ __forceinline__ void fft_round_a(const cf32 (&x)[8], int h, cf32* lds
         dst[s ^ j1] = make_float4(a[2 * s].re, a[2 * s].im, a[2 * s + 1].re, a[2 * s + 1].im);
 }
 
-// Rounds B and C.  Out: v[j] = X[t + 128 j].  Starts with the barrier that publishes round A's stores.
-template <bool INV>
-__device__ __forceinline__ void fft_rounds_bc(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t)
+// Rounds B and C.  Out: v[j] = X[t + 128 j].  Starts with the barrier that publishes round A's stores; `after_a` runs
+// right behind that barrier (every thread has consumed its round-A inputs: the place to start fetching the next symbol).
+struct FftNoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool INV, typename Hook = FftNoHook>
+__device__ __forceinline__ void fft_rounds_bc(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t, Hook after_a = Hook())
 {
     __syncthreads();
+    after_a();
     {
         const int c = t >> 3, k = t & 7;
         const int sw = (8 * (c & 3)) ^ (2 * (c >> 2));
@@ -115,14 +116,14 @@ __device__ __forceinline__ void fft_rounds_bc(cf32 (&v)[16], cf32* lds, const Ff
 #pragma unroll
             for (int a = 0; a < 4; a++) v[4 * b + a] = lds[(128 * c + k + 8 * a + 32 * b) ^ sw];
         {
-            const cf32 w1 = twc<INV>(w.twB[4 * k]), w2 = twc<INV>(w.twB[8 * k]), w3 = twc<INV>(w.twB[12 * k]);   // tw[64k(i+1)]
+            const cf32 w1 = w.twB[4 * k], w2 = w.twB[8 * k], w3 = w.twB[12 * k];   // tw[64k(i+1)]
 #pragma unroll
             for (int b = 0; b < 4; b++) bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], w1, w2, w3);
         }
 #pragma unroll
         for (int a = 0; a < 4; a++) {
             const int kp = k + 8 * a;                                                                              // tw[16 k'(i+1)]
-            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.twB[kp]), twc<INV>(w.twB[2 * kp]), twc<INV>(w.twB[3 * kp]));
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], w.twB[kp], w.twB[2 * kp], w.twB[3 * kp]);
         }
         __syncthreads();        // everyone has read exchange 1
         const int sw2 = 8 * (c & 1);
@@ -139,10 +140,10 @@ __device__ __forceinline__ void fft_rounds_bc(cf32 (&v)[16], cf32* lds, const Ff
             for (int a = 0; a < 4; a++) v[4 * b + a] = lds[(t + 128 * a + 512 * b) ^ (8 * (a & 1))];
 #pragma unroll
         for (int b = 0; b < 4; b++)
-            bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], twc<INV>(w.c128[0]), twc<INV>(w.c128[1]), twc<INV>(w.c128[2]));
+            bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], w.c128[0], w.c128[1], w.c128[2]);
 #pragma unroll
         for (int a = 0; a < 4; a++)
-            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], twc<INV>(w.c512[a][0]), twc<INV>(w.c512[a][1]), twc<INV>(w.c512[a][2]));
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], w.c512[a][0], w.c512[a][1], w.c512[a][2]);
     }
     // v[4b + a] = X[t + 128a + 512b] = X[t + 128 (a + 4b)]  -> already in j = a + 4b order
 }

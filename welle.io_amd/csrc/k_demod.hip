@@ -14,6 +14,7 @@
 // leave as coalesced 8-byte stores.
 #include "fft2048.h"
 #include "dabphy_kernels.h"
+#include <dabphy_wave_ops.h>
 
 namespace dabphy {
 
@@ -26,11 +27,31 @@ __device__ __forceinline__ int32_t mod_rate(int64_t x)
 
 // Position of a symbol's useful part as seen by thread t: ring index of its sample t and that sample's oscillator phase.
 struct SymCursor { uint32_t a; int32_t ph; };
-struct MixSteps { int32_t s128, s256, sTS; };          // (128 f, 256 f, T_s f) mod RATE
+struct MixSteps { int32_t s128, sTS; uint32_t s256_bytes; };   // (128 f, T_s f) mod RATE; 8 * ((256 f) mod RATE)
 
-// One half of a symbol in round-A order: x[j] = sample (t + 128h + 256j) * osc[phase]   (ofdm-processor.cpp:211-214)
-__device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__ iq, uint32_t ring, const cf32* __restrict__ nco,
-                                          const SymCursor& c, const MixSteps& st, int h, int mix)
+constexpr uint32_t NCO_BYTES = (uint32_t)INPUT_RATE * 8u;      // the oscillator table, one cf32 per phase step
+
+// Oscillator values of one symbol in round-A order: o[8h + j] = osc[phase(t + 128h + 256j)]   (ofdm-processor.cpp:211-214).
+// The phase walks in table BYTES so that a load is uniform base + 32-bit lane offset; p - s wraps through
+// min(p - s, p - s + size) in unsigned arithmetic.  Issued one symbol ahead: the gather (L2 latency, HBM for large
+// |f|) is in flight while the previous symbol is demapped.
+__device__ __forceinline__ void osc_fetch(cf32 (&o)[16], const cf32* __restrict__ nco, const SymCursor& c, const MixSteps& st)
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        int32_t ph = c.ph; if (h) { ph -= st.s128; if (ph < 0) ph += INPUT_RATE; }
+        uint32_t pb = (uint32_t)ph * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            o[8 * h + j] = *reinterpret_cast<const cf32*>(reinterpret_cast<const char*>(nco) + pb);
+            pb -= st.s256_bytes; { const uint32_t w_ = pb + NCO_BYTES; pb = w_ < pb ? w_ : pb; }
+        }
+    }
+}
+
+// One half of a symbol straight from the sample ring in HBM: x[j] = sample (t + 128h + 256j), times o[8h + j] when mixing
+__device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__ iq, uint32_t ring, const SymCursor& c,
+                                          const cf32 (&o)[16], int h, int mix)
 {
     uint32_t a = c.a + 128u * h; if (a >= ring) a -= ring;
 #pragma unroll
@@ -38,26 +59,53 @@ __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__
         x[j] = iq[a];
         a += 256u; if (a >= ring) a -= ring;
     }
-    if (!mix) return;
-    int32_t ph = c.ph; if (h) { ph -= st.s128; if (ph < 0) ph += INPUT_RATE; }
-    cf32 o[8];
+    if (mix) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        o[j] = nco[(uint32_t)ph];
-        ph -= st.s256; if (ph < 0) ph += INPUT_RATE;
+        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[8 * h + j]);
     }
-#pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = cmul(x[j], o[j]);
 }
 
-// bins held by thread t after the transform: t + 128 j.  Carriers live in j = 0..5 (k = +1..+768; bin 0 itself is
-// unused), j = 6 (bin 768, thread 0 only) and j = 10..15 (k = -768..-1).  PJ maps those 13 j to a compact index.
-__device__ __forceinline__ constexpr int pj_of(int j) { return j < 7 ? j : j - 3; }
+// ... or from the LDS stage an earlier LDS-DMA filled with the symbol's 2048 samples in natural order
+__device__ __forceinline__ void stage_half(cf32 (&x)[8], const cf32* stage, const cf32 (&o)[16], int h, int mix, int t)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = stage[t + 128 * h + 256 * j];
+    if (mix) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[8 * h + j]);
+    }
+}
 
+// Bins held by thread t after the transform: t + 128 j.  Carriers are k = +1..+768 (bins 1..768) and k = -768..-1 (bins
+// 1280..2047): j = 0..5 and 10..15 for every thread but thread 0, whose j = 0 is the unused DC bin and which owns bin 768
+// (j = 6) instead.  So every thread demaps exactly 12 carriers: slot q < 6 is j = q (thread 0, q = 0: j = 6), slot q >= 6
+// is j = q + 4.
+constexpr int N_SLOTS = 12;
+#ifndef DIV127_VARIANT
+#define DIV127_VARIANT 0
+#endif
+#ifndef DEMOD_STAGE
+#define DEMOD_STAGE 1
+#endif
+__device__ __forceinline__ void carrier_slots(cf32 (&c)[N_SLOTS], const cf32 (&v)[16], int t)
+{
+    c[0].re = t == 0 ? v[6].re : v[0].re; c[0].im = t == 0 ? v[6].im : v[0].im;
+#pragma unroll
+    for (int q = 1; q < 6; q++) c[q] = v[q];
+#pragma unroll
+    for (int q = 6; q < N_SLOTS; q++) c[q] = v[q + 4];
+}
+
+template <bool CON>
 __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
 {
     __shared__ __attribute__((aligned(16))) cf32 tile[T_U];
     __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
+#if DEMOD_STAGE
+    __shared__ __attribute__((aligned(16))) cf32 stage[T_U];      // next symbol's raw samples, filled by LDS-DMA
+#else
+    cf32* const stage = nullptr;
+#endif
     __shared__ __attribute__((aligned(16))) int8_t softbuf[SOFT_PER_SYM];
     const int t = threadIdx.x;
     const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
@@ -71,14 +119,11 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     if (s_begin >= L_SYM) return;
 
     FftTwiddles w; fft_load_twiddles(w, A.tab.tw, twB, t);
-    uint32_t sidx2[7];                                           // packed int16 pairs: soft-bit index of the 13 carrier bins
+    int sidx[N_SLOTS];                                           // soft-bit index (freq-interleaver.cpp:88-91 inverted) of each slot
 #pragma unroll
-    for (int q = 0; q < 7; q++) {
-        const int j0 = 2 * q, j1 = 2 * q + 1;                    // compact indices 2q, 2q+1 -> j
-        const int ja = j0 < 7 ? j0 : j0 + 3, jb = j1 < 7 ? j1 : j1 + 3;
-        const uint32_t lo = (uint16_t)A.tab.bin2soft[t + 128 * ja];
-        const uint32_t hi = (j1 < 13) ? (uint16_t)A.tab.bin2soft[t + 128 * jb] : 0xffffu;
-        sidx2[q] = lo | (hi << 16);
+    for (int q = 0; q < N_SLOTS; q++) {
+        const int j = q >= 6 ? q + 4 : (q == 0 && t == 0) ? 6 : q;
+        sidx[q] = A.tab.bin2soft[t + 128 * j];
     }
 
     // offset (from d.pos) of the useful part of symbol s: PRS at start_index; s >= 1 at J0 + (s-1) T_s + T_g.
@@ -91,17 +136,18 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         else c.ph = mod_rate((int64_t)d.L1 - (int64_t)(off - J0 + t + 1) * d.f_sym);
         return c;
     };
-    auto steps_for = [&](int32_t fhz) { MixSteps m; m.s128 = mod_rate(128LL * fhz); m.s256 = mod_rate(256LL * fhz); m.sTS = mod_rate((int64_t)T_S * fhz); return m; };
+    auto steps_for = [&](int32_t fhz) { MixSteps m; m.s128 = mod_rate(128LL * fhz); m.s256_bytes = 8u * (uint32_t)mod_rate(256LL * fhz); m.sTS = mod_rate((int64_t)T_S * fhz); return m; };
 
-    cf32 prev[13], v[16];
+    cf32 prev[N_SLOTS], v[16], osc[16];
     {   // reference symbol of the chunk (the PRS for chunk 0)
         const int sref = s_begin - 1;
         const int32_t off = sref == 0 ? d.start_index : J0 + (sref - 1) * T_S + T_G;
         const SymCursor c = cursor_at(off);
         const MixSteps ms = steps_for(sref == 0 ? d.f_prs : d.f_sym);
+        if (A.mix) osc_fetch(osc, nco, c, ms);
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, nco, c, ms, h, A.mix); fft_round_a<false>(x, h, tile, w, t); }
+        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, h, A.mix); fft_round_a<false>(x, h, tile, w, t); }
         fft_rounds_bc<false>(v, tile, w, t);
         if (sref == 0 && A.prs_mag) {
             // |bin| of the PRS for the SNR estimate (ofdm-decoder.cpp:240-266): stored in bin order, summed by k_snr_frames
@@ -109,37 +155,85 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
 #pragma unroll
             for (int j = 0; j < 16; j++) pm[t + 128 * j] = hypotf_exact(v[j].re, v[j].im);
         }
-#pragma unroll
-        for (int j = 0; j < 16; j++) if (j < 7 || j > 9) prev[pj_of(j)] = v[j];
+        carrier_slots(prev, v, t);
     }
     const size_t slot = (size_t)((d.frame_no) % A.soft_ring);
     int8_t* soft_frame = A.soft + ((size_t)b * A.soft_ring + slot) * SOFT_PER_FRAME;
-    cf32* con_frame = A.con ? A.con + ((size_t)b * A.n_frames + f) * 1200 : nullptr;
+    cf32* con_frame = CON ? A.con + ((size_t)b * A.n_frames + f) * 1200 : nullptr;
 
     SymCursor cur = cursor_at(J0 + (s_begin - 1) * T_S + T_G);
     const MixSteps ms = steps_for(d.f_sym);
+    // Sample prefetch: while symbol s is transformed, the 16 KiB of symbol s+1 travel HBM -> LDS by LDS-DMA (no VGPRs, no
+    // wave waiting on HBM).  Wave w copies samples 1024w .. 1024w+1023 as 8 x 1 KiB (lane l of KiB c: samples 128c + 2l,
+    // 128c + 2l + 1), four KiB per address computation.  A symbol whose useful part wraps around the end of the sample ring
+    // (once per ring revolution) takes the direct path instead.
+    const int lane = t & 63, wv = t >> 6;
+    uint32_t sym0 = (uint32_t)((d.pos + J0 + (int64_t)(s_begin - 1) * T_S + T_G) % A.ring);   // ring index of sample 0 (uniform)
+    auto dma_ok = [&](uint32_t a0) { return DEMOD_STAGE && a0 + (uint32_t)T_U <= ring; };
+    auto dma_issue = [&](uint32_t a0) {
+        const cf32* g = iq + a0 + 1024 * wv + 2 * lane;
+        cf32* l = stage + 1024 * wv;
+        lds_dma16<0>(g, l); lds_dma16<1024>(g, l); lds_dma16<2048>(g, l); lds_dma16<3072>(g, l);
+        lds_dma16<0>(g + 512, l + 512); lds_dma16<1024>(g + 512, l + 512); lds_dma16<2048>(g + 512, l + 512); lds_dma16<3072>(g + 512, l + 512);
+    };
+    bool staged = dma_ok(sym0);
+    if (A.mix) osc_fetch(osc, nco, cur, ms);
+    if (staged) dma_issue(sym0);       // overlaps nothing yet (the reference symbol is done), but primes the pipeline
     for (int s = s_begin; s < s_end; s++) {
-        __syncthreads();                                         // tile + softbuf free again
+        if (staged) lds_dma_wait();
+        __syncthreads();                                         // tile + softbuf free again, stage complete
 #pragma unroll
-        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, nco, cur, ms, h, A.mix); fft_round_a<false>(x, h, tile, w, t); }
-        fft_rounds_bc<false>(v, tile, w, t);
+        for (int h = 0; h < 2; h++) {
+            cf32 x[8];
+            if (staged) stage_half(x, stage, osc, h, A.mix, t); else load_half(x, iq, ring, cur, osc, h, A.mix);
+            fft_round_a<false>(x, h, tile, w, t);
+        }
+        uint32_t next0 = sym0 + T_S; if (next0 >= ring) next0 -= ring;
+        const bool next_staged = (s + 1 < s_end) && dma_ok(next0);
+        fft_rounds_bc<false>(v, tile, w, t, [&]() { if (next_staged) dma_issue(next0); });
+        sym0 = next0; staged = next_staged;
         cur.a += T_S; if (cur.a >= ring) cur.a -= ring;
         cur.ph -= ms.sTS; if (cur.ph < 0) cur.ph += INPUT_RATE;
+        if (A.mix && s + 1 < s_end) osc_fetch(osc, nco, cur, ms);             // lands while this symbol is demapped
+        cf32 r1[N_SLOTS]; float l1[N_SLOTS];
+        {
+            cf32 cs[N_SLOTS]; carrier_slots(cs, v, t);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (j >= 7 && j <= 9) continue;
-            const int p = pj_of(j);
-            const int idx = (int)(int16_t)((sidx2[p >> 1] >> (16 * (p & 1))) & 0xffffu);
-            if (idx >= 0) {
-                const cf32 r1 = cmul(v[j], cconj(prev[p]));                   // ofdm-decoder.cpp:206
-                const float ab1 = 127.0f / l1norm(r1);                        // :208
-                const float vr = (-r1.re) * ab1, vi = (-r1.im) * ab1;        // :211-212
-                // float -> int8: C truncation; NaN (r1 == 0 -> inf * 0) becomes 0 as with cvttss2si on the reference's x86-64 build
-                softbuf[idx] = (vr != vr) ? (int8_t)0 : (int8_t)(int)vr;
-                softbuf[K_CARR + idx] = (vi != vi) ? (int8_t)0 : (int8_t)(int)vi;
-                if (con_frame && (idx % 96) == 0) con_frame[(s - 1) * 16 + idx / 96] = r1;   // :214-216
+            for (int q = 0; q < N_SLOTS; q++) {
+                r1[q] = pk_cmulc(cs[q], prev[q]);                             // ofdm-decoder.cpp:206
+                l1[q] = l1norm(r1[q]);
+                prev[q] = cs[q];                                              // :207
             }
-            prev[p] = v[j];                                                   // :207
+        }
+        float lo = l1[0], hi = l1[0];
+#pragma unroll
+        for (int q = 1; q < N_SLOTS; q++) { lo = fminf(lo, l1[q]); hi = fmaxf(hi, l1[q]); }
+        if (wave_all(lo >= DIV127_LO && hi <= DIV127_HI)) {
+            // every |r1| of the wave is an ordinary number: reciprocal-based 127/x (proven equal to the IEEE quotient on
+            // this range by dabphy_selftest_div127), products bounded by 127, so the conversion needs no special cases.
+            // (A NaN l1 hides from fminf/fmaxf; it makes vr, vi NaN, which v_cvt_i32_f32 turns into 0 like the reference.)
+#pragma unroll
+            for (int q = 0; q < N_SLOTS; q++) {
+                const float ab1 = div127_fast<DIV127_VARIANT>(l1[q]);         // :208
+                const float vr = (-r1[q].re) * ab1, vi = (-r1[q].im) * ab1;  // :211-212
+                softbuf[sidx[q]] = (int8_t)cvt_i32_trunc(vr);
+                softbuf[K_CARR + sidx[q]] = (int8_t)cvt_i32_trunc(vi);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < N_SLOTS; q++) {
+                const float ab1 = 127.0f / l1[q];
+                const float vr = (-r1[q].re) * ab1, vi = (-r1[q].im) * ab1;
+                // float -> int8 as the reference's x86-64 build does it: cvttss2si yields 0x80000000 for NaN (r1 == 0 ->
+                // inf * 0) and for anything out of int range, whose low byte is 0
+                softbuf[sidx[q]] = (fabsf(vr) < 2147483648.0f) ? (int8_t)(int)vr : (int8_t)0;
+                softbuf[K_CARR + sidx[q]] = (fabsf(vi) < 2147483648.0f) ? (int8_t)(int)vi : (int8_t)0;
+            }
+        }
+        if (CON) {
+#pragma unroll
+            for (int q = 0; q < N_SLOTS; q++)
+                if (sidx[q] % 96 == 0) con_frame[(s - 1) * 16 + sidx[q] / 96] = r1[q];   // :214-216
         }
         __syncthreads();
         {
@@ -188,10 +282,33 @@ __global__ void k_snr(SnrArgs A)
     st.snr = snr; st.snr_count = cnt;
 }
 
+// Exhaustive check of div127_fast against the IEEE quotient: one thread per float bit pattern (2^32 of them)
+__global__ void k_selftest_div127(unsigned long long* out)
+{
+    unsigned long long bad0 = 0, bad1 = 0, tried = 0;
+    for (uint32_t i = 0; i < 256; i++) {
+        const uint32_t bits = (blockIdx.x * 256u + i) * 256u + threadIdx.x;
+        const float x = __uint_as_float(bits);
+        if (!(x >= DIV127_LO && x <= DIV127_HI)) continue;
+        const float want = 127.0f / x;
+        bad0 += __float_as_uint(div127_fast<0>(x)) != __float_as_uint(want);
+        bad1 += __float_as_uint(div127_fast<1>(x)) != __float_as_uint(want);
+        tried++;
+    }
+    if (bad0) atomicAdd(&out[0], bad0);
+    if (bad1) atomicAdd(&out[1], bad1);
+    if (tried) atomicAdd(&out[2], tried);
+}
+void launch_selftest_div127(unsigned long long* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_div127, dim3(1u << 16), dim3(256), 0, s, out);
+}
+
 void launch_demod(const DemodArgs& a, int n_ens, hipStream_t s)
 {
     const int chunks = (75 + a.chunk_len - 1) / a.chunk_len;
-    hipLaunchKernelGGL(k_demod, dim3(chunks, a.n_frames, n_ens), dim3(FFT_THREADS), 0, s, a);
+    if (a.con) hipLaunchKernelGGL(k_demod<true>, dim3(chunks, a.n_frames, n_ens), dim3(FFT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_demod<false>, dim3(chunks, a.n_frames, n_ens), dim3(FFT_THREADS), 0, s, a);
 }
 
 void launch_snr(const SnrArgs& a, hipStream_t s)
