@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ensembles", type=int, default=256, help="ensembles per GPU")
     ap.add_argument("--frames", type=int, default=20, help="transmission frames per ensemble and step")
+    ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,10 +97,16 @@ def main():
     gbase = torch.from_numpy(base).cuda()
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
     iq = torch.empty((B, N), dtype=torch.complex64, device="cuda")
-    for b in range(B):                                     # per-ensemble AWGN, sigma = 0.02 per axis (SURVEY 8d throughput setting)
+    # per-ensemble carrier frequency offset (a multiple of RATE/N so that the looping recording stays phase-continuous) and
+    # AWGN, sigma = 0.02 per axis (SURVEY 8d throughput setting): every ensemble runs its own coarse/fine correctors
+    rs = np.random.RandomState(4321 + rank)
+    cfo_hz = np.round(rs.uniform(-args.cfo_max_hz, args.cfo_max_hz, B) * N / 2048000.0) * 2048000.0 / N
+    n_idx = torch.arange(N, device="cuda", dtype=torch.float64)
+    for b in range(B):
         noise = torch.randn((N, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.02
-        iq[b] = gbase[b % n_distinct] + torch.view_as_complex(noise)
-    del gbase
+        rot = torch.polar(torch.ones_like(n_idx), n_idx * (2.0 * np.pi * cfo_hz[b] / 2048000.0)).to(torch.complex64)
+        iq[b] = gbase[b % n_distinct] * rot + torch.view_as_complex(noise)
+    del gbase, n_idx, rot
     torch.cuda.synchronize()
 
     dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.path.join(PKG_DIR, "libdabphy_hip.so"),
@@ -125,12 +132,13 @@ def main():
     for W in range(max(1, args.warmup)):
         if align is None:
             dev.process(F)
+            found = np.full(B, -1, np.int32)
             for o in range(5):
                 corr, unc = dev.rs_decode_msc(-1, np.full(B, o, np.int32))
-                if unc.sum() == 0:
-                    align = np.full(B, o, np.int32)
-                    break
-            assert align is not None, "no Reed-Solomon alignment found: decoded MSC is not valid"
+                good = unc.reshape(B, -1).sum(1) == 0
+                found[good & (found < 0)] = o
+            assert (found >= 0).all(), "no Reed-Solomon alignment found for %d ensembles: decoded MSC is not valid" % (found < 0).sum()
+            align = found
         else:
             step(align)
     fib, ok, corr, unc = step(align)
@@ -179,7 +187,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 (FFT/demap) + u16 (Viterbi metrics) + u8 (GF(256))", "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of %d synthetic Mode-I ensembles x %d frames (2.048 Msps cf32, HBM-resident, 18 x 64 kbit/s DAB+ EEP-3A sub-channels each), full chain incl. Viterbi + Reed-Solomon" % (B, F),
-                       "ensembles_per_gpu": B, "frames_per_step": F, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B},
+                       "ensembles_per_gpu": B, "frames_per_step": F, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B},
             "roofline": {"kernel": "k_demod (NCO + 2048-pt FFT + DQPSK demap + freq de-interleave)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": B * F * ALG_BYTES_DEMOD_PER_FRAME, "kernel_ms": demod_ms,

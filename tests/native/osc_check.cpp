@@ -1,0 +1,63 @@
+// TEST INFRASTRUCTURE: host-side check of welle.io_amd/csrc/osc_exact.h (compiled with g++ against the hipemu header).
+//   1. osc_exp(i) vs long-double libm for every table index: max abs error
+//   2. oscillator chains as k_demod / k_sync run them (base from osc_exp, up to CHAIN multiplications by osc_step factors):
+//      every sample osc_round does not flag must equal the reference's table entry (float)cos/sin(2 pi i / RATE) bit for bit;
+//      the flag rate is reported.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "osc_exact.h"
+using namespace dabphy;
+
+int main(int argc, char** argv)
+{
+    const long n_chains = argc > 1 ? atol(argv[1]) : 20000;
+    long double maxerr = 0;
+    std::vector<cf32> table(INPUT_RATE);
+    for (int i = 0; i < INPUT_RATE; i++) {
+        table[i].re = (float)cos(2.0 * M_PI * i / INPUT_RATE);       // ofdm-processor.cpp:93-95
+        table[i].im = (float)sin(2.0 * M_PI * i / INPUT_RATE);
+        const long double th = 2.0L * 3.14159265358979323846264338327950288L * i / INPUT_RATE;
+        const dc64 e = osc_exp(i);
+        const long double er = fabsl((long double)e.re - cosl(th)), ei = fabsl((long double)e.im - sinl(th));
+        if (er > maxerr) maxerr = er;
+        if (ei > maxerr) maxerr = ei;
+    }
+    unsigned long long x = 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    long bad = 0, hard = 0, total = 0;
+    long double maxchain = 0;
+    for (long c = 0; c < n_chains; c++) {
+        int32_t ph = (int32_t)(rnd() % INPUT_RATE);
+        const int32_t f = (int32_t)(rnd() % 70001) - 35000;              // coarse + fine corrector range
+        const dc64 d256 = osc_step(256, f), dts = osc_step(2552, f), d128 = osc_step(128, f);
+        dc64 base = osc_exp(ph);
+        for (int s = 0; s < 16; s++) {
+            for (int h = 0; h < 2; h++) {
+                dc64 e = h ? osc_mul(base, d128) : base;
+                int64_t p = ph - (int64_t)128 * h * f;
+                for (int j = 0; j < 8; j++) {
+                    int64_t pi = p % INPUT_RATE; if (pi < 0) pi += INPUT_RATE;
+                    cf32 o; const uint32_t hd = osc_round(e, o);
+                    total++;
+                    const long double th = 2.0L * 3.14159265358979323846264338327950288L * pi / INPUT_RATE;
+                    const long double er = fabsl((long double)e.re - cosl(th)), ei = fabsl((long double)e.im - sinl(th));
+                    if (er > maxchain) maxchain = er;
+                    if (ei > maxchain) maxchain = ei;
+                    if (hd) hard++;
+                    else if (memcmp(&o, &table[pi], 8) != 0) bad++;
+                    e = osc_mul(e, d256); p -= (int64_t)256 * f;
+                }
+            }
+            base = osc_mul(base, dts);
+            int64_t np = ((int64_t)ph - (int64_t)2552 * f) % INPUT_RATE; if (np < 0) np += INPUT_RATE;
+            ph = (int32_t)np;
+        }
+    }
+    printf("{\"exp_max_err\": %.3Le, \"chain_max_err\": %.3Le, \"samples\": %ld, \"hard\": %ld, \"mismatch\": %ld, \"margin\": %.3e}\n",
+           maxerr, maxchain, total, hard, bad, OSC_MARGIN);
+    return bad != 0;
+}

@@ -1,0 +1,19 @@
+"""Host-side check of the computed oscillator (welle.io_amd/csrc/osc_exact.h): accuracy of osc_exp over every table index,
+and -- for chains as the kernels run them -- that every sample the rounding test does not flag equals the reference's
+table entry (float)cos/sin(2 pi i / INPUT_RATE) (ofdm-processor.cpp:93-95) bit for bit."""
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_osc_exact_chain_matches_table(tmp_path):
+    exe = str(tmp_path / "osc_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tests", "hipemu"), "-I", os.path.join(ROOT, "welle.io_amd", "csrc"),
+                           "-o", exe, os.path.join(ROOT, "tests", "native", "osc_check.cpp")])
+    r = json.loads(subprocess.check_output([exe, "8000"]).decode())
+    assert r["mismatch"] == 0
+    assert r["exp_max_err"] < 1e-15
+    assert r["chain_max_err"] * 6 < r["margin"]          # the margin the rounding test uses covers the chain error 6x over
+    assert r["hard"] < 1e-4 * r["samples"]                # flagged samples (re-read from the table) stay rare

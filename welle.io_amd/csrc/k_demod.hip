@@ -15,6 +15,7 @@
 #include "fft2048.h"
 #include "dabphy_kernels.h"
 #include <dabphy_wave_ops.h>
+#include "osc_exact.h"
 
 namespace dabphy {
 
@@ -31,27 +32,42 @@ struct MixSteps { int32_t s128, sTS; uint32_t s256_bytes; };   // (128 f, T_s f)
 
 constexpr uint32_t NCO_BYTES = (uint32_t)INPUT_RATE * 8u;      // the oscillator table, one cf32 per phase step
 
-// Oscillator values of one symbol in round-A order: o[8h + j] = osc[phase(t + 128h + 256j)]   (ofdm-processor.cpp:211-214).
-// The phase walks in table BYTES so that a load is uniform base + 32-bit lane offset; p - s wraps through
-// min(p - s, p - s + size) in unsigned arithmetic.  Issued one symbol ahead: the gather (L2 latency, HBM for large
-// |f|) is in flight while the previous symbol is demapped.
-__device__ __forceinline__ void osc_fetch(cf32 (&o)[16], const cf32* __restrict__ nco, const SymCursor& c, const MixSteps& st)
+// The oscillator of one thread: exp(j 2 pi phase / RATE) of its sample t of the current symbol, and the factors that
+// advance it by 128 / 256 / T_s samples (osc_exact.h).
+struct OscChain { dc64 base, d128, d256, dts; };
+
+__device__ __forceinline__ void osc_chain_steps(OscChain& k, int32_t f_hz)
 {
+    k.d128 = osc_step(128, f_hz); k.d256 = osc_step(256, f_hz); k.dts = osc_step(T_S, f_hz);
+}
+
+// Oscillator values of one half of a symbol in round-A order: o[j] = oscillatorTable[phase(t + 128h + 256j)]
+// (ofdm-processor.cpp:211-214), computed, not gathered.  A sample whose double sits too close to a float rounding boundary
+// (about 4 in 10^5) is read from the table; the walk over the integer phases only happens in a wave that has one.
+__device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const cf32* __restrict__ nco, const SymCursor& c,
+                                         const MixSteps& st, int h)
+{
+    dc64 e = h ? osc_mul(k.base, k.d128) : k.base;
+    uint32_t hard = 0;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int j = 0; j < 8; j++) {
+        hard |= osc_round(e, o[j]) << j;
+        if (j < 7) e = osc_mul(e, k.d256);
+    }
+    if (!wave_all(hard == 0)) {
         int32_t ph = c.ph; if (h) { ph -= st.s128; if (ph < 0) ph += INPUT_RATE; }
         uint32_t pb = (uint32_t)ph * 8u;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            o[8 * h + j] = *reinterpret_cast<const cf32*>(reinterpret_cast<const char*>(nco) + pb);
+            if ((hard >> j) & 1u) o[j] = *reinterpret_cast<const cf32*>(reinterpret_cast<const char*>(nco) + pb);
             pb -= st.s256_bytes; { const uint32_t w_ = pb + NCO_BYTES; pb = w_ < pb ? w_ : pb; }
         }
     }
 }
 
-// One half of a symbol straight from the sample ring in HBM: x[j] = sample (t + 128h + 256j), times o[8h + j] when mixing
+// One half of a symbol straight from the sample ring in HBM: x[j] = sample (t + 128h + 256j), times its oscillator value
 __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__ iq, uint32_t ring, const SymCursor& c,
-                                          const cf32 (&o)[16], int h, int mix)
+                                          const OscChain& k, const cf32* __restrict__ nco, const MixSteps& st, int h, int mix)
 {
     uint32_t a = c.a + 128u * h; if (a >= ring) a -= ring;
 #pragma unroll
@@ -60,19 +76,22 @@ __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__
         a += 256u; if (a >= ring) a -= ring;
     }
     if (mix) {
+        cf32 o[8]; osc_half(o, k, nco, c, st, h);
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[8 * h + j]);
+        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[j]);
     }
 }
 
 // ... or from the LDS stage an earlier LDS-DMA filled with the symbol's 2048 samples in natural order
-__device__ __forceinline__ void stage_half(cf32 (&x)[8], const cf32* stage, const cf32 (&o)[16], int h, int mix, int t)
+__device__ __forceinline__ void stage_half(cf32 (&x)[8], const cf32* stage, const SymCursor& c, const OscChain& k,
+                                           const cf32* __restrict__ nco, const MixSteps& st, int h, int mix, int t)
 {
 #pragma unroll
     for (int j = 0; j < 8; j++) x[j] = stage[t + 128 * h + 256 * j];
     if (mix) {
+        cf32 o[8]; osc_half(o, k, nco, c, st, h);
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[8 * h + j]);
+        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[j]);
     }
 }
 
@@ -138,16 +157,17 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     };
     auto steps_for = [&](int32_t fhz) { MixSteps m; m.s128 = mod_rate(128LL * fhz); m.s256_bytes = 8u * (uint32_t)mod_rate(256LL * fhz); m.sTS = mod_rate((int64_t)T_S * fhz); return m; };
 
-    cf32 prev[N_SLOTS], v[16], osc[16];
+    cf32 prev[N_SLOTS], v[16];
+    OscChain osc{};
     {   // reference symbol of the chunk (the PRS for chunk 0)
         const int sref = s_begin - 1;
         const int32_t off = sref == 0 ? d.start_index : J0 + (sref - 1) * T_S + T_G;
         const SymCursor c = cursor_at(off);
         const MixSteps ms = steps_for(sref == 0 ? d.f_prs : d.f_sym);
-        if (A.mix) osc_fetch(osc, nco, c, ms);
+        if (A.mix) { osc_chain_steps(osc, sref == 0 ? d.f_prs : d.f_sym); osc.base = osc_exp(c.ph); }
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, h, A.mix); fft_round_a<false>(x, h, tile, w, t); }
+        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, nco, ms, h, A.mix); fft_round_a<false>(x, h, tile, w, t); }
         fft_rounds_bc<false>(v, tile, w, t);
         if (sref == 0 && A.prs_mag) {
             // |bin| of the PRS for the SNR estimate (ofdm-decoder.cpp:240-266): stored in bin order, summed by k_snr_frames
@@ -177,7 +197,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         lds_dma16<0>(g + 512, l + 512); lds_dma16<1024>(g + 512, l + 512); lds_dma16<2048>(g + 512, l + 512); lds_dma16<3072>(g + 512, l + 512);
     };
     bool staged = dma_ok(sym0);
-    if (A.mix) osc_fetch(osc, nco, cur, ms);
+    if (A.mix) { osc_chain_steps(osc, d.f_sym); osc.base = osc_exp(cur.ph); }
     if (staged) dma_issue(sym0);       // overlaps nothing yet (the reference symbol is done), but primes the pipeline
     for (int s = s_begin; s < s_end; s++) {
         if (staged) lds_dma_wait();
@@ -185,7 +205,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             cf32 x[8];
-            if (staged) stage_half(x, stage, osc, h, A.mix, t); else load_half(x, iq, ring, cur, osc, h, A.mix);
+            if (staged) stage_half(x, stage, cur, osc, nco, ms, h, A.mix, t); else load_half(x, iq, ring, cur, osc, nco, ms, h, A.mix);
             fft_round_a<false>(x, h, tile, w, t);
         }
         uint32_t next0 = sym0 + T_S; if (next0 >= ring) next0 -= ring;
@@ -194,7 +214,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         sym0 = next0; staged = next_staged;
         cur.a += T_S; if (cur.a >= ring) cur.a -= ring;
         cur.ph -= ms.sTS; if (cur.ph < 0) cur.ph += INPUT_RATE;
-        if (A.mix && s + 1 < s_end) osc_fetch(osc, nco, cur, ms);             // lands while this symbol is demapped
+        if (A.mix) osc.base = osc_mul(osc.base, osc.dts);
         cf32 r1[N_SLOTS]; float l1[N_SLOTS];
         {
             cf32 cs[N_SLOTS]; carrier_slots(cs, v, t);

@@ -15,6 +15,7 @@
 #include "fft2048.h"
 #include "dabphy_kernels.h"
 #include <dabphy_wave_ops.h>
+#include "osc_exact.h"
 
 namespace dabphy {
 
@@ -35,18 +36,34 @@ __device__ __forceinline__ cf32 mixed_sample(const cf32* __restrict__ iq, int64_
 }
 
 // 2048 samples starting `off` after pos, phase progression from (L, f) with the first sample at relative index rel0,
-// delivered in round-A order: v[8h + j] = x[t + 128h + 256j]
+// delivered in round-A order: v[8h + j] = x[t + 128h + 256j].  The oscillator values are computed (osc_exact.h); the
+// table is only read for the rare sample whose rounding the computation cannot decide.
 __device__ __forceinline__ void load_mix2048(cf32 (&v)[16], const cf32* __restrict__ iq, int64_t ring, int64_t pos, int64_t off,
                                              const cf32* __restrict__ nco, int32_t L, int32_t f, int64_t rel0, int t)
 {
     int64_t a = (pos + off + t) % ring;
-    int32_t ph = mod_rate64((int64_t)L - (rel0 + t + 1) * (int64_t)f);
+    const int32_t ph0 = mod_rate64((int64_t)L - (rel0 + t + 1) * (int64_t)f);
     const int32_t step = mod_rate64(128LL * f);
+    cf32 o[16];
+    uint32_t hard = 0;
+    {
+        dc64 e = osc_exp(ph0);
+        const dc64 d = osc_step(128, f);
+#pragma unroll
+        for (int i = 0; i < 16; i++) { hard |= osc_round(e, o[i]) << i; if (i < 15) e = osc_mul(e, d); }
+    }
+    if (!wave_all(hard == 0)) {
+        int32_t ph = ph0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if ((hard >> i) & 1u) o[i] = nco[ph];
+            ph -= step; if (ph < 0) ph += INPUT_RATE;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        v[(i & 1) * 8 + (i >> 1)] = cmul(iq[a], nco[ph]);
+        v[(i & 1) * 8 + (i >> 1)] = cmul(iq[a], o[i]);
         a += 128; if (a >= ring) a -= ring;
-        ph -= step; if (ph < 0) ph += INPUT_RATE;
     }
 }
 
@@ -350,21 +367,42 @@ __global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
     const int32_t J0 = d.start_index + T_U;
     const int64_t rel = (int64_t)sy * T_S + t;                                   // index of buf[t] after the PRS
     const int32_t stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
-    int32_t ph = mod_rate64((int64_t)d.L1 - (rel + 1) * (int64_t)d.f_sym);
+    const int32_t ph0 = mod_rate64((int64_t)d.L1 - (rel + 1) * (int64_t)d.f_sym);
     int64_t a = (d.pos + J0 + rel) % A.ring;
     cf32* out = A.prods + ((size_t)b * 75 + sy) * 512;
+    // oscillator values of buf[j] (o[2k]) and buf[2048 + j] (o[2k+1]), j = t + 128k, computed (osc_exact.h)
+    cf32 o[8];
+    uint32_t hard = 0;
+    {
+        dc64 e = osc_exp(ph0);
+        const dc64 d128 = osc_step(128, d.f_sym), dTU = osc_step(T_U, d.f_sym);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            hard |= osc_round(e, o[2 * k]) << (2 * k);
+            hard |= osc_round(osc_mul(e, dTU), o[2 * k + 1]) << (2 * k + 1);
+            if (k < 3) e = osc_mul(e, d128);
+        }
+    }
+    if (!wave_all(hard == 0)) {
+        int32_t ph = ph0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
+            if ((hard >> (2 * k)) & 1u) o[2 * k] = nco[ph];
+            if ((hard >> (2 * k + 1)) & 1u) o[2 * k + 1] = nco[ph_hi];
+            ph -= step128; if (ph < 0) ph += INPUT_RATE;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = t + 128 * k;
         if (j < T_G) {
             int64_t a_hi = a + T_U; if (a_hi >= A.ring) a_hi -= A.ring;
-            int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
-            const cf32 lo = cmul(iq[a], nco[ph]);
-            const cf32 hi = cmul(iq[a_hi], nco[ph_hi]);
+            const cf32 lo = cmul(iq[a], o[2 * k]);
+            const cf32 hi = cmul(iq[a_hi], o[2 * k + 1]);
             out[j] = cmul(hi, cconj(lo));
         }
         a += 128; if (a >= A.ring) a -= A.ring;
-        ph -= step128; if (ph < 0) ph += INPUT_RATE;
     }
 }
 
