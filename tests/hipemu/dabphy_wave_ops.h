@@ -35,6 +35,17 @@ static inline int cvt_i32_trunc(float x)
     return (int)x;
 }
 
+typedef unsigned short u16x2 __attribute__((vector_size(4)));
+static inline u16x2 pk_dup_lo(u16x2 v) { u16x2 r = {v[0], v[0]}; return r; }
+static inline u16x2 pk_dup_hi(u16x2 v) { u16x2 r = {v[1], v[1]}; return r; }
+static inline u16x2 pk_swap(u16x2 v) { u16x2 r = {v[1], v[0]}; return r; }
+static inline uint32_t opaque_sgpr(uint32_t x) { return x; }
+static inline uint32_t and_or(uint32_t x, uint32_t mask, uint32_t acc) { return (x & mask) | acc; }
+static inline uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
+{
+    return ((a[0] & 0x8000) ? 0xffu : 0u) | ((b[0] & 0x8000) ? 0xff00u : 0u) | ((a[1] & 0x8000) ? 0xff0000u : 0u) | ((b[1] & 0x8000) ? 0xff000000u : 0u);
+}
+
 template <int VARIANT> static inline float div127_fast(float x) { return 127.0f / x; }
 constexpr float DIV127_LO = 0x1p-100f, DIV127_HI = 0x1p100f;
 // the model decides per lane: both sides of a wave_all() branch must compute the same result wherever the fast side is legal

@@ -71,6 +71,26 @@ __device__ __forceinline__ cf32 pk_add_ib(cf32 a, cf32 b)
 // float -> int32 as v_cvt_i32_f32 does it (truncate, NaN -> 0, saturate)
 __device__ __forceinline__ int cvt_i32_trunc(float x) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 
+// ---- packed uint16 pairs (Viterbi path metrics): half selections the compiler folds into the op_sel bits of the
+// consuming v_pk_*_u16, and the v_perm_b32 selectors 8..11 that expand the sign bit of a 16-bit half into a whole byte
+typedef unsigned short u16x2 __attribute__((vector_size(4)));
+__device__ __forceinline__ u16x2 pk_dup_lo(u16x2 v) { return __builtin_shufflevector(v, v, 0, 0); }
+__device__ __forceinline__ u16x2 pk_dup_hi(u16x2 v) { return __builtin_shufflevector(v, v, 1, 1); }
+__device__ __forceinline__ u16x2 pk_swap(u16x2 v) { return __builtin_shufflevector(v, v, 1, 0); }
+// a wave-uniform constant the compiler must keep in a scalar register instead of folding it into literals
+__device__ __forceinline__ uint32_t opaque_sgpr(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+// (x & wave-uniform mask) | acc in one instruction
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t acc)
+{
+    uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(acc)); return r;
+}
+// bytes (0xff if negative else 0) of the int16 halves [a.lo, b.lo, a.hi, b.hi]
+__device__ __forceinline__ uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
+{
+    uint32_t au, bu; __builtin_memcpy(&au, &a, 4); __builtin_memcpy(&bu, &b, 4);
+    return __builtin_amdgcn_perm(bu, au, 0x0b090a08u);       // pool {S0 = b, S1 = a}: 8 = a[15], 10 = b[15], 9 = a[31], 11 = b[31]
+}
+
 // 127 / x for x in [2^-100, 2^100]: v_rcp_f32 (1 ulp) + one residual correction, 4 instructions instead of the 11 of the
 // IEEE division sequence.  DIV127_VARIANT 1 adds a second correction.  dabphy_selftest_div127 compares every variant
 // with the correctly rounded quotient for ALL floats of that range on the device it runs on; k_demod only uses the

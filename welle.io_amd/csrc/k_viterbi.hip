@@ -11,18 +11,18 @@
 //
 // MI355X mapping.  The reference decodes one codeword at a time with 64 scalar states.  Here ONE LANE
 // decodes ONE CODEWORD: a wavefront carries 64 independent codewords, the 64 path metrics of each live in
-// 32 VGPRs as packed uint16 pairs (state j | state j+32 << 16) and a trellis step is 16 packed butterflies
-// (v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_i16) with no cross-lane traffic and no LDS.  Decisions (64 bit per
+// 32 VGPRs as packed uint16 pairs (state 2j | state 2j+1 << 16) and a trellis step is 32 packed butterflies of
+// 2 x v_pk_add_u16 + v_pk_min_u16 + v_pk_sub_i16 with no cross-lane traffic and no LDS.  Decisions (64 bit per
 // step and codeword) stream to HBM as one coalesced 8-byte store per lane and are read back by the same
 // lane during traceback.  Exact-integer equivalence with the reference: metrics are uint16 without
 // wrap-around (minimum subtracted every 16 steps; spread <= 6*1020, growth <= 16*1020), decisions are
 // "m0 > m1" evaluated on the true integers, ties keep the m0/m2 branch -- the reference's own
 // renormalisation schedule (viterbi.cpp:104-120) changes no decision, so none of it is mimicked.
 #include "dabphy_kernels.h"
+#include <dabphy_wave_ops.h>
 
 namespace dabphy {
 
-typedef unsigned short u16x2 __attribute__((vector_size(4)));
 __device__ __forceinline__ uint32_t asu(u16x2 a) { uint32_t r; __builtin_memcpy(&r, &a, 4); return r; }
 __device__ __forceinline__ u16x2 asv(uint32_t a) { u16x2 r; __builtin_memcpy(&r, &a, 4); return r; }
 __device__ __forceinline__ u16x2 pkmin(u16x2 a, u16x2 b) { return (a < b) ? a : b; }
@@ -36,45 +36,63 @@ __host__ __device__ constexpr int bf_pattern(int i)
     return parity6((2 * i) & 0155) | (parity6((2 * i) & 0117) << 1) | (parity6((2 * i) & 0123) << 2);
 }
 
-// Decision words.  The sign bits of (m1 - m0) and (m3 - m2) are the decisions (viterbi.cpp:271-272: d = m0 > m1).
-// For butterfly pair i the four sign-carrying bytes are gathered with one v_perm_b32 into
-//   [ d(2i) | d(2i+32) | d(2i+1) | d(2i+33) ]  (bit 7 of bytes 0..3)
-// and shifted so that pair i lands on bit (i & 7) of each byte of word (i >> 3).  Decision of state s at a step:
-//   word (s >> 4) & 1,  byte 2 * (s & 1) + (s >> 5),  bit (s >> 1) & 7.
-template <int I>
-__device__ __forceinline__ void bfly_pair(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&MV)[8], uint32_t& accA, uint32_t& accB)
+// Register layout: R[j] = (metric of state 2j | metric of state 2j+1 << 16).  Butterfly k (0..31) reads old[k] and
+// old[k+32] -- half (k & 1) of R[k >> 1] and of R[16 + (k >> 1)], broadcast to both halves by the op_sel bits of the
+// packed add -- and produces new[2k], new[2k+1] = N[k]: the layout is stationary, no register is ever re-paired.
+//   P = (old[k],    old[k])    + (bm(p), bm(p^7))   = (m0, m2)          (viterbi.cpp:263-268 BFLY)
+//   Q = (old[k+32], old[k+32]) + (bm(p^7), bm(p))   = (m1, m3)
+//   N[k] = min(P, Q);  decisions d = m0 > m1 | m2 > m3 = sign bits of Q - P (ties keep the m0 / m2 branch)
+// Decision words: pk_sign_bytes(D[i], D[i+16]) = bytes [d(2i), d(2i+32), d(2i+1), d(2i+33)] as 0x00 / 0xff, masked onto
+// bit (i & 7) of word (i >> 3).  Decision of state s at a step: word (s >> 4) & 1, byte 2 * (s & 1) + (s >> 5), bit (s >> 1) & 7.
+template <int K>
+__device__ __forceinline__ void bfly(const u16x2 (&R)[32], u16x2 (&N)[32], u16x2 (&D)[32], const u16x2 (&BM)[4])
 {
-    constexpr int p = bf_pattern(I);
-    const u16x2 A = asv(__builtin_amdgcn_perm(asu(R[I + 16]), asu(R[I]), 0x05040100u));   // (old[i],    old[i+16])
-    const u16x2 B = asv(__builtin_amdgcn_perm(asu(R[I + 16]), asu(R[I]), 0x07060302u));   // (old[i+32], old[i+48])
-    const u16x2 m0 = A + MV[p], m1 = B + MV[p ^ 7], m2 = A + MV[p ^ 7], m3 = B + MV[p];
-    N[2 * I] = pkmin(m0, m1);                  // (new[2i],   new[2i+32])
-    N[2 * I + 1] = pkmin(m2, m3);              // (new[2i+1], new[2i+33])
-    const uint32_t signs = __builtin_amdgcn_perm(asu(m3 - m2), asu(m1 - m0), 0x07050301u);
-    if (I < 8) accA = ((signs >> (7 - (I & 7))) & 0x01010101u * (1u << (I & 7))) | accA;
-    else       accB = ((signs >> (7 - (I & 7))) & 0x01010101u * (1u << (I & 7))) | accB;
+    constexpr int p = bf_pattern(K & 15) ^ (K >> 4);
+    const u16x2 a = (K & 1) ? pk_dup_hi(R[K >> 1]) : pk_dup_lo(R[K >> 1]);
+    const u16x2 b = (K & 1) ? pk_dup_hi(R[16 + (K >> 1)]) : pk_dup_lo(R[16 + (K >> 1)]);
+    const u16x2 bm = (p < 4) ? BM[p] : pk_swap(BM[p ^ 7]);                                     // (bm(p), bm(p^7))
+    const u16x2 P = a + bm, Q = b + pk_swap(bm);
+    N[K] = pkmin(P, Q);
+    D[K] = Q - P;
 }
 
-__device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out)
+template <int I>
+__device__ __forceinline__ void decide(const u16x2 (&D)[32], uint32_t& accA, uint32_t& accB, uint32_t ones)
+{
+    // `ones` = 0x01010101 kept in an SGPR (opaque to the compiler) so that mask-and-merge is one v_and_or_b32 (a VOP3
+    // instruction cannot carry a 32-bit literal)
+    const uint32_t x = pk_sign_bytes(D[I], D[I + 16]);
+    if (I < 8) accA = and_or(x, ones << (I & 7), accA);
+    else       accB = and_or(x, ones << (I & 7), accB);
+}
+
+template <int K>
+__device__ __forceinline__ void bfly_all(const u16x2 (&R)[32], u16x2 (&N)[32], u16x2 (&D)[32], const u16x2 (&BM)[4])
+{
+    bfly<K>(R, N, D, BM);
+    if constexpr (K + 1 < 32) bfly_all<K + 1>(R, N, D, BM);
+}
+template <int I>
+__device__ __forceinline__ void decide_all(const u16x2 (&D)[32], uint32_t& accA, uint32_t& accB, uint32_t ones)
+{
+    decide<I>(D, accA, accB, ones);
+    if constexpr (I + 1 < 16) decide_all<I + 1>(D, accA, accB, ones);
+}
+
+__device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out, uint32_t ones)
 {
     // sy = 4 symbols 0..255 (byte j = output j of the mother code).  Branch metric of pattern p:
-    // sum_j (bit_j(p) ? 255 - s_j : s_j), outputs 0 and 3 share bit 0 (viterbi.cpp:259-261).
-    const uint32_t s0 = sy & 0xff, s1 = (sy >> 8) & 0xff, s2 = (sy >> 16) & 0xff, s3 = sy >> 24;
-    const uint32_t t0 = s0 + s3;
-    const u16x2 X0 = asv(t0 | ((510u - t0) << 16));        // (b0=0 | b0=1)
-    const u16x2 X1 = asv((510u - t0) | (t0 << 16));
-    const u16x2 Y0 = splat(s1), Y1 = splat(255u - s1), Z0 = splat(s2), Z1 = splat(255u - s2);
-    const u16x2 W00 = Y0 + Z0, W10 = Y1 + Z0, W01 = Y0 + Z1, W11 = Y1 + Z1;
-    u16x2 MV[8];   // MV[p] = (metric of pattern p, metric of pattern p^1)
-    MV[0] = X0 + W00; MV[1] = X1 + W00; MV[2] = X0 + W10; MV[3] = X1 + W10;
-    MV[4] = X0 + W01; MV[5] = X1 + W01; MV[6] = X0 + W11; MV[7] = X1 + W11;
+    // sum_j (bit_j(p) ? 255 - s_j : s_j), outputs 0 and 3 share bit 0 (viterbi.cpp:259-261); bm(p ^ 7) = 1020 - bm(p).
+    const uint32_t s1 = (sy >> 8) & 0xff, s2 = (sy >> 16) & 0xff;
+    const uint32_t t0 = (sy & 0xff) + (sy >> 24);
+    const uint32_t m0 = t0 + s1 + s2, m1 = 510u - t0 + s1 + s2, m2 = t0 + 255u - s1 + s2, m3 = 765u - t0 - s1 + s2;
+    u16x2 BM[4];    // BM[p] = (bm(p), bm(p ^ 7))
+    BM[0] = asv(m0 | ((1020u - m0) << 16)); BM[1] = asv(m1 | ((1020u - m1) << 16));
+    BM[2] = asv(m2 | ((1020u - m2) << 16)); BM[3] = asv(m3 | ((1020u - m3) << 16));
+    u16x2 D[32];
+    bfly_all<0>(R, N, D, BM);
     uint32_t accA = 0, accB = 0;
-    bfly_pair<0>(R, N, MV, accA, accB);  bfly_pair<1>(R, N, MV, accA, accB);  bfly_pair<2>(R, N, MV, accA, accB);
-    bfly_pair<3>(R, N, MV, accA, accB);  bfly_pair<4>(R, N, MV, accA, accB);  bfly_pair<5>(R, N, MV, accA, accB);
-    bfly_pair<6>(R, N, MV, accA, accB);  bfly_pair<7>(R, N, MV, accA, accB);  bfly_pair<8>(R, N, MV, accA, accB);
-    bfly_pair<9>(R, N, MV, accA, accB);  bfly_pair<10>(R, N, MV, accA, accB); bfly_pair<11>(R, N, MV, accA, accB);
-    bfly_pair<12>(R, N, MV, accA, accB); bfly_pair<13>(R, N, MV, accA, accB); bfly_pair<14>(R, N, MV, accA, accB);
-    bfly_pair<15>(R, N, MV, accA, accB);
+    decide_all<0>(D, accA, accB, ones);
     *dec_out = make_uint2(accA, accB);
 }
 
@@ -98,6 +116,7 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
     const uint32_t* __restrict__ sym = A.c.sym + (size_t)g * nsteps * 64 + lane;
     uint2* __restrict__ dec = A.c.dec + (size_t)g * nsteps * 64 + lane;
 
+    const uint32_t ones = opaque_sgpr(0x01010101u);
     u16x2 R[32], N[32];
     // init_viterbi (viterbi.cpp:342-354): all 63, start state 0 biased to 0
 #pragma unroll
@@ -111,13 +130,13 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
     for (; s + 1 < nsteps; s += 2) {
         const int sn = (s + 3 < nsteps) ? s + 2 : s;             // clamp: the last iteration re-reads valid memory
         const uint32_t n0 = sym[(size_t)sn * 64], n1 = sym[(size_t)(sn + 1) * 64];
-        trellis_step(R, N, y0, dec + (size_t)s * 64);
-        trellis_step(N, R, y1, dec + (size_t)(s + 1) * 64);
+        trellis_step(R, N, y0, dec + (size_t)s * 64, ones);
+        trellis_step(N, R, y1, dec + (size_t)(s + 1) * 64, ones);
         if ((s & 14) == 14) renorm(R);
         y0 = n0; y1 = n1;
     }
     if (s < nsteps) {
-        trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64);
+        trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64, ones);
     }
 
     // chainback_viterbi (viterbi.cpp:313-339) from state 0, skipping the 6 tail steps; bits are packed MSB
