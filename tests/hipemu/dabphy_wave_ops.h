@@ -53,6 +53,7 @@ static inline bool wave_all(bool p) { return p; }
 
 // LDS-DMA model: the copy happens at issue time
 template <int OFF> static inline void lds_dma16(const void* gptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + OFF + 16 * hipemu_lane(), (const char*)gptr + OFF, 16); }
+static inline void lds_dma4(const void* gptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu_lane(), gptr, 4); }
 static inline void lds_dma_wait() {}
 
 } // namespace dabphy

@@ -120,6 +120,12 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
 }
+// 4-byte variant: lane l's dword lands at lds_wave_base + 4 l (inactive lanes transfer nothing)
+__device__ __forceinline__ void lds_dma4(const void* gptr, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 } // namespace dabphy

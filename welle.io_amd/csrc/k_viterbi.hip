@@ -291,23 +291,31 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
             const int u = A.map[4 * s0 + t];
             s_map[t] = (u >= 0) ? (map16[u & 15] * (GT_PITCHW * 4) + (u - u_lo)) : -1;
         }
+        // rows travel HBM -> LDS by LDS-DMA: nothing waits between the (up to 28) row requests of a wave
         for (int row = wave; row < nrows; row += 4) {
             const long long src = s_rowsrc[row];
-            if (lane < ndw) tile[row * GT_PITCHW + lane] = (src >= 0) ? *reinterpret_cast<const uint32_t*>(A.soft + src + u_lo + 4 * lane) : 0u;
+            if (lane < ndw) {
+                if (src >= 0) lds_dma4(A.soft + src + u_lo + 4 * lane, &tile[row * GT_PITCHW]);
+                else tile[row * GT_PITCHW + lane] = 0u;
+            }
         }
+        lds_dma_wait();
         __syncthreads();
         const int rb = rowbase * (GT_PITCHW * 4);
-        for (int s = s0 + wave; s < s1; s += 4) {
-            const int4 mo = *reinterpret_cast<const int4*>(&s_map[4 * (s - s0)]);
-            int v0 = (mo.x >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.x] : 0;
-            int v1 = (mo.y >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.y] : 0;
-            int v2 = (mo.z >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.z] : 0;
-            int v3 = (mo.w >= 0 && rowbase >= 0) ? (int)tile8[rb + mo.w] : 0;
-            v0 += 127; v0 = v0 < 0 ? 0 : v0;            // viterbi.cpp:233-236 (an int8 + 127 never exceeds 254)
-            v1 += 127; v1 = v1 < 0 ? 0 : v1;
-            v2 += 127; v2 = v2 < 0 ? 0 : v2;
-            v3 += 127; v3 = v3 < 0 ? 0 : v3;
-            dst[(size_t)s * 64] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+        auto pick = [&](int off) { int v = (off >= 0 && rowbase >= 0) ? (int)tile8[rb + off] : 0; v += 127; return v < 0 ? 0 : v; };   // viterbi.cpp:233-236 (an int8 + 127 never exceeds 254)
+        int s = s0 + wave;
+        for (; s + 4 < s1; s += 8) {                     // two steps per iteration: their LDS reads overlap
+            const int4 ma = *reinterpret_cast<const int4*>(&s_map[4 * (s - s0)]);
+            const int4 mb = *reinterpret_cast<const int4*>(&s_map[4 * (s + 4 - s0)]);
+            const int a0 = pick(ma.x), a1 = pick(ma.y), a2 = pick(ma.z), a3 = pick(ma.w);
+            const int b0 = pick(mb.x), b1 = pick(mb.y), b2 = pick(mb.z), b3 = pick(mb.w);
+            dst[(size_t)s * 64] = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
+            dst[(size_t)(s + 4) * 64] = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
+        }
+        if (s < s1) {
+            const int4 ma = *reinterpret_cast<const int4*>(&s_map[4 * (s - s0)]);
+            const int a0 = pick(ma.x), a1 = pick(ma.y), a2 = pick(ma.z), a3 = pick(ma.w);
+            dst[(size_t)s * 64] = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
         }
         __syncthreads();
     }
