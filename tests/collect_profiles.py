@@ -1,0 +1,73 @@
+"""Not a test: copies the rocprofv3 summaries that tests/make_profiles.sh left under gpurun_out/prof/ into profiles/
+(tracked) and derives profiles/demod_hbm_traffic.json, the per-launch HBM traffic bench.py reports as roofline.traffic."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+B, F = 256, 20
+
+shutil.copy(os.path.join(SRC, "stats_kernel_stats.csv"), os.path.join(DST, TAG + "_bench_kernel_stats.csv"))
+
+
+def rows(name):
+    return list(csv.DictReader(open(os.path.join(SRC, name))))
+
+
+def per_kernel(name, counter):
+    acc = {}
+    for r in rows(name):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        acc.setdefault(k, []).append(float(r["Counter_Value"]))
+    return acc
+
+
+def dump(name, out, counters):
+    rr = [r for r in rows(name) if r["Counter_Name"] in counters]
+    keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+            "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(os.path.join(DST, out), "w", newline="") as f:
+        w = csv.DictWriter(f, keep); w.writeheader()
+        for r in rr:
+            w.writerow({k: r.get(k, "") for k in keep})
+
+
+dump("pmc_fetch_counter_collection.csv", TAG + "_pmc_fetch_size.csv", {"FETCH_SIZE"})
+dump("pmc_write_counter_collection.csv", TAG + "_pmc_write_size.csv", {"WRITE_SIZE"})
+sq = {"SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES",
+      "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM", "SQ_WAVES", "GRBM_GUI_ACTIVE"}
+with open(os.path.join(DST, TAG + "_pmc_sq_demod.csv"), "w", newline="") as f:
+    w = None
+    for name in ("pmc_sq1_counter_collection.csv", "pmc_sq2_counter_collection.csv"):
+        for r in rows(name):
+            if r["Counter_Name"] in sq:
+                if w is None:
+                    w = csv.DictWriter(f, ["Dispatch_Id", "Kernel_Name", "VGPR_Count", "LDS_Block_Size", "Counter_Name", "Counter_Value"]); w.writeheader()
+                w.writerow({k: r.get(k, "") for k in w.fieldnames})
+
+fetch = per_kernel("pmc_fetch_counter_collection.csv", "FETCH_SIZE")
+write = per_kernel("pmc_write_counter_collection.csv", "WRITE_SIZE")
+kd = [k for k in fetch if "k_demod" in k][0]
+# steady-state launches only (the first launch of a run demodulates fewer frames: acquisition)
+fk = sorted(fetch[kd])[len(fetch[kd]) // 2]; wk = sorted(write[kd])[len(write[kd]) // 2]
+alg = B * F * (76 * 2048 * 8 + 75 * 3072)
+hbm = int(fk * 1024 * 2 + wk * 1024)
+json.dump({
+    "kernel": "dabphy::k_demod", "ensembles": B, "frames": F,
+    "fetch_size_kb_raw": fk, "write_size_kb_raw": wk,
+    "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 counts 128-B requests of wide coalesced streams at 64 B, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported",
+    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
+    "command": "tests/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-include-regex ... -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline",
+    "source": "profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv (median launch)" % (TAG, TAG),
+    "traffic_over_algorithmic": hbm / alg,
+}, open(os.path.join(DST, "demod_hbm_traffic.json"), "w"), indent=1)
+print(open(os.path.join(DST, "demod_hbm_traffic.json")).read())
+for k in sorted(fetch):
+    print("%-60s fetch %10.0f KB  write %10.0f KB" % (k[:60], sorted(fetch[k])[len(fetch[k]) // 2], sorted(write.get(k, [0]))[len(write.get(k, [0])) // 2]))

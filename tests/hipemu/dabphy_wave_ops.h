@@ -40,6 +40,7 @@ static inline u16x2 pk_dup_lo(u16x2 v) { u16x2 r = {v[0], v[0]}; return r; }
 static inline u16x2 pk_dup_hi(u16x2 v) { u16x2 r = {v[1], v[1]}; return r; }
 static inline u16x2 pk_swap(u16x2 v) { u16x2 r = {v[1], v[0]}; return r; }
 static inline uint32_t opaque_sgpr(uint32_t x) { return x; }
+static inline double uniform_f64(double x) { return x; }
 static inline uint32_t and_or(uint32_t x, uint32_t mask, uint32_t acc) { return (x & mask) | acc; }
 static inline uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
 {

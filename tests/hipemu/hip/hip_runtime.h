@@ -41,6 +41,7 @@ static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "gfx950:hipemu"); p->multiProcessorCount = 1; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
@@ -65,6 +66,9 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 static inline hipError_t hipPointerGetAttributes(void*, const void*) { return hipErrorInvalidValue; }
 #define hipStreamNonBlocking 1
+#define __noinline__ __attribute__((noinline))
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 #define hipHostMallocDefault 0
 
 // ---- execution engine (hipemu.cpp) ----

@@ -31,6 +31,7 @@ struct dabphy_handle {
     Tables tab{};
     // grow-only scratch
     DevBuf iq, soft, con, prs_mag, snr, desc, in8, map, vsym, vdec, vout, ok;
+    DevBuf fsym, fdec;                      // Viterbi scratch of the FIC class (it decodes beside the MSC classes on aux_stream)
     RxState* d_state = nullptr;       // [n_ensembles] synchroniser state
     DecState* d_dec = nullptr;        // [n_ensembles] decoder state
     std::vector<void*> owned;
@@ -48,6 +49,7 @@ struct dabphy_handle {
     std::vector<MscClass> classes;
     DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr;
     hipEvent_t ev_chain_beg[2]{}, ev_chain_end[2]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
     bool need_acquire = true;         // queue k_acquire in front of every frame step
@@ -155,6 +157,8 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
         if (hipStreamCreateWithPriority(&h->sync_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(DABPHY_ERR_HIP);
     }
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
@@ -168,6 +172,9 @@ void dabphy_destroy(dabphy_handle* h)
     hipError_t e;
     if (h->sync_stream) { e = hipStreamSynchronize(h->sync_stream); e = hipStreamDestroy(h->sync_stream); }
     if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
+    if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
+    if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);
+    if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < 2; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
@@ -175,7 +182,7 @@ void dabphy_destroy(dabphy_handle* h)
     DevBuf* more[] = {&h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
-    DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok};
+    DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
     (void)e;
     delete h;
@@ -435,9 +442,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     h->soft_ring = ring_frames;
 
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) h->ev_used[i] = false;
-    auto mark = [&](int stage, bool end) {
+    auto mark = [&](int stage, bool end, hipStream_t st = nullptr) {
         if (!h->profiling) return;
-        hipError_t e = hipEventRecord(end ? h->ev_end[stage] : h->ev_beg[stage], h->stream); (void)e;
+        hipError_t e = hipEventRecord(end ? h->ev_end[stage] : h->ev_beg[stage], st ? st : h->stream); (void)e;
         h->ev_used[stage] = true;
     };
     // The synchroniser runs on its own stream.  Pipelined mode (cfg.pipeline_sync): while this batch is decoded on the
@@ -489,24 +496,30 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     launch_snr(sn, h->stream);
     mark(dabphy_handle::ST_SNR, true);
 
-    // FIC: 4 codewords per frame
+    // FIC: 4 codewords per frame.  Only B*F/16 wavefronts of 774 serial trellis steps: it runs on its own stream beside the
+    // MSC classes (own Viterbi scratch), filling execution slots instead of holding the whole device for a latency-bound tail.
     {
         VitClass c{};
-        if ((r = prepare_class(h, c, 768, (int)(B * F * 4), 1))) return r;
-        c.out = h->s_fib.as<uint8_t>();
-        // the class output must hold whole groups of 64 codewords
-        if ((r = ensure(h, h->s_fib, (size_t)c.n_groups * 64 * 96))) return r;
-        c.out = h->s_fib.as<uint8_t>();
+        c.nbits = 768; c.nsteps = 774; c.n_cw = (int)(B * F * 4); c.n_groups = (c.n_cw + 63) / 64; c.dedisperse = 1;
+        const size_t cells = (size_t)c.n_groups * c.nsteps * 64;
+        if ((r = ensure(h, h->fsym, cells * sizeof(uint32_t)))) return r;
+        if ((r = ensure(h, h->fdec, cells * sizeof(uint2)))) return r;
+        if ((r = ensure(h, h->s_fib, (size_t)c.n_groups * 64 * 96))) return r;      // the class output holds whole groups of 64 codewords
+        c.sym = h->fsym.as<uint32_t>(); c.dec = h->fdec.as<uint2>(); c.out = h->s_fib.as<uint8_t>();
         FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
-        mark(dabphy_handle::ST_FIC, false);
-        launch_fic_gather(g, h->stream);
+        hipStream_t fs = h->aux_stream;
+        HIPCHK(h, hipEventRecord(h->ev_demod_done, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(fs, h->ev_demod_done, 0));
+        mark(dabphy_handle::ST_FIC, false, fs);
+        launch_fic_gather(g, fs);
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
-        launch_viterbi(v, h->stream);
+        launch_viterbi(v, fs);
         CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F;
-        launch_fib_crc(k, h->stream);
-        launch_fic_ratio(k, h->stream);
-        mark(dabphy_handle::ST_FIC, true);
+        launch_fib_crc(k, fs);
+        launch_fic_ratio(k, fs);
+        mark(dabphy_handle::ST_FIC, true, fs);
+        HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
     // MSC: one launch pair per protection class (stage events bracket the first class only: one class in the canonical ensemble)
     for (auto& cls : h->classes) {
@@ -525,6 +538,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         launch_viterbi(v, h->stream);
         if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
     }
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
     h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
     HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_snr.data(), h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -77,6 +77,14 @@ typedef unsigned short u16x2 __attribute__((vector_size(4)));
 __device__ __forceinline__ u16x2 pk_dup_lo(u16x2 v) { return __builtin_shufflevector(v, v, 0, 0); }
 __device__ __forceinline__ u16x2 pk_dup_hi(u16x2 v) { return __builtin_shufflevector(v, v, 1, 1); }
 __device__ __forceinline__ u16x2 pk_swap(u16x2 v) { return __builtin_shufflevector(v, v, 1, 0); }
+// a double that is the same in every lane, moved to scalar registers (two v_readfirstlane_b32)
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    unsigned long long u; __builtin_memcpy(&u, &x, 8);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    u = ((unsigned long long)hi << 32) | lo; __builtin_memcpy(&x, &u, 8);
+    return x;
+}
 // a wave-uniform constant the compiler must keep in a scalar register instead of folding it into literals
 __device__ __forceinline__ uint32_t opaque_sgpr(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 // (x & wave-uniform mask) | acc in one instruction

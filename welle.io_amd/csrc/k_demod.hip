@@ -38,7 +38,11 @@ struct OscChain { dc64 base, d128, d256, dts; };
 
 __device__ __forceinline__ void osc_chain_steps(OscChain& k, int32_t f_hz)
 {
-    k.d128 = osc_step(128, f_hz); k.d256 = osc_step(256, f_hz); k.dts = osc_step(T_S, f_hz);
+    // the same in every lane (f_hz is per frame): kept in scalar registers, 24 VGPRs less
+    const dc64 a = osc_step(128, f_hz), b = osc_step(256, f_hz), c = osc_step(T_S, f_hz);
+    k.d128.re = uniform_f64(a.re); k.d128.im = uniform_f64(a.im);
+    k.d256.re = uniform_f64(b.re); k.d256.im = uniform_f64(b.im);
+    k.dts.re = uniform_f64(c.re); k.dts.im = uniform_f64(c.im);
 }
 
 // Oscillator values of one half of a symbol in round-A order: o[j] = oscillatorTable[phase(t + 128h + 256j)]
@@ -108,7 +112,10 @@ constexpr int N_SLOTS = 12;
 #endif
 __device__ __forceinline__ void carrier_slots(cf32 (&c)[N_SLOTS], const cf32 (&v)[16], int t)
 {
-    c[0].re = t == 0 ? v[6].re : v[0].re; c[0].im = t == 0 ? v[6].im : v[0].im;
+    // bitwise blend (the compiler turns a cf32 ?: into an indexed load from a stack copy)
+    const uint32_t m = t == 0 ? 0xffffffffu : 0u;
+    c[0].re = __uint_as_float((__float_as_uint(v[6].re) & m) | (__float_as_uint(v[0].re) & ~m));
+    c[0].im = __uint_as_float((__float_as_uint(v[6].im) & m) | (__float_as_uint(v[0].im) & ~m));
 #pragma unroll
     for (int q = 1; q < 6; q++) c[q] = v[q];
 #pragma unroll

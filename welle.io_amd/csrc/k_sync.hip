@@ -102,15 +102,14 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
 //                           float additions), updates the fine/coarse correctors, consumes the null symbol, commits the state
 // Both serial kernels are kept small (<= 17 KiB LDS) so that they find room next to the decode kernels of the
 // previous batch that run concurrently on the main stream.
-__global__ void __launch_bounds__(FFT_THREADS) k_sync_finish(SyncArgs A)
+__device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b, const int frame)
 {
     __shared__ __attribute__((aligned(16))) cf32 tile[3 * 256 * 2];      // 3-slot ring of 504 (+8 pad) products
     __shared__ float s_sum;
-    __builtin_amdgcn_s_setprio(3);
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x;
     // ------------------------------------------------------------------------------------------ finish frame-1
     {
-        FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + A.frame];
+        FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + frame];
         const int pending = dfin.valid;
         __syncthreads();
         if (pending == 2) {
@@ -176,7 +175,13 @@ __global__ void __launch_bounds__(FFT_THREADS) k_sync_finish(SyncArgs A)
     }
 }
 
-__global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
+__global__ void __launch_bounds__(FFT_THREADS) k_sync_finish(SyncArgs A)
+{
+    __builtin_amdgcn_s_setprio(3);
+    sync_finish_body(A, blockIdx.x, A.frame);
+}
+
+__device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, const int frame)
 {
     // 17 KiB of LDS, reused phase by phase (FFT tile -> |IFFT| + window maxima)
     __shared__ __attribute__((aligned(16))) cf32 tile[T_U + 96];
@@ -186,8 +191,7 @@ __global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
     __shared__ int redi[FFT_THREADS];
     __shared__ float s_sum;
     __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
-    __builtin_amdgcn_s_setprio(3);
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
     struct { int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced; } st;
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
         const RxState& g = A.state[b];
         st.pos = g.pos; st.frame_no = g.frame_no; st.local_phase = g.local_phase; st.coarse = g.coarse; st.fine = g.fine; st.synced = g.synced;
     }
-    FrameDesc& dout = A.desc[(size_t)b * A.n_frames + A.frame];
+    FrameDesc& dout = A.desc[(size_t)b * A.n_frames + frame];
     FrameDesc d;
     d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
     d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0;
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
     fft2048_wg<true>(u, tile, w, t);
     __syncthreads();                                                       // all round-C reads of the tile are done: it becomes lbuf / pa
     const float factor = 1.0f / (float)T_U;                                // fft.cpp:154
-    float* cir = A.cir ? A.cir + ((size_t)b * A.n_frames + A.frame) * T_U : nullptr;
+    float* cir = A.cir ? A.cir + ((size_t)b * A.n_frames + frame) * T_U : nullptr;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const float a = hypotf_exact(u[j].re * factor, u[j].im * factor);  // phasereference.cpp:214-215
@@ -357,10 +361,16 @@ __global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
 
 // Cyclic-prefix products of one pending frame: grid (75 symbols, B ensembles).  prods[b][sym][j] =
 // buf[2048 + j] * conj(buf[j]), j < 504, both samples oscillator-corrected (ofdm-processor.cpp:211-214,440-441).
-__global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
+__global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
 {
-    const int t = threadIdx.x, sy = blockIdx.x, b = blockIdx.y;
-    const FrameDesc d = A.desc[(size_t)b * A.n_frames + A.frame];
+    __builtin_amdgcn_s_setprio(3);
+    sync_find_body(A, blockIdx.x, A.frame);
+}
+
+__device__ __forceinline__ void cp_products_body(const SyncArgs& A, const int sy, const int b, const int frame)
+{
+    const int t = threadIdx.x;
+    const FrameDesc d = A.desc[(size_t)b * A.n_frames + frame];
     if (d.valid != 2) return;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
@@ -404,6 +414,11 @@ __global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
         }
         a += 128; if (a >= A.ring) a -= A.ring;
     }
+}
+
+__global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
+{
+    cp_products_body(A, blockIdx.x, blockIdx.y, A.frame);
 }
 
 // ---- acquisition: OFDMProcessor::run from "Initing" / notSynced to SyncOnPhase (ofdm-processor.cpp:249-319).
