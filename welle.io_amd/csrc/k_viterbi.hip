@@ -15,7 +15,7 @@
 // 2 x v_pk_add_u16 + v_pk_min_u16 + v_pk_sub_i16 with no cross-lane traffic and no LDS.  Decisions (64 bit per
 // step and codeword) stream to HBM as one coalesced 8-byte store per lane and are read back by the same
 // lane during traceback.  Exact-integer equivalence with the reference: metrics are uint16 without
-// wrap-around (minimum subtracted every 16 steps; spread <= 6*1020, growth <= 16*1020), decisions are
+// wrap-around (minimum subtracted every 32 steps; spread <= 6*1020, growth <= 32*1020), decisions are
 // "m0 > m1" evaluated on the true integers, ties keep the m0/m2 branch -- the reference's own
 // renormalisation schedule (viterbi.cpp:104-120) changes no decision, so none of it is mimicked.
 #include "dabphy_kernels.h"
@@ -36,6 +36,18 @@ __host__ __device__ constexpr int bf_pattern(int i)
     return parity6((2 * i) & 0155) | (parity6((2 * i) & 0117) << 1) | (parity6((2 * i) & 0123) << 2);
 }
 
+// Symbol word of one trellis step as the gathers store it.  s0..s3 = the four soft symbols 0..255 of the step (output j of
+// the mother code, viterbi.cpp:233-238 mapping applied); outputs 0 and 3 share a generator, so three branch-metric terms
+// describe the step (viterbi.cpp:259-261):  m0 = bm(pattern 0) = s0+s3 + s1 + s2,  m1 = bm(pattern 1) = 510-(s0+s3) + s1 + s2,
+// c = 255 - 2 s1 (bm(p | 2) = bm(p) + c).  Packed m0 | m1 << 10 | (c + 256) << 20, so the decoder spends its
+// instructions on the trellis, not on unpacking bytes.
+__device__ __forceinline__ uint32_t pack_step(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3)
+{
+    const uint32_t t0 = s0 + s3, u = s1 + s2;
+    return (t0 + u) | ((510u - t0 + u) << 10) | ((511u - 2u * s1) << 20);
+}
+__device__ __forceinline__ uint32_t pack_step_word(uint32_t w) { return pack_step(w & 0xff, (w >> 8) & 0xff, (w >> 16) & 0xff, w >> 24); }
+
 // Register layout: R[j] = (metric of state 2j | metric of state 2j+1 << 16).  Butterfly k (0..31) reads old[k] and
 // old[k+32] -- half (k & 1) of R[k >> 1] and of R[16 + (k >> 1)], broadcast to both halves by the op_sel bits of the
 // packed add -- and produces new[2k], new[2k+1] = N[k]: the layout is stationary, no register is ever re-paired.
@@ -44,6 +56,8 @@ __host__ __device__ constexpr int bf_pattern(int i)
 //   N[k] = min(P, Q);  decisions d = m0 > m1 | m2 > m3 = sign bits of Q - P (ties keep the m0 / m2 branch)
 // Decision words: pk_sign_bytes(D[i], D[i+16]) = bytes [d(2i), d(2i+32), d(2i+1), d(2i+33)] as 0x00 / 0xff, masked onto
 // bit (i & 7) of word (i >> 3).  Decision of state s at a step: word (s >> 4) & 1, byte 2 * (s & 1) + (s >> 5), bit (s >> 1) & 7.
+constexpr int VIT_PF = 4;        // trellis steps per software-pipeline stage (even, divides 32)
+
 template <int K>
 __device__ __forceinline__ void bfly(const u16x2 (&R)[32], u16x2 (&N)[32], u16x2 (&D)[32], const u16x2 (&BM)[4])
 {
@@ -66,33 +80,27 @@ __device__ __forceinline__ void decide(const u16x2 (&D)[32], uint32_t& accA, uin
     else       accB = and_or(x, ones << (I & 7), accB);
 }
 
-template <int K>
-__device__ __forceinline__ void bfly_all(const u16x2 (&R)[32], u16x2 (&N)[32], u16x2 (&D)[32], const u16x2 (&BM)[4])
-{
-    bfly<K>(R, N, D, BM);
-    if constexpr (K + 1 < 32) bfly_all<K + 1>(R, N, D, BM);
-}
+// butterflies I and I + 16 followed at once by their decision bytes: the two difference registers die immediately
 template <int I>
-__device__ __forceinline__ void decide_all(const u16x2 (&D)[32], uint32_t& accA, uint32_t& accB, uint32_t ones)
+__device__ __forceinline__ void bfly_pairs(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&BM)[4], uint32_t& accA, uint32_t& accB, uint32_t ones)
 {
+    u16x2 D[32];
+    bfly<I>(R, N, D, BM);
+    bfly<I + 16>(R, N, D, BM);
     decide<I>(D, accA, accB, ones);
-    if constexpr (I + 1 < 16) decide_all<I + 1>(D, accA, accB, ones);
+    if constexpr (I + 1 < 16) bfly_pairs<I + 1>(R, N, BM, accA, accB, ones);
 }
 
 __device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out, uint32_t ones)
 {
-    // sy = 4 symbols 0..255 (byte j = output j of the mother code).  Branch metric of pattern p:
-    // sum_j (bit_j(p) ? 255 - s_j : s_j), outputs 0 and 3 share bit 0 (viterbi.cpp:259-261); bm(p ^ 7) = 1020 - bm(p).
-    const uint32_t s1 = (sy >> 8) & 0xff, s2 = (sy >> 16) & 0xff;
-    const uint32_t t0 = (sy & 0xff) + (sy >> 24);
-    const uint32_t m0 = t0 + s1 + s2, m1 = 510u - t0 + s1 + s2, m2 = t0 + 255u - s1 + s2, m3 = 765u - t0 - s1 + s2;
+    // sy = pack_step(): bm(0), bm(1) and c with bm(p | 2) = bm(p) + c; bm(p ^ 7) = 1020 - bm(p)
+    const uint32_t m0 = sy & 0x3ffu, m1 = (sy >> 10) & 0x3ffu;
+    const uint32_t m2 = m0 + (sy >> 20) - 256u, m3 = m1 + (sy >> 20) - 256u;
     u16x2 BM[4];    // BM[p] = (bm(p), bm(p ^ 7))
     BM[0] = asv(m0 | ((1020u - m0) << 16)); BM[1] = asv(m1 | ((1020u - m1) << 16));
     BM[2] = asv(m2 | ((1020u - m2) << 16)); BM[3] = asv(m3 | ((1020u - m3) << 16));
-    u16x2 D[32];
-    bfly_all<0>(R, N, D, BM);
     uint32_t accA = 0, accB = 0;
-    decide_all<0>(D, accA, accB, ones);
+    bfly_pairs<0>(R, N, BM, accA, accB, ones);
     *dec_out = make_uint2(accA, accB);
 }
 
@@ -127,17 +135,33 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
     for (int j = 0; j < 32; j++) R[j] = splat(63);
     R[0] = asv(63u << 16);
 
-    // two trellis steps per iteration (R -> N -> R); the symbols of the next iteration are requested before the
-    // current ones are consumed, so a wave never waits on its own load (nor on its decision stores)
+    // VIT_PF trellis steps per iteration (R -> N -> R ...); the symbols of the NEXT iteration are requested before the
+    // current ones are consumed, so a wave waits neither on its own loads nor on the completion of its decision stores
+    // (one vmcnt counter covers both on gfx9: a wait for a load also waits for every older store).
     int s = 0;
-    uint32_t y0 = sym[0], y1 = nsteps > 1 ? sym[64] : 0u;
+    uint32_t y[VIT_PF];
+#pragma unroll
+    for (int k = 0; k < VIT_PF; k++) y[k] = sym[(size_t)(k < nsteps ? k : nsteps - 1) * 64];
+    for (; s + VIT_PF <= nsteps; s += VIT_PF) {
+        uint32_t n[VIT_PF];
+        {
+            const int i0 = (s + 2 * VIT_PF <= nsteps) ? s + VIT_PF : nsteps - VIT_PF;     // clamp: the last iterations re-read valid memory
+            const uint32_t* __restrict__ q = sym + (size_t)i0 * 64;
+#pragma unroll
+            for (int k = 0; k < VIT_PF; k++) n[k] = q[k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < VIT_PF; k += 2) {
+            trellis_step(R, N, y[k], dec + (size_t)(s + k) * 64, ones);
+            trellis_step(N, R, y[k + 1], dec + (size_t)(s + k + 1) * 64, ones);
+        }
+        if ((s & 24) == 24 && ((s + VIT_PF) & 31) == 0) renorm(R);   // every 32 steps: 6120 + 32 * 1020 < 65536
+#pragma unroll
+        for (int k = 0; k < VIT_PF; k++) y[k] = n[k];
+    }
     for (; s + 1 < nsteps; s += 2) {
-        const int sn = (s + 3 < nsteps) ? s + 2 : s;             // clamp: the last iteration re-reads valid memory
-        const uint32_t n0 = sym[(size_t)sn * 64], n1 = sym[(size_t)(sn + 1) * 64];
-        trellis_step(R, N, y0, dec + (size_t)s * 64, ones);
-        trellis_step(N, R, y1, dec + (size_t)(s + 1) * 64, ones);
-        if ((s & 14) == 14) renorm(R);
-        y0 = n0; y1 = n1;
+        trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64, ones);
+        trellis_step(N, R, sym[(size_t)(s + 1) * 64], dec + (size_t)(s + 1) * 64, ones);
     }
     if (s < nsteps) {
         trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64, ones);
@@ -196,7 +220,7 @@ __global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
             v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
             word |= (uint32_t)v << (8 * j);
         }
-        dst[(size_t)s * 64] = word;
+        dst[(size_t)s * 64] = pack_step_word(word);
     }
 }
 
@@ -281,7 +305,7 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
                 v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
                 word |= (uint32_t)v << (8 * j);
             }
-            dst[(size_t)s * 64] = word;
+            dst[(size_t)s * 64] = pack_step_word(word);
         }
         return;
     }
@@ -314,13 +338,13 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
             const int4 mb = *reinterpret_cast<const int4*>(&s_map[4 * (s + 4 - s0)]);
             const int a0 = pick(ma.x), a1 = pick(ma.y), a2 = pick(ma.z), a3 = pick(ma.w);
             const int b0 = pick(mb.x), b1 = pick(mb.y), b2 = pick(mb.z), b3 = pick(mb.w);
-            dst[(size_t)s * 64] = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
-            dst[(size_t)(s + 4) * 64] = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
+            dst[(size_t)s * 64] = pack_step(a0, a1, a2, a3);
+            dst[(size_t)(s + 4) * 64] = pack_step(b0, b1, b2, b3);
         }
         if (s < s1) {
             const int4 ma = *reinterpret_cast<const int4*>(&s_map[4 * (s - s0)]);
             const int a0 = pick(ma.x), a1 = pick(ma.y), a2 = pick(ma.z), a3 = pick(ma.w);
-            dst[(size_t)s * 64] = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
+            dst[(size_t)s * 64] = pack_step(a0, a1, a2, a3);
         }
         __syncthreads();
     }
@@ -345,7 +369,7 @@ __global__ void __launch_bounds__(256) k_lin_gather(LinGatherArgs A)
             v += 127; v = v < 0 ? 0 : v; v = v > 255 ? 255 : v;
             word |= (uint32_t)v << (8 * j);
         }
-        dst[(size_t)s * 64] = word;
+        dst[(size_t)s * 64] = pack_step_word(word);
     }
 }
 
