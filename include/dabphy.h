@@ -129,6 +129,18 @@ int dabphy_stream_open(dabphy_handle* h, uint64_t ring_samples);
 int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples);
 uint64_t dabphy_stream_consumed(dabphy_handle* h);
 
+/* The same, from the sample formats the reference's file / SDR front ends deliver (CRAWFileFormat, input/raw_file.h;
+ * conversion = CRAWFile::convertSamples, input/raw_file.cpp:324-366, done on the device: u8 moves 2 bytes per sample
+ * over PCIe instead of 8).  data = [ensemble][n_samples] interleaved I/Q in `format`.  DABPHY_FMT_S16LE / _S16BE keep
+ * the reference's byte order for those names ((byte0 << 8) | byte1 and (byte1 << 8) | byte0) and its missing scaling. */
+typedef enum { DABPHY_FMT_CF32 = 0, DABPHY_FMT_U8 = 1, DABPHY_FMT_S8 = 2, DABPHY_FMT_S16LE = 3, DABPHY_FMT_S16BE = 4 } dabphy_sample_format;
+int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format);
+
+/* Page-locked host memory for the buffers handed to dabphy_stream_write / _write_raw (DMA at PCIe rate instead of a
+ * staged copy); plain malloc'ed buffers work too. */
+int dabphy_host_alloc(size_t bytes, void** out);
+void dabphy_host_free(void* p);
+
 /* OFDMProcessor::restart (ofdm-processor.cpp:115-132): correctors, phase, sync state, FIC counter, SNR filter cleared */
 int dabphy_reset(dabphy_handle* h);
 

@@ -159,3 +159,62 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
             assert len(got) > 0 or n < 5
             assert got == o["msc"][i][:len(got)], "MSC bytes of sub-channel %d differ" % i
     return logs, o, tx
+
+
+# ---- live ring fed in raw sample formats (dabphy_stream_open / dabphy_stream_write_raw = CRAWFile::convertSamples on the device)
+def raw_encode(x, fmt):
+    """-> (raw array [n][2] as stored in a file of that CRAWFileFormat, cf32 samples raw_file.cpp:324-366 makes of it)"""
+    iq = np.stack([x.real, x.imag], 1)
+    if fmt == "u8":
+        raw = np.clip(np.round(iq * 127.0) + 128, 0, 255).astype(np.uint8)
+        f = ((raw.astype(np.int32) - 128).astype(np.float32) / np.float32(128.0)).astype(np.float32)
+    elif fmt == "s8":
+        raw = np.clip(np.round(iq * 127.0), -128, 127).astype(np.int8)
+        f = (raw.astype(np.float32) / np.float32(128.0)).astype(np.float32)
+    else:
+        v = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+        # the reference's "S16LE" reads (byte0 << 8) | byte1, its "S16BE" (byte1 << 8) | byte0
+        raw = v.astype(">i2" if fmt == "s16le" else "<i2")
+        f = v.astype(np.float32)
+    return raw, (f[:, 0] + 1j * f[:, 1]).astype(np.complex64)
+
+
+def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35):
+    T_F = 196608
+    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=300, return_tx=True, seed=seed)
+    subs = [tx.subchs[2], tx.subchs[11]]
+    raw, xf = raw_encode(x, fmt)
+    o = R.orc_receiver_run(xf, subchs=subs)
+    d = d_factory(n_ensembles=1, max_frames=1, want_constellation=False)
+    try:
+        d.stream_open(6 * T_F)
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+        fibs, oks, msc = [], [], [[] for _ in subs]
+        wr = 0
+        def feed(n):
+            nonlocal wr
+            n = min(n, len(raw) - wr)
+            if n > 0:
+                d.stream_write_raw(raw[wr:wr + n], fmt); wr += n
+        feed(3 * T_F)
+        idle = 0
+        while idle < 3:
+            d.process(1)
+            info = d.frame_info()
+            if info[0, 0]["valid"] == 1:
+                fb, ok = d.fibs(); fibs.append(fb[0, 0]); oks.append(ok[0, 0]); idle = 0
+                for i in range(len(subs)):
+                    m, fv = d.msc(i); msc[i].append(m[0, fv[0]:4].tobytes())
+            else:
+                idle += 1
+            room = 6 * T_F - (wr - d.stream_consumed())
+            feed(min(room, T_F))
+        n = len(fibs)
+        assert n >= o["n_frames"] - 1, (n, o["n_frames"])
+        ofib = o["fib"][:12 * n].reshape(n, 12, 33)
+        assert np.array_equal(np.array(oks), ofib[:, :, 0]) and np.array_equal(np.array(fibs), ofib[:, :, 1:]), "FIBs differ"
+        for i in range(len(subs)):
+            got = b"".join(msc[i]); want = bytes(o["msc"][i])
+            assert len(got) > 0 and got == want[:len(got)], "MSC bytes of sub-channel %d differ" % i
+    finally:
+        d.close()

@@ -33,3 +33,9 @@ def test_pipelined_sync(emu):
 
 def test_stream_without_constellation(emu):
     P.check_stream_vs_oracle(factory, 12, 75, 10, 7, False, con=False)
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
+def test_live_ring_raw_formats(emu, fmt):
+    """samples appended to the library's ring in the reference's file formats, converted on the device"""
+    P.check_live_raw_vs_oracle(factory, fmt)

@@ -50,3 +50,9 @@ def test_pipelined_sync(gpu):
 def test_stream_without_constellation(gpu):
     """the demod kernel variant without the constellation tap (what the throughput path runs)"""
     P.check_stream_vs_oracle(factory, 12, 75, 10, 10, False, con=False)
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
+def test_live_ring_raw_formats(gpu, fmt):
+    """samples appended to the library's ring in the reference's file formats, converted on the device"""
+    P.check_live_raw_vs_oracle(factory, fmt)

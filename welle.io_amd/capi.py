@@ -160,6 +160,38 @@ class DabPhy:
         self._n_sub = len(subs); self._sub_bytes = [s[3].nbits // 8 for s in subs]
         self._chk(self.lib.dabphy_set_subchannels(self.h, arr, len(subs)))
 
+    def host_alloc(self, shape, dtype):
+        """page-locked numpy array (dabphy_host_alloc); release with host_free(arr)"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self.lib.dabphy_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+        arr = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {}); self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        self.lib.dabphy_host_free.restype = None
+        self.lib.dabphy_host_free(self._pinned.pop(arr.ctypes.data))
+
+    def stream_open(self, ring_samples):
+        self._chk(self.lib.dabphy_stream_open(self.h, C.c_uint64(ring_samples)))
+
+    def stream_write(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64).reshape(self.cfg.n_ensembles, -1)
+        self._chk(self.lib.dabphy_stream_write(self.h, _p(iq), C.c_uint64(iq.shape[1])))
+
+    def stream_write_raw(self, data, fmt):
+        """data: [ensemble][n_samples][2] integers in the sample format fmt ("u8", "s8", "s16le", "s16be": CRAWFileFormat names)"""
+        code = {"u8": 1, "s8": 2, "s16le": 3, "s16be": 4}[fmt]
+        data = np.ascontiguousarray(data)
+        bps = 2 if code <= 2 else 4
+        n = data.nbytes // (self.cfg.n_ensembles * bps)
+        self._chk(self.lib.dabphy_stream_write_raw(self.h, _p(data), C.c_uint64(n), code))
+
+    def stream_consumed(self):
+        self.lib.dabphy_stream_consumed.restype = C.c_uint64
+        return int(self.lib.dabphy_stream_consumed(self.h))
+
     def process(self, n_frames):
         self._chk(self.lib.dabphy_process(self.h, n_frames))
         self._last = n_frames

@@ -47,6 +47,7 @@ struct dabphy_handle {
     uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
+    DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
     DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr;
@@ -179,7 +180,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_raw, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
@@ -358,6 +359,33 @@ int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples)
     h->s_valid += n_samples;
     return sync(h);
 }
+
+int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format)
+{
+    if (format == DABPHY_FMT_CF32) return dabphy_stream_write(h, reinterpret_cast<const float*>(data), n_samples);
+    if (!h || !data || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring ||
+        format < DABPHY_FMT_U8 || format > DABPHY_FMT_S16BE) return DABPHY_ERR_INVALID;
+    const size_t bps = (format == DABPHY_FMT_U8 || format == DABPHY_FMT_S8) ? 2 : 4;
+    const uint32_t B = h->cfg.n_ensembles;
+    int r;
+    if ((r = ensure(h, h->s_raw, (size_t)B * n_samples * bps))) return r;
+    HIPCHK(h, hipStreamSynchronize(h->sync_stream));           // the chain that may be running ahead must not race with the write
+    HIPCHK(h, hipMemcpyAsync(h->s_raw.p, data, (size_t)B * n_samples * bps, hipMemcpyHostToDevice, h->stream));
+    IngestArgs a{};
+    a.raw = h->s_raw.as<uint8_t>(); a.raw_stride = n_samples * bps; a.iq = h->s_iq_own.as<cf32>(); a.iq_stride = h->s_stride;
+    a.ring = h->s_ring; a.w = h->s_valid % h->s_ring; a.n = n_samples; a.format = format;
+    launch_ingest(a, (int)B, h->stream);
+    h->s_valid += n_samples;
+    return sync(h);
+}
+
+int dabphy_host_alloc(size_t bytes, void** out)
+{
+    if (!out || !bytes) return DABPHY_ERR_INVALID;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DABPHY_OK : DABPHY_ERR_NOMEM;
+}
+
+void dabphy_host_free(void* p) { if (p) { hipError_t e = hipHostFree(p); (void)e; } }
 
 uint64_t dabphy_stream_consumed(dabphy_handle* h)
 {

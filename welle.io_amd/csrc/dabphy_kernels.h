@@ -125,6 +125,14 @@ struct LinGatherArgs {
     VitClass c;
 };
 
+// Sample ingest (k_ingest.hip): n samples per ensemble of raw format `format` -> ring positions w, w+1, ... (mod ring)
+struct IngestArgs {
+    const uint8_t* raw; size_t raw_stride;               // bytes between ensembles
+    cf32* iq; size_t iq_stride; uint64_t ring, w, n;
+    int format;                                           // dabphy_sample_format
+};
+void launch_ingest(const IngestArgs& a, int n_ens, hipStream_t s);
+
 // Reed-Solomon (k_rs.hip)
 struct RsArgs {            // contiguous superframes [n_sf][sf_stride], s = bitrate/8 codewords each
     uint8_t* data; size_t sf_stride; int n_sf, s;

@@ -1,0 +1,43 @@
+// welle.io_amd/csrc/k_ingest.hip -- sample ingest: raw device-format IQ -> cf32 in the per-ensemble sample ring.
+//
+// Replaces CRAWFile::convertSamples (input/raw_file.cpp:324-366), which every file/SDR front end of the reference
+// funnels through before OFDMProcessor sees a sample.  Converting on the GPU means 2 bytes per sample cross PCIe for
+// u8/s8 (4 for s16) instead of 8 for cf32.  The arithmetic is the reference's: u8 (b - 128) / 128.0, s8 b / 128.0 (both
+// exact in float), s16 the raw integer value unscaled -- and its byte order: the reference's "S16LE" assembles
+// (byte0 << 8) | byte1 and "S16BE" (byte1 << 8) | byte0; the names are kept, the behaviour too.
+#include "dabphy_kernels.h"
+
+namespace dabphy {
+
+__global__ void __launch_bounds__(256) k_ingest(IngestArgs A)
+{
+    const int b = blockIdx.y;
+    const uint8_t* __restrict__ src = A.raw + (size_t)b * A.raw_stride;
+    cf32* __restrict__ dst = A.iq + (size_t)b * A.iq_stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        cf32 v;
+        if (A.format == 1) {                                  // U8
+            const uint16_t w = reinterpret_cast<const uint16_t*>(src)[i];
+            v.re = (float)((int)(w & 0xff) - 128) * 0.0078125f; v.im = (float)((int)(w >> 8) - 128) * 0.0078125f;
+        } else if (A.format == 2) {                           // S8
+            const uint16_t w = reinterpret_cast<const uint16_t*>(src)[i];
+            v.re = (float)(int8_t)(w & 0xff) * 0.0078125f; v.im = (float)(int8_t)(w >> 8) * 0.0078125f;
+        } else {                                              // S16 "LE" (3) / "BE" (4)
+            const uint32_t w = reinterpret_cast<const uint32_t*>(src)[i];
+            const uint32_t b0 = w & 0xff, b1 = (w >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
+            const int16_t I = A.format == 3 ? (int16_t)((b0 << 8) | b1) : (int16_t)((b1 << 8) | b0);
+            const int16_t Q = A.format == 3 ? (int16_t)((b2 << 8) | b3) : (int16_t)((b3 << 8) | b2);
+            v.re = (float)I; v.im = (float)Q;
+        }
+        uint64_t p = A.w + i; if (p >= A.ring) p -= A.ring;
+        dst[p] = v;
+    }
+}
+
+void launch_ingest(const IngestArgs& a, int n_ens, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::min<uint64_t>((a.n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_ingest, dim3(blocks, n_ens), dim3(256), 0, s, a);
+}
+
+} // namespace dabphy
