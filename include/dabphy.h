@@ -196,6 +196,26 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
 
 /* ---- per-stage device time of the last dabphy_process (HIP events on the handle's stream) -------------------
  * ms[0..6] = sync chain, demod kernel, SNR, FIC (gather+Viterbi+CRC), MSC gather, MSC Viterbi, Reed-Solomon */
+/* DAB+ superframe filter on the device (SuperframeFilter::Feed / CheckSync, dabplus_decoder.cpp:50-213) for sub-channel
+ * subch_index of every ensemble, over the logical frames of the last dabphy_process() batch: 5-frame sliding window,
+ * Reed-Solomon, Fire-code synchronisation, access-unit table and AU CRCs.  The window state is carried from batch to
+ * batch, so call it exactly once per dabphy_process() for every sub-channel it is used on.
+ *   events   [n_ensembles][4 * n_frames]: one record per decode attempt (= per FECInfo() call of the reference), in order
+ *   n_events [n_ensembles]
+ *   sf       [n_ensembles][n_slots][120 * bitrate/8], n_slots = 4 * n_frames / 5 + 1: the corrected superframes of the
+ *            synchronised attempts (event.sf_slot); may be NULL
+ * The access units of a synchronised superframe are sf[au_start[i] .. au_start[i+1]) with the last two bytes = CRC. */
+typedef struct {
+    int32_t cif;                         /* logical frame (0 .. 4*n_frames-1 of the batch) that completed the window */
+    int32_t corrected, uncorrectable;    /* RSDecoder::DecodeSuperframe totals (what onRsErrors / FECInfo report) */
+    int32_t sync;                        /* CheckSync() */
+    int32_t format;                      /* sf[2]: dac_rate 0x40, sbr 0x20, aac_channel_mode 0x10, ps 0x08, mpeg_surround 0x07 */
+    int32_t num_aus, au_start[7];
+    int32_t au_crc_ok;                   /* bit i = access unit i passed its CRC-16 */
+    int32_t sf_slot;                     /* index into sf, -1 when not synchronised */
+} dabphy_sf_event;
+int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf);
+
 int dabphy_set_profiling(dabphy_handle* h, int32_t on);
 int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);
 

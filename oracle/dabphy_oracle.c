@@ -709,6 +709,74 @@ void orc_rs_superframe(uint8_t* sf, int sf_len, int* total_corr, int* uncorr)
     }
 }
 
+/* ------------------------------------------------------------------------------------------ DAB+ superframe filter */
+
+/* CalcCRC (tools.cpp:41-72): MSB-first CRC-16, optional initial / final inversion */
+uint16_t orc_crc16(const uint8_t* data, int len, int initial_invert, int final_invert, uint16_t poly)
+{
+    uint16_t crc = initial_invert ? 0xFFFF : 0x0000;
+    for (int o = 0; o < len; o++) {
+        crc ^= (uint16_t)(data[o] << 8);
+        for (int i = 0; i < 8; i++) crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ poly) : (uint16_t)(crc << 1);
+    }
+    return final_invert ? (uint16_t)~crc : crc;
+}
+
+/* SuperframeFilter::CheckSync (dabplus_decoder.cpp:160-213) on a corrected superframe; fills num_aus / au_start */
+static int sf_check_sync(const uint8_t* sf, int sf_len, int* num_aus_out, int* au_start)
+{
+    if (sf[3] == 0x00 && sf[4] == 0x00) return 0;
+    uint16_t crc_stored = (uint16_t)(sf[0] << 8 | sf[1]);
+    uint16_t crc_calced = orc_crc16(sf + 2, 9, 0, 0, 0x782F);                 /* CalcCRC_FIRE_CODE, tools.cpp:37 */
+    if (crc_stored != crc_calced) return 0;
+    int dac_rate = sf[2] & 0x40, sbr_flag = sf[2] & 0x20;
+    int num_aus = dac_rate ? (sbr_flag ? 3 : 6) : (sbr_flag ? 2 : 4);
+    au_start[0] = dac_rate ? (sbr_flag ? 6 : 11) : (sbr_flag ? 5 : 8);
+    au_start[num_aus] = sf_len / 120 * 110;
+    au_start[1] = sf[3] << 4 | sf[4] >> 4;
+    if (num_aus >= 3) au_start[2] = (sf[4] & 0x0F) << 8 | sf[5];
+    if (num_aus >= 4) au_start[3] = sf[6] << 4 | sf[7] >> 4;
+    if (num_aus == 6) { au_start[4] = (sf[7] & 0x0F) << 8 | sf[8]; au_start[5] = sf[9] << 4 | sf[10] >> 4; }
+    *num_aus_out = num_aus;                                                   /* the member is set before the plausibility check */
+    for (int i = 0; i < num_aus; i++) if (au_start[i] >= au_start[i + 1]) return 0;
+    return 1;
+}
+
+/* SuperframeFilter::Feed (dabplus_decoder.cpp:50-157) for one logical frame.  st: frame_count + 5 raw frames, caller
+ * allocated (orc_sf_state_bytes(len)) and zeroed.  Returns 1 when the call ran a decode attempt and filled ev; on sync the
+ * corrected superframe (5 * len bytes) is written to sf_out. */
+int orc_sf_state_bytes(int frame_len) { return 16 + 5 * frame_len; }
+
+int orc_superframe_feed(uint8_t* st, const uint8_t* frame, int len, int frame_index, orc_sf_event* ev, uint8_t* sf_out)
+{
+    int32_t* frame_count = (int32_t*)st; uint8_t* sf_raw = st + 16;
+    const int sf_len = 5 * len;
+    if (len < 10 || (5 * len) % 120) return 0;                                /* :59-66: frame ignored */
+    if (*frame_count == 5) {
+        for (int i = 0; i < 4; i++) memcpy(sf_raw + i * len, sf_raw + (i + 1) * len, len);
+    } else (*frame_count)++;
+    memcpy(sf_raw + (*frame_count - 1) * len, frame, len);
+    if (*frame_count < 5) return 0;
+    memset(ev, 0, sizeof *ev);
+    ev->cif = frame_index; ev->sf_slot = -1;
+    memcpy(sf_out, sf_raw, sf_len);
+    int corr, unc; orc_rs_superframe(sf_out, sf_len, &corr, &unc);
+    ev->corrected = corr; ev->uncorrectable = unc;
+    int num_aus = 0, au_start[7] = {0};
+    if (!sf_check_sync(sf_out, sf_len, &num_aus, au_start)) return 1;
+    ev->sync = 1; ev->format = sf_out[2]; ev->num_aus = num_aus;
+    for (int i = 0; i <= num_aus; i++) ev->au_start[i] = au_start[i];
+    for (int i = 0; i < num_aus; i++) {                                       /* :122-131 AU CRC (CRC16-CCITT, both inversions) */
+        const uint8_t* au = sf_out + au_start[i]; int au_len = au_start[i + 1] - au_start[i];
+        /* an AU shorter than its CRC reads out of bounds in the reference (size_t underflow): treated as a CRC failure here */
+        if (au_len < 2) continue;
+        uint16_t stored = (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]);
+        if (stored == orc_crc16(au, au_len - 2, 1, 1, 0x1021)) ev->au_crc_ok |= 1 << i;
+    }
+    *frame_count = 0;                                                         /* :156: wait for a complete new superframe */
+    return 1;
+}
+
 /* ------------------------------------------------------------------------------------------ receiver */
 
 typedef struct {

@@ -94,6 +94,20 @@ int orc_subch_process(orc_subch* s, const int8_t* cif_slice, uint8_t* out_bytes)
 
 /* dabplus_decoder.cpp:326-359 + libs/fec decode_rs.h (8,0x11D,fcr 0,prim 1,10 roots,pad 135) */
 void orc_rs_superframe(uint8_t* sf, int len, int* corrected, int* uncorrectable);
+
+/* DAB+ superframe filter (SuperframeFilter::Feed / CheckSync, dabplus_decoder.cpp:50-213): one record per decode attempt */
+typedef struct {
+    int32_t cif;             /* index of the logical frame that completed the 5-frame window */
+    int32_t corrected, uncorrectable;   /* RSDecoder::DecodeSuperframe totals = FECInfo() arguments */
+    int32_t sync;            /* CheckSync() result */
+    int32_t format;          /* sf[2] (valid when sync) */
+    int32_t num_aus, au_start[7];
+    int32_t au_crc_ok;       /* bit i: access unit i passed its CRC */
+    int32_t sf_slot;         /* device API: where the corrected superframe was stored, -1 = not kept */
+} orc_sf_event;
+uint16_t orc_crc16(const uint8_t* data, int len, int initial_invert, int final_invert, uint16_t poly);
+int orc_sf_state_bytes(int frame_len);
+int orc_superframe_feed(uint8_t* st, const uint8_t* frame, int len, int frame_index, orc_sf_event* ev, uint8_t* sf_out);
 void orc_rs_encode120(const uint8_t* data110, uint8_t* parity10);          /* encode_rs.h (test input generation) */
 
 /* Full receiver: ofdm-processor.cpp:235-501 driving all of the above in lock step. */

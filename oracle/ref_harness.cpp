@@ -43,6 +43,7 @@
 #define private public
 #define protected public
 #include "radio-receiver.h"
+#include "dabplus_decoder.h"
 #undef private
 #undef protected
 #include "energy_dispersal.h"
@@ -311,6 +312,42 @@ void ref_nco_entry(int i, float* out2)
 {
     DSPCOMPLEX c(cos(2.0 * M_PI * i / INPUT_RATE), sin(2.0 * M_PI * i / INPUT_RATE));
     out2[0] = c.real(); out2[1] = c.imag();
+}
+
+// ---- the real SuperframeFilter (dabplus_decoder.cpp) fed frame by frame; one record per decode attempt, filled from
+// the observer callbacks (FECInfo, AudioError) and the filter's members after Feed() returns
+struct ref_sf_event { int32_t cif, corrected, uncorrectable, sync, format, num_aus, au_start[7], au_crc_ok, sf_slot; };
+
+namespace {
+struct SfRecorder : SubchannelSinkObserver {
+    bool attempted = false; int corr = 0; bool unc = false; unsigned bad_aus = 0;
+    void FECInfo(int c, bool u) override { attempted = true; corr = c; unc = u; }
+    void AudioError(const std::string& hint) override { if (hint.rfind("AU #", 0) == 0) bad_aus |= 1u << atoi(hint.c_str() + 4); }
+};
+}
+
+int ref_superframe_run(const uint8_t* frames, int n_frames, int frame_len, ref_sf_event* events, int cap, uint8_t* sf_out)
+{
+    SfRecorder rec;
+    SuperframeFilter f(&rec, false, false);
+    int ne = 0;
+    for (int i = 0; i < n_frames; i++) {
+        rec.attempted = false; rec.bad_aus = 0;
+        f.Feed(frames + (size_t)i * frame_len, (size_t)frame_len);
+        if (!rec.attempted || ne >= cap) continue;
+        ref_sf_event& e = events[ne];
+        memset(&e, 0, sizeof e);
+        e.cif = i; e.corrected = rec.corr; e.uncorrectable = rec.unc ? 1 : 0; e.sf_slot = -1;
+        e.sync = f.frame_count == 0 ? 1 : 0;                     // Feed() ends with frame_count = 0 only after a successful CheckSync
+        if (e.sync) {
+            e.format = f.sf[2]; e.num_aus = f.num_aus;
+            for (int k = 0; k <= f.num_aus; k++) e.au_start[k] = f.au_start[k];
+            e.au_crc_ok = ((1u << f.num_aus) - 1) & ~rec.bad_aus;
+            memcpy(sf_out + (size_t)ne * 5 * frame_len, f.sf, (size_t)5 * frame_len);
+        }
+        ne++;
+    }
+    return ne;
 }
 
 } // extern "C"

@@ -218,3 +218,61 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35):
             assert len(got) > 0 and got == want[:len(got)], "MSC bytes of sub-channel %d differ" % i
     finally:
         d.close()
+
+
+# ---- DAB+ superframe filter on the device vs the oracle's (itself pinned to the real SuperframeFilter)
+def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True):
+    """superframes straddle the batches (12 logical frames per batch, 5 per superframe); the noise level makes the Viterbi
+    output carry byte errors for Reed-Solomon to correct (no loss of lock: batch mode and the reference drop different
+    frames then), and the transmitter damages some superframes beyond repair: a broken access unit, more byte errors than
+    RS(120,110) corrects, a Fire-code hit that costs the synchronisation"""
+    base = synth.dabplus_payload_fn(80, seed)
+
+    def payload(sc, r):
+        data = bytearray(base(sc, r))
+        if damage:
+            q, k = (r % 80) // 5, r % 5
+            if q == 6 and k == 2: data[40] ^= 0x5A                                   # inside an access unit of superframe 6: AU CRC fails after RS has nothing to say
+            if q == 6 and k == 2:
+                for j in range(12): data[3 + j * (sc.bitrate // 8)] ^= 0x33          # ... because codeword 3 is beyond repair
+            if q == 8 and k == 0: data[0] ^= 0xFF; data[sc.bitrate // 8] ^= 0xFF; data[2 * (sc.bitrate // 8)] ^= 1; data[3 * (sc.bitrate // 8)] ^= 7
+            if q == 8 and k == 0:
+                for j in range(4, 10): data[j * (sc.bitrate // 8)] ^= 0x81           # header column uncorrectable -> Fire code fails -> window slides
+        return bytes(data)
+    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=20, delay=50, return_tx=True, seed=seed, payload_fn=payload)
+    subs = [tx.subchs[1], tx.subchs[6]]
+    o = R.orc_receiver_run(x, subchs=subs)
+    d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
+    try:
+        d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+        got = [[[] for _ in subs] for _ in range(B)]; got_sf = [[[] for _ in subs] for _ in range(B)]
+        for _ in range((nf + F - 1) // F):
+            d.process(F)
+            info = d.frame_info()
+            if not (info["valid"] == 1).any():
+                break
+            for i, sc in enumerate(subs):
+                ev, ne, sf = d.superframes(i, sc.bitrate)
+                for b in range(B):
+                    for k in range(ne[b]):
+                        e = ev[b, k]
+                        got[b][i].append((int(e["corrected"]), int(e["uncorrectable"]), int(e["sync"]), int(e["format"]), int(e["num_aus"]),
+                                          tuple(int(v) for v in e["au_start"][:e["num_aus"] + 1]) if e["sync"] else (), int(e["au_crc_ok"])))
+                        if e["sync"]:
+                            got_sf[b][i].append(sf[b, e["sf_slot"]].copy())
+        for i, sc in enumerate(subs):
+            fb = 3 * sc.bitrate
+            frames = np.frombuffer(bytes(o["msc"][i]), np.uint8)
+            frames = frames[:len(frames) // fb * fb].reshape(-1, fb)
+            eo, so = R.orc_superframe_run(frames)
+            want = [e[1:] for e in eo]
+            for b in range(B):
+                n = len(got[b][i])
+                assert n >= len(want) - 4 and n > 0, (n, len(want))
+                assert got[b][i] == [(w[0], w[1], w[2], w[3], w[4], w[5], w[6]) for w in want[:n]], "superframe events of sub-channel %d differ" % i
+                ns = len(got_sf[b][i])
+                assert ns >= 1 and all(np.array_equal(got_sf[b][i][k], so[k]) for k in range(ns)), "corrected superframes differ"
+        return got
+    finally:
+        d.close()

@@ -368,3 +368,38 @@ def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_p
     return dict(fib=fib[:io.n_fib], cir=cir[:io.n_cir], con=con[:io.n_con], snr=snr[:io.n_snr], corr=corr[:io.n_corr], msc=msc,
                 n_sync_true=io.n_sync_true, n_sync_false=io.n_sync_false, n_services=io.n_services,
                 rs_calls=list(io.rs_calls), rs_uncorr=list(io.rs_uncorr), rs_corr=list(io.rs_corr))
+
+
+# ---- DAB+ superframe filter (SuperframeFilter::Feed): oracle restatement and the real class
+class SfEvent(C.Structure):
+    _fields_ = [("cif", C.c_int32), ("corrected", C.c_int32), ("uncorrectable", C.c_int32), ("sync", C.c_int32), ("format", C.c_int32),
+                ("num_aus", C.c_int32), ("au_start", C.c_int32 * 7), ("au_crc_ok", C.c_int32), ("sf_slot", C.c_int32)]
+
+
+def _ev_tuple(e):
+    return (e.cif, e.corrected, e.uncorrectable, e.sync, e.format if e.sync else 0, e.num_aus if e.sync else 0,
+            tuple(e.au_start[:e.num_aus + 1]) if e.sync else (), e.au_crc_ok if e.sync else 0)
+
+
+def orc_superframe_run(frames):
+    """frames: [n][len] uint8 -> (list of event tuples, list of corrected superframes for the synced ones)"""
+    frames = np.ascontiguousarray(frames, np.uint8); n, ln = frames.shape
+    lib = orc()
+    lib.orc_sf_state_bytes.restype = C.c_int
+    st = np.zeros(lib.orc_sf_state_bytes(ln), np.uint8)
+    out = np.zeros(5 * ln, np.uint8)
+    evs, sfs = [], []
+    for i in range(n):
+        e = SfEvent()
+        if lib.orc_superframe_feed(_p(st), _p(frames[i]), ln, i, C.byref(e), _p(out)):
+            evs.append(_ev_tuple(e))
+            if e.sync:
+                sfs.append(out.copy())
+    return evs, sfs
+
+
+def ref_superframe_run(frames):
+    frames = np.ascontiguousarray(frames, np.uint8); n, ln = frames.shape
+    ev = (SfEvent * n)(); out = np.zeros((n, 5 * ln), np.uint8)
+    ne = ref().ref_superframe_run(_p(frames), n, ln, ev, n, _p(out))
+    return [_ev_tuple(ev[i]) for i in range(ne)], [out[i].copy() for i in range(ne) if ev[i].sync]

@@ -112,3 +112,25 @@ def test_receiver_end_to_end(snr, cfo, delay, nf):
         # and both equal what was transmitted
         pay = b"".join(tx.payload_log[subs[0].subch_id])
         assert a["msc"][0] in pay and len(a["msc"][0]) > 0
+
+
+@pytest.mark.parametrize("bitrate,seed", [(64, 1), (32, 2), (128, 3), (8, 4)])
+def test_superframe_filter_equals_reference(oracle_built, bitrate, seed):
+    """SuperframeFilter::Feed (sliding 5-frame window, RS, Fire-code sync, AU CRCs) on a stream that starts mid-superframe,
+    carries byte errors within and beyond the RS capacity, a broken AU and a header hit"""
+    rng = np.random.RandomState(seed)
+    fb = 3 * bitrate
+    sfs = [synth.make_superframe(bitrate, rng) for _ in range(9)]
+    sfs[2][7 * (bitrate // 8) + 1] ^= 0x55                                  # one correctable symbol
+    for k in range(4):
+        sfs[3][(20 + k) * (bitrate // 8)] ^= 0xA0 + k                        # 4 symbols in codeword 0
+    a = sfs[4]; a[40] ^= 1; a[40 + bitrate // 8] ^= 2                          # errors in two codewords
+    for k in range(7):
+        sfs[5][(30 + 3 * k) * (bitrate // 8) + (1 % (bitrate // 8))] ^= 0x11 * (k + 1)   # beyond capacity: uncorrectable or miscorrected
+    stream = np.concatenate(sfs).reshape(-1, fb)[3:]                          # start 3 frames into a superframe
+    stream = np.concatenate([stream[:23], stream[24:]])                       # drop one frame: sync lost and found again
+    eo, so = R.orc_superframe_run(stream)
+    er, sr = R.ref_superframe_run(stream)
+    assert eo == er
+    assert len(so) == len(sr) and all(np.array_equal(x, y) for x, y in zip(so, sr))
+    assert sum(e[3] for e in eo) >= 5 and any(e[2] for e in eo)

@@ -28,6 +28,10 @@ class Subchannel(C.Structure):
     _fields_ = [("subch_id", C.c_int32), ("start_cu", C.c_int32), ("size_cu", C.c_int32), ("prot", Protection)]
 
 
+SF_EVENT_DTYPE = np.dtype([("cif", "<i4"), ("corrected", "<i4"), ("uncorrectable", "<i4"), ("sync", "<i4"), ("format", "<i4"), ("num_aus", "<i4"),
+                           ("au_start", "<i4", 7), ("au_crc_ok", "<i4"), ("sf_slot", "<i4")])
+
+
 class DabPhyError(RuntimeError):
     pass
 
@@ -128,6 +132,14 @@ class DabPhy:
         ms = C.c_float(0)
         self._chk(self.lib.dabphy_time_demod(self.h, _p(frames), frames.shape[0], n_ens, n_frames, mix, f_hz, iters, C.byref(ms)))
         return ms.value
+
+    def superframes(self, subch_index, bitrate):
+        """-> (events structured array [B][4F], n_events [B], corrected superframes [B][n_slots][120*bitrate/8])"""
+        B, F = self.cfg.n_ensembles, self._last
+        ev = np.zeros((B, 4 * F), SF_EVENT_DTYPE); ne = np.zeros(B, np.int32)
+        sf = np.zeros((B, 4 * F // 5 + 1, 15 * bitrate), np.uint8)
+        self._chk(self.lib.dabphy_superframes(self.h, subch_index, _p(ev), _p(ne), _p(sf)))
+        return ev, ne, sf
 
     def selftest_div127(self):
         c = (C.c_uint64 * 3)()

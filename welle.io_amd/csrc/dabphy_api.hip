@@ -48,6 +48,8 @@ struct dabphy_handle {
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
+    std::vector<DevBuf> sf_state;           // per sub-channel: SuperframeFilter window state of every ensemble
+    DevBuf sf_events, sf_count, sf_bytes; const FrameDesc* last_desc = nullptr;
     DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr;
@@ -182,6 +184,8 @@ void dabphy_destroy(dabphy_handle* h)
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
     DevBuf* more[] = {&h->s_raw, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
+    for (auto& b : h->sf_state) if (b.p) e = hipFree(b.p);
+    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
@@ -309,7 +313,8 @@ int dabphy_reset(dabphy_handle* h)
     memset(init.data(), 0, init.size() * sizeof(RxState));
     for (auto& s : init) { s.acq_phase = 0; s.acq_left = T_F / 2; }
     HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
-    h->last_frames = 0;
+    h->last_frames = 0; h->last_desc = nullptr;
+    for (auto& b : h->sf_state) if (b.p) HIPCHK(h, hipMemsetAsync(b.p, 0, b.cap, h->stream));      // decoders restart too (RadioReceiver::restart_decoder)
     return sync(h);
 }
 
@@ -406,6 +411,8 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         if (!protection_valid(&s.prot) || s.prot.nbits > PRBS_MAX_BITS || s.start_cu < 0 || s.size_cu <= 0 || s.start_cu + s.size_cu > 864 ||
             protection_input_bits(&s.prot) > s.size_cu * 64) { h->err = "invalid sub-channel " + std::to_string(i); return DABPHY_ERR_INVALID; }
     }
+    for (auto& b : h->sf_state) if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    h->sf_state.clear();
     for (auto& c : h->classes) {
         hipError_t e;
         if (c.map.p) e = hipFree(c.map.p);
@@ -509,6 +516,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     if (h->cfg.pipeline_sync) { launch_sync_chain(cur ^ 1); h->presynced = F; h->desc_sel = cur ^ 1; }
     else h->presynced = 0;
     FrameDesc* const d_desc = h->s_desc2[cur].as<FrameDesc>();
+    h->last_desc = d_desc;
     h->cur_cir = h->cfg.want_impulse_response ? h->s_cir2[cur].as<float>() : nullptr;
 
     DemodArgs da{};
@@ -738,6 +746,42 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
         }
     }
     return sync(h);
+}
+
+int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
+{
+    static_assert(sizeof(dabphy_sf_event) == sizeof(SfEvent), "event layouts must match");
+    if (!h || !events || !n_events || subch_index >= h->subch.size() || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    for (auto& cls : h->classes)
+        for (size_t m = 0; m < cls.members.size(); m++) {
+            if (cls.members[m] != (int)subch_index) continue;
+            const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
+            if (bitrate % 8 || fb < 10) { h->err = "sub-channel bit rate is not a DAB+ rate"; return DABPHY_ERR_INVALID; }
+            const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+            const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
+            int r;
+            if (h->sf_state.size() < h->subch.size()) h->sf_state.resize(h->subch.size());
+            DevBuf& st = h->sf_state[subch_index];
+            if (st.cap < stride * B) {
+                if ((r = ensure(h, st, stride * B))) return r;
+                HIPCHK(h, hipMemsetAsync(st.p, 0, st.cap, h->stream));           // frame_count = 0: nothing collected yet
+            }
+            if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * n_cif))) return r;
+            if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B))) return r;
+            if ((r = ensure(h, h->sf_bytes, (size_t)B * n_slots * 5 * fb))) return r;
+            SfArgs a{};
+            a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = (int)cls.members.size(); a.frame_bytes = fb;
+            a.s = bitrate / 8; a.member = (int)m; a.desc = h->last_desc; a.n_frames = (int)F;
+            a.state = st.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
+            a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots;
+            launch_superframe(a, h->stream);
+            HIPCHK(h, hipMemcpyAsync(events, h->sf_events.p, sizeof(SfEvent) * B * n_cif, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(n_events, h->sf_count.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+            if (sf) HIPCHK(h, hipMemcpyAsync(sf, h->sf_bytes.p, (size_t)B * n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
+            return sync(h);
+        }
+    return DABPHY_ERR_INVALID;
 }
 
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)

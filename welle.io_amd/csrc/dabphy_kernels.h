@@ -144,6 +144,18 @@ struct RsMscArgs {         // superframes inside a class's MSC output [B][n_memb
     const int* first_cif;                         // [B] logical-frame slot (in this batch) where the first superframe starts
     int* result;                                  // [B][n_sf_per_ens][n_members][2] = corrected symbols, uncorrectable flag
 };
+// DAB+ superframe filter (k_rs.hip: k_superframe): SuperframeFilter::Feed over the logical frames of one batch
+struct SfEvent {           // = dabphy_sf_event (include/dabphy.h)
+    int32_t cif, corrected, uncorrectable, sync, format, num_aus, au_start[7], au_crc_ok, sf_slot;
+};
+struct SfArgs {
+    const uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s, member;    // class output [B][members][n_cif][frame_bytes]
+    const FrameDesc* desc; int n_frames;
+    uint8_t* state; size_t state_stride;          // [B] records: int32 frame_count (+12 pad), raw[5 * frame_bytes]
+    SfEvent* events; int32_t* n_events;           // [B][n_cif], [B]
+    uint8_t* sf; int n_slots;                     // [B][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
+};
+void launch_superframe(const SfArgs& a, hipStream_t s);
 void launch_rs_superframes(const RsArgs& a, hipStream_t s);
 void launch_rs_msc(const RsMscArgs& a, hipStream_t s);
 

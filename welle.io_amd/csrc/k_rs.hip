@@ -173,6 +173,105 @@ __global__ void __launch_bounds__(256) k_rs_msc(RsMscArgs A)
     else if (c > 0) atomicAdd(cnt, c);
 }
 
+// ------------------------------------------------------------------------------------------ DAB+ superframe filter
+// SuperframeFilter::Feed / CheckSync (dabplus_decoder.cpp:50-213) for one sub-channel of every ensemble: one 64-thread
+// work-group per ensemble walks the logical frames of the batch in order with the reference's state machine -- 5-frame
+// sliding window, Reed-Solomon on a copy (thread i = codeword i), Fire-code / AU-table check, AU CRCs (thread i = access
+// unit i), and after a hit a fresh window -- and carries frame_count + the raw window to the next batch.  Only events and
+// corrected, synchronised superframes leave the device.
+__device__ __forceinline__ uint16_t crc16_msb(const uint8_t* data, int len, bool initial_invert, bool final_invert, uint16_t poly)
+{
+    uint16_t crc = initial_invert ? 0xFFFF : 0x0000;                           // CalcCRC, tools.cpp:41-72
+    for (int o = 0; o < len; o++) {
+        crc ^= (uint16_t)(data[o] << 8);
+        for (int i = 0; i < 8; i++) crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ poly) : (uint16_t)(crc << 1);
+    }
+    return final_invert ? (uint16_t)~crc : crc;
+}
+
+__global__ void __launch_bounds__(64) k_superframe(SfArgs A)
+{
+    __shared__ uint8_t alpha_to[256], index_of[256];
+    __shared__ int s_corr, s_unc, s_sync, s_auok, s_num_aus, s_au_start[8];
+    rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int fb = A.frame_bytes, sf_len = 5 * fb;
+    uint8_t* st = A.state + (size_t)b * A.state_stride;
+    uint8_t* raw = st + 16;
+    int frame_count = *reinterpret_cast<const int32_t*>(st);
+    int ne = 0, slot = 0;
+    SfEvent* ev = A.events + (size_t)b * A.n_cif;
+    for (int r = 0; r < A.n_cif; r++) {
+        const FrameDesc& d = A.desc[(size_t)b * A.n_frames + (r >> 2)];
+        // frames the reference's DabAudio would have emitted: synchronised transmission frames, after the 16-CIF fill of
+        // the time de-interleaver (dab-audio.cpp:146-149)
+        if (d.valid != 1 || 4 * d.frame_no + (r & 3) < 16) continue;
+        const uint8_t* src = A.out + (((size_t)b * A.n_members + A.member) * A.n_cif + r) * fb;
+        __syncthreads();
+        if (frame_count == 5) {                                                // :78-81 shift the previous frames
+            for (int base = 0; base < 4 * fb; base += 64) {
+                const int i = base + t;
+                const uint8_t v = i < 4 * fb ? raw[i + fb] : 0;
+                __syncthreads();
+                if (i < 4 * fb) raw[i] = v;
+                __syncthreads();
+            }
+        } else frame_count++;
+        for (int i = t; i < fb; i += 64) raw[(frame_count - 1) * fb + i] = src[i];
+        __syncthreads();
+        if (frame_count < 5) continue;
+        uint8_t* sf = A.sf + ((size_t)b * A.n_slots + slot) * sf_len;
+        for (int i = t; i < sf_len; i += 64) sf[i] = raw[i];                   // :97 decode on a copy
+        if (t == 0) { s_corr = 0; s_unc = 0; s_auok = 0; }
+        __syncthreads();
+        if (t < A.s) {
+            RsIo io; io.base = sf + t; io.pos_stride = (size_t)A.s;
+            const int c = rs_decode120(io, alpha_to, index_of);
+            if (c < 0) atomicOr(&s_unc, 1); else if (c > 0) atomicAdd(&s_corr, c);
+        }
+        __syncthreads();
+        if (t == 0) {                                                          // CheckSync, :160-213
+            int sync = 0, num_aus = 0;
+            if (!(sf[3] == 0x00 && sf[4] == 0x00) && (uint16_t)(sf[0] << 8 | sf[1]) == crc16_msb(sf + 2, 9, false, false, 0x782F)) {
+                const int dac_rate = sf[2] & 0x40, sbr_flag = sf[2] & 0x20;
+                num_aus = dac_rate ? (sbr_flag ? 3 : 6) : (sbr_flag ? 2 : 4);
+                s_au_start[0] = dac_rate ? (sbr_flag ? 6 : 11) : (sbr_flag ? 5 : 8);
+                s_au_start[num_aus] = sf_len / 120 * 110;
+                s_au_start[1] = sf[3] << 4 | sf[4] >> 4;
+                if (num_aus >= 3) s_au_start[2] = (sf[4] & 0x0F) << 8 | sf[5];
+                if (num_aus >= 4) s_au_start[3] = sf[6] << 4 | sf[7] >> 4;
+                if (num_aus == 6) { s_au_start[4] = (sf[7] & 0x0F) << 8 | sf[8]; s_au_start[5] = sf[9] << 4 | sf[10] >> 4; }
+                sync = 1;
+                for (int i = 0; i < num_aus; i++) if (s_au_start[i] >= s_au_start[i + 1]) sync = 0;
+            }
+            s_sync = sync; s_num_aus = num_aus;
+        }
+        __syncthreads();
+        if (s_sync && t < s_num_aus) {                                         // :122-131 AU CRC-16-CCITT
+            const uint8_t* au = sf + s_au_start[t]; const int au_len = s_au_start[t + 1] - s_au_start[t];
+            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb(au, au_len - 2, true, true, 0x1021)) atomicOr(&s_auok, 1 << t);
+        }
+        __syncthreads();
+        if (t == 0) {
+            SfEvent e{};
+            e.cif = r; e.corrected = s_corr; e.uncorrectable = s_unc; e.sync = s_sync; e.sf_slot = -1;
+            if (s_sync) {
+                e.format = sf[2]; e.num_aus = s_num_aus; e.au_crc_ok = s_auok; e.sf_slot = slot;
+                for (int i = 0; i <= s_num_aus; i++) e.au_start[i] = s_au_start[i];
+            }
+            ev[ne] = e;
+        }
+        ne++;
+        if (s_sync) { frame_count = 0; if (slot + 1 < A.n_slots) slot++; }     // :156 wait for a complete new superframe
+    }
+    if (t == 0) { *reinterpret_cast<int32_t*>(st) = frame_count; A.n_events[b] = ne; }
+}
+
+void launch_superframe(const SfArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_superframe, dim3(a.n_ens), dim3(64), 0, s, a);
+}
+
 void launch_rs_superframes(const RsArgs& a, hipStream_t s)
 {
     const int total = a.n_sf * a.s;

@@ -376,13 +376,37 @@ def rs_parity(data110):
     return np.array(rem, np.uint8)
 
 
-def make_superframe(bitrate, rng):
-    """120*s random bytes (s = bitrate/8) whose s column-interleaved codewords (bytes pos*s+i) are valid RS words"""
+def crc16(data, initial_invert, final_invert, poly):
+    """CalcCRC of the reference (tools.cpp:41-72): MSB-first CRC-16"""
+    crc = 0xFFFF if initial_invert else 0
+    for b in bytes(data):
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ poly) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc ^ 0xFFFF if final_invert else crc
+
+
+def make_superframe(bitrate, rng, header=True):
+    """a DAB+ audio superframe (ETSI TS 102 563) of 120*s bytes, s = bitrate/8: Fire-code protected header announcing
+    48 kHz + SBR (3 access units), access units of random bytes each closed by its CRC-16-CCITT, and the 10 parity bytes of
+    every column-interleaved RS(120,110) codeword (bytes pos*s+i).  header=False: random data with valid RS parity only."""
     s = bitrate // 8
+    data = rng.randint(0, 256, 110 * s).astype(np.uint8)
+    if header:
+        n = 110 * s
+        a0 = 6
+        a1 = a0 + (n - a0) // 3 + int(rng.randint(0, 5)); a2 = a1 + (n - a0) // 3 - int(rng.randint(0, 5))
+        data[2] = 0x40 | 0x20 | 0x10                       # dac_rate = 48 kHz, SBR, stereo -> 3 AUs, au_start[0] = 6
+        data[3] = a1 >> 4; data[4] = ((a1 & 0xF) << 4) | (a2 >> 8); data[5] = a2 & 0xFF
+        for lo, hi in ((a0, a1), (a1, a2), (a2, n)):
+            c = crc16(data[lo:hi - 2], True, True, 0x1021)
+            data[hi - 2] = c >> 8; data[hi - 1] = c & 0xFF
+        c = crc16(data[2:11], False, False, 0x782F)        # Fire code over bytes 2..10
+        data[0] = c >> 8; data[1] = c & 0xFF
     sf = np.zeros(120 * s, np.uint8)
+    sf[:110 * s] = data
     for i in range(s):
-        d = rng.randint(0, 256, 110).astype(np.uint8)
-        sf[i::s] = np.concatenate([d, rs_parity(d)])
+        sf[110 * s + i::s] = rs_parity(data[i::s])
     return sf
 
 
