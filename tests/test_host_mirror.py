@@ -55,7 +55,8 @@ def test_reference_superframe_filter_sees_valid_rs(emu):
     compare_runs(a, b, 1)
     # the reference also decodes the very last frame of a finite stream (its null symbol is cut off); the streaming
     # receiver waits for complete frames, so it feeds up to one transmission frame (4 logical frames) less
-    assert a["rs_calls"][0] > 20 and 0 <= a["rs_calls"][0] - b["rs_calls"][0] <= 4
+    # (the payload carries valid Fire-code headers: once synchronised the filter decodes one window per 5 logical frames)
+    assert a["rs_calls"][0] >= 8 and 0 <= a["rs_calls"][0] - b["rs_calls"][0] <= 4
     assert 0 <= a["rs_uncorr"][0] - b["rs_uncorr"][0] <= 4
     aligned_ok = a["rs_calls"][0] - a["rs_uncorr"][0]
     assert aligned_ok >= 5 and 0 <= aligned_ok - (b["rs_calls"][0] - b["rs_uncorr"][0]) <= 1
