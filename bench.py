@@ -116,35 +116,22 @@ def main():
     dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
     dev.set_profiling(True)
 
-    def step(first_cif):
+    def step():
         dev.process(F)
-        corr = unc = None
-        if first_cif is not None:
-            corr, unc = dev.rs_decode_msc(-1, first_cif)
+        sf = dev.superframes_stats()                       # DAB+ superframe filter of all 18 sub-channels on the device: Fire-code sync, RS, AU CRCs
         fib, ok = dev.fibs()                               # decoded FIBs + CRC flags to the host of this rank
         if dist is not None:                               # final FIC gather to rank 0 over RCCL/xGMI
             gather_fibs(dist, fib, ok, rank, world, device="cuda")
-        return fib, ok, corr, unc
+        return fib, ok, sf
 
-    # warm-up: acquisition + interleaver fill, then find the superframe alignment like SuperframeFilter does (try all 5)
-    step(None)
-    align = None
-    for W in range(max(1, args.warmup)):
-        if align is None:
-            dev.process(F)
-            found = np.full(B, -1, np.int32)
-            for o in range(5):
-                corr, unc = dev.rs_decode_msc(-1, np.full(B, o, np.int32))
-                good = unc.reshape(B, -1).sum(1) == 0
-                found[good & (found < 0)] = o
-            assert (found >= 0).all(), "no Reed-Solomon alignment found for %d ensembles: decoded MSC is not valid" % (found < 0).sum()
-            align = found
-        else:
-            step(align)
-    fib, ok, corr, unc = step(align)
-    # sanity outside the timed region: all FIBs pass CRC, RS sees valid superframes, FIBs of ensemble 0 are the transmitted ones
+    # warm-up: acquisition, time-de-interleaver fill, superframe synchronisation
+    for W in range(max(2, args.warmup)):
+        step()
+    fib, ok, sf = step()
+    # sanity outside the timed region: all FIBs pass CRC; every sub-channel of every ensemble delivers its 4F/5 superframes per
+    # step, none uncorrectable, every access unit passes its CRC; the FIBs of ensemble 0 are the transmitted ones
     assert ok.all(), "FIB CRC failures in the benchmark signal"
-    assert unc.sum() == 0
+    assert (sf[:, 0] == len(subchs) * (4 * F // 5)).all() and (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all(), "superframe filter: %s" % sf[:4]
     sent = set(b"".join(f) for f in txs[0].fib_log)
     assert all(fib[0, f].tobytes() in sent for f in range(F)), "decoded FIBs differ from the transmitted ones"
 
@@ -154,7 +141,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(align)
+        step()
         for k, v in dev.stage_times().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     torch.cuda.synchronize()

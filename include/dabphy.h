@@ -215,6 +215,10 @@ typedef struct {
     int32_t sf_slot;                     /* index into sf, -1 when not synchronised */
 } dabphy_sf_event;
 int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf);
+/* The same filter over EVERY DAB+ sub-channel of every ensemble in one launch per protection class (instead of, not in
+ * addition to, dabphy_superframes for this batch); nothing but totals leaves the device:
+ * stats [n_ensembles][4] = synchronised superframes, corrected symbols, uncorrectable attempts, access units failing their CRC */
+int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats);
 
 int dabphy_set_profiling(dabphy_handle* h, int32_t on);
 int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);

@@ -273,6 +273,23 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
                 assert got[b][i] == [(w[0], w[1], w[2], w[3], w[4], w[5], w[6]) for w in want[:n]], "superframe events of sub-channel %d differ" % i
                 ns = len(got_sf[b][i])
                 assert ns >= 1 and all(np.array_equal(got_sf[b][i][k], so[k]) for k in range(ns)), "corrected superframes differ"
-        return got
     finally:
         d.close()
+    # the all-sub-channels variant: only totals leave the device
+    d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
+    try:
+        d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+        tot = np.zeros((B, 4), np.int64)
+        for _ in range((nf + F - 1) // F):
+            d.process(F)
+            if not (d.frame_info()["valid"] == 1).any():
+                break
+            tot += d.superframes_stats()
+        for b in range(B):
+            ev = [e for i in range(len(subs)) for e in got[b][i]]
+            want = (sum(e[2] for e in ev), sum(e[0] for e in ev), sum(e[1] for e in ev), sum(e[4] - bin(e[6]).count("1") for e in ev if e[2]))
+            assert tuple(tot[b]) == want, (tuple(tot[b]), want)
+    finally:
+        d.close()
+    return got

@@ -141,6 +141,11 @@ class DabPhy:
         self._chk(self.lib.dabphy_superframes(self.h, subch_index, _p(ev), _p(ne), _p(sf)))
         return ev, ne, sf
 
+    def superframes_stats(self):
+        st = np.zeros((self.cfg.n_ensembles, 4), np.int32)
+        self._chk(self.lib.dabphy_superframes_stats(self.h, _p(st)))
+        return st
+
     def selftest_div127(self):
         c = (C.c_uint64 * 3)()
         self._chk(self.lib.dabphy_selftest_div127(self.h, c))

@@ -41,6 +41,7 @@ struct dabphy_handle {
         dabphy_protection prot{};
         std::vector<int> members;     // indices into subch
         DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
+        DevBuf sf_state;                     // SuperframeFilter window of every (ensemble, member)
     };
     const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
     DevBuf s_iq_own;
@@ -48,8 +49,7 @@ struct dabphy_handle {
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
-    std::vector<DevBuf> sf_state;           // per sub-channel: SuperframeFilter window state of every ensemble
-    DevBuf sf_events, sf_count, sf_bytes; const FrameDesc* last_desc = nullptr;
+    DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
     DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr;
@@ -184,9 +184,8 @@ void dabphy_destroy(dabphy_handle* h)
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
     DevBuf* more[] = {&h->s_raw, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
-    for (auto& b : h->sf_state) if (b.p) e = hipFree(b.p);
-    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
-    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); }
+    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
+    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
     (void)e;
@@ -314,7 +313,7 @@ int dabphy_reset(dabphy_handle* h)
     for (auto& s : init) { s.acq_phase = 0; s.acq_left = T_F / 2; }
     HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
-    for (auto& b : h->sf_state) if (b.p) HIPCHK(h, hipMemsetAsync(b.p, 0, b.cap, h->stream));      // decoders restart too (RadioReceiver::restart_decoder)
+    for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
     return sync(h);
 }
 
@@ -411,13 +410,12 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         if (!protection_valid(&s.prot) || s.prot.nbits > PRBS_MAX_BITS || s.start_cu < 0 || s.size_cu <= 0 || s.start_cu + s.size_cu > 864 ||
             protection_input_bits(&s.prot) > s.size_cu * 64) { h->err = "invalid sub-channel " + std::to_string(i); return DABPHY_ERR_INVALID; }
     }
-    for (auto& b : h->sf_state) if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
-    h->sf_state.clear();
     for (auto& c : h->classes) {
         hipError_t e;
         if (c.map.p) e = hipFree(c.map.p);
         if (c.start_bits.p) e = hipFree(c.start_bits.p);
         if (c.tiles.p) e = hipFree(c.tiles.p);
+        if (c.sf_state.p) e = hipFree(c.sf_state.p);
         if (c.out.p) e = hipFree(c.out.p);
         (void)e;
     }
@@ -748,6 +746,32 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
     return sync(h);
 }
 
+namespace {
+// launches k_superframe for one class: member >= 0 -> that member only, -1 -> all members
+int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats)
+{
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
+    const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+    const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
+    int r;
+    if (cls.sf_state.cap < stride * B * M) {
+        if ((r = ensure(h, cls.sf_state, stride * B * M))) return r;
+        HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
+    }
+    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * M * n_cif))) return r;
+    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B * M))) return r;
+    if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
+    SfArgs a{};
+    a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = M; a.frame_bytes = fb;
+    a.s = bitrate / 8; a.member = member; a.desc = h->last_desc; a.n_frames = (int)F;
+    a.state = cls.sf_state.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
+    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats;
+    launch_superframe(a, h->stream);
+    return 0;
+}
+}
+
 int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
 {
     static_assert(sizeof(dabphy_sf_event) == sizeof(SfEvent), "event layouts must match");
@@ -756,32 +780,40 @@ int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* 
     for (auto& cls : h->classes)
         for (size_t m = 0; m < cls.members.size(); m++) {
             if (cls.members[m] != (int)subch_index) continue;
-            const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
+            const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
             if (bitrate % 8 || fb < 10) { h->err = "sub-channel bit rate is not a DAB+ rate"; return DABPHY_ERR_INVALID; }
             const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
-            const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
             int r;
-            if (h->sf_state.size() < h->subch.size()) h->sf_state.resize(h->subch.size());
-            DevBuf& st = h->sf_state[subch_index];
-            if (st.cap < stride * B) {
-                if ((r = ensure(h, st, stride * B))) return r;
-                HIPCHK(h, hipMemsetAsync(st.p, 0, st.cap, h->stream));           // frame_count = 0: nothing collected yet
+            if ((r = run_superframes(h, cls, (int)m, nullptr))) return r;
+            for (uint32_t b = 0; b < B; b++) {          // rows of member m
+                const size_t bm = (size_t)b * M + m;
+                HIPCHK(h, hipMemcpyAsync(events + (size_t)b * n_cif, h->sf_events.as<SfEvent>() + bm * n_cif, sizeof(SfEvent) * n_cif, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(n_events + b, h->sf_count.as<int32_t>() + bm, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                if (sf) HIPCHK(h, hipMemcpyAsync(sf + (size_t)b * n_slots * 5 * fb, h->sf_bytes.as<uint8_t>() + bm * n_slots * 5 * fb, (size_t)n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
             }
-            if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * n_cif))) return r;
-            if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B))) return r;
-            if ((r = ensure(h, h->sf_bytes, (size_t)B * n_slots * 5 * fb))) return r;
-            SfArgs a{};
-            a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = (int)cls.members.size(); a.frame_bytes = fb;
-            a.s = bitrate / 8; a.member = (int)m; a.desc = h->last_desc; a.n_frames = (int)F;
-            a.state = st.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
-            a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots;
-            launch_superframe(a, h->stream);
-            HIPCHK(h, hipMemcpyAsync(events, h->sf_events.p, sizeof(SfEvent) * B * n_cif, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(n_events, h->sf_count.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
-            if (sf) HIPCHK(h, hipMemcpyAsync(sf, h->sf_bytes.p, (size_t)B * n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
             return sync(h);
         }
     return DABPHY_ERR_INVALID;
+}
+
+int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
+{
+    if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles;
+    int r;
+    if ((r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
+    HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));
+    bool first_launch = true;
+    for (auto& cls : h->classes) {
+        const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
+        if (bitrate % 8 || fb < 10) continue;
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
+        if ((r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>()))) return r;
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
+        first_launch = false;
+    }
+    HIPCHK(h, hipMemcpyAsync(stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
 }
 
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)

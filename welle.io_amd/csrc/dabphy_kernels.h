@@ -149,11 +149,13 @@ struct SfEvent {           // = dabphy_sf_event (include/dabphy.h)
     int32_t cif, corrected, uncorrectable, sync, format, num_aus, au_start[7], au_crc_ok, sf_slot;
 };
 struct SfArgs {
-    const uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s, member;    // class output [B][members][n_cif][frame_bytes]
+    const uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s;    // class output [B][members][n_cif][frame_bytes]
+    int member;                                   // >= 0: only this member (grid (1, B)); -1: every member (grid (members, B))
     const FrameDesc* desc; int n_frames;
-    uint8_t* state; size_t state_stride;          // [B] records: int32 frame_count (+12 pad), raw[5 * frame_bytes]
-    SfEvent* events; int32_t* n_events;           // [B][n_cif], [B]
-    uint8_t* sf; int n_slots;                     // [B][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
+    uint8_t* state; size_t state_stride;          // [B][members] records: int32 frame_count (+12 pad), raw[5 * frame_bytes]
+    SfEvent* events; int32_t* n_events;           // [B][members][n_cif], [B][members]
+    uint8_t* sf; int n_slots;                     // [B][members][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
+    int32_t* stats;                               // optional [B][4]: synchronised superframes, corrected symbols, uncorrectable attempts, AUs failing their CRC
 };
 void launch_superframe(const SfArgs& a, hipStream_t s);
 void launch_rs_superframes(const RsArgs& a, hipStream_t s);

@@ -31,24 +31,49 @@ struct RsIo {                         // byte `pos` of codeword i
 
 // returns the number of corrected symbols, -1 when uncorrectable (decode_rs.h:71-298, no_eras = 0)
 template <typename IO>
-__device__ int rs_decode120(const IO& io, const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
+__device__ __forceinline__ int rs_correct120(const IO& io, const uint32_t (&syn)[RS_NROOTS], const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of);
+
+template <typename IO>
+__device__ __forceinline__ int rs_decode120(const IO& io, const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
 {
-    uint8_t s[RS_NROOTS];
+    // the syndromes of the common case live in registers: `syn` is only ever indexed by unrolled constants (the array the
+    // Berlekamp-Massey iteration indexes dynamically is a copy made on the error path -- sharing one array sent every
+    // Horner step through scratch memory, 10x slower)
+    uint32_t syn[RS_NROOTS];
     {
-        const uint8_t d0 = io.get(0);
+        const uint32_t d0 = io.get(0);
 #pragma unroll
-        for (int i = 0; i < RS_NROOTS; i++) s[i] = d0;
+        for (int i = 0; i < RS_NROOTS; i++) syn[i] = d0;
     }
+#pragma unroll 2
     for (int j = 1; j < RS_LEN; j++) {
-        const uint8_t dj = io.get(j);
+        const uint32_t dj = io.get(j);
 #pragma unroll
         for (int i = 0; i < RS_NROOTS; i++)
-            s[i] = (s[i] == 0) ? dj : (uint8_t)(dj ^ alpha_to[rs_modnn(index_of[s[i]] + i)]);     // FCR = 0, PRIM = 1
+        {
+            // FCR = 0, PRIM = 1.  index_of[..] + i <= 254 + 9, where modnn() is one conditional subtraction: written
+            // branch-free so that the ten Horner chains overlap their two table look-ups instead of queueing behind ten loops
+            // Both look-ups are unconditional (index_of[0] = 255 is harmless, its result is discarded by the select): a
+            // look-up under `if (syn != 0)` is a branch per syndrome, ten serial round trips to LDS per byte.
+            const uint32_t e = index_of[syn[i]] + i;
+            const uint32_t a = alpha_to[e >= RS_NN ? e - RS_NN : e];
+            syn[i] = (syn[i] == 0) ? dj : (dj ^ a);
+        }
     }
-    int syn_error = 0;
+    return rs_correct120(io, syn, alpha_to, index_of);
+}
+
+// Errors from the ten syndromes (polynomial form) on: Berlekamp-Massey, Chien, Forney (decode_rs.h:117-298)
+template <typename IO>
+__device__ __forceinline__ int rs_correct120(const IO& io, const uint32_t (&syn)[RS_NROOTS], const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
+{
+    uint32_t syn_error = 0;
 #pragma unroll
-    for (int i = 0; i < RS_NROOTS; i++) { syn_error |= s[i]; s[i] = index_of[s[i]]; }
+    for (int i = 0; i < RS_NROOTS; i++) syn_error |= syn[i];
     if (!syn_error) return 0;
+    uint8_t s[RS_NROOTS];
+#pragma unroll
+    for (int i = 0; i < RS_NROOTS; i++) s[i] = index_of[syn[i]];
 
     uint8_t lambda[RS_NROOTS + 1], b[RS_NROOTS + 1], t[RS_NROOTS + 1], omega[RS_NROOTS + 1], root[RS_NROOTS], reg[RS_NROOTS + 1], loc[RS_NROOTS];
     for (int i = 1; i <= RS_NROOTS; i++) lambda[i] = 0;
@@ -189,48 +214,83 @@ __device__ __forceinline__ uint16_t crc16_msb(const uint8_t* data, int len, bool
     return final_invert ? (uint16_t)~crc : crc;
 }
 
-__global__ void __launch_bounds__(64) k_superframe(SfArgs A)
+template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
+__global__ void __launch_bounds__(64, 5) k_superframe(SfArgs A)
 {
+    // LDS: the raw 5-frame window (a ring: `head` = oldest frame, nothing is ever shifted) and the working copy
+    __shared__ __attribute__((aligned(16))) uint8_t s_dyn[2 * SF_MAX];
     __shared__ uint8_t alpha_to[256], index_of[256];
-    __shared__ int s_corr, s_unc, s_sync, s_auok, s_num_aus, s_au_start[8];
+    __shared__ int s_corr, s_unc, s_sync, s_au_start[8], s_aubad;
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
-    const int t = threadIdx.x, b = blockIdx.x;
+    if (threadIdx.x == 0) s_aubad = 0;
+    const int t = threadIdx.x, b = blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb;
-    uint8_t* st = A.state + (size_t)b * A.state_stride;
-    uint8_t* raw = st + 16;
+    uint8_t* const s_raw = s_dyn;
+    uint8_t* const s_sf = s_dyn + SF_MAX;
+    const size_t bm = (size_t)b * A.n_members + m;
+    uint8_t* st = A.state + bm * A.state_stride;
     int frame_count = *reinterpret_cast<const int32_t*>(st);
+    for (int i = t; i < frame_count * fb; i += 64) s_raw[i] = st[16 + i];     // carried frames, oldest first
+    int head = 0;                                                              // ring slot of the oldest frame
     int ne = 0, slot = 0;
-    SfEvent* ev = A.events + (size_t)b * A.n_cif;
+    SfEvent* ev = A.events + bm * A.n_cif;
+    int tot_sync = 0, tot_corr = 0, tot_unc = 0;
     for (int r = 0; r < A.n_cif; r++) {
         const FrameDesc& d = A.desc[(size_t)b * A.n_frames + (r >> 2)];
         // frames the reference's DabAudio would have emitted: synchronised transmission frames, after the 16-CIF fill of
         // the time de-interleaver (dab-audio.cpp:146-149)
         if (d.valid != 1 || 4 * d.frame_no + (r & 3) < 16) continue;
-        const uint8_t* src = A.out + (((size_t)b * A.n_members + A.member) * A.n_cif + r) * fb;
+        const uint8_t* src = A.out + (bm * A.n_cif + r) * fb;
         __syncthreads();
-        if (frame_count == 5) {                                                // :78-81 shift the previous frames
-            for (int base = 0; base < 4 * fb; base += 64) {
-                const int i = base + t;
-                const uint8_t v = i < 4 * fb ? raw[i + fb] : 0;
-                __syncthreads();
-                if (i < 4 * fb) raw[i] = v;
-                __syncthreads();
-            }
-        } else frame_count++;
-        for (int i = t; i < fb; i += 64) raw[(frame_count - 1) * fb + i] = src[i];
+        int dst_slot;
+        if (frame_count == 5) { dst_slot = head; head = head == 4 ? 0 : head + 1; }   // :78-81 "shift the previous frames": drop the oldest
+        else { dst_slot = head + frame_count; if (dst_slot >= 5) dst_slot -= 5; frame_count++; }
+        for (int i = t; i < fb; i += 64) s_raw[dst_slot * fb + i] = src[i];
         __syncthreads();
         if (frame_count < 5) continue;
-        uint8_t* sf = A.sf + ((size_t)b * A.n_slots + slot) * sf_len;
-        for (int i = t; i < sf_len; i += 64) sf[i] = raw[i];                   // :97 decode on a copy
-        if (t == 0) { s_corr = 0; s_unc = 0; s_auok = 0; }
+        for (int k = 0; k < 5; k++) {                                          // :97 decode on a copy, frames in age order
+            int sl = head + k; if (sl >= 5) sl -= 5;
+            for (int i = t; i < fb; i += 64) s_sf[k * fb + i] = s_raw[sl * fb + i];
+        }
+        if (t == 0) { s_corr = 0; s_unc = 0; }
         __syncthreads();
-        if (t < A.s) {
-            RsIo io; io.base = sf + t; io.pos_stride = (size_t)A.s;
-            const int c = rs_decode120(io, alpha_to, index_of);
-            if (c < 0) atomicOr(&s_unc, 1); else if (c > 0) atomicAdd(&s_corr, c);
+        // Syndromes, eight codewords at a time with the whole wave: S_i = XOR_j d_j alpha^(i (119 - j)) is a sum, so lane
+        // (codeword c = l & 7, byte group l >> 3 = 15 positions) adds its terms without any chain of dependent look-ups and
+        // three butterfly exchanges fold the eight groups (Horner's 119 dependent steps were the whole cost of this kernel).
+        for (int c0 = 0; c0 < A.s; c0 += 8) {
+            const int c = c0 + (t & 7), jg = t >> 3;
+            uint32_t syn[RS_NROOTS];
+#pragma unroll
+            for (int i = 0; i < RS_NROOTS; i++) syn[i] = 0;
+            if (c < A.s) {
+#pragma unroll 3
+                for (int jj = 0; jj < 15; jj++) {
+                    const int j = jg * 15 + jj;
+                    const uint32_t dj = s_sf[j * A.s + c];
+                    const uint32_t k = (uint32_t)(RS_LEN - 1 - j);               // exponent step: x^(119 - j) at x = alpha^i
+                    uint32_t e = index_of[dj];                                   // 255 for dj = 0: the terms are masked below
+                    syn[0] ^= dj;
+#pragma unroll
+                    for (int i = 1; i < RS_NROOTS; i++) {
+                        e += k; e = e >= RS_NN ? e - RS_NN : e;
+                        const uint32_t a = alpha_to[e >= RS_NN ? e - RS_NN : e];
+                        syn[i] ^= dj ? a : 0u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RS_NROOTS; i++) {
+                syn[i] ^= __shfl_xor(syn[i], 8); syn[i] ^= __shfl_xor(syn[i], 16); syn[i] ^= __shfl_xor(syn[i], 32);
+            }
+            if (jg == 0 && c < A.s) {
+                RsIo io; io.base = s_sf + c; io.pos_stride = (size_t)A.s;
+                const int n = rs_correct120(io, syn, alpha_to, index_of);
+                if (n < 0) atomicOr(&s_unc, 1); else if (n > 0) atomicAdd(&s_corr, n);
+            }
         }
         __syncthreads();
         if (t == 0) {                                                          // CheckSync, :160-213
+            const uint8_t* sf = s_sf;
             int sync = 0, num_aus = 0;
             if (!(sf[3] == 0x00 && sf[4] == 0x00) && (uint16_t)(sf[0] << 8 | sf[1]) == crc16_msb(sf + 2, 9, false, false, 0x782F)) {
                 const int dac_rate = sf[2] & 0x40, sbr_flag = sf[2] & 0x20;
@@ -244,32 +304,57 @@ __global__ void __launch_bounds__(64) k_superframe(SfArgs A)
                 sync = 1;
                 for (int i = 0; i < num_aus; i++) if (s_au_start[i] >= s_au_start[i + 1]) sync = 0;
             }
-            s_sync = sync; s_num_aus = num_aus;
-        }
-        __syncthreads();
-        if (s_sync && t < s_num_aus) {                                         // :122-131 AU CRC-16-CCITT
-            const uint8_t* au = sf + s_au_start[t]; const int au_len = s_au_start[t + 1] - s_au_start[t];
-            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb(au, au_len - 2, true, true, 0x1021)) atomicOr(&s_auok, 1 << t);
-        }
-        __syncthreads();
-        if (t == 0) {
+            s_sync = sync;
             SfEvent e{};
-            e.cif = r; e.corrected = s_corr; e.uncorrectable = s_unc; e.sync = s_sync; e.sf_slot = -1;
-            if (s_sync) {
-                e.format = sf[2]; e.num_aus = s_num_aus; e.au_crc_ok = s_auok; e.sf_slot = slot;
-                for (int i = 0; i <= s_num_aus; i++) e.au_start[i] = s_au_start[i];
+            e.cif = r; e.corrected = s_corr; e.uncorrectable = s_unc; e.sync = sync; e.sf_slot = -1;
+            if (sync) {
+                e.format = sf[2]; e.num_aus = num_aus; e.sf_slot = slot;
+                for (int i = 0; i <= num_aus; i++) e.au_start[i] = s_au_start[i];
             }
             ev[ne] = e;
         }
+        __syncthreads();
         ne++;
-        if (s_sync) { frame_count = 0; if (slot + 1 < A.n_slots) slot++; }     // :156 wait for a complete new superframe
+        tot_corr += s_corr; tot_unc += s_unc;
+        if (s_sync) {
+            uint8_t* gsf = A.sf + (bm * A.n_slots + slot) * sf_len;             // only synchronised superframes are kept
+            for (int i = t; i < sf_len; i += 64) gsf[i] = s_sf[i];
+            tot_sync++;
+            frame_count = 0; head = 0; if (slot + 1 < A.n_slots) slot++;       // :156 wait for a complete new superframe
+        }
     }
-    if (t == 0) { *reinterpret_cast<int32_t*>(st) = frame_count; A.n_events[b] = ne; }
+    __syncthreads();
+    // :122-131 AU CRC-16-CCITT.  The verdicts do not steer the state machine, so all access units of the batch are checked
+    // here side by side, one lane each (events and superframes were written by this work-group: visible after the barrier).
+    int tot_aubad = 0;
+    for (int base = 0; base < ne * 6; base += 64) {
+        const int k = base + t, e_i = k / 6, au_i = k % 6;
+        if (e_i < ne && ev[e_i].sync && au_i < ev[e_i].num_aus) {
+            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
+            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
+            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb(au, au_len - 2, true, true, 0x1021)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
+            else atomicAdd(&s_aubad, 1);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < frame_count * fb; i += 64) {                           // carry the window, oldest frame first
+        int sl = head + i / fb; if (sl >= 5) sl -= 5;
+        st[16 + i] = s_raw[sl * fb + i % fb];
+    }
+    if (t == 0) {
+        tot_aubad = s_aubad;
+        *reinterpret_cast<int32_t*>(st) = frame_count; A.n_events[bm] = ne;
+        if (A.stats) { atomicAdd(A.stats + 4 * b, tot_sync); atomicAdd(A.stats + 4 * b + 1, tot_corr); atomicAdd(A.stats + 4 * b + 2, tot_unc); atomicAdd(A.stats + 4 * b + 3, tot_aubad); }
+    }
 }
 
 void launch_superframe(const SfArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_superframe, dim3(a.n_ens), dim3(64), 0, s, a);
+    const dim3 grid(a.member >= 0 ? 1 : a.n_members, a.n_ens);
+    const int sf_len = 5 * a.frame_bytes;
+    if (sf_len <= 960) hipLaunchKernelGGL(k_superframe<960>, grid, dim3(64), 0, s, a);            // <= 64 kbit/s
+    else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe<2880>, grid, dim3(64), 0, s, a);     // <= 192 kbit/s
+    else hipLaunchKernelGGL(k_superframe<5760>, grid, dim3(64), 0, s, a);                         // <= 384 kbit/s
 }
 
 void launch_rs_superframes(const RsArgs& a, hipStream_t s)
