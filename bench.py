@@ -116,7 +116,8 @@ def main():
     torch.cuda.synchronize()
 
     dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.path.join(PKG_DIR, "libdabphy_hip.so"),
-                      want_constellation=False, want_impulse_response=False, disable_coarse=False, pipeline_sync=os.environ.get("DABPHY_PIPELINE", "1") != "0")
+                      want_constellation=False, want_impulse_response=False, disable_coarse=False, pipeline_sync=os.environ.get("DABPHY_PIPELINE", "1") != "0",
+                      demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
     dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
     subchs = txs[0].subchs
     dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
