@@ -10,7 +10,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/prof; rm -rf $O; mkdir -p $O
 BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $BENCH > $O/stats.log 2>&1
-KR='k_demod|k_viterbi|k_msc_gather|k_cp_products|k_sync_find|k_sync_finish|k_fic_gather|k_rs_msc'
+KR='k_demod|k_viterbi|k_msc_gather|k_cp_products|k_sync_find|k_sync_finish|k_fic_gather|k_rs_msc|k_superframe'
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_write -- $BENCH > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --kernel-include-regex k_demod --output-format csv -d $O -o pmc_sq1 -- python tests/prof_demod.py > $O/pmc_sq1.log 2>&1
