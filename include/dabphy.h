@@ -179,6 +179,9 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensemble
  * its first frame on the 17th CIF, dab-audio.cpp:146-149). */
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t* first_valid);
 int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_frames][2048] */);      /* onNewImpulseResponse */
+/* onNewNullSymbol (ofdm-processor.cpp:462-469): the 2656 oscillator-corrected samples of the null symbol that follows each
+ * demodulated frame of the last batch, out[n_ensembles][n_frames][2656][2] (zeros where valid != 1).  Computed on request. */
+int dabphy_get_null_symbols(dabphy_handle* h, float* out);
 int dabphy_get_constellation(dabphy_handle* h, float* out /* [n_ensembles][n_frames][1200] cf32 */);   /* onConstellationPoints */
 int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, int8_t* out /* 75*3072 */);
 

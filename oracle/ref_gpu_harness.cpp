@@ -28,6 +28,7 @@ struct Rec : RadioControllerInterface {
     float* con = nullptr; int con_cap = 0; std::atomic<int> n_con{0};
     float* snr = nullptr; int snr_cap = 0; std::atomic<int> n_snr{0};
     int32_t* corr = nullptr; int corr_cap = 0; std::atomic<int> n_corr{0};
+    float* nul = nullptr; int nul_cap = 0; std::atomic<int> n_nul{0};
     std::atomic<int> n_sync_true{0}, n_sync_false{0}, n_services{0};
     std::atomic<bool> failed{false};
     void onSNR(float s) override { int k = n_snr++; if (k < snr_cap) snr[k] = s; }
@@ -47,7 +48,7 @@ struct Rec : RadioControllerInterface {
     }
     void onNewImpulseResponse(std::vector<float>&& d) override { int k = n_cir++; if (k < cir_cap && d.size() == 2048) memcpy(cir + 2048 * (size_t)k, d.data(), 8192); }
     void onConstellationPoints(std::vector<DSPCOMPLEX>&& d) override { int k = n_con++; if (k < con_cap && d.size() == 1200) memcpy(con + 2400 * (size_t)k, d.data(), 9600); }
-    void onNewNullSymbol(std::vector<DSPCOMPLEX>&&) override {}
+    void onNewNullSymbol(std::vector<DSPCOMPLEX>&& d) override { int k = n_nul++; if (k < nul_cap && d.size() == 2656) memcpy(nul + 5312 * (size_t)k, d.data(), 5312 * 4); }
     void onTIIMeasurement(tii_measurement_t&&) override {}
     void onMessage(message_level_t, const std::string&, const std::string&) override {}
     void onInputFailure() override { failed = true; }
@@ -81,13 +82,14 @@ struct gpu_run_io {
     uint8_t* fib; int32_t fib_cap; float* cir; int32_t cir_cap; float* con; int32_t con_cap; float* snr; int32_t snr_cap; int32_t* corr; int32_t corr_cap;
     int32_t n_fib, n_cir, n_con, n_snr, n_corr, n_sync_true, n_sync_false, n_services;
     int32_t rs_calls[16], rs_uncorr[16], rs_corr[16];
+    float* nul; int32_t nul_cap, n_nul;
 };
 
 int gpu_receiver_run(gpu_run_io* io)
 {
     Rec rec;
     rec.fib = io->fib; rec.fib_cap = io->fib_cap; rec.cir = io->cir; rec.cir_cap = io->cir_cap; rec.con = io->con; rec.con_cap = io->con_cap;
-    rec.snr = io->snr; rec.snr_cap = io->snr_cap; rec.corr = io->corr; rec.corr_cap = io->corr_cap;
+    rec.snr = io->snr; rec.snr_cap = io->snr_cap; rec.corr = io->corr; rec.corr_cap = io->corr_cap; rec.nul = io->nul; rec.nul_cap = io->nul_cap;
     MemInput in(io->iq, io->n_samples);
     RadioReceiverOptions rro;
     rro.decodeTII = false; rro.disableCoarseCorrector = io->disable_coarse != 0;
@@ -111,7 +113,7 @@ int gpu_receiver_run(gpu_run_io* io)
         fprintf(stderr, "gpu_receiver_run: %s\n", e.what());
         return -1;
     }
-    io->n_fib = rec.n_fib; io->n_cir = rec.n_cir; io->n_con = rec.n_con; io->n_snr = rec.n_snr; io->n_corr = rec.n_corr;
+    io->n_fib = rec.n_fib; io->n_cir = rec.n_cir; io->n_con = rec.n_con; io->n_snr = rec.n_snr; io->n_corr = rec.n_corr; io->n_nul = rec.n_nul;
     io->n_sync_true = rec.n_sync_true; io->n_sync_false = rec.n_sync_false; io->n_services = rec.n_services;
     for (int i = 0; i < io->n_subch && i < 16; i++) { io->rs_calls[i] = handlers[i].rs_calls; io->rs_uncorr[i] = handlers[i].rs_uncorr; io->rs_corr[i] = handlers[i].rs_corr; }
     return 0;

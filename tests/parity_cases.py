@@ -108,18 +108,19 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
-        logs = [dict(fib=[], ok=[], info=[], con=[], soft=[], msc=[[] for _ in subs]) for _ in range(B)]
+        logs = [dict(fib=[], ok=[], info=[], con=[], soft=[], nul=[], msc=[[] for _ in subs]) for _ in range(B)]
         done = 0
         while done < n_frames_total:
             d.process(F)
             info = d.frame_info(); fb, ok = d.fibs(); cn = d.constellation() if con else np.zeros((B, F, 1200), np.complex64)
+            nl = d.null_symbols()
             mscs = [d.msc(i) for i in range(len(subs))]
             for b in range(B):
                 nv = 0
                 for f in range(F):
                     if info[b, f]["valid"] == 1:
                         L = logs[b]
-                        L["fib"].append(fb[b, f]); L["ok"].append(ok[b, f]); L["info"].append(info[b, f]); L["con"].append(cn[b, f])
+                        L["fib"].append(fb[b, f]); L["ok"].append(ok[b, f]); L["info"].append(info[b, f]); L["con"].append(cn[b, f]); L["nul"].append(nl[b, f])
                         if b == 0:
                             L["soft"].append(d.soft_bits(b, f))
                         nv += 1
@@ -150,6 +151,8 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
         assert np.array_equal(np.stack([inf["fine"], inf["coarse"]], 1), o["corr"][:n]), "correctors differ"
         if con:
             assert np.array_equal(np.array(L["con"][:n]).view(np.uint32), o["con"][:n].view(np.uint32)), "constellation differs"
+        kn = min(n, len(o["nul"]))
+        assert np.array_equal(np.array(L["nul"][:kn]).view(np.uint32), o["nul"][:kn].view(np.uint32)), "null symbols differ"
         if b == 0:
             assert np.array_equal(np.array(L["soft"][:n]), o["soft"][:n]), "soft bits differ"
         rep = inf["snr"][~np.isnan(inf["snr"])]
@@ -293,3 +296,26 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
     finally:
         d.close()
     return got
+
+
+def check_mixed_ensemble(d_factory, F=4, nf=11, snr_db=12, seed=31):
+    """an ensemble whose sub-channels all differ: bit rates 8..192 kbit/s, EEP profiles A and B, levels 1..4 -- one Viterbi
+    class (one gather + decode launch pair) per sub-channel, code words of 192..4608 bits, groups of 64 code words that
+    straddle ensembles"""
+    cfgs = [(1, 32, False, 1), (2, 128, False, 2), (3, 64, True, 3), (4, 48, False, 4), (5, 8, False, 3), (6, 192, False, 3), (7, 32, True, 1)]
+    subchs = []; cu = 0
+    for sid, br, pb, lvl in cfgs:
+        sc = synth.SubchannelCfg(sid, cu, br, pb, lvl, dabplus=False); subchs.append(sc); cu += sc.size_cu
+    assert cu <= 864
+    x, tx = synth.make_stream(nf, subchs=subchs, snr_db=snr_db, cfo_hz=-55, delay=123, return_tx=True, seed=seed)
+    o = R.orc_receiver_run(x, subchs=subchs)
+    logs = run_stream(d_factory, x, subchs, F, o["n_frames"], B=2)
+    for b in range(2):
+        L = logs[b]
+        n = min(len(L["fib"]), len(o["fib"]) // 12)
+        assert n >= o["n_frames"] - F
+        ofib = o["fib"][:12 * n].reshape(n, 12, 33)
+        assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]) and np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:])
+        for i in range(len(subchs)):
+            got = b"".join(L["msc"][i])
+            assert len(got) > 0 and got == bytes(o["msc"][i])[:len(got)], "MSC bytes of sub-channel %d (%d kbit/s) differ" % (i, subchs[i].bitrate)

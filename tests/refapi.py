@@ -335,7 +335,8 @@ class GpuRunIO(C.Structure):
                 ("corr", C.c_void_p), ("corr_cap", C.c_int32),
                 ("n_fib", C.c_int32), ("n_cir", C.c_int32), ("n_con", C.c_int32), ("n_snr", C.c_int32), ("n_corr", C.c_int32),
                 ("n_sync_true", C.c_int32), ("n_sync_false", C.c_int32), ("n_services", C.c_int32),
-                ("rs_calls", C.c_int32 * 16), ("rs_uncorr", C.c_int32 * 16), ("rs_corr", C.c_int32 * 16)]
+                ("rs_calls", C.c_int32 * 16), ("rs_uncorr", C.c_int32 * 16), ("rs_corr", C.c_int32 * 16),
+                ("nul", C.c_void_p), ("nul_cap", C.c_int32), ("n_nul", C.c_int32)]
 
 
 def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, lib=GPU_EMU_SO):
@@ -358,6 +359,7 @@ def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_p
     con = np.zeros((nf, 1200), np.complex64); io.con = _p(con); io.con_cap = nf
     snr = np.zeros(nf, np.float32); io.snr = _p(snr); io.snr_cap = nf
     corr = np.zeros((nf, 2), np.int32); io.corr = _p(corr); io.corr_cap = nf
+    nul = np.zeros((nf, 2656), np.complex64); io.nul = _p(nul); io.nul_cap = nf
     r = L.gpu_receiver_run(C.byref(io))
     assert r == 0, "GpuRadioReceiver run failed"
     msc = []
@@ -365,7 +367,7 @@ def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_p
         msc.append(open(pth, "rb").read() if os.path.exists(pth) else b"")
         if os.path.exists(pth):
             os.remove(pth)
-    return dict(fib=fib[:io.n_fib], cir=cir[:io.n_cir], con=con[:io.n_con], snr=snr[:io.n_snr], corr=corr[:io.n_corr], msc=msc,
+    return dict(fib=fib[:io.n_fib], cir=cir[:io.n_cir], con=con[:io.n_con], snr=snr[:io.n_snr], corr=corr[:io.n_corr], msc=msc, nul=nul[:io.n_nul],
                 n_sync_true=io.n_sync_true, n_sync_false=io.n_sync_false, n_services=io.n_services,
                 rs_calls=list(io.rs_calls), rs_uncorr=list(io.rs_uncorr), rs_corr=list(io.rs_corr))
 

@@ -46,3 +46,7 @@ def test_superframe_filter(emu):
     got = P.check_superframes_vs_oracle(factory, nf=20)
     ev = got[0][0]
     assert any(e[0] > 0 for e in ev) and any(e[1] and e[2] and e[6] != 7 for e in ev) and any(not e[2] for e in ev[2:])   # corrections, a broken AU, a lost sync
+
+
+def test_mixed_protection_classes(emu):
+    P.check_mixed_ensemble(factory)

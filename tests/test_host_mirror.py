@@ -24,6 +24,8 @@ def compare_runs(a, b, n_sub):
     assert np.array_equal(a["con"][:k].view(np.uint32), b["con"][:k].view(np.uint32))
     kk = min(len(a["cir"]), len(b["cir"]))
     assert np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))
+    kn = min(len(a["nul"]), len(b["nul"]))
+    assert kn >= len(a["nul"]) - 1 and kn > 2 and np.array_equal(a["nul"][:kn].view(np.uint32), b["nul"][:kn].view(np.uint32))   # onNewNullSymbol
     ks = min(len(a["snr"]), len(b["snr"]))
     assert np.allclose(a["snr"][:ks], b["snr"][:ks], rtol=1e-5, atol=1e-5)
     for i in range(n_sub):

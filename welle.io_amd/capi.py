@@ -247,6 +247,11 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_impulse_response(self.h, _p(out)))
         return out
 
+    def null_symbols(self):
+        out = np.zeros((self.cfg.n_ensembles, self._last, 2656), np.complex64)
+        self._chk(self.lib.dabphy_get_null_symbols(self.h, _p(out)))
+        return out
+
     def constellation(self):
         B, F = self.cfg.n_ensembles, self._last
         out = np.zeros((B, F, 1200), np.complex64)

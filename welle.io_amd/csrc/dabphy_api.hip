@@ -49,6 +49,7 @@ struct dabphy_handle {
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
+    DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
     DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
     DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
@@ -182,7 +183,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_raw, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_raw, &h->s_null, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); }
@@ -647,6 +648,20 @@ int dabphy_get_impulse_response(dabphy_handle* h, float* out)
 {
     if (!h || !out || !h->last_frames || !h->cfg.want_impulse_response) return DABPHY_ERR_INVALID;
     HIPCHK(h, hipMemcpyAsync(out, h->cur_cir, (size_t)h->cfg.n_ensembles * h->last_frames * T_U * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_null_symbols(dabphy_handle* h, float* out)
+{
+    if (!h || !out || !h->last_frames || !h->last_desc || !h->s_iq) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    int r;
+    if ((r = ensure(h, h->s_null, (size_t)B * F * T_NULL * sizeof(cf32)))) return r;
+    NullArgs a{};
+    a.tab = h->tab; a.iq = h->s_iq; a.iq_stride = h->s_stride; a.ring = (int64_t)h->s_ring; a.desc = h->last_desc; a.n_frames = (int)F;
+    a.out = h->s_null.as<cf32>();
+    launch_null_symbols(a, (int)B, h->stream);
+    HIPCHK(h, hipMemcpyAsync(out, h->s_null.p, (size_t)B * F * T_NULL * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
 

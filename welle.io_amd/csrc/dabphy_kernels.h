@@ -125,6 +125,14 @@ struct LinGatherArgs {
     VitClass c;
 };
 
+// Null symbols of the demodulated frames as OFDMProcessor hands them to onNewNullSymbol (k_ingest.hip: k_null_symbols)
+struct NullArgs {
+    Tables tab; const cf32* iq; size_t iq_stride; int64_t ring;
+    const FrameDesc* desc; int n_frames;
+    cf32* out;                                            // [B][n_frames][T_NULL], zeros for frames that were not demodulated
+};
+void launch_null_symbols(const NullArgs& a, int n_ens, hipStream_t s);
+
 // Sample ingest (k_ingest.hip): n samples per ensemble of raw format `format` -> ring positions w, w+1, ... (mod ring)
 struct IngestArgs {
     const uint8_t* raw; size_t raw_stride;               // bytes between ensembles

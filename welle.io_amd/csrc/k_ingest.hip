@@ -34,6 +34,32 @@ __global__ void __launch_bounds__(256) k_ingest(IngestArgs A)
     }
 }
 
+// The null symbol that follows frame (b, f), pulled like the reference pulls it: getSamples(nullSymbol, coarse + fine) with
+// the correctors as updated by this frame (ofdm-processor.cpp:462-469, NCO :211-214).  Sample j sits T_u + 75 T_s after
+// the PRS start and carries phase (null_L - (j + 1) null_f) mod RATE.  Diagnostic tap (spectrum / TII consumers): plain
+// table look-ups.
+__global__ void __launch_bounds__(256) k_null_symbols(NullArgs A)
+{
+    const int f = blockIdx.y, b = blockIdx.z;
+    const FrameDesc d = A.desc[(size_t)b * A.n_frames + f];
+    cf32* out = A.out + ((size_t)b * A.n_frames + f) * T_NULL;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T_NULL; j += gridDim.x * blockDim.x) {
+        cf32 v; v.re = 0.0f; v.im = 0.0f;
+        if (d.valid == 1) {
+            const int64_t p = (d.pos + d.start_index + T_U + 75LL * T_S + j) % A.ring;
+            int64_t ph = ((int64_t)d.null_L - (int64_t)(j + 1) * d.null_f) % INPUT_RATE; if (ph < 0) ph += INPUT_RATE;
+            v = cmul(iq[p], A.tab.nco[ph]);
+        }
+        out[j] = v;
+    }
+}
+
+void launch_null_symbols(const NullArgs& a, int n_ens, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_null_symbols, dim3(4, a.n_frames, n_ens), dim3(256), 0, s, a);
+}
+
 void launch_ingest(const IngestArgs& a, int n_ens, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::min<uint64_t>((a.n + 255) / 256, 4096);

@@ -215,7 +215,7 @@ __device__ __forceinline__ uint16_t crc16_msb(const uint8_t* data, int len, bool
 }
 
 template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
-__global__ void __launch_bounds__(64, 5) k_superframe(SfArgs A)
+__global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArgs A)
 {
     // LDS: the raw 5-frame window (a ring: `head` = oldest frame, nothing is ever shifted) and the working copy
     __shared__ __attribute__((aligned(16))) uint8_t s_dyn[2 * SF_MAX];

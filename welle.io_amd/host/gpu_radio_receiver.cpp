@@ -196,6 +196,11 @@ bool GpuRadioReceiver::decode_one_frame(uint64_t written)
         dabphy_get_constellation(phy, reinterpret_cast<float*>(con.data()));
         rci.onConstellationPoints(std::move(con));                      // ofdm-decoder.cpp:119-121
     }
+    {
+        std::vector<DSPCOMPLEX> nul(2656);
+        if (dabphy_get_null_symbols(phy, reinterpret_cast<float*>(nul.data())) == DABPHY_OK)
+            rci.onNewNullSymbol(std::move(nul));                        // ofdm-processor.cpp:469
+    }
     // thread C: decoded logical frames, 4 per transmission frame, in CIF order (dab-audio.cpp:151-160)
     {
         std::lock_guard<std::mutex> lock(mutex);
