@@ -63,6 +63,22 @@ def main():
     out["e2e_msc0_len"] = np.array([len(r["msc"][0])])
     out["e2e_msc0_head"] = np.frombuffer(r["msc"][0][:384], np.uint8)
     out["e2e_con_sha"] = np.frombuffer(sha(r["con"]).encode(), np.uint8)
+    # SuperframeFilter::Feed (the real class): a 64 kbit/s stream that starts mid-superframe, with correctable and
+    # uncorrectable byte errors, a broken access unit and a dropped frame
+    r2 = np.random.RandomState(99)
+    sf = [synth.make_superframe(64, r2) for _ in range(8)]
+    sf[2][7 * 8 + 1] ^= 0x55
+    for k in range(4):
+        sf[3][(20 + k) * 8] ^= 0xA0 + k
+    sf[4][300] ^= 0x0F                                     # inside an access unit, within RS capacity
+    for k in range(7):
+        sf[5][(30 + 3 * k) * 8 + 1] ^= 0x11 * (k + 1)
+    frames = np.concatenate(sf).reshape(-1, 192)[3:]
+    frames = np.concatenate([frames[:23], frames[24:]])
+    ev, sfs = R.ref_superframe_run(frames)
+    out["sf_frames"] = frames
+    out["sf_events"] = np.array([[e[0], e[1], e[2], e[3], e[4], e[5], e[7]] + list(e[6]) + [0] * (7 - len(e[6])) for e in ev], np.int32)
+    out["sf_corrected_sha"] = np.frombuffer(sha(np.concatenate(sfs)).encode(), np.uint8)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")), "bytes")
 
