@@ -55,6 +55,9 @@ static inline bool wave_all(bool p) { return p; }
 // LDS-DMA model: the copy happens at issue time
 template <int OFF> static inline void lds_dma16(const void* gptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + OFF + 16 * hipemu_lane(), (const char*)gptr + OFF, 16); }
 static inline void lds_dma4(const void* gptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu_lane(), gptr, 4); }
-static inline void lds_dma_wait() {}
+// the hardware executes a wave's DMA requests for all lanes at once; the fibers of the model do not run in lock-step, so
+// "the data has landed" must also mean "every lane of the wave has issued its part": a wave-wide rendezvous
+static inline void lds_dma_wait() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
+template <int N> static inline void lds_dma_wait_but() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 
 } // namespace dabphy

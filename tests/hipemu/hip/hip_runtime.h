@@ -74,13 +74,24 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { retu
 // ---- execution engine (hipemu.cpp) ----
 void hipemu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void hipemu_syncthreads();
-unsigned hipemu_wave_exchange(unsigned v, int src_lane, bool valid);   // returns v of src_lane
-unsigned long long hipemu_ballot(bool p);
+unsigned hipemu_wave_exchange_impl(unsigned v, int src_lane, bool valid);   // returns v of src_lane
+unsigned long long hipemu_ballot_impl(bool p);
+// Every rendezvous is also a COMPILER barrier: other fibers run on this thread while one is parked, and they write the
+// function-local statics that stand in for LDS.  g++ proves that the address of such a static never escapes and would keep
+// its contents in registers across the (opaque) call; the "memory" clobber forbids that.
+static inline unsigned hipemu_wave_exchange(unsigned v, int src_lane, bool valid)
+{
+    asm volatile("" ::: "memory"); const unsigned r = hipemu_wave_exchange_impl(v, src_lane, valid); asm volatile("" ::: "memory"); return r;
+}
+static inline unsigned long long hipemu_ballot(bool p)
+{
+    asm volatile("" ::: "memory"); const unsigned long long r = hipemu_ballot_impl(p); asm volatile("" ::: "memory"); return r;
+}
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu_launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 
-static inline void __syncthreads() { hipemu_syncthreads(); }
+static inline void __syncthreads() { asm volatile("" ::: "memory"); hipemu_syncthreads(); asm volatile("" ::: "memory"); }
 static inline int hipemu_lane() { return (int)((threadIdx.x + threadIdx.y * blockDim.x) & 63); }
 template <typename T> static inline T __shfl(T v, int src, int width = 64) {
     static_assert(sizeof(T) == 4, "4-byte shuffles only"); unsigned u; memcpy(&u, &v, 4);

@@ -64,7 +64,7 @@ static void wave_barrier(int w) {
     else while (B.w_gen[w] == gen) yield_();
 }
 
-unsigned hipemu_wave_exchange(unsigned v, int src_lane, bool) {
+unsigned hipemu_wave_exchange_impl(unsigned v, int src_lane, bool) {
     // double-buffered: a lane can only reach its second-next exchange after every lane has left this one
     int t = B.cur, w = t / 64, l = t & 63;
     const unsigned tog = (B.w_tog[w][l]++) & 1;
@@ -73,7 +73,7 @@ unsigned hipemu_wave_exchange(unsigned v, int src_lane, bool) {
     return B.w_val[tog][w][src_lane & 63];
 }
 
-unsigned long long hipemu_ballot(bool p) {
+unsigned long long hipemu_ballot_impl(bool p) {
     int t = B.cur, w = t / 64, l = t & 63;
     B.w_pred[w][l] = p;
     wave_barrier(w);

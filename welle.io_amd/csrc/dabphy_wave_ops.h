@@ -135,5 +135,8 @@ __device__ __forceinline__ void lds_dma4(const void* gptr, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... until at most N of the wave's memory operations are still in flight (they complete in order: "everything but the
+// last N requests has landed")
+template <int N> __device__ __forceinline__ void lds_dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 } // namespace dabphy
