@@ -319,3 +319,34 @@ def check_mixed_ensemble(d_factory, F=4, nf=11, snr_db=12, seed=31):
         for i in range(len(subchs)):
             got = b"".join(L["msc"][i])
             assert len(got) > 0 and got == bytes(o["msc"][i])[:len(got)], "MSC bytes of sub-channel %d (%d kbit/s) differ" % (i, subchs[i].bitrate)
+
+
+def check_error_behaviour(d_factory):
+    """signal problems never raise (they surface as valid = 0 / CRC false, like the reference's callbacks); programming errors
+    come back as negative status codes with a message, never as a crash (the reference throws std::logic_error / out_of_range)"""
+    from welle_io_amd.capi import DabPhyError
+    d = d_factory(n_ensembles=2, max_frames=2)
+    try:
+        def bad(fn):
+            try:
+                fn()
+            except DabPhyError as e:
+                assert "status -" in str(e)
+                return
+            raise AssertionError("expected an error status")
+        bad(lambda: d.process(1))                                                 # no stream bound
+        bad(lambda: d.protection_eep(64, 0, 7))                                   # level out of range
+        p = d.protection_eep(64, 0, 3)
+        bad(lambda: d.set_subchannels([(1, 850, 48, p)]))                         # runs past CU 864
+        bad(lambda: d.set_subchannels([(1, 0, 10, p)]))                           # too small for its protection profile
+        x = np.zeros((2, 3 * 196608), np.complex64)
+        d.stream_upload(x)
+        bad(lambda: d.process(3))                                                 # more frames than max_frames
+        d.process(2)                                                              # silence: no null symbol, no frame -- not an error
+        assert (d.frame_info()["valid"] != 1).all()                             # (valid = 3: a window search that found nothing, reported like the reference does)
+        bad(lambda: d.superframes(0, 64))                                         # no such sub-channel
+        d.stream_open(4 * 196608)
+        bad(lambda: d.stream_write(np.zeros((2, 5 * 196608), np.complex64)))      # more than the ring holds
+        bad(lambda: d.stream_write_raw(np.zeros((2, 100, 2), np.uint8), "u8") if False else d._chk(d.lib.dabphy_stream_write_raw(d.h, None, 100, 1)))   # null buffer
+    finally:
+        d.close()

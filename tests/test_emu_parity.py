@@ -33,3 +33,9 @@ def test_demod_zero_carriers(emu):
     frames = np.zeros((1, 2048 + 75 * 2552), np.complex64)
     soft, con, _ = emu.demod_frames(frames)
     assert not soft.any()
+
+
+def test_error_behaviour(emu):
+    from welle_io_amd import capi
+    import conftest
+    P.check_error_behaviour(lambda **kw: capi.DabPhy(lib_path=conftest.EMU_LIB, **kw))

@@ -79,3 +79,9 @@ def test_demod_then_fic_roundtrip_full_batch(gpu):
     assert ok.all() and ratio == 100
     sent = np.frombuffer(b"".join(b"".join(f) for f in tx.fib_log[:nf]), np.uint8).reshape(nf, 12, 32)
     assert np.array_equal(fib, sent)
+
+
+def test_error_behaviour(gpu):
+    from welle_io_amd import capi
+    import conftest
+    P.check_error_behaviour(lambda **kw: capi.DabPhy(lib_path=conftest.GPU_LIB, **kw))
