@@ -64,8 +64,22 @@ def cpu_baseline(base_stream, n_loops):
         res = [json.loads(p.stdout.readline()) for p in procs]
         for p in procs:
             p.wait()
+        # one receiver of the REAL reference backend (oracle/_ref, built from /root/reference where that exists), alone on the
+        # host: its own 2-3 threads, and it also runs the layers above the PHY (FIG parsing, superframe filter, AAC)
+        ref_rate = None
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref.so")):
+            try:
+                p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py"), rec, str(max(1, n_loops // 4)), "7", "reference"],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+                if p.stdout.readline().strip() == "READY":
+                    p.stdin.write("go\n"); p.stdin.flush()
+                    rr = json.loads(p.stdout.readline()); ref_rate = rr["frames"] * FRAME_S / rr["seconds"]
+                p.wait()
+            except Exception:
+                ref_rate = None
     nfr = sum(r["frames"] for r in res); slowest = max(r["seconds"] for r in res)
-    return dict(value=nfr * FRAME_S / slowest, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
+    return dict(reference_backend_single_receiver=ref_rate,
+                value=nfr * FRAME_S / slowest, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
                 per_core=res[0]["frames"] * FRAME_S / res[0]["seconds"],
                 sample="%d receivers x %d frames (%.1f s of IQ each) of the canonical ensemble, 18 sub-channels, oracle C restatement, slowest receiver %.1f s"
                        % (cores, res[0]["frames"], res[0]["frames"] * FRAME_S, slowest),
