@@ -110,9 +110,9 @@ def main():
     from welle_io_amd.distributed import gather_fibs
 
     B, F = args.ensembles, args.frames
-    assert F % 5 == 0 and F % 4 == 0, "frames per step must keep superframes and the interleaver period aligned (multiple of 20)"
+    REC = 20            # frames per looping recording: 80 CIFs = a whole number of superframes (5 CIFs) and interleaver periods (16)
     n_distinct = 4
-    base, txs = make_base_streams(n_distinct, F, seed0=100 * rank)
+    base, txs = make_base_streams(n_distinct, REC, seed0=100 * rank)
     N = base.shape[1]
     gbase = torch.from_numpy(base).cuda()
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
@@ -152,7 +152,8 @@ def main():
     # sanity outside the timed region: all FIBs pass CRC; every sub-channel of every ensemble delivers its 4F/5 superframes per
     # step, none uncorrectable, every access unit passes its CRC; the FIBs of ensemble 0 are the transmitted ones
     assert ok.all(), "FIB CRC failures in the benchmark signal"
-    assert (sf[:, 0] == len(subchs) * (4 * F // 5)).all() and (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all(), "superframe filter: %s" % sf[:4]
+    assert (sf[:, 0] >= len(subchs) * (4 * F // 5)).all() and (sf[:, 0] <= len(subchs) * ((4 * F + 4) // 5)).all(), "superframe filter: %s" % sf[:4]
+    assert (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all(), "superframe filter: %s" % sf[:4]
     sent = set(b"".join(f) for f in txs[0].fib_log)
     assert all(fib[0, f].tobytes() in sent for f in range(F)), "decoded FIBs differ from the transmitted ones"
 
