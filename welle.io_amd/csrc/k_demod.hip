@@ -206,9 +206,19 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     bool staged = dma_ok(sym0);
     if (A.mix) { osc_chain_steps(osc, d.f_sym); osc.base = osc_exp(cur.ph); }
     if (staged) dma_issue(sym0);       // overlaps nothing yet (the reference symbol is done), but primes the pipeline
+    // The 3 KiB of soft bits of symbol s leave at the START of iteration s+1: the barrier that opens an iteration is then also
+    // the one that completes the soft-bit staging (4 barriers per symbol, not 5), and the wait for the LDS-DMA -- the wave's
+    // only memory counter also counts stores -- finds stores that are a whole symbol old instead of ones just issued.
+    auto store_soft = [&](int sym) {
+        const uint2* src = reinterpret_cast<const uint2*>(softbuf);
+        uint2* dst = reinterpret_cast<uint2*>(soft_frame + (size_t)(sym - 1) * SOFT_PER_SYM);
+#pragma unroll
+        for (int i = 0; i < 3; i++) dst[t + 128 * i] = src[t + 128 * i];
+    };
     for (int s = s_begin; s < s_end; s++) {
         if (staged) lds_dma_wait();
-        __syncthreads();                                         // tile + softbuf free again, stage complete
+        __syncthreads();                                         // tile free again, stage complete, soft bits of s-1 complete
+        if (s > s_begin) store_soft(s - 1);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             cf32 x[8];
@@ -262,14 +272,9 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
             for (int q = 0; q < N_SLOTS; q++)
                 if (sidx[q] % 96 == 0) con_frame[(s - 1) * 16 + sidx[q] / 96] = r1[q];   // :214-216
         }
-        __syncthreads();
-        {
-            const uint2* src = reinterpret_cast<const uint2*>(softbuf);
-            uint2* dst = reinterpret_cast<uint2*>(soft_frame + (size_t)(s - 1) * SOFT_PER_SYM);
-#pragma unroll
-            for (int i = 0; i < 3; i++) dst[t + 128 * i] = src[t + 128 * i];
-        }
     }
+    __syncthreads();
+    store_soft(s_end - 1);
 }
 
 // SNR estimate of OfdmDecoder::get_snr(method 1) (ofdm-decoder.cpp:240-266): one thread per (ensemble, frame) runs the
