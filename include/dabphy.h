@@ -37,11 +37,12 @@ typedef struct {
     uint32_t n_ensembles;           /* independent ensembles (streams) decoded in lock step; >= 1 */
     uint32_t max_frames;            /* transmission frames per dabphy_process call and ensemble; >= 1 */
     int32_t device;                 /* HIP device ordinal */
-    int32_t fft_placement;          /* FFTPlacementMethod: 2 = ThresholdBeforePeak (default), 0 = StrongestPeak */
+    int32_t fft_placement;          /* FFTPlacementMethod: 2 = ThresholdBeforePeak (default), 1 = EarliestPeakWithBinning, 0 = StrongestPeak */
     int32_t disable_coarse;         /* RadioReceiverOptions::disableCoarseCorrector */
     int32_t want_constellation;     /* keep the 1200 constellation points per frame (onConstellationPoints) */
     int32_t want_impulse_response;  /* keep the 2048-float CIR per frame (onNewImpulseResponse) */
     int32_t demod_chunk;            /* data symbols per work-group of the demod kernel; 0 = default */
+    int32_t freqsync_method;        /* FreqsyncMethod of the coarse corrector: 2 = PatternOfZeros (default), 1 = CorrelatePRS, 0 = GetMiddle */
     int32_t pipeline_sync;          /* 1: synchronise batch k+1 on a second stream while batch k is decoded (throughput mode:
                                        constant n_frames, samples of the next batch already in the ring; the coarse-corrector
                                        feedback then lags one more batch) */

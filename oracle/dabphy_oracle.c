@@ -217,6 +217,38 @@ int orc_find_index(const orc_cf32* v, int method, float* impulse)
         if (max < 3 * sum / ORC_TU) return (int)(-fabsf(max * ORC_TU / sum) - 1);
         return maxIndex;
     }
+    if (method == 1) {                                              /* EarliestPeakWithBinning :125-211 */
+        enum { BIN = 20, NB = (ORC_TU - 1) / BIN };                 /* i + bin_size < Tu: 102 bins, samples 2040..2047 are never looked at */
+        float val[NB]; int idx[NB], order[NB];
+        float mean = 0;
+        for (int k = 0; k < NB; k++) {
+            val[k] = 0; idx[k] = -1;
+            for (int j = 0; j < BIN; j++) {
+                const float value = cabs_(r[BIN * k + j]);
+                mean += value; ir[BIN * k + j] = value;
+                if (value > val[k]) { val[k] = value; idx[k] = BIN * k + j; }
+            }
+        }
+        for (int i = BIN * NB; i < ORC_TU; i++) ir[i] = 0;          /* the member buffer keeps its initial zeros there */
+        mean /= ORC_TU;
+        /* std::sort by value, descending (ties -- exact float equality of two bin maxima -- in bin order here) */
+        for (int k = 0; k < NB; k++) order[k] = k;
+        for (int a = 1; a < NB; a++) { int o = order[a], bpos = a; while (bpos > 0 && val[order[bpos - 1]] < val[o]) { order[bpos] = order[bpos - 1]; bpos--; } order[bpos] = o; }
+        const int peak_index = idx[order[0]];
+        /* not farther than 500 from the highest peak, then the 4 highest, then those above 3 * mean; min_element over the
+         * survivors (an all-zero input leaves bins of index -1 that survive: 0 < 0 is false) */
+        {
+            int found = 0, mn = 0, kept = 0;
+            for (int a = 0; a < NB && kept < 4; a++) {
+                const int k = order[a];
+                if (abs(idx[k] - peak_index) > 500) continue;
+                kept++;
+                if (val[k] < 3 * mean) continue;
+                if (!found || idx[k] < mn) { mn = idx[k]; found = 1; }
+            }
+            return found ? mn : -1;
+        }
+    }
     /* ThresholdBeforePeak :212-252 */
     for (int i = 0; i < ORC_TU; i++) { const float a = cabs_(r[i]); ir[i] = a; sum += a; }
     const int windowsize = 100;
@@ -237,11 +269,42 @@ int orc_find_index(const orc_cf32* v, int method, float* impulse)
     return -1;
 }
 
-/* ofdm-processor.cpp:537-616 (FreqsyncMethod::PatternOfZeros) */
-int orc_coarse_prs(const orc_cf32* v)
+/* ofdm-processor.cpp:537-616: method = FreqsyncMethod (0 GetMiddle, 1 CorrelatePRS, 2 PatternOfZeros) */
+int orc_coarse_prs_method(const orc_cf32* v, int method)
 {
+    orc_init();
     orc_cf32 f[ORC_TU];
     orc_fft2048(v, f, 0);
+    if (method == 0) {                                               /* getMiddle :618-644 (abs of a complex: std::abs = hypotf) */
+        float sum = 0, oldMax = 0; int maxIndex = 0;
+        for (int i = 40; i < 1536 + 40; i++) sum += cabs_(f[(ORC_TU / 2 + i) % ORC_TU]);
+        for (int i = 40; i < ORC_TU - (1536 - 40); i++) {
+            sum -= cabs_(f[(ORC_TU / 2 + i) % ORC_TU]);
+            sum += cabs_(f[(ORC_TU / 2 + i + 1536) % ORC_TU]);
+            if (sum > oldMax) { sum = oldMax; maxIndex = i; }         /* sic: the running sum is reset, oldMax stays 0 */
+        }
+        return maxIndex - (ORC_TU - 1536) / 2;
+    }
+    if (method == 1) {                                               /* CorrelatePRS :547-581 */
+        float refArg[24], cv[72 + 24];
+        for (int i = 0; i < 24; i++) {                                /* :97-101 */
+            const orc_cf32 z = cmul(g_reftable[(ORC_TU + i) % ORC_TU], cconj(g_reftable[(ORC_TU + i + 1) % ORC_TU]));
+            refArg[i] = carg_(z);
+        }
+        for (int i = 0; i < 72 + 24; i++) {
+            const int base = ORC_TU - 36 + i;
+            cv[i] = carg_(cmul(f[base % ORC_TU], cconj(f[(base + 1) % ORC_TU])));
+        }
+        float MMax = 0; int index = 100;
+        for (int i = 0; i < 72; i++) {
+            float sum = 0;
+            for (int j = 0; j < 24; j++) {
+                sum += (float)abs((int)(refArg[j] * cv[i + j]));      /* ::abs(int) again: the product is truncated first */
+                if (sum > MMax) { MMax = sum; index = i; }
+            }
+        }
+        return ORC_TU - 36 + index - ORC_TU;
+    }
     int index = 100; float Mmin = 1000;
 #define FB(i) f[(i) % ORC_TU]
 #define ARGD(a, b) carg_(cmul(FB(a), cconj(FB(b))))
@@ -266,6 +329,8 @@ int orc_coarse_prs(const orc_cf32* v)
 #undef FB
     return index - ORC_TU;
 }
+
+int orc_coarse_prs(const orc_cf32* v) { return orc_coarse_prs_method(v, 2); }
 
 /* -------------------------------------------------------------------------------------------- demod */
 
@@ -889,7 +954,7 @@ SyncOnPhase:
         io->n_sync_true++;
         rx_get_samples(&R, &ofdmBuffer[ofdmBufferIndex], ORC_TU - ofdmBufferIndex, R.coarse + R.fine); if (R.failed) goto done;
         if (!io->disable_coarse && fic_ratio * 10 < 50) {
-            int correction = orc_coarse_prs(ofdmBuffer);
+            int correction = orc_coarse_prs_method(ofdmBuffer, io->freqsync_sel == 1 ? 0 : io->freqsync_sel == 2 ? 1 : 2);
             if (correction != 100) {
                 R.coarse += correction * 1000;
                 if (abs(R.coarse) > 35000) R.coarse = 0;

@@ -47,6 +47,7 @@ int orc_find_index(const orc_cf32* v, int method, float* impulse2048);
 
 /* ofdm-processor.cpp:537-616, PatternOfZeros; returns carrier offset (100 = none) */
 int orc_coarse_prs(const orc_cf32* prs2048);
+int orc_coarse_prs_method(const orc_cf32* prs2048, int freqsync_method /* 0 GetMiddle, 1 CorrelatePRS, 2 PatternOfZeros */);
 
 /* ofdm-decoder.cpp:144-230.  state: phase reference (2048 cf32), snr (float), snrCount. */
 typedef struct {
@@ -133,6 +134,7 @@ typedef struct {
     uint8_t** msc; int64_t* msc_cap; int64_t* msc_len;   /* per sub-channel byte streams */
     /* counts */
     int n_fib, n_frames, n_snr, n_sync_true, n_sync_false, n_cir;
+    int freqsync_sel;          /* 0 = PatternOfZeros (default), 1 = GetMiddle, 2 = CorrelatePRS */
 } orc_run_io;
 int orc_receiver_run(orc_run_io* io);
 

@@ -83,6 +83,7 @@ struct gpu_run_io {
     int32_t n_fib, n_cir, n_con, n_snr, n_corr, n_sync_true, n_sync_false, n_services;
     int32_t rs_calls[16], rs_uncorr[16], rs_corr[16];
     float* nul; int32_t nul_cap, n_nul;
+    int32_t freqsync;                 // FreqsyncMethod (reference numbering)
 };
 
 int gpu_receiver_run(gpu_run_io* io)
@@ -93,7 +94,9 @@ int gpu_receiver_run(gpu_run_io* io)
     MemInput in(io->iq, io->n_samples);
     RadioReceiverOptions rro;
     rro.decodeTII = false; rro.disableCoarseCorrector = io->disable_coarse != 0;
-    rro.fftPlacementMethod = io->fft_placement == 0 ? FFTPlacementMethod::StrongestPeak : FFTPlacementMethod::ThresholdBeforePeak;
+    rro.freqsyncMethod = io->freqsync == 0 ? FreqsyncMethod::GetMiddle : io->freqsync == 1 ? FreqsyncMethod::CorrelatePRS : FreqsyncMethod::PatternOfZeros;
+    rro.fftPlacementMethod = io->fft_placement == 0 ? FFTPlacementMethod::StrongestPeak
+                           : io->fft_placement == 1 ? FFTPlacementMethod::EarliestPeakWithBinning : FFTPlacementMethod::ThresholdBeforePeak;
     std::vector<NullProgrammeHandler> handlers(io->n_subch > 0 ? io->n_subch : 1);
     try {
         GpuRadioReceiver rx(rec, in, rro);

@@ -101,10 +101,10 @@ def check_demod_degenerate(d, seed=21):
         assert np.array_equal(soft, so), "%d of %d soft bits differ" % ((soft != so).sum(), soft.size)
 
 
-def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True):
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2):
     """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
     from welle_io_amd import capi  # noqa: F401
-    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con)
+    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
@@ -135,11 +135,11 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
         d.close()
 
 
-def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True):
+def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True, fft_placement=2, freqsync=2):
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
-    o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse)
-    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con)
+    o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse, fft_placement=fft_placement, freqsync=freqsync)
+    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con, fft_placement=fft_placement, freqsync=freqsync)
     for b in range(B):
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)

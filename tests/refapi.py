@@ -181,7 +181,8 @@ class OrcRunIO(C.Structure):
                 ("start_index", C.c_void_p), ("frame_pos", C.c_void_p), ("sidx_cap", C.c_int),
                 ("soft", C.c_void_p), ("soft_cap", C.c_int),
                 ("msc", C.POINTER(C.c_void_p)), ("msc_cap", C.POINTER(C.c_int64)), ("msc_len", C.POINTER(C.c_int64)),
-                ("n_fib", C.c_int), ("n_frames", C.c_int), ("n_snr", C.c_int), ("n_sync_true", C.c_int), ("n_sync_false", C.c_int), ("n_cir", C.c_int)]
+                ("n_fib", C.c_int), ("n_frames", C.c_int), ("n_snr", C.c_int), ("n_sync_true", C.c_int), ("n_sync_false", C.c_int), ("n_cir", C.c_int),
+                ("freqsync_sel", C.c_int)]
 
 
 def orc():
@@ -293,10 +294,11 @@ def orc_demod_frames(frames):
     return soft, con.reshape(n, 1200), np.array(snrs, np.float32)
 
 
-def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_soft=False):
+def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_soft=False, freqsync=2):
     iq = np.ascontiguousarray(iq, np.complex64); nf = len(iq) // 196608 + 2
     io = OrcRunIO(); io.iq = _p(iq); io.n_samples = len(iq)
     io.disable_coarse = int(disable_coarse); io.fft_placement = fft_placement
+    io.freqsync_sel = {2: 0, 0: 1, 1: 2}[freqsync]          # reference enum: 0 GetMiddle, 1 CorrelatePRS, 2 PatternOfZeros
     cfg = (OrcSubchCfg * max(1, len(subchs)))()
     bufs = []; ptrs = (C.c_void_p * max(1, len(subchs)))(); caps = (C.c_int64 * max(1, len(subchs)))(); lens = (C.c_int64 * max(1, len(subchs)))()
     for i, s in enumerate(subchs):
@@ -336,15 +338,15 @@ class GpuRunIO(C.Structure):
                 ("n_fib", C.c_int32), ("n_cir", C.c_int32), ("n_con", C.c_int32), ("n_snr", C.c_int32), ("n_corr", C.c_int32),
                 ("n_sync_true", C.c_int32), ("n_sync_false", C.c_int32), ("n_services", C.c_int32),
                 ("rs_calls", C.c_int32 * 16), ("rs_uncorr", C.c_int32 * 16), ("rs_corr", C.c_int32 * 16),
-                ("nul", C.c_void_p), ("nul_cap", C.c_int32), ("n_nul", C.c_int32)]
+                ("nul", C.c_void_p), ("nul_cap", C.c_int32), ("n_nul", C.c_int32), ("freqsync", C.c_int32)]
 
 
-def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, lib=GPU_EMU_SO):
+def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, lib=GPU_EMU_SO, freqsync=2):
     """Run GpuRadioReceiver (the facade mirror) over a cf32 stream; same outputs as receiver_run()."""
     L = C.CDLL(lib)
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     nf = len(iq) // 196608 + 2
-    io = GpuRunIO(); io.iq = _p(iq); io.n_samples = len(iq); io.disable_coarse = int(disable_coarse); io.fft_placement = fft_placement
+    io = GpuRunIO(); io.iq = _p(iq); io.n_samples = len(iq); io.disable_coarse = int(disable_coarse); io.fft_placement = fft_placement; io.freqsync = freqsync
     arr = (RefSubch * max(1, len(subchs)))(); paths = []
     for i, s in enumerate(subchs):
         arr[i].subChId = s.subch_id; arr[i].startAddr = s.start_cu; arr[i].length = s.size_cu

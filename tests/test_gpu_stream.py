@@ -67,3 +67,15 @@ def test_superframe_filter(gpu):
 
 def test_mixed_protection_classes(gpu):
     P.check_mixed_ensemble(factory)
+
+
+@pytest.mark.parametrize("method,snr,cfo", [(1, 15, 90), (1, None, -300), (0, 12, 40)])
+def test_other_fft_placement_methods(gpu, method, snr, cfo):
+    """RadioReceiverOptions::fftPlacementMethod: EarliestPeakWithBinning (1) and StrongestPeak (0)"""
+    P.check_stream_vs_oracle(factory, snr, cfo, 211, 9, True, fft_placement=method)
+
+
+@pytest.mark.parametrize("freqsync,cfo,snr", [(0, 2300, 20), (1, 2300, 20), (1, -1000, 14), (0, 17400, None)])
+def test_other_freqsync_methods(gpu, freqsync, cfo, snr):
+    """RadioReceiverOptions::freqsyncMethod: GetMiddle (0) and CorrelatePRS (1) drive the coarse corrector"""
+    P.check_stream_vs_oracle(factory, snr, cfo, 250, 10, True, seed=50 + freqsync, freqsync=freqsync)

@@ -62,3 +62,15 @@ def test_reference_superframe_filter_sees_valid_rs(emu):
     assert 0 <= a["rs_uncorr"][0] - b["rs_uncorr"][0] <= 4
     aligned_ok = a["rs_calls"][0] - a["rs_uncorr"][0]
     assert aligned_ok >= 5 and 0 <= aligned_ok - (b["rs_calls"][0] - b["rs_uncorr"][0]) <= 1
+
+
+def test_facade_accepts_all_sync_options(emu):
+    """EarliestPeakWithBinning + CorrelatePRS through the façade: same callbacks as the reference façade with the same options"""
+    x, tx = synth.make_stream(10, snr_db=18, cfo_hz=2300, delay=300, return_tx=True, seed=6)
+    subs = [tx.subchs[0]]
+    a = R.receiver_run(x, subchs=subs, fft_placement=1, freqsync=1)
+    b = R.gpu_receiver_run(x, subchs=subs, lib=R.GPU_EMU_SO, fft_placement=1, freqsync=1)
+    n = min(len(a["fib"]), len(b["fib"]))
+    assert n >= len(a["fib"]) - 12 and n > 24 and np.array_equal(a["fib"][:n], b["fib"][:n])
+    kk = min(len(a["cir"]), len(b["cir"]))
+    assert np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))

@@ -134,3 +134,34 @@ def test_superframe_filter_equals_reference(oracle_built, bitrate, seed):
     assert eo == er
     assert len(so) == len(sr) and all(np.array_equal(x, y) for x, y in zip(so, sr))
     assert sum(e[3] for e in eo) >= 5 and any(e[2] for e in eo)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_receiver_other_fft_placement_methods(oracle_built, method):
+    """end to end through RadioReceiver with fftPlacementMethod = StrongestPeak / EarliestPeakWithBinning"""
+    x, tx = synth.make_stream(9, snr_db=14, cfo_hz=60, delay=400, return_tx=True, seed=44)
+    subs = [tx.subchs[3]]
+    a = R.receiver_run(x, subchs=subs, fft_placement=method)
+    b = R.orc_receiver_run(x, subchs=subs, fft_placement=method)
+    n = min(len(a["fib"]), len(b["fib"]))
+    assert n >= 12 * 6 and np.array_equal(a["fib"][:n], b["fib"][:n])
+    k = min(len(a["cir"]), len(b["cir"]))
+    assert np.array_equal(a["cir"][:k].view(np.uint32), b["cir"][:k].view(np.uint32))
+    m = min(len(a["msc"][0]), len(b["msc"][0]))
+    assert m > 0 and a["msc"][0][:m] == bytes(b["msc"][0])[:m]
+
+
+@pytest.mark.parametrize("freqsync,cfo,snr", [(0, 2300, 20), (1, 2300, 20), (1, -1000, 14), (0, 17400, None), (1, 60, 9), (0, -400, 12)])
+def test_receiver_other_freqsync_methods(oracle_built, freqsync, cfo, snr):
+    """RadioReceiverOptions::freqsyncMethod GetMiddle (0) / CorrelatePRS (1): the coarse corrector they drive while the FIC does
+    not decode, end to end through RadioReceiver -- correctors frame by frame, FIBs, MSC bytes"""
+    x, tx = synth.make_stream(10, snr_db=snr, cfo_hz=cfo, delay=250, return_tx=True, seed=50 + freqsync)
+    subs = [tx.subchs[7]]
+    a = R.receiver_run(x, subchs=subs, freqsync=freqsync)
+    b = R.orc_receiver_run(x, subchs=subs, freqsync=freqsync)
+    k = min(len(a["corr"]), len(b["corr"]))
+    assert k >= 5 and np.array_equal(a["corr"][:k], b["corr"][:k]), (a["corr"][:k].T, b["corr"][:k].T)
+    n = min(len(a["fib"]), len(b["fib"]))
+    assert np.array_equal(a["fib"][:n], b["fib"][:n])
+    m = min(len(a["msc"][0]), len(b["msc"][0]))
+    assert a["msc"][0][:m] == bytes(b["msc"][0])[:m]

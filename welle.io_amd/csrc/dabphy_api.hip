@@ -137,6 +137,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
+    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2) return fail(DABPHY_ERR_INVALID);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
@@ -488,7 +489,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         SyncArgs sa{};
         sa.tab = h->tab; sa.iq = h->s_iq; sa.iq_stride = h->s_stride; sa.ring = (int64_t)h->s_ring; sa.n_valid = (int64_t)h->s_valid;
         sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
-        sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse;
+        sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse; sa.freqsync = h->cfg.freqsync_method;
         sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
         sa.prods = h->s_prods.as<cf32>();
         { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }

@@ -54,7 +54,7 @@ struct SyncArgs {
     int64_t n_valid;                                     // samples written so far (absolute); ignored when loop != 0
     int loop;                                            // the ring is a looping recording (CRAWFile with rewind, raw_file.cpp:284-286)
     RxState* state; const DecState* dec; FrameDesc* desc; int n_ens, n_frames, frame;
-    int fft_placement, disable_coarse;
+    int fft_placement, disable_coarse, freqsync;        // FFTPlacementMethod, disableCoarseCorrector, FreqsyncMethod (reference numbering)
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
     cf32* prods;                                         // [B][75][512] cyclic-prefix products of the pending frame
 };

@@ -254,6 +254,44 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
         if (sum == 0) startIndex = -1;
         else if (gmax < 3 * sum / T_U) startIndex = (int)(-fabsf(gmax * T_U / sum) - 1);
         else startIndex = first;
+    } else if (A.fft_placement == 1) {
+        // EarliestPeakWithBinning (phasereference.cpp:125-211): peaks over 102 bins of 20 samples (2040..2047 are never
+        // looked at), the highest peak, the 4 highest bins within 500 samples of it, those above 3 * mean, the earliest.
+        float* const bval = pa; int* const bidx = reinterpret_cast<int*>(pa + 128);
+        if (t == 0) { float s = 0; for (int i = 0; i < 2040; i++) s += lbuf[i]; s_sum = s; }    // `mean += value` in index order
+        if (t < 102) {
+            float pv = 0.0f; int pi = -1;
+            for (int j = 0; j < 20; j++) { const float v2 = lbuf[20 * t + j]; if (v2 > pv) { pv = v2; pi = 20 * t + j; } }
+            bval[t] = pv; bidx[t] = pi;
+        }
+        if (cir && t < 8) cir[2040 + t] = 0.0f;                                                  // the reference's buffer keeps its zeros there
+        __syncthreads();
+        if (t == 0) {
+            const float mean = s_sum / T_U;
+            // std::sort by value (descending) is replaced by selection: the order among exactly equal peaks is the bin order
+            int top = 0;
+            for (int k = 1; k < 102; k++) if (bval[k] > bval[top]) top = k;
+            const int peak_index = bidx[top];
+            unsigned long long used_lo = 0, used_hi = 0;
+            int found = 0, mn = 0;
+            for (int pass = 0; pass < 4; pass++) {
+                int best = -1;
+                for (int k = 0; k < 102; k++) {
+                    const bool used = k < 64 ? (used_lo >> k) & 1 : (used_hi >> (k - 64)) & 1;
+                    const int dist = bidx[k] - peak_index;
+                    if (used || (dist < 0 ? -dist : dist) > 500) continue;
+                    if (best < 0 || bval[k] > bval[best]) best = k;
+                }
+                if (best < 0) break;
+                if (best < 64) used_lo |= 1ull << best; else used_hi |= 1ull << (best - 64);
+                if (bval[best] < 3 * mean) continue;
+                if (!found || bidx[best] < mn) { mn = bidx[best]; found = 1; }
+            }
+            redi[0] = found ? mn : -1;
+        }
+        __syncthreads();
+        startIndex = redi[0];
+        __syncthreads();
     } else {
         // ThresholdBeforePeak (phasereference.cpp:212-252)
         if (t == 0) {                                                                          // :214-218, in order
@@ -324,6 +362,52 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
 #pragma unroll
         for (int j = 0; j < 16; j++) tile[t + 128 * j] = v[j];          // natural bin order
         __syncthreads();
+        if (A.freqsync != 2) {
+            // FreqsyncMethod::GetMiddle (0, ofdm-processor.cpp:618-644) / CorrelatePRS (1, :547-581): rarely selected, only run
+            // while the FIC does not decode -- one thread walks them exactly as written (ordered float sums, the int-abs quirk)
+            if (t == 0) {
+                int correction;
+                if (A.freqsync == 0) {
+                    float sum = 0, oldMax = 0; int maxIndex = 0;
+                    for (int i = 40; i < K_CARR + 40; i++) { const cf32 z = tile[(T_U / 2 + i) % T_U]; sum += hypotf_exact(z.re, z.im); }
+                    for (int i = 40; i < T_U - (K_CARR - 40); i++) {
+                        const cf32 z0 = tile[(T_U / 2 + i) % T_U], z1 = tile[(T_U / 2 + i + K_CARR) % T_U];
+                        sum -= hypotf_exact(z0.re, z0.im);
+                        sum += hypotf_exact(z1.re, z1.im);
+                        if (sum > oldMax) { sum = oldMax; maxIndex = i; }         // sic (the reference resets the running sum)
+                    }
+                    correction = maxIndex - (T_U - K_CARR) / 2;
+                } else {
+                    float refArg[24], cv[72 + 24];
+                    for (int i = 0; i < 24; i++) {
+                        const cf32 z = cmul(A.tab.ref[(T_U + i) % T_U], cconj(A.tab.ref[(T_U + i + 1) % T_U]));
+                        refArg[i] = fdlibm_atan2f(z.im, z.re);
+                    }
+                    for (int i = 0; i < 72 + 24; i++) {
+                        const int base = T_U - 36 + i;
+                        const cf32 z = cmul(tile[base % T_U], cconj(tile[(base + 1) % T_U]));
+                        cv[i] = fdlibm_atan2f(z.im, z.re);
+                    }
+                    float MMax = 0; int index = 100;
+                    for (int i = 0; i < 72; i++) {
+                        float sum = 0;
+                        for (int j = 0; j < 24; j++) {
+                            sum += (float)abs((int)(refArg[j] * cv[i + j]));       // ::abs(int): the product is truncated first
+                            if (sum > MMax) { MMax = sum; index = i; }
+                        }
+                    }
+                    correction = T_U - 36 + index - T_U;
+                }
+                redi[0] = correction;
+            }
+            __syncthreads();
+            const int correction = redi[0];
+            __syncthreads();
+            if (correction != 100) {
+                coarse += correction * 1000;
+                if (abs(coarse) > 35000) coarse = 0;
+            }
+        } else {
         float sum = 3.0e38f; int idx = 1 << 20;
         if (t < 72) {
             const int i = T_U - 36 + t;
@@ -355,6 +439,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
                 coarse += correction * 1000;
                 if (abs(coarse) > 35000) coarse = 0;
             }
+        }
         }
     }
     d.f_sym = coarse + st.fine;

@@ -34,11 +34,9 @@ GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterfac
     dabphy_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.n_ensembles = 1; cfg.max_frames = 1; cfg.device = 0;
-    cfg.fft_placement = rro.fftPlacementMethod == FFTPlacementMethod::StrongestPeak ? 0 : 2;
-    if (rro.fftPlacementMethod == FFTPlacementMethod::EarliestPeakWithBinning)
-        throw std::logic_error("GpuRadioReceiver: EarliestPeakWithBinning is not implemented on the GPU path");
-    if (rro.freqsyncMethod != FreqsyncMethod::PatternOfZeros && !rro.disableCoarseCorrector)
-        throw std::logic_error("GpuRadioReceiver: only the PatternOfZeros coarse corrector is implemented");
+    cfg.fft_placement = rro.fftPlacementMethod == FFTPlacementMethod::StrongestPeak ? 0
+                      : rro.fftPlacementMethod == FFTPlacementMethod::EarliestPeakWithBinning ? 1 : 2;
+    cfg.freqsync_method = (int32_t)rro.freqsyncMethod;                  // GetMiddle = 0, CorrelatePRS = 1, PatternOfZeros = 2
     cfg.disable_coarse = rro.disableCoarseCorrector;
     cfg.want_constellation = 1; cfg.want_impulse_response = 1;
     const int r = dabphy_create(&cfg, &phy);
