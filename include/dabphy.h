@@ -137,6 +137,15 @@ uint64_t dabphy_stream_consumed(dabphy_handle* h);
 typedef enum { DABPHY_FMT_CF32 = 0, DABPHY_FMT_U8 = 1, DABPHY_FMT_S8 = 2, DABPHY_FMT_S16LE = 3, DABPHY_FMT_S16BE = 4 } dabphy_sample_format;
 int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format);
 
+/* The same without waiting: the copy and the conversion run on the library's copy stream while earlier batches are decoded.
+ * The samples become visible to dabphy_process only after dabphy_stream_commit (which costs nothing; dabphy_process then
+ * orders its kernels behind the committed copies).  Double buffering:
+ *     commit();  write_raw_async(batch k+1);  process(batch k);     -- k+1 crosses PCIe while k is decoded
+ * `data` (page-locked memory, see below) must stay untouched until the next-but-one call of this function returns, i.e.
+ * alternate between two host buffers. */
+int dabphy_stream_write_raw_async(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format);
+int dabphy_stream_commit(dabphy_handle* h);
+
 /* Page-locked host memory for the buffers handed to dabphy_stream_write / _write_raw (DMA at PCIe rate instead of a
  * staged copy); plain malloc'ed buffers work too. */
 int dabphy_host_alloc(size_t bytes, void** out);

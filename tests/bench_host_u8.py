@@ -28,9 +28,19 @@ pin[:] = u8[None]
 dev.stream_open((2 * F + 4) * T_F)
 subs = tx.subchs
 dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+ASYNC = os.environ.get("HOSTU8_ASYNC", "1") != "0"
+pin2 = dev.host_alloc((B, F * T_F, 2), np.uint8); pin2[:] = pin
+bufs = [pin, pin2]; turn = [0]
+if ASYNC:
+    dev.stream_write_raw_async(bufs[0], "u8"); turn[0] = 1       # batch 0 is on its way before the first process()
 def step():
-    dev.stream_write_raw(pin, "u8")                     # one contiguous page-locked block: B x F frames of u8 IQ
-    dev.process(F)
+    if ASYNC:                                           # batch k+1 crosses PCIe while batch k is decoded
+        dev.stream_commit()
+        dev.stream_write_raw_async(bufs[turn[0] & 1], "u8"); turn[0] += 1
+        dev.process(F)
+    else:
+        dev.stream_write_raw(pin, "u8")                 # one contiguous page-locked block: B x F frames of u8 IQ, then decode
+        dev.process(F)
     return dev.fibs()
 step()
 fib, ok = step()
@@ -38,6 +48,6 @@ t0 = time.perf_counter()
 for _ in range(STEPS):
     fib, ok = step()
 dt = (time.perf_counter() - t0) / STEPS
-print(json.dumps({"what": "host u8 -> FIBs/MSC bytes, PCIe and conversion included (serial: copy, then decode)", "ensembles": B, "frames_per_step": F,
+print(json.dumps({"what": "host u8 -> FIBs/MSC bytes, PCIe and conversion included (%s)" % ("copy of batch k+1 overlapped with the decode of batch k" if ASYNC else "serial: copy, then decode"), "ensembles": B, "frames_per_step": F,
                   "ms_per_step": dt * 1e3, "x_real_time": B * F * 0.096 / dt, "host_GBps": B * F * T_F * 2 / dt / 1e9, "fib_crc_ok": float(ok.mean())}))
 dev.close()

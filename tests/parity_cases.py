@@ -182,7 +182,7 @@ def raw_encode(x, fmt):
     return raw, (f[:, 0] + 1j * f[:, 1]).astype(np.complex64)
 
 
-def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35):
+def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, asynchronous=False):
     T_F = 196608
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=300, return_tx=True, seed=seed)
     subs = [tx.subchs[2], tx.subchs[11]]
@@ -194,11 +194,17 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35):
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
         fibs, oks, msc = [], [], [[] for _ in subs]
         wr = 0
+        hold = [None, None]
         def feed(n):
             nonlocal wr
             n = min(n, len(raw) - wr)
             if n > 0:
-                d.stream_write_raw(raw[wr:wr + n], fmt); wr += n
+                if asynchronous:                                   # two alternating host buffers, as the contract asks
+                    buf = hold[len(hold) % 2] = np.ascontiguousarray(raw[wr:wr + n]).copy(); hold.append(None)
+                    d.stream_write_raw_async(buf, fmt); d.stream_commit()
+                else:
+                    d.stream_write_raw(raw[wr:wr + n], fmt)
+                wr += n
         feed(3 * T_F)
         idle = 0
         while idle < 3:

@@ -79,3 +79,8 @@ def test_other_fft_placement_methods(gpu, method, snr, cfo):
 def test_other_freqsync_methods(gpu, freqsync, cfo, snr):
     """RadioReceiverOptions::freqsyncMethod: GetMiddle (0) and CorrelatePRS (1) drive the coarse corrector"""
     P.check_stream_vs_oracle(factory, snr, cfo, 250, 10, True, seed=50 + freqsync, freqsync=freqsync)
+
+
+def test_live_ring_async_ingest(gpu):
+    """dabphy_stream_write_raw_async: copy + conversion on the copy stream, dabphy_process orders itself behind them"""
+    P.check_live_raw_vs_oracle(factory, "u8", asynchronous=True)

@@ -205,6 +205,15 @@ class DabPhy:
         n = data.nbytes // (self.cfg.n_ensembles * bps)
         self._chk(self.lib.dabphy_stream_write_raw(self.h, _p(data), C.c_uint64(n), code))
 
+    def stream_write_raw_async(self, data, fmt):
+        code = {"u8": 1, "s8": 2, "s16le": 3, "s16be": 4}[fmt]
+        assert data.flags["C_CONTIGUOUS"]
+        bps = 2 if code <= 2 else 4
+        self._chk(self.lib.dabphy_stream_write_raw_async(self.h, _p(data), C.c_uint64(data.nbytes // (self.cfg.n_ensembles * bps)), code))
+
+    def stream_commit(self):
+        self._chk(self.lib.dabphy_stream_commit(self.h))
+
     def stream_consumed(self):
         self.lib.dabphy_stream_consumed.restype = C.c_uint64
         return int(self.lib.dabphy_stream_consumed(self.h))

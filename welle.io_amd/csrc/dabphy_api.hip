@@ -49,6 +49,8 @@ struct dabphy_handle {
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
+    DevBuf s_raw2[2]; hipStream_t copy_stream = nullptr; hipEvent_t ev_ingest[2] = {nullptr, nullptr}; int raw_sel = 0;   // dabphy_stream_write_raw_async
+    uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
     DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
     DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
     DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
@@ -163,6 +165,8 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     }
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_ingest[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
@@ -178,13 +182,15 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->sync_stream) { e = hipStreamSynchronize(h->sync_stream); e = hipStreamDestroy(h->sync_stream); }
     if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
     if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
+    if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }
+    for (int i = 0; i < 2; i++) if (h->ev_ingest[i]) e = hipEventDestroy(h->ev_ingest[i]);
     if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < 2; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_raw, &h->s_null, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); }
@@ -324,7 +330,7 @@ int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_
 {
     if (!h || !d_iq || ring_samples < (uint64_t)T_F || stride_samples < ring_samples) return DABPHY_ERR_INVALID;
     h->s_iq = reinterpret_cast<const cf32*>(d_iq); h->s_ring = ring_samples; h->s_stride = stride_samples;
-    h->s_valid = n_valid; h->s_loop = loop;
+    h->s_valid = n_valid; h->s_enqueued = 0; h->commit_slot = -1; h->s_loop = loop;
     return dabphy_reset(h);
 }
 
@@ -383,6 +389,35 @@ int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_sampl
     launch_ingest(a, (int)B, h->stream);
     h->s_valid += n_samples;
     return sync(h);
+}
+
+int dabphy_stream_write_raw_async(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format)
+{
+    if (!h || !data || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring ||
+        format < DABPHY_FMT_U8 || format > DABPHY_FMT_S16BE) return DABPHY_ERR_INVALID;
+    const size_t bps = (format == DABPHY_FMT_U8 || format == DABPHY_FMT_S8) ? 2 : 4;
+    const uint32_t B = h->cfg.n_ensembles;
+    if (h->s_enqueued < h->s_valid) h->s_enqueued = h->s_valid;            // synchronous writes in between
+    const int slot = h->raw_sel; h->raw_sel ^= 1;
+    // the staging slot (and with it the host buffer of the call before last) is free once its previous conversion has run
+    HIPCHK(h, hipEventSynchronize(h->ev_ingest[slot]));
+    int r;
+    if ((r = ensure(h, h->s_raw2[slot], (size_t)B * n_samples * bps))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->s_raw2[slot].p, data, (size_t)B * n_samples * bps, hipMemcpyHostToDevice, h->copy_stream));
+    IngestArgs a{};
+    a.raw = h->s_raw2[slot].as<uint8_t>(); a.raw_stride = n_samples * bps; a.iq = h->s_iq_own.as<cf32>(); a.iq_stride = h->s_stride;
+    a.ring = h->s_ring; a.w = h->s_enqueued % h->s_ring; a.n = n_samples; a.format = format;
+    launch_ingest(a, (int)B, h->copy_stream);
+    HIPCHK(h, hipEventRecord(h->ev_ingest[slot], h->copy_stream));
+    h->s_enqueued += n_samples;
+    return DABPHY_OK;
+}
+
+int dabphy_stream_commit(dabphy_handle* h)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    if (h->s_enqueued > h->s_valid) { h->s_valid = h->s_enqueued; h->commit_slot = h->raw_sel ^ 1; }
+    return DABPHY_OK;
 }
 
 int dabphy_host_alloc(size_t bytes, void** out)
@@ -505,6 +540,13 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
     };
     if (h->presynced != 0 && h->presynced != F) { h->err = "pipelined mode needs a constant n_frames"; return DABPHY_ERR_STATE; }
+    if (h->commit_slot >= 0) {
+        // asynchronous ingest: everything committed must have landed before this call's kernels read the ring (the copy stream is
+        // in order, the event of the last committed write covers the older ones); uncommitted writes keep flowing meanwhile
+        HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_ingest[h->commit_slot], 0));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ingest[h->commit_slot], 0));
+        h->commit_slot = -1;
+    }
     const int cur = h->desc_sel;
     if (h->presynced == 0) {
         // the previous batch's decoder results (FIC ratio) must be final before the chain consults them
