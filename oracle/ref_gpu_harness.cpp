@@ -9,6 +9,8 @@
 #include <chrono>
 #include <vector>
 #include "gpu_radio_receiver.h"
+#include "gpu_batch_receiver.h"
+#include "../include/dabphy.h"
 
 namespace {
 struct NullProgrammeHandler : ProgrammeHandlerInterface {
@@ -119,6 +121,31 @@ int gpu_receiver_run(gpu_run_io* io)
     io->n_fib = rec.n_fib; io->n_cir = rec.n_cir; io->n_con = rec.n_con; io->n_snr = rec.n_snr; io->n_corr = rec.n_corr; io->n_nul = rec.n_nul;
     io->n_sync_true = rec.n_sync_true; io->n_sync_false = rec.n_sync_false; io->n_services = rec.n_services;
     for (int i = 0; i < io->n_subch && i < 16; i++) { io->rs_calls[i] = handlers[i].rs_calls; io->rs_uncorr[i] = handlers[i].rs_uncorr; io->rs_corr[i] = handlers[i].rs_corr; }
+    return 0;
+}
+
+// ---- batch mode: n_ens ensembles (streams of equal length, [n_ens][n_samples] cf32), each with its own FIBProcessor;
+// out per ensemble: ensemble id, number of services listed, number of FIBs that passed the CRC, onServiceDetected calls
+int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected)
+{
+    std::vector<std::unique_ptr<Rec>> recs;
+    std::vector<RadioControllerInterface*> ctl;
+    std::vector<int> fib_ok(n_ens, 0);
+    struct CountRec : Rec { int* ok; void onFIBDecodeSuccess(bool good, const uint8_t* bits) override { if (good) (*ok)++; Rec::onFIBDecodeSuccess(good, bits); } };
+    for (int e = 0; e < n_ens; e++) { auto r = std::unique_ptr<CountRec>(new CountRec); r->ok = &fib_ok[e]; ctl.push_back(r.get()); recs.push_back(std::move(r)); }
+    try {
+        RadioReceiverOptions rro; rro.decodeTII = false;
+        GpuBatchReceiver rx(ctl, (uint32_t)frames_per_step, rro);
+        if (dabphy_stream_upload(rx.phy(), iq, (uint64_t)n_samples, 0) != DABPHY_OK) return -2;
+        for (int k = 0; k < n_steps; k++) rx.process((uint32_t)frames_per_step);
+        for (int e = 0; e < n_ens; e++) {
+            eid[e] = rx.getEnsembleId(e); n_listed[e] = (int32_t)rx.getServiceList(e).size(); n_fib_ok[e] = fib_ok[e];
+            n_detected[e] = recs[e]->n_services;
+        }
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "gpu_batch_run: %s\n", ex.what());
+        return -1;
+    }
     return 0;
 }
 }

@@ -74,3 +74,20 @@ def test_facade_accepts_all_sync_options(emu):
     assert n >= len(a["fib"]) - 12 and n > 24 and np.array_equal(a["fib"][:n], b["fib"][:n])
     kk = min(len(a["cir"]), len(b["cir"]))
     assert np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))
+
+
+def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(emu):
+    """batch mode: three different ensembles decoded in lock step, each one's FIBs parsed by its own (reference) FIBProcessor:
+    same ensemble id and service list as the reference facade reports for that stream alone"""
+    nf = 9
+    streams, want = [], []
+    for e, (eid, cfo) in enumerate([(0x10A1, 0), (0x20B2, 120), (0x30C3, -80)]):
+        x = synth.make_stream(nf, eid=eid, snr_db=20, cfo_hz=cfo, seed=40 + e)
+        streams.append(x)
+        a = R.gpu_receiver_run(x, lib=R.GPU_EMU_SO)            # the single-ensemble facade (itself compared with the reference above)
+        want.append((eid, a["n_services"]))
+    eid, listed, ok, detected = R.gpu_batch_run(np.stack(streams), 4, 2, lib=R.GPU_EMU_SO)
+    for e in range(3):
+        assert eid[e] == want[e][0]
+        assert listed[e] == 18 and detected[e] == want[e][1]
+        assert ok[e] >= 12 * 4 and ok[e] % 12 == 0      # every FIB of every demodulated frame passed its CRC

@@ -1,0 +1,55 @@
+// welle.io_amd/host/gpu_batch_receiver.cpp -- see gpu_batch_receiver.h
+#include "gpu_batch_receiver.h"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/dabphy.h"
+
+GpuBatchReceiver::GpuBatchReceiver(const std::vector<RadioControllerInterface*>& controllers, uint32_t max_frames_, RadioReceiverOptions rro, int device) :
+    rci(controllers), synced(controllers.size(), 0), max_frames(max_frames_)
+{
+    if (controllers.empty() || max_frames == 0) throw std::logic_error("GpuBatchReceiver: needs at least one ensemble and one frame");
+    for (auto* c : rci) fib.emplace_back(new FIBProcessor(*c));
+    dabphy_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_ensembles = (uint32_t)rci.size(); cfg.max_frames = max_frames; cfg.device = device;
+    cfg.fft_placement = rro.fftPlacementMethod == FFTPlacementMethod::StrongestPeak ? 0
+                      : rro.fftPlacementMethod == FFTPlacementMethod::EarliestPeakWithBinning ? 1 : 2;
+    cfg.freqsync_method = (int32_t)rro.freqsyncMethod;
+    cfg.disable_coarse = rro.disableCoarseCorrector;
+    if (dabphy_create(&cfg, &handle) != DABPHY_OK) throw std::runtime_error("GpuBatchReceiver: dabphy_create failed (no gfx950 device?)");
+}
+
+GpuBatchReceiver::~GpuBatchReceiver() { dabphy_destroy(handle); }
+
+size_t GpuBatchReceiver::process(uint32_t n_frames)
+{
+    if (n_frames == 0 || n_frames > max_frames) throw std::out_of_range("GpuBatchReceiver::process: n_frames");
+    if (dabphy_process(handle, n_frames) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
+    const size_t B = rci.size();
+    std::vector<dabphy_frame_info> info(B * n_frames);
+    std::vector<uint8_t> fibs(B * n_frames * 12 * 32), ok(B * n_frames * 12);
+    dabphy_get_frame_info(handle, info.data());
+    dabphy_get_fibs(handle, fibs.data(), ok.data());
+    size_t decoded = 0;
+    for (size_t e = 0; e < B; e++)
+        for (uint32_t f = 0; f < n_frames; f++) {
+            const dabphy_frame_info& fi = info[e * n_frames + f];
+            if (fi.valid == 3) { if (synced[e]) { rci[e]->onSyncChange(false); synced[e] = 0; } continue; }   // ofdm-processor.cpp:347-350
+            if (fi.valid != 1) continue;
+            if (!synced[e]) { rci[e]->onSyncChange(true); synced[e] = 1; }                                      // :369
+            decoded++;
+            for (int k = 0; k < 12; k++) {
+                const uint8_t* p = &fibs[((e * n_frames + f) * 12 + k) * 32];
+                uint8_t bits[256];
+                for (int i = 0; i < 256; i++) bits[i] = (p[i >> 3] >> (7 - (i & 7))) & 1;
+                const bool good = ok[(e * n_frames + f) * 12 + k] != 0;
+                rci[e]->onFIBDecodeSuccess(good, bits);                                                          // fic-handler.cpp:215-218
+                if (good) fib[e]->processFIB(bits, (uint16_t)(k / 3));                                           // :221-229
+            }
+            if (!std::isnan(fi.snr)) rci[e]->onSNR(fi.snr);
+        }
+    return decoded;
+}
