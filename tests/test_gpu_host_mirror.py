@@ -21,3 +21,23 @@ def test_same_callbacks_as_reference_facade(gpu, snr, cfo, delay, nf):
     compare_runs(a, b, len(subs))
     if cfo == 0:
         assert b["n_services"] >= 18      # the reference's FIBProcessor, fed with our FIBs, announced every service
+
+
+def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(gpu):
+    """GpuBatchReceiver on the device: three ensembles in lock step, each parsed by its own reference FIBProcessor"""
+    import numpy as np
+    streams, eids = [], [0x10A1, 0x20B2, 0x30C3]
+    for e, (eid, cfo) in enumerate(zip(eids, (0, 120, -80))):
+        streams.append(synth.make_stream(9, eid=eid, snr_db=20, cfo_hz=cfo, seed=40 + e))
+    eid, listed, ok, detected = R.gpu_batch_run(np.stack(streams), 4, 2, lib=R.GPU_HIP_SO)
+    assert list(eid) == eids and (listed == 18).all() and (ok >= 48).all() and (ok % 12 == 0).all()
+
+
+def test_facade_accepts_all_sync_options(gpu):
+    import numpy as np
+    x, tx = synth.make_stream(10, snr_db=18, cfo_hz=2300, delay=300, return_tx=True, seed=6)
+    subs = [tx.subchs[0]]
+    a = R.receiver_run(x, subchs=subs, fft_placement=1, freqsync=1)
+    b = R.gpu_receiver_run(x, subchs=subs, lib=R.GPU_HIP_SO, fft_placement=1, freqsync=1)
+    n = min(len(a["fib"]), len(b["fib"]))
+    assert n >= len(a["fib"]) - 12 and n > 24 and np.array_equal(a["fib"][:n], b["fib"][:n])
