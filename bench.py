@@ -45,45 +45,59 @@ def make_base_streams(n_distinct, n_frames, seed0):
     return np.stack(out), txs
 
 
-def cpu_baseline(base_stream, n_loops):
-    """the oracle (CPU restatement of the reference algorithm, oracle/dabphy_oracle.c, gcc -O2) on a bounded sample of the
-    same workload: one canonical ensemble with all 18 sub-channels per receiver, one single-threaded receiver process per
-    host core running concurrently (capped at 32) -- the reference's own concurrency model is one receiver per ensemble"""
+def _run_receivers(rec, n_proc, n_loops, mode, env):
+    """n_proc concurrent receiver processes over the same recording; returns their result records"""
     import subprocess
+    args = [sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py"), rec, str(n_loops)]
+    procs = [subprocess.Popen(args + [str(7 + i)] + (["reference"] if mode == "reference" else []),
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(n_proc)]
+    for p in procs:
+        if p.stdout.readline().strip() != "READY":
+            raise RuntimeError("CPU baseline worker did not start")
+    for p in procs:
+        p.stdin.write("go\n"); p.stdin.flush()            # all receivers start together
+    res = [json.loads(p.stdout.readline()) for p in procs]
+    for p in procs:
+        p.wait()
+    return res
+
+
+def cpu_baseline(base_stream, n_loops):
+    """The CPU side of the same workload on this host, a bounded sample (one canonical ensemble with all 18 sub-channels per
+    receiver; the reference's own concurrency model is one receiver per ensemble):
+      * kind "reference": the REAL reference backend (oracle/_ref, built from /root/reference where that exists) -- RadioReceiver
+        with its own 2-3 threads and SSE Viterbi; it also runs the layers above the PHY (FIG parsing, superframe filter, AAC).
+        cores/2 receivers run concurrently so that every core is busy.
+      * the oracle (C restatement of the PHY only, single-threaded), one receiver per core, as a second figure (or as the
+        baseline, kind "port", where oracle/_ref is absent)."""
     import tempfile
     cores = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     with tempfile.TemporaryDirectory() as td:
         rec = os.path.join(td, "rec.npy"); np.save(rec, base_stream)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py"), rec, str(n_loops), str(7 + i)],
-                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for i in range(cores)]
-        for p in procs:
-            assert p.stdout.readline().strip() == "READY"
-        for p in procs:
-            p.stdin.write("go\n"); p.stdin.flush()
-        res = [json.loads(p.stdout.readline()) for p in procs]
-        for p in procs:
-            p.wait()
-        # one receiver of the REAL reference backend (oracle/_ref, built from /root/reference where that exists), alone on the
-        # host: its own 2-3 threads, and it also runs the layers above the PHY (FIG parsing, superframe filter, AAC)
-        ref_rate = None
+        res = _run_receivers(rec, cores, n_loops, "port", env)
+        ref = None
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref.so")):
             try:
-                p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py"), rec, str(max(1, n_loops // 4)), "7", "reference"],
-                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
-                if p.stdout.readline().strip() == "READY":
-                    p.stdin.write("go\n"); p.stdin.flush()
-                    rr = json.loads(p.stdout.readline()); ref_rate = rr["frames"] * FRAME_S / rr["seconds"]
-                p.wait()
+                ref = _run_receivers(rec, max(1, cores // 2), max(1, n_loops // 2), "reference", env)
             except Exception:
-                ref_rate = None
-    nfr = sum(r["frames"] for r in res); slowest = max(r["seconds"] for r in res)
-    return dict(reference_backend_single_receiver=ref_rate,
-                value=nfr * FRAME_S / slowest, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
-                per_core=res[0]["frames"] * FRAME_S / res[0]["seconds"],
-                sample="%d receivers x %d frames (%.1f s of IQ each) of the canonical ensemble, 18 sub-channels, oracle C restatement, slowest receiver %.1f s"
-                       % (cores, res[0]["frames"], res[0]["frames"] * FRAME_S, slowest),
+                ref = None
+    port_value = sum(r["frames"] for r in res) * FRAME_S / max(r["seconds"] for r in res)
+    port = dict(value=port_value, per_core=res[0]["frames"] * FRAME_S / res[0]["seconds"], receivers=cores,
                 fib_ok=sum(r["fib_ok"] for r in res), fibs=sum(r["fibs"] for r in res))
+    if ref:
+        slowest = max(r["seconds"] for r in ref)
+        return dict(value=sum(r["frames"] for r in ref) * FRAME_S / slowest, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores,
+                    kind="reference", per_receiver=ref[0]["frames"] * FRAME_S / ref[0]["seconds"],
+                    sample="%d concurrent RadioReceivers of the reference backend (each 2-3 threads; PHY + FIG parsing + superframe filter + AAC; lock-step input so that no frame is dropped) x %d frames "
+                           "(%.1f s of IQ each) of the canonical ensemble, 18 sub-channels, slowest receiver %.1f s"
+                           % (len(ref), ref[0]["frames"], ref[0]["frames"] * FRAME_S, slowest),
+                    fib_ok=sum(r["fib_ok"] for r in ref), fibs=sum(r["fibs"] for r in ref), oracle_port=port)
+    return dict(value=port_value, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
+                per_core=port["per_core"],
+                sample="%d receivers x %d frames (%.1f s of IQ each) of the canonical ensemble, 18 sub-channels, oracle C restatement, slowest receiver %.1f s"
+                       % (cores, res[0]["frames"], res[0]["frames"] * FRAME_S, max(r["seconds"] for r in res)),
+                fib_ok=port["fib_ok"], fibs=port["fibs"])
 
 
 def main():
