@@ -1,4 +1,4 @@
-"""Not a test: copies the rocprofv3 summaries that tests/make_profiles.sh left under gpurun_out/prof/ into profiles/
+"""Not a test: copies the rocprofv3 summaries that tools/make_profiles.sh left under gpurun_out/prof/ into profiles/
 (tracked) and derives profiles/demod_hbm_traffic.json, the per-launch HBM traffic bench.py reports as roofline.traffic."""
 import csv
 import json
@@ -64,7 +64,7 @@ json.dump({
     "fetch_size_kb_raw": fk, "write_size_kb_raw": wk,
     "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 counts 128-B requests of wide coalesced streams at 64 B, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported",
     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
-    "command": "tests/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-include-regex ... -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline",
+    "command": "tools/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-include-regex ... -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline",
     "source": "profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv (median launch)" % (TAG, TAG),
     "traffic_over_algorithmic": hbm / alg,
 }, open(os.path.join(DST, "demod_hbm_traffic.json"), "w"), indent=1)

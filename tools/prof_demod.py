@@ -2,7 +2,7 @@
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import GPU_LIB  # noqa: E402
 import parity_cases as P  # noqa: E402
 from welle_io_amd import capi, synth  # noqa: E402
