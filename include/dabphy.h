@@ -233,6 +233,25 @@ int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* 
  * stats [n_ensembles][4] = synchronised superframes, corrected symbols, uncorrectable attempts, access units failing their CRC */
 int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats);
 
+/* ---- TIIDecoder (tii-decoder.cpp:189-383), fed by OFDMProcessor::run with the PRS and the trailing NULL symbol of every
+ * frame (ofdm-processor.cpp:381-386,462-466) when RadioReceiverOptions::decodeTII is set (radio-receiver-options.h:75; welle-cli
+ * sets it by default, welle-cli.cpp:409).  dabphy_set_tii switches the side path on or off for the following dabphy_process calls
+ * (setReceiverOptions semantics).  Every demodulated frame is analysed -- the reference decoder drops pairs while its thread is
+ * busy -- and its arithmetic is kept literally: uint64 error sums updated through float, 5 measurements per report, the winner
+ * picked in the iteration order of the C++ library's unordered_map<float, uint64_t> (taken from the host's own container).
+ * dabphy_get_tii returns what onTIIMeasurement (radio-controller.h:128) would have been called with during the last batch:
+ * out [n_ensembles][max_per_ensemble], n[b] = measurements of ensemble b (may exceed what was stored), ordered by frame, then by
+ * (comb, pattern) -- the reference's order inside one frame is unspecified.  Up to 32 comb/pattern pairs are tracked per
+ * ensemble (the reference's map is unbounded). */
+typedef struct {
+    int32_t frame;                       /* frame of the batch whose NULL symbol completed the 5th measurement */
+    int32_t comb, pattern;               /* tii_measurement_t (radio-controller.h:56-63) */
+    int32_t delay_samples;
+    float error;
+} dabphy_tii_measurement;
+int dabphy_set_tii(dabphy_handle* h, int32_t on);
+int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, uint32_t max_per_ensemble);
+
 int dabphy_set_profiling(dabphy_handle* h, int32_t on);
 int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);
 

@@ -842,6 +842,114 @@ int orc_superframe_feed(uint8_t* st, const uint8_t* frame, int len, int frame_in
     return 1;
 }
 
+/* ------------------------------------------------------------------ TII (tii-decoder.cpp:189-383)
+ * One call = one pass of TIIDecoder::run over a (NULL symbol, PRS) pair as OFDMProcessor hands them over
+ * (ofdm-processor.cpp:381-386,462-466).  The reference decoder drops pairs while its thread is busy; the restatement
+ * (like the device path) looks at every frame.
+ *
+ * Reference behaviour restated literally:
+ *  - error_per_correction is an unordered_map<float, uint64_t> (tii-decoder.h:97): the running sum is converted to float,
+ *    the frame's float error added, and the result truncated back to uint64;
+ *  - std::min_element walks that map in ITS iteration order and keeps the first minimum (tii-decoder.cpp:360-366); the
+ *    truncated sums tie often, so the order decides.  It is a property of the C++ library, not of welle.io: the caller
+ *    passes it in as rank[cycle][err + 4] (cycle 0: a map filled for the first time, 1: refilled after clear()), taken
+ *    from the real container by oracle/tii_order.cpp. */
+static uint8_t g_tii_pattern[70];            /* tii-decoder.cpp:29-99: the 70 octets of weight 4 in ascending order, b = 0 is the MSB */
+static int g_tii_ready;
+static void tii_init(void)
+{
+    if (g_tii_ready) return;
+    int n = 0;
+    for (int v = 0; v < 256; v++) if (__builtin_popcount(v) == 4) g_tii_pattern[n++] = (uint8_t)v;
+    g_tii_ready = 1;
+}
+static int tii_pat(int p, int b) { return (g_tii_pattern[p] >> (7 - b)) & 1; }
+
+typedef struct { int32_t num; int32_t cycle; int32_t filled; uint64_t acc[ORC_TII_NERR]; } tii_meas;
+struct orc_tii_state { tii_meas m[24 * 70]; };
+size_t orc_tii_state_bytes(void) { return sizeof(struct orc_tii_state); }
+void orc_tii_reset(orc_tii_state* st) { memset(st, 0, sizeof *st); }
+
+/* CombPattern::generateCarriers (tii-decoder.cpp:106-129), sorted ascending: 4 blocks x 4 pairs */
+static void tii_carriers(int comb, int pattern, int* carriers /* 32 */)
+{
+    static const int off[4] = {-769, -385, 0, 384};
+    int n = 0;
+    for (int g = 0; g < 4; g++)
+        for (int b = 0; b < 8; b++)
+            if (tii_pat(pattern, b)) { const int k = 1 + 2 * comb + 48 * b; carriers[n++] = k + off[g]; carriers[n++] = k + off[g] + 1; }
+}
+
+int orc_tii_frame(orc_tii_state* st, const orc_cf32* null2656, const orc_cf32* prs2048, const int32_t* rank,
+                  orc_tii_event* ev, int max_ev, uint8_t* detect192)
+{
+    tii_init();
+    static _Thread_local orc_cf32 n[ORC_TU], p[ORC_TU];
+    orc_fft2048(null2656 + (ORC_TNULL - ORC_TU), n, 0);           /* :235-237 skip the cyclic prefix of the NULL */
+    orc_fft2048(prs2048, p, 0);                                    /* :244-245 */
+    orc_cf32 bm[192]; float pw[192]; uint8_t det[192];
+    for (int i = 0; i < 192; i++) { const orc_cf32 z = p[1 + 2 * i]; pw[i] = z.re * z.re + z.im * z.im; bm[i].re = 0; bm[i].im = 0; }   /* std::norm :272-275 */
+    static const int k_start[4] = {2048 - 768, 2048 - 384, 1, 385};
+    for (int g = 0; g < 4; g++)
+        for (int i = 0; i < 192; i++) {
+            const int k = k_start[g];
+            const orc_cf32 m = cmul(n[k + 2 * i], cconj(n[k + 2 * i + 1]));    /* :279-287 */
+            bm[i].re += m.re; bm[i].im += m.im;
+        }
+    for (int i = 0; i < 192; i++) det[i] = cabs_(bm[i]) > pw[i] * 0.4f;         /* :298-306, carrier k = 2i + 1 */
+    if (detect192) memcpy(detect192, det, 192);
+    /* :308-323 cp_count[(c, p)] = number of detected carriers 1 + 2c + 48b with pattern bit b set; "likely" when >= 4 */
+    int likely[24 * 70], n_likely = 0;
+    for (int c = 0; c < 24; c++)
+        for (int q = 0; q < 70; q++) {
+            int cnt = 0;
+            for (int b = 0; b < 8; b++) cnt += tii_pat(q, b) && det[c + 24 * b];
+            if (cnt >= 4) likely[n_likely++] = c * 70 + q;
+        }
+    int n_ev = 0;
+    if (n_likely >= 10) return 0;                                               /* :327 */
+    for (int l = 0; l < n_likely; l++) {
+        /* analyse_phase :336-383 */
+        const int comb = likely[l] / 70, pattern = likely[l] % 70;
+        int carriers[32]; float phases_prs[32];
+        tii_carriers(comb, pattern, carriers);
+        for (int i = 0; i < 32; i += 2) {
+            const int ix = carriers[i] < 0 ? 2048 + carriers[i] : carriers[i];
+            phases_prs[i] = carg_(p[ix]); phases_prs[i + 1] = phases_prs[i];
+        }
+        tii_meas* meas = &st->m[likely[l]];
+        for (int err = -4; err < 500; err++) {
+            float abs_err = 0;
+            for (int j = 0; j < 32; j++) {
+                const int ix = carriers[j] < 0 ? 2048 + carriers[j] : carriers[j];
+                const float pi = (float)M_PI;
+                const float theta = 2.0f * pi * err * carriers[j] / 2048.0f;
+                const orc_cf32 rot = {1.0f * cosf(theta), 1.0f * sinf(theta)};   /* std::polar(1.0f, theta) */
+                const float delta = carg_(cmul(n[ix], rot)) - phases_prs[j];
+                abs_err += fabsf(delta);
+            }
+            meas->acc[err + 4] = (uint64_t)((float)meas->acc[err + 4] + abs_err);  /* uint64 += float */
+        }
+        meas->filled = 1;
+        meas->num++;
+        if (meas->num >= 5) {
+            const int32_t* rk = rank + ORC_TII_NERR * meas->cycle;
+            int best = 0;
+            for (int e = 1; e < ORC_TII_NERR; e++)
+                if (meas->acc[e] < meas->acc[best] || (meas->acc[e] == meas->acc[best] && rk[e] < rk[best])) best = e;
+            if (n_ev < max_ev) {
+                ev[n_ev].comb = comb; ev[n_ev].pattern = pattern;
+                ev[n_ev].error = (float)meas->acc[best];                          /* m.error = best->second */
+                ev[n_ev].delay_samples = (int)(float)(best - 4);                  /* m.delay_samples = best->first */
+            }
+            n_ev++;
+            memset(meas->acc, 0, sizeof meas->acc);                              /* clear() */
+            meas->num = 0; meas->cycle = 1;
+        }
+    }
+    return n_ev;
+}
+
 /* ------------------------------------------------------------------------------------------ receiver */
 
 typedef struct {
@@ -1008,6 +1116,14 @@ SyncOnPhase:
         R.fine = (int16_t)(R.fine + 0.1 * carg_(FreqCorr) / M_PI * (1000 / 2));
         rx_get_samples(&R, nullSymbol, ORC_TNULL, R.coarse + R.fine); if (R.failed) { io->n_frames = ++frame; goto done; }
         if (frame < io->nul_cap && io->nul) memcpy(io->nul + 2656 * (size_t)frame, nullSymbol, sizeof nullSymbol);
+        if (io->tii_state) {                                                       /* :464-466 pushSymbols(nullSymbol, prs) */
+            orc_tii_event tev[16];
+            const int ne = orc_tii_frame((orc_tii_state*)io->tii_state, nullSymbol, syms, io->tii_rank, tev, 16, NULL);
+            for (int k = 0; k < ne && k < 16; k++) {
+                if (io->n_tii < io->tii_cap) { tev[k].frame = frame; io->tii_ev[io->n_tii] = tev[k]; }
+                io->n_tii++;
+            }
+        }
         if (frame < io->corr_cap && io->corr) { io->corr[2 * frame] = R.fine; io->corr[2 * frame + 1] = R.coarse; }
         if (R.fine > 1000 / 2) { R.coarse += 1000; R.fine -= 1000; }
         else if (R.fine < -1000 / 2) { R.coarse -= 1000; R.fine += 1000; }

@@ -111,6 +111,19 @@ int orc_sf_state_bytes(int frame_len);
 int orc_superframe_feed(uint8_t* st, const uint8_t* frame, int len, int frame_index, orc_sf_event* ev, uint8_t* sf_out);
 void orc_rs_encode120(const uint8_t* data110, uint8_t* parity10);          /* encode_rs.h (test input generation) */
 
+/* TII (tii-decoder.cpp:189-383): one (NULL symbol, PRS) pair per call, every frame looked at.  rank[2][504] = position of
+ * key float(err), err = -4..499, in the iteration order of the reference's unordered_map<float, uint64_t> when it is
+ * filled for the first time ([0]) and refilled after clear() ([1]) -- see oracle/tii_order.cpp.  Returns the number of
+ * onTIIMeasurement calls, in ascending (comb, pattern) order (the reference's order within a frame is unspecified). */
+#define ORC_TII_NERR 504
+typedef struct { int32_t frame, comb, pattern, delay_samples; float error; } orc_tii_event;
+typedef struct orc_tii_state orc_tii_state;
+size_t orc_tii_state_bytes(void);
+void orc_tii_reset(orc_tii_state* st);
+int orc_tii_frame(orc_tii_state* st, const orc_cf32* null2656, const orc_cf32* prs2048, const int32_t* rank,
+                  orc_tii_event* ev, int max_ev, uint8_t* detect192);
+void orc_tii_iteration_rank(int32_t* rank2x504);                            /* oracle/tii_order.cpp */
+
 /* Full receiver: ofdm-processor.cpp:235-501 driving all of the above in lock step. */
 typedef struct {
     int subch_id, start_cu, length_cu;
@@ -135,6 +148,8 @@ typedef struct {
     /* counts */
     int n_fib, n_frames, n_snr, n_sync_true, n_sync_false, n_cir;
     int freqsync_sel;          /* 0 = PatternOfZeros (default), 1 = GetMiddle, 2 = CorrelatePRS */
+    /* decodeTII: state (orc_tii_state_bytes(), zeroed) or NULL; rank as for orc_tii_frame; events out */
+    void* tii_state; const int32_t* tii_rank; orc_tii_event* tii_ev; int tii_cap; int n_tii;
 } orc_run_io;
 int orc_receiver_run(orc_run_io* io);
 

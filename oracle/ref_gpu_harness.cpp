@@ -51,7 +51,12 @@ struct Rec : RadioControllerInterface {
     void onNewImpulseResponse(std::vector<float>&& d) override { int k = n_cir++; if (k < cir_cap && d.size() == 2048) memcpy(cir + 2048 * (size_t)k, d.data(), 8192); }
     void onConstellationPoints(std::vector<DSPCOMPLEX>&& d) override { int k = n_con++; if (k < con_cap && d.size() == 1200) memcpy(con + 2400 * (size_t)k, d.data(), 9600); }
     void onNewNullSymbol(std::vector<DSPCOMPLEX>&& d) override { int k = n_nul++; if (k < nul_cap && d.size() == 2656) memcpy(nul + 5312 * (size_t)k, d.data(), 5312 * 4); }
-    void onTIIMeasurement(tii_measurement_t&&) override {}
+    struct TiiEv { int32_t frame, comb, pattern, delay_samples; float error; };
+    TiiEv* tii = nullptr; int tii_cap = 0; std::atomic<int> n_tii{0};
+    void onTIIMeasurement(tii_measurement_t&& m) override {
+        int k = n_tii++;
+        if (k < tii_cap) { tii[k].frame = n_nul.load() - 1; tii[k].comb = m.comb; tii[k].pattern = m.pattern; tii[k].delay_samples = m.delay_samples; tii[k].error = m.error; }
+    }
     void onMessage(message_level_t, const std::string&, const std::string&) override {}
     void onInputFailure() override { failed = true; }
 };
@@ -78,6 +83,7 @@ struct MemInput : InputInterface {
 
 extern "C" {
 struct gpu_subch { int32_t subChId, startAddr, length, shortForm, uepTableIndex, uepLevel, eepProfileB, eepLevel, dabplus; char dump_path[256]; };
+struct gpu_tii_event { int32_t frame, comb, pattern, delay_samples; float error; };
 struct gpu_run_io {
     const float* iq; int64_t n_samples; int32_t disable_coarse, fft_placement;
     int32_t n_subch; const gpu_subch* subch;
@@ -86,6 +92,7 @@ struct gpu_run_io {
     int32_t rs_calls[16], rs_uncorr[16], rs_corr[16];
     float* nul; int32_t nul_cap, n_nul;
     int32_t freqsync;                 // FreqsyncMethod (reference numbering)
+    int32_t decode_tii; gpu_tii_event* tii; int32_t tii_cap, n_tii;   // RadioReceiverOptions::decodeTII and the onTIIMeasurement log
 };
 
 int gpu_receiver_run(gpu_run_io* io)
@@ -95,7 +102,8 @@ int gpu_receiver_run(gpu_run_io* io)
     rec.snr = io->snr; rec.snr_cap = io->snr_cap; rec.corr = io->corr; rec.corr_cap = io->corr_cap; rec.nul = io->nul; rec.nul_cap = io->nul_cap;
     MemInput in(io->iq, io->n_samples);
     RadioReceiverOptions rro;
-    rro.decodeTII = false; rro.disableCoarseCorrector = io->disable_coarse != 0;
+    rro.decodeTII = io->decode_tii != 0; rro.disableCoarseCorrector = io->disable_coarse != 0;
+    rec.tii = reinterpret_cast<Rec::TiiEv*>(io->tii); rec.tii_cap = io->tii_cap;
     rro.freqsyncMethod = io->freqsync == 0 ? FreqsyncMethod::GetMiddle : io->freqsync == 1 ? FreqsyncMethod::CorrelatePRS : FreqsyncMethod::PatternOfZeros;
     rro.fftPlacementMethod = io->fft_placement == 0 ? FFTPlacementMethod::StrongestPeak
                            : io->fft_placement == 1 ? FFTPlacementMethod::EarliestPeakWithBinning : FFTPlacementMethod::ThresholdBeforePeak;
@@ -119,7 +127,7 @@ int gpu_receiver_run(gpu_run_io* io)
         return -1;
     }
     io->n_fib = rec.n_fib; io->n_cir = rec.n_cir; io->n_con = rec.n_con; io->n_snr = rec.n_snr; io->n_corr = rec.n_corr; io->n_nul = rec.n_nul;
-    io->n_sync_true = rec.n_sync_true; io->n_sync_false = rec.n_sync_false; io->n_services = rec.n_services;
+    io->n_sync_true = rec.n_sync_true; io->n_sync_false = rec.n_sync_false; io->n_services = rec.n_services; io->n_tii = rec.n_tii;
     for (int i = 0; i < io->n_subch && i < 16; i++) { io->rs_calls[i] = handlers[i].rs_calls; io->rs_uncorr[i] = handlers[i].rs_uncorr; io->rs_corr[i] = handlers[i].rs_corr; }
     return 0;
 }

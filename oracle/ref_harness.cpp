@@ -350,4 +350,40 @@ int ref_superframe_run(const uint8_t* frames, int n_frames, int frame_len, ref_s
     return ne;
 }
 
+// ---- the real TIIDecoder (tii-decoder.cpp) fed one (NULL, PRS) pair at a time.  pushSymbols() drops a pair while the decoder
+// thread is busy; the tap waits for State::Idle before the next pair so that every frame is analysed (what the restatement and
+// the device path do).  Events: frame of the pair that triggered onTIIMeasurement, comb, pattern, delay_samples, error.
+struct ref_tii_event { int32_t frame, comb, pattern, delay_samples; float error; };
+
+namespace {
+struct TiiRecorder : Recorder {
+    std::mutex mu; ref_tii_event* ev = nullptr; int cap = 0, n = 0, frame = 0;
+    void onTIIMeasurement(tii_measurement_t&& m) override {
+        std::lock_guard<std::mutex> g(mu);
+        if (n < cap) { ev[n].frame = frame; ev[n].comb = m.comb; ev[n].pattern = m.pattern; ev[n].delay_samples = m.delay_samples; ev[n].error = m.error; }
+        n++;
+    }
+};
+}
+
+int ref_tii_run(const float* nulls, const float* prss, int n_pairs, ref_tii_event* events, int cap)
+{
+    TiiRecorder rec; rec.ev = events; rec.cap = cap;
+    DABParams params(1);
+    {
+        TIIDecoder dec(params, rec);
+        for (int i = 0; i < n_pairs; i++) {
+            { std::lock_guard<std::mutex> g(rec.mu); rec.frame = i; }
+            std::vector<complexf> nul((const complexf*)nulls + (size_t)i * 2656, (const complexf*)nulls + (size_t)(i + 1) * 2656);
+            std::vector<complexf> prs((const complexf*)prss + (size_t)i * 2048, (const complexf*)prss + (size_t)(i + 1) * 2048);
+            dec.pushSymbols(nul, prs);
+            for (;;) {
+                { std::unique_lock<std::mutex> lock(dec.m_state_mutex); if (dec.m_state == TIIDecoder::State::Idle) break; }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+    }
+    return rec.n;
+}
+
 } // extern "C"

@@ -79,6 +79,14 @@ def main():
     out["sf_frames"] = frames
     out["sf_events"] = np.array([[e[0], e[1], e[2], e[3], e[4], e[5], e[7]] + list(e[6]) + [0] * (7 - len(e[6])) for e in ev], np.int32)
     out["sf_corrected_sha"] = np.frombuffer(sha(np.concatenate(sfs)).encode(), np.uint8)
+    # TIIDecoder (the real class, every pair analysed): two transmitters, 16 (NULL, PRS) pairs regenerated from seeds by the test
+    x = synth.make_stream(17, snr_db=18, seed=61, noise_seed=62, tii=P.TII_NETWORKS[0])
+    nul, prs = P.tii_pairs(x, 16)
+    out["tii_input_sha"] = np.frombuffer(sha(np.concatenate([nul.ravel(), prs.ravel()])).encode(), np.uint8)
+    out["tii_events"] = np.array([[e[0], e[1], e[2], e[3], int(np.float32(e[4]).view(np.int32))] for e in R.ref_tii_run(nul, prs)], np.int32)
+    out["tii_pair0"] = np.concatenate([nul[0], prs[0]])       # one pair verbatim (its 5-fold repetition gives a platform-independent case)
+    out["tii_pair0_events"] = np.array([[e[0], e[1], e[2], e[3], int(np.float32(e[4]).view(np.int32))]
+                                        for e in R.ref_tii_run(np.stack([nul[0]] * 10), np.stack([prs[0]] * 10))], np.int32)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")), "bytes")
 

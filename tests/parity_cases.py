@@ -327,6 +327,60 @@ def check_mixed_ensemble(d_factory, F=4, nf=11, snr_db=12, seed=31):
             assert len(got) > 0 and got == bytes(o["msc"][i])[:len(got)], "MSC bytes of sub-channel %d (%d kbit/s) differ" % (i, subchs[i].bitrate)
 
 
+def tii_pairs(x, n, early=100):
+    """(NULL, PRS) pairs as OFDMProcessor would cut them from a clean stream with the FFT window `early` samples inside the prefix"""
+    nul = np.zeros((n, 2656), np.complex64); prs = np.zeros((n, 2048), np.complex64)
+    for f in range(n):
+        p0 = f * 196608 + 2656 + 504 - early
+        prs[f] = x[p0:p0 + 2048]
+        nul[f] = x[p0 + 2048 + 75 * 2552:p0 + 2048 + 75 * 2552 + 2656]
+    return nul, prs
+
+
+TII_NETWORKS = [
+    [(3, 17, 0, 1.0), (11, 40, 37, 0.6)],          # two transmitters, 37 samples apart
+    [(23, 69, 0, 1.0)],                            # last comb, last pattern
+    None,                                          # no TII in the null symbol: nothing to report
+    [(0, 0, 0, 0.8), (1, 0, 12, 0.7), (5, 35, 60, 0.5)],
+]
+
+
+def check_tii_vs_oracle(d_factory, F=4, nf=17, snr_db=20, cfo=70, pipeline_sync=False):
+    """TII side path over a batch of different single-frequency networks vs the restated TIIDecoder fed by the oracle receiver
+    (itself pinned to the real class, test_oracle_vs_ref.py).  Measurements must agree exactly: comb, pattern, the frame that
+    completed them, delay_samples and the float error."""
+    B = len(TII_NETWORKS)
+    xs = [synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo * (1 - b), delay=100 + 50 * b, seed=40 + b, noise_seed=7 + b, tii=TII_NETWORKS[b]) for b in range(B)]
+    n = max(len(x) for x in xs)
+    xs = [np.concatenate([x, np.zeros(n - len(x), np.complex64)]) for x in xs]
+    want = [R.orc_receiver_run(x, tii=True) for x in xs]
+    assert len(want[0]["tii"]) >= 4 and len(want[1]["tii"]) >= 2 and len(want[2]["tii"]) == 0 and len(want[3]["tii"]) >= 4, [len(w["tii"]) for w in want]
+    d = d_factory(n_ensembles=B, max_frames=F, pipeline_sync=pipeline_sync, want_constellation=False)
+    try:
+        d.stream_upload(np.stack(xs))
+        d.set_tii(True)
+        got = [[] for _ in range(B)]; nvalid = [0] * B
+        for step in range((nf + F - 1) // F):
+            d.process(F)
+            info = d.frame_info(); ev, n = d.tii()
+            if not (info["valid"] == 1).any():
+                break
+            for b in range(B):
+                assert n[b] == len(ev[b])
+                valid_before = np.concatenate([[0], np.cumsum(info[b]["valid"] == 1)])
+                for e in ev[b]:
+                    assert info[b, e["frame"]]["valid"] == 1
+                    got[b].append((nvalid[b] + int(valid_before[e["frame"]]), int(e["comb"]), int(e["pattern"]), int(e["delay_samples"]), float(e["error"])))
+                nvalid[b] += int(valid_before[-1])
+        for b in range(B):
+            nfr = nvalid[b]
+            w = [e for e in want[b]["tii"] if e[0] < nfr]
+            assert sorted(got[b]) == w, "TII measurements of ensemble %d differ:\n got  %s\n want %s" % (b, sorted(got[b]), w)
+            assert nfr >= want[b]["n_frames"] - F * (2 if pipeline_sync else 1)
+    finally:
+        d.close()
+
+
 def check_error_behaviour(d_factory):
     """signal problems never raise (they surface as valid = 0 / CRC false, like the reference's callbacks); programming errors
     come back as negative status codes with a message, never as a crash (the reference throws std::logic_error / out_of_range)"""

@@ -182,7 +182,11 @@ class OrcRunIO(C.Structure):
                 ("soft", C.c_void_p), ("soft_cap", C.c_int),
                 ("msc", C.POINTER(C.c_void_p)), ("msc_cap", C.POINTER(C.c_int64)), ("msc_len", C.POINTER(C.c_int64)),
                 ("n_fib", C.c_int), ("n_frames", C.c_int), ("n_snr", C.c_int), ("n_sync_true", C.c_int), ("n_sync_false", C.c_int), ("n_cir", C.c_int),
-                ("freqsync_sel", C.c_int)]
+                ("freqsync_sel", C.c_int),
+                ("tii_state", C.c_void_p), ("tii_rank", C.c_void_p), ("tii_ev", C.c_void_p), ("tii_cap", C.c_int), ("n_tii", C.c_int)]
+
+
+TII_EVENT_DTYPE = np.dtype([("frame", "<i4"), ("comb", "<i4"), ("pattern", "<i4"), ("delay_samples", "<i4"), ("error", "<f4")])
 
 
 def orc():
@@ -294,7 +298,40 @@ def orc_demod_frames(frames):
     return soft, con.reshape(n, 1200), np.array(snrs, np.float32)
 
 
-def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_soft=False, freqsync=2):
+def orc_tii_rank():
+    """[2][504] iteration rank of the reference's unordered_map<float, uint64_t> (oracle/tii_order.cpp)"""
+    r = np.zeros((2, 504), np.int32); orc().orc_tii_iteration_rank(_p(r)); return r
+
+
+def _tii_sorted(ev):
+    return sorted((int(e["frame"]), int(e["comb"]), int(e["pattern"]), int(e["delay_samples"]), float(e["error"])) for e in ev)
+
+
+def orc_tii_run(nulls, prss, want_detect=False):
+    """TIIDecoder restatement over (NULL, PRS) pairs -> sorted events (frame, comb, pattern, delay_samples, error)"""
+    nulls = np.ascontiguousarray(nulls, np.complex64); prss = np.ascontiguousarray(prss, np.complex64)
+    lib = orc(); lib.orc_tii_state_bytes.restype = C.c_size_t
+    st = np.zeros(lib.orc_tii_state_bytes(), np.uint8); rank = orc_tii_rank()
+    out = []; det = np.zeros((len(nulls), 192), np.uint8)
+    for i in range(len(nulls)):
+        ev = np.zeros(16, TII_EVENT_DTYPE)
+        n = lib.orc_tii_frame(_p(st), _p(nulls[i]), _p(prss[i]), _p(rank), _p(ev), 16, _p(det[i]))
+        ev["frame"] = i
+        out += list(ev[:n])
+    out = _tii_sorted(out)
+    return (out, det) if want_detect else out
+
+
+def ref_tii_run(nulls, prss):
+    """the reference's TIIDecoder class over the same pairs"""
+    nulls = np.ascontiguousarray(nulls, np.complex64); prss = np.ascontiguousarray(prss, np.complex64)
+    ev = np.zeros(16 * len(nulls) + 16, TII_EVENT_DTYPE)
+    n = ref().ref_tii_run(_p(nulls), _p(prss), len(nulls), _p(ev), len(ev))
+    assert n <= len(ev)
+    return _tii_sorted(ev[:n])
+
+
+def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_soft=False, freqsync=2, tii=False):
     iq = np.ascontiguousarray(iq, np.complex64); nf = len(iq) // 196608 + 2
     io = OrcRunIO(); io.iq = _p(iq); io.n_samples = len(iq)
     io.disable_coarse = int(disable_coarse); io.fft_placement = fft_placement
@@ -315,8 +352,14 @@ def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_
     sidx = np.zeros(nf, np.int32); fpos = np.zeros(nf, np.int64); io.start_index = _p(sidx); io.frame_pos = _p(fpos); io.sidx_cap = nf
     soft = np.zeros((nf if want_soft else 0, 75, 3072), np.int8)
     io.soft = _p(soft) if want_soft else None; io.soft_cap = nf if want_soft else 0
+    if tii:
+        orc().orc_tii_state_bytes.restype = C.c_size_t
+        tst = np.zeros(orc().orc_tii_state_bytes(), np.uint8); trank = orc_tii_rank(); tev = np.zeros(16 * nf, TII_EVENT_DTYPE)
+        io.tii_state = _p(tst); io.tii_rank = _p(trank); io.tii_ev = _p(tev); io.tii_cap = len(tev)
     orc().orc_receiver_run(C.byref(io))
     k = io.n_frames
+    if tii:
+        return dict(nul=nul[:k], tii=_tii_sorted(tev[:io.n_tii]), n_frames=k, fib=fib[:io.n_fib], corr=corr[:k])
     return dict(fib=fib[:io.n_fib], cir=cir[:min(io.n_cir, nf)], con=con[:k], nul=nul[:k], snr=snr[:io.n_snr], corr=corr[:k],
                 start_index=sidx[:k], frame_pos=fpos[:k], soft=soft[:k] if want_soft else None,
                 msc=[bufs[i][:lens[i]].tobytes() for i in range(len(subchs))],
@@ -338,10 +381,11 @@ class GpuRunIO(C.Structure):
                 ("n_fib", C.c_int32), ("n_cir", C.c_int32), ("n_con", C.c_int32), ("n_snr", C.c_int32), ("n_corr", C.c_int32),
                 ("n_sync_true", C.c_int32), ("n_sync_false", C.c_int32), ("n_services", C.c_int32),
                 ("rs_calls", C.c_int32 * 16), ("rs_uncorr", C.c_int32 * 16), ("rs_corr", C.c_int32 * 16),
-                ("nul", C.c_void_p), ("nul_cap", C.c_int32), ("n_nul", C.c_int32), ("freqsync", C.c_int32)]
+                ("nul", C.c_void_p), ("nul_cap", C.c_int32), ("n_nul", C.c_int32), ("freqsync", C.c_int32),
+                ("decode_tii", C.c_int32), ("tii", C.c_void_p), ("tii_cap", C.c_int32), ("n_tii", C.c_int32)]
 
 
-def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, lib=GPU_EMU_SO, freqsync=2):
+def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, lib=GPU_EMU_SO, freqsync=2, tii=False):
     """Run GpuRadioReceiver (the facade mirror) over a cf32 stream; same outputs as receiver_run()."""
     L = C.CDLL(lib)
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
@@ -362,6 +406,7 @@ def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_p
     snr = np.zeros(nf, np.float32); io.snr = _p(snr); io.snr_cap = nf
     corr = np.zeros((nf, 2), np.int32); io.corr = _p(corr); io.corr_cap = nf
     nul = np.zeros((nf, 2656), np.complex64); io.nul = _p(nul); io.nul_cap = nf
+    tev = np.zeros(16 * nf, TII_EVENT_DTYPE); io.decode_tii = int(tii); io.tii = _p(tev); io.tii_cap = len(tev)
     r = L.gpu_receiver_run(C.byref(io))
     assert r == 0, "GpuRadioReceiver run failed"
     msc = []
@@ -371,7 +416,7 @@ def gpu_receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_p
             os.remove(pth)
     return dict(fib=fib[:io.n_fib], cir=cir[:io.n_cir], con=con[:io.n_con], snr=snr[:io.n_snr], corr=corr[:io.n_corr], msc=msc, nul=nul[:io.n_nul],
                 n_sync_true=io.n_sync_true, n_sync_false=io.n_sync_false, n_services=io.n_services,
-                rs_calls=list(io.rs_calls), rs_uncorr=list(io.rs_uncorr), rs_corr=list(io.rs_corr))
+                rs_calls=list(io.rs_calls), rs_uncorr=list(io.rs_uncorr), rs_corr=list(io.rs_corr), tii=_tii_sorted(tev[:io.n_tii]))
 
 
 # ---- DAB+ superframe filter (SuperframeFilter::Feed): oracle restatement and the real class

@@ -67,3 +67,8 @@ def test_other_freqsync_methods(emu, freqsync, cfo, snr):
 def test_live_ring_async_ingest(emu):
     """dabphy_stream_write_raw_async: copy + conversion on the copy stream, dabphy_process orders itself behind them"""
     P.check_live_raw_vs_oracle(factory, "u8", asynchronous=True)
+
+
+def test_tii_side_path(emu):
+    """TIIDecoder on the device: four ensembles with different transmitter sets, sums carried across batches"""
+    P.check_tii_vs_oracle(factory)

@@ -41,3 +41,13 @@ def test_facade_accepts_all_sync_options(gpu):
     b = R.gpu_receiver_run(x, subchs=subs, lib=R.GPU_HIP_SO, fft_placement=1, freqsync=1)
     n = min(len(a["fib"]), len(b["fib"]))
     assert n >= len(a["fib"]) - 12 and n > 24 and np.array_equal(a["fib"][:n], b["fib"][:n])
+
+
+def test_facade_reports_tii_measurements(gpu):
+    """decodeTII through the façade on the device: onTIIMeasurement = the TIIDecoder restatement over the same frames"""
+    import parity_cases as P
+    x = synth.make_stream(13, snr_db=20, cfo_hz=-40, delay=210, seed=44, tii=P.TII_NETWORKS[0])
+    o = R.orc_receiver_run(x, tii=True)
+    b = R.gpu_receiver_run(x, lib=R.GPU_HIP_SO, tii=True)
+    nfr = len(b["nul"])
+    assert b["tii"] == [e for e in o["tii"] if e[0] < nfr] and len(b["tii"]) >= 2

@@ -84,3 +84,9 @@ def test_other_freqsync_methods(gpu, freqsync, cfo, snr):
 def test_live_ring_async_ingest(gpu):
     """dabphy_stream_write_raw_async: copy + conversion on the copy stream, dabphy_process orders itself behind them"""
     P.check_live_raw_vs_oracle(factory, "u8", asynchronous=True)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_tii_side_path(gpu, pipelined):
+    """TIIDecoder on the device: four ensembles with different transmitter sets, sums carried across batches"""
+    P.check_tii_vs_oracle(factory, pipeline_sync=pipelined)

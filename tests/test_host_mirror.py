@@ -10,6 +10,7 @@ import os
 import numpy as np
 import pytest
 
+import parity_cases as P
 import refapi as R
 from welle_io_amd import synth
 
@@ -91,3 +92,16 @@ def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(emu):
         assert eid[e] == want[e][0]
         assert listed[e] == 18 and detected[e] == want[e][1]
         assert ok[e] >= 12 * 4 and ok[e] % 12 == 0      # every FIB of every demodulated frame passed its CRC
+
+
+def test_facade_reports_tii_measurements(emu):
+    """RadioReceiverOptions::decodeTII through the façade: onTIIMeasurement carries what the TIIDecoder restatement computes from the
+    same frames (the reference's own decoder thread drops frames at will, so the oracle -- pinned to the real class fed pair by
+    pair -- is the comparison); with the option off, nothing is reported"""
+    x = synth.make_stream(13, snr_db=20, cfo_hz=-40, delay=210, seed=44, tii=P.TII_NETWORKS[0])
+    o = R.orc_receiver_run(x, tii=True)
+    b = R.gpu_receiver_run(x, lib=R.GPU_EMU_SO, tii=True)
+    assert len(o["tii"]) >= 4
+    nfr = len(b["nul"])
+    assert b["tii"] == [e for e in o["tii"] if e[0] < nfr] and len(b["tii"]) >= 2
+    assert R.gpu_receiver_run(x[:6 * 196608], lib=R.GPU_EMU_SO, tii=False)["tii"] == []

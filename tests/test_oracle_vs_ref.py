@@ -4,6 +4,7 @@ Skipped where the prebuilt reference libraries are absent (they are built in the
 import numpy as np
 import pytest
 
+import parity_cases as P
 import refapi as R
 from welle_io_amd import synth
 
@@ -134,6 +135,38 @@ def test_superframe_filter_equals_reference(oracle_built, bitrate, seed):
     assert eo == er
     assert len(so) == len(sr) and all(np.array_equal(x, y) for x, y in zip(so, sr))
     assert sum(e[3] for e in eo) >= 5 and any(e[2] for e in eo)
+
+
+@pytest.mark.parametrize("net", range(len(P.TII_NETWORKS)))
+@pytest.mark.parametrize("snr", [25, 8])
+def test_tii_decoder_equals_reference(oracle_built, net, snr):
+    """TIIDecoder::run + analyse_phase (the real class, one pair at a time) vs the restatement: same comb/pattern pairs, same
+    frames, same delay (= same tie-break order of the unordered_map) and same float error, over three report cycles"""
+    x = synth.make_stream(17, snr_db=snr, seed=50 + net, noise_seed=3 * net + snr, tii=P.TII_NETWORKS[net])
+    nul, prs = P.tii_pairs(x, 16, early=60 + 20 * net)
+    eo = R.orc_tii_run(nul, prs)
+    er = R.ref_tii_run(nul, prs)
+    assert eo == er
+    if P.TII_NETWORKS[net] is None:
+        assert eo == []
+    else:
+        assert len(eo) >= 2
+        if snr >= 20:                                            # (at 8 dB the reference itself reports neighbouring patterns too)
+            assert {e[1:3] for e in eo} <= {t[:2] for t in P.TII_NETWORKS[net]}
+
+
+def test_tii_decoder_noise_and_garbage(oracle_built):
+    """noise-only NULL symbols, a NULL symbol that lights every carrier (>= 10 likely pairs: the frame is skipped), zeros"""
+    rng = np.random.RandomState(5)
+    x = synth.make_stream(8, snr_db=15, seed=9, tii=[(7, 33, 0, 1.0)])
+    nul, prs = P.tii_pairs(x, 7)
+    nul[1] = (rng.randn(2656) + 1j * rng.randn(2656)).astype(np.complex64) * 0.05
+    nul[2] = 0
+    nul[3] = prs[3][np.arange(2656) % 2048] * 3.0            # a PRS-like NULL: all pairs over the threshold
+    nul2, prs2 = np.concatenate([nul] * 3), np.concatenate([prs] * 3)
+    eo, det = R.orc_tii_run(nul2, prs2, want_detect=True)
+    assert eo == R.ref_tii_run(nul2, prs2) and len(eo) >= 2
+    assert det[3].sum() > 100 and det[2].sum() == 0
 
 
 @pytest.mark.parametrize("method", [0, 1])

@@ -28,6 +28,7 @@ class Subchannel(C.Structure):
     _fields_ = [("subch_id", C.c_int32), ("start_cu", C.c_int32), ("size_cu", C.c_int32), ("prot", Protection)]
 
 
+TII_DTYPE = np.dtype([("frame", "<i4"), ("comb", "<i4"), ("pattern", "<i4"), ("delay_samples", "<i4"), ("error", "<f4")])
 SF_EVENT_DTYPE = np.dtype([("cif", "<i4"), ("corrected", "<i4"), ("uncorrectable", "<i4"), ("sync", "<i4"), ("format", "<i4"), ("num_aus", "<i4"),
                            ("au_start", "<i4", 7), ("au_crc_ok", "<i4"), ("sf_slot", "<i4")])
 
@@ -145,6 +146,18 @@ class DabPhy:
         st = np.zeros((self.cfg.n_ensembles, 4), np.int32)
         self._chk(self.lib.dabphy_superframes_stats(self.h, _p(st)))
         return st
+
+    def set_tii(self, on=True):
+        """RadioReceiverOptions::decodeTII for the following process() calls"""
+        self._chk(self.lib.dabphy_set_tii(self.h, int(on)))
+
+    def tii(self, max_per_ensemble=None):
+        """onTIIMeasurement calls of the last batch: list per ensemble of records (frame, comb, pattern, delay_samples, error)"""
+        B = self.cfg.n_ensembles
+        m = 9 * self.cfg.max_frames if max_per_ensemble is None else max_per_ensemble
+        ev = np.zeros((B, max(m, 1)), TII_DTYPE); n = np.zeros(B, np.int32)
+        self._chk(self.lib.dabphy_get_tii(self.h, _p(ev), _p(n), m))
+        return [ev[b, :min(int(n[b]), m)].copy() for b in range(B)], n
 
     def selftest_div127(self):
         c = (C.c_uint64 * 3)()

@@ -71,6 +71,10 @@ struct dabphy_handle {
     hipEvent_t ev_beg[ST_COUNT]{}, ev_end[ST_COUNT]{};
     bool ev_used[ST_COUNT]{};
     DevBuf rs_first, rs_result;
+    // TII (RadioReceiverOptions::decodeTII): constants, per-batch scratch, per-ensemble sums that live across batches
+    bool tii_on = false; bool tii_ran = false;
+    DevBuf tii_rot, tii_rank, tii_pat, tii_err, tii_likely, tii_state, tii_events, tii_nev, tii_ovf;
+    uint32_t tii_max_events = 0;
 };
 
 namespace {
@@ -193,6 +197,7 @@ void dabphy_destroy(dabphy_handle* h)
     DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* tb[] = {&h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
@@ -322,6 +327,8 @@ int dabphy_reset(dabphy_handle* h)
     HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
     for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
+    if (h->tii_state.p) HIPCHK(h, hipMemsetAsync(h->tii_state.p, 0, h->tii_state.cap, h->stream));      // a new OFDMProcessor owns a new TIIDecoder
+    h->tii_ran = false;
     return sync(h);
 }
 
@@ -597,6 +604,24 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         launch_fib_crc(k, fs);
         launch_fic_ratio(k, fs);
         mark(dabphy_handle::ST_FIC, true, fs);
+        h->tii_ran = false;
+        if (h->tii_on) {
+            // TII side path (ofdm-processor.cpp:462-466 -> TIIDecoder): needs only the samples and the frame descriptors, rides behind
+            // the FIC on the auxiliary stream
+            if ((r = ensure(h, h->tii_err, (size_t)B * F * TII_MAX_LIKELY * TII_NERR * sizeof(float)))) return r;
+            if ((r = ensure(h, h->tii_likely, (size_t)B * F * (1 + TII_MAX_LIKELY) * sizeof(int32_t)))) return r;
+            h->tii_max_events = TII_MAX_LIKELY * h->cfg.max_frames;
+            if ((r = ensure(h, h->tii_events, (size_t)B * h->tii_max_events * sizeof(TiiEvent)))) return r;
+            if ((r = ensure(h, h->tii_nev, (size_t)B * sizeof(int32_t)))) return r;
+            TiiArgs ta{};
+            ta.tab = h->tab; ta.iq = h->s_iq; ta.iq_stride = h->s_stride; ta.ring = (int64_t)h->s_ring; ta.desc = d_desc; ta.n_ens = (int)B; ta.n_frames = (int)F;
+            ta.rot = h->tii_rot.as<cf32>(); ta.rank = h->tii_rank.as<int32_t>(); ta.pattern = h->tii_pat.as<uint8_t>();
+            ta.abs_err = h->tii_err.as<float>(); ta.likely = h->tii_likely.as<int32_t>(); ta.state = h->tii_state.as<TiiSlot>();
+            ta.events = h->tii_events.as<TiiEvent>(); ta.n_events = h->tii_nev.as<int32_t>(); ta.max_events = (int)h->tii_max_events;
+            ta.overflow = h->tii_ovf.as<int32_t>();
+            launch_tii(ta, fs);
+            h->tii_ran = true;
+        }
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
     // MSC: one launch pair per protection class (stage events bracket the first class only: one class in the canonical ensemble)
@@ -872,6 +897,47 @@ int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
     }
     HIPCHK(h, hipMemcpyAsync(stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
     return sync(h);
+}
+
+// RadioReceiverOptions::decodeTII (radio-receiver-options.h:75, consulted once per frame at ofdm-processor.cpp:376-386,464)
+int dabphy_set_tii(dabphy_handle* h, int32_t on)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    if (on && !h->tii_rot.p) {
+        const TiiTables& T = tii_tables();
+        const uint32_t B = h->cfg.n_ensembles;
+        int r;
+        if ((r = ensure(h, h->tii_rot, T.rot.size() * sizeof(cf32)))) return r;
+        if ((r = ensure(h, h->tii_rank, sizeof T.rank))) return r;
+        if ((r = ensure(h, h->tii_pat, sizeof T.pattern))) return r;
+        if ((r = ensure(h, h->tii_state, (size_t)B * TII_SLOTS * sizeof(TiiSlot)))) return r;
+        if ((r = ensure(h, h->tii_ovf, (size_t)B * sizeof(int32_t)))) return r;
+        HIPCHK(h, hipMemcpyAsync(h->tii_rot.p, T.rot.data(), T.rot.size() * sizeof(cf32), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->tii_rank.p, T.rank, sizeof T.rank, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->tii_pat.p, T.pattern, sizeof T.pattern, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->tii_state.p, 0, h->tii_state.cap, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->tii_ovf.p, 0, h->tii_ovf.cap, h->stream));
+        if ((r = sync(h))) return r;
+    }
+    h->tii_on = on != 0;
+    return DABPHY_OK;
+}
+
+int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, uint32_t max_per_ensemble)
+{
+    if (!h || !n || (!out && max_per_ensemble) || !h->last_frames) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles;
+    if (!h->tii_ran) { for (uint32_t b = 0; b < B; b++) n[b] = 0; return DABPHY_OK; }
+    static_assert(sizeof(dabphy_tii_measurement) == sizeof(TiiEvent), "dabphy_tii_measurement layout");
+    std::vector<TiiEvent> ev((size_t)B * h->tii_max_events);
+    HIPCHK(h, hipMemcpyAsync(n, h->tii_nev.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ev.data(), h->tii_events.p, ev.size() * sizeof(TiiEvent), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (uint32_t b = 0; b < B; b++) {
+        const uint32_t k = std::min<uint32_t>((uint32_t)n[b], std::min(max_per_ensemble, h->tii_max_events));
+        if (k) memcpy(out + (size_t)b * max_per_ensemble, ev.data() + (size_t)b * h->tii_max_events, k * sizeof(TiiEvent));
+    }
+    return DABPHY_OK;
 }
 
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)

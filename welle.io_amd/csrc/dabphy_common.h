@@ -15,6 +15,8 @@ constexpr int SOFT_PER_SYM = 2 * K_CARR;           // 3072
 constexpr int SOFT_PER_FRAME = 75 * SOFT_PER_SYM;  // 230400
 constexpr int CIF_BITS = 55296;
 constexpr int FFT_THREADS = 128;                   // one work-group = one 2048-point transform
+constexpr int TII_NERR = 504;                      // TII: candidate delays err = -4 .. 499 (tii-decoder.cpp:349)
+constexpr int TII_CARRIER_ROWS = 1537;             // TII: carriers k = -768 .. 768
 
 struct cf32 { float re, im; };
 

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <complex>
+#include <unordered_map>
 
 namespace dabphy {
 
@@ -96,6 +98,38 @@ const HostTables& host_tables()
     static HostTables T;
     static std::once_flag once;
     std::call_once(once, [] { build(T); });
+    return T;
+}
+
+// ------------------------------------------------------------------------------------------ TII
+// Constants of TIIDecoder (tii-decoder.cpp): the 70 patterns, the rotators analyse_phase recomputes for every carrier and
+// candidate delay, and the order in which its unordered_map<float, uint64_t> presents the candidates to std::min_element.
+const TiiTables& tii_tables()
+{
+    static TiiTables T;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int n = 0;
+        for (int v = 0; v < 256; v++) if (__builtin_popcount(v) == 4) T.pattern[n++] = (uint8_t)v;   // tii-decoder.cpp:29-99, b = 0 is the MSB
+        // tii-decoder.cpp:355-356: polar(1.0f, 2.0f * pi * err * carriers[j] / 2048.0f), same operand types, same libm
+        T.rot.resize((size_t)TII_CARRIER_ROWS * TII_NERR);
+        constexpr float pi = M_PI;
+        for (int k = -768; k <= 768; k++)
+            for (int err = -4; err < 500; err++) {
+                const std::complex<float> r = std::polar(1.0f, 2.0f * pi * err * k / 2048.0f);
+                cf32 c; c.re = r.real(); c.im = r.imag();
+                T.rot[(size_t)(k + 768) * TII_NERR + (err + 4)] = c;
+            }
+        // tii-decoder.cpp:360-366: min_element keeps the first minimum in the container's iteration order, a property of the
+        // C++ library the receiver is built with -- so ask the same container: filled for the first time, and refilled after clear()
+        std::unordered_map<float, uint64_t> m;
+        for (int cycle = 0; cycle < 2; cycle++) {
+            for (int err = -4; err < 500; err++) m[err] += 0.0f;
+            int pos = 0;
+            for (const auto& kv : m) T.rank[cycle][(int)kv.first + 4] = pos++;
+            m.clear();
+        }
+    });
     return T;
 }
 

@@ -17,6 +17,13 @@ struct HostTables {
 };
 const HostTables& host_tables();
 
+struct TiiTables {
+    uint8_t pattern[70];                 // bit (7 - b) = tii_pattern[p][b]
+    std::vector<cf32> rot;               // [TII_CARRIER_ROWS][TII_NERR]
+    int32_t rank[2][TII_NERR];
+};
+const TiiTables& tii_tables();           // built on first use (decodeTII)
+
 int protection_fic(dabphy_protection* p);
 int protection_eep(dabphy_protection* p, int bitrate, int profile_b, int level);
 int protection_uep(dabphy_protection* p, int bitrate, int level);

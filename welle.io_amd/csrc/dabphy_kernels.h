@@ -133,6 +133,23 @@ struct NullArgs {
 };
 void launch_null_symbols(const NullArgs& a, int n_ens, hipStream_t s);
 
+// TII (k_tii.hip): TIIDecoder::run + analyse_phase (tii-decoder.cpp:189-383) over the (NULL, PRS) pair of every frame
+constexpr int TII_MAX_LIKELY = 9;        // the reference skips frames with 10 or more likely comb/pattern pairs
+constexpr int TII_SLOTS = 32;            // comb/pattern pairs tracked per ensemble
+struct TiiSlot { int32_t cp1, num, cycle, pad; unsigned long long acc[TII_NERR]; };   // cp1 = comb * 70 + pattern + 1, 0 = free
+struct TiiEvent { int32_t frame, comb, pattern, delay_samples; float error; };       // = dabphy_tii_measurement
+struct TiiArgs {
+    Tables tab; const cf32* iq; size_t iq_stride; int64_t ring;
+    const FrameDesc* desc; int n_ens, n_frames;
+    const cf32* rot; const int32_t* rank; const uint8_t* pattern;
+    float* abs_err;                      // [B][F][TII_MAX_LIKELY][TII_NERR] this frame's error per candidate delay
+    int32_t* likely;                     // [B][F][1 + TII_MAX_LIKELY] count, comb * 70 + pattern ascending
+    TiiSlot* state;                      // [B][TII_SLOTS]
+    TiiEvent* events; int32_t* n_events; int max_events;   // [B][max_events], [B] (counts every measurement, stored or not)
+    int32_t* overflow;                   // [B] measurements dropped because all slots were taken
+};
+void launch_tii(const TiiArgs& a, hipStream_t s);
+
 // Sample ingest (k_ingest.hip): n samples per ensemble of raw format `format` -> ring positions w, w+1, ... (mod ring)
 struct IngestArgs {
     const uint8_t* raw; size_t raw_stride;               // bytes between ensembles

@@ -77,7 +77,7 @@ void GpuRadioReceiver::stop()
 void GpuRadioReceiver::setReceiverOptions(const RadioReceiverOptions rro)
 {
     std::lock_guard<std::mutex> lock(mutex);
-    options = rro;      // placement / coarse settings are fixed at construction on the GPU path; TII stays host-side
+    options = rro;      // placement / coarse settings are fixed at construction on the GPU path; decodeTII is consulted per frame
 }
 
 bool GpuRadioReceiver::serviceHasAudioComponent(const Service& s) const
@@ -167,6 +167,12 @@ bool GpuRadioReceiver::decode_one_frame(uint64_t written)
         std::lock_guard<std::mutex> lock(mutex);
         if (subchannels_dirty) push_subchannels_locked();
     }
+    bool tii;
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        tii = options.decodeTII;                                        // read once per frame, ofdm-processor.cpp:376-380
+    }
+    if (dabphy_set_tii(phy, tii) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
     if (dabphy_process(phy, 1) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
     dabphy_frame_info info;
     dabphy_get_frame_info(phy, &info);
@@ -198,6 +204,15 @@ bool GpuRadioReceiver::decode_one_frame(uint64_t written)
         std::vector<DSPCOMPLEX> nul(2656);
         if (dabphy_get_null_symbols(phy, reinterpret_cast<float*>(nul.data())) == DABPHY_OK)
             rci.onNewNullSymbol(std::move(nul));                        // ofdm-processor.cpp:469
+    }
+    if (tii) {
+        dabphy_tii_measurement m[9]; int32_t n = 0;
+        if (dabphy_get_tii(phy, m, &n, 9) == DABPHY_OK)
+            for (int i = 0; i < n && i < 9; i++) {
+                tii_measurement_t t;
+                t.comb = m[i].comb; t.pattern = m[i].pattern; t.delay_samples = m[i].delay_samples; t.error = m[i].error;
+                rci.onTIIMeasurement(std::move(t));                     // tii-decoder.cpp:371-377
+            }
     }
     // thread C: decoded logical frames, 4 per transmission frame, in CIF order (dab-audio.cpp:151-160)
     {

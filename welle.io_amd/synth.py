@@ -239,11 +239,26 @@ def build_fibs(eid, subchs, cif_count):
     return [make_fib(f) for f in fibs]
 
 
+TII_PATTERNS = [v for v in range(256) if bin(v).count("1") == 4]     # the 70 octets of weight 4, ascending (table 67)
+
+
+def tii_carriers(comb, pattern):
+    """Carriers k (-768..768) of the TII signal of (comb, pattern) in Mode I, ascending: 4 blocks x 4 pairs."""
+    ks = [1 + 2 * comb + 48 * b for b in range(8) if (TII_PATTERNS[pattern] >> (7 - b)) & 1]
+    out = []
+    for off in (-769, -385, 0, 384):
+        for k in ks:
+            out += [k + off, k + off + 1]
+    return out
+
+
 class EnsembleTx:
     """Generates consecutive Mode-I transmission frames (cf64 numpy arrays of T_F samples)."""
 
-    def __init__(self, eid=0x1000, subchs=None, seed=0, payload_fn=None, amplitude=0.25):
+    def __init__(self, eid=0x1000, subchs=None, seed=0, payload_fn=None, amplitude=0.25, tii=None, tii_gain=1.0):
         self.eid = eid
+        self.tii = tii                  # (comb 0..23, pattern 0..69): fills the null symbol (EN 300 401 clause 14.8)
+        self.tii_gain = tii_gain
         self.subchs = default_subchannels() if subchs is None else subchs
         self.rng = np.random.RandomState(seed)
         self.payload_fn = payload_fn
@@ -298,16 +313,31 @@ class EnsembleTx:
             syms[l + 1] = z
         t = np.fft.ifft(syms, axis=1) * T_U     # unnormalised inverse DFT
         t = np.concatenate([t[:, -T_G:], t], axis=1).reshape(-1)
-        frame = np.concatenate([np.zeros(T_NULL, np.complex128), t])
+        null = np.zeros(T_NULL, np.complex128)
+        if self.tii is not None:
+            zn = np.zeros(T_U, np.complex128)
+            for k in tii_carriers(*self.tii)[0::2]:          # both carriers of a pair carry the PRS phase of the first
+                zn[k % T_U] = zn[(k + 1) % T_U] = self.prs[k % T_U] * self.tii_gain
+            tn = np.fft.ifft(zn) * T_U
+            null = np.concatenate([tn[-(T_NULL - T_U):], tn])
+        frame = np.concatenate([null, t])
         rms = np.sqrt(np.mean(np.abs(t) ** 2))
         return frame * (self.amplitude / rms)
 
 
 def make_stream(n_frames, eid=0x1000, subchs=None, seed=0, snr_db=None, cfo_hz=0.0, delay=0,
-                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False):
-    """cf32 interleaved stream of n_frames frames (+ `delay` leading noise/zero samples)."""
-    tx = EnsembleTx(eid, subchs, seed, payload_fn, amplitude)
+                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False, tii=None):
+    """cf32 interleaved stream of n_frames frames (+ `delay` leading noise/zero samples).
+    tii: None, or a list of transmitters (comb, pattern, delay_samples, gain) of a single-frequency network: identical
+    frames, each with its own TII in the null symbol, summed with their relative delays."""
+    tx = EnsembleTx(eid, subchs, seed, payload_fn, amplitude, tii=tii[0][:2] if tii else None)
     x = np.concatenate([tx.next_frame() for _ in range(n_frames)])
+    if tii:
+        x = np.concatenate([np.zeros(tii[0][2], np.complex128), x])[:len(x)] * tii[0][3]
+        for comb, pattern, d, g in tii[1:]:
+            t2 = EnsembleTx(eid, subchs, seed, payload_fn, amplitude, tii=(comb, pattern))
+            y = np.concatenate([t2.next_frame() for _ in range(n_frames)])
+            x = x + g * np.concatenate([np.zeros(d, np.complex128), y])[:len(x)]
     if delay:
         x = np.concatenate([np.zeros(delay, np.complex128), x])
     if cfo_hz:
