@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--frames", type=int, default=20, help="transmission frames per ensemble and step")
     ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-schedule", action="store_true", help="skip the extra (untimed) pass with the other pipelined schedule")
     args = ap.parse_args()
 
     import torch
@@ -143,8 +144,9 @@ def main():
     del gbase, n_idx, rot
     torch.cuda.synchronize()
 
+    sched = int(os.environ.get("DABPHY_PIPELINE", "1"))
     dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.path.join(PKG_DIR, "libdabphy_hip.so"),
-                      want_constellation=False, want_impulse_response=False, disable_coarse=False, pipeline_sync=os.environ.get("DABPHY_PIPELINE", "1") != "0",
+                      want_constellation=False, want_impulse_response=False, disable_coarse=False, pipeline_sync=sched,
                       demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
     dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
     subchs = txs[0].subchs
@@ -220,10 +222,34 @@ def main():
             "viterbi": {"codeword_steps_per_s": n_cw_steps / ((stages["fic"] + stages["msc_viterbi"]) * 1e-3) if stages["msc_viterbi"] > 0 else None,
                         "bound": "VALU int16 (v_pk_add/min_u16), metrics in VGPRs: no LDS traffic"},
         }
+        line["config"]["schedule"] = {0: "serial synchroniser", 1: "pipelined: the next batch's synchroniser starts behind this batch's demod kernel",
+                                      2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)"}[sched]
+        if world == 1 and sched in (1, 2) and not args.no_alt_schedule:
+            # the other pipelined schedule, measured the same way right after the timed region (reported, never `value`)
+            dev.close(); dev = None
+            alt = 3 - sched
+            dev2 = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.path.join(PKG_DIR, "libdabphy_hip.so"), want_constellation=False,
+                               want_impulse_response=False, disable_coarse=False, pipeline_sync=alt, demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
+            dev2.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
+            dev2.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev2.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
+            dev2.set_profiling(True)
+            def step2():
+                dev2.process(F); dev2.superframes_stats(); return dev2.fibs()
+            for _ in range(3):
+                step2()
+            torch.cuda.synchronize(); t1 = time.perf_counter(); dm = 0.0
+            for _ in range(args.steps):
+                step2(); dm += dev2.stage_times()["demod"]
+            torch.cuda.synchronize(); dt2 = (time.perf_counter() - t1) / args.steps
+            dm /= args.steps
+            line["alt_schedule"] = {"pipeline_sync": alt, "value": B * F * FRAME_S / dt2, "ms_per_step": dt2 * 1e3, "demod_kernel_ms": dm,
+                                    "roofline_frac": B * F * ALG_BYTES_DEMOD_PER_FRAME / (dm * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            dev2.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(base[0], n_loops=12)
         print(json.dumps(line))
-    dev.close()
+    if dev is not None:
+        dev.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -43,9 +43,11 @@ typedef struct {
     int32_t want_impulse_response;  /* keep the 2048-float CIR per frame (onNewImpulseResponse) */
     int32_t demod_chunk;            /* data symbols per work-group of the demod kernel; 0 = default */
     int32_t freqsync_method;        /* FreqsyncMethod of the coarse corrector: 2 = PatternOfZeros (default), 1 = CorrelatePRS, 0 = GetMiddle */
-    int32_t pipeline_sync;          /* 1: synchronise batch k+1 on a second stream while batch k is decoded (throughput mode:
+    int32_t pipeline_sync;          /* 1 or 2: synchronise batch k+1 on a second stream while batch k is decoded (throughput mode:
                                        constant n_frames, samples of the next batch already in the ring; the coarse-corrector
-                                       feedback then lags one more batch) */
+                                       feedback then lags one more batch).  1: the next batch's synchroniser is queued behind this
+                                       batch's demod kernel; 2: at once (it then competes with the demod kernel: more frames per
+                                       second in total, a slower FFT stage) */
 } dabphy_config;
 
 /* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)

@@ -42,9 +42,11 @@ def test_big_batch_tiled_gather(gpu):
     P.check_stream_vs_oracle(factory, 14, 30, 200, 43, False, F=20)
 
 
-def test_pipelined_sync(gpu):
-    """batch k+1 is synchronised on a second stream while batch k is decoded: same bytes as the serial order"""
-    P.check_stream_vs_oracle(factory, 16, -20, 50, 26, False, F=4, pipeline_sync=True, disable_coarse=True, B=3)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pipelined_sync(gpu, mode):
+    """batch k+1 is synchronised on a second stream while batch k is decoded (queued behind the demod kernel, or at once): same
+    bytes as the serial order"""
+    P.check_stream_vs_oracle(factory, 16, -20, 50, 26, False, F=4, pipeline_sync=mode, disable_coarse=True, B=3)
 
 
 def test_stream_without_constellation(gpu):

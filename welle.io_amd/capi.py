@@ -56,7 +56,7 @@ class DabPhy:
                  want_constellation=True, want_impulse_response=True, demod_chunk=0, pipeline_sync=False, freqsync_method=2):
         self.lib = load_library(lib_path)
         cfg = Config(n_ensembles, max_frames, device, fft_placement, int(disable_coarse), int(want_constellation),
-                     int(want_impulse_response), demod_chunk, freqsync_method, int(pipeline_sync))
+                     int(want_impulse_response), demod_chunk, freqsync_method, int(pipeline_sync))   # pipeline_sync: False/True/2
         self.cfg = cfg
         self.h = C.c_void_p()
         r = self.lib.dabphy_create(C.byref(cfg), C.byref(self.h))

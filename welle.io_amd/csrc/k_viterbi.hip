@@ -58,6 +58,9 @@ __device__ __forceinline__ uint32_t pack_step_word(uint32_t w) { return pack_ste
 // bit (i & 7) of word (i >> 3).  Decision of state s at a step: word (s >> 4) & 1, byte 2 * (s & 1) + (s >> 5), bit (s >> 1) & 7.
 constexpr int VIT_PF = 4;        // trellis steps per software-pipeline stage (even, divides 32)
 
+#ifndef VIT_INTERLEAVE
+#define VIT_INTERLEAVE 1
+#endif
 template <int K>
 __device__ __forceinline__ void bfly(const u16x2 (&R)[32], u16x2 (&N)[32], u16x2 (&D)[32], const u16x2 (&BM)[4])
 {
@@ -85,10 +88,20 @@ template <int I>
 __device__ __forceinline__ void bfly_pairs(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&BM)[4], uint32_t& accA, uint32_t& accB, uint32_t ones)
 {
     u16x2 D[32];
+#if VIT_INTERLEAVE
+    bfly<I>(R, N, D, BM);
+    bfly<I + 16>(R, N, D, BM);
+    bfly<I + 1>(R, N, D, BM);
+    bfly<I + 17>(R, N, D, BM);
+    decide<I>(D, accA, accB, ones);
+    decide<I + 1>(D, accA, accB, ones);
+    if constexpr (I + 2 < 16) bfly_pairs<I + 2>(R, N, BM, accA, accB, ones);
+#else
     bfly<I>(R, N, D, BM);
     bfly<I + 16>(R, N, D, BM);
     decide<I>(D, accA, accB, ones);
     if constexpr (I + 1 < 16) bfly_pairs<I + 1>(R, N, BM, accA, accB, ones);
+#endif
 }
 
 __device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out, uint32_t ones)
@@ -106,10 +119,14 @@ __device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32
 
 __device__ __forceinline__ void renorm(u16x2 (&R)[32])
 {
-    u16x2 m = R[0];
+    u16x2 t[16];                                                       // tree, not a chain: no back-to-back dependent packed ops
 #pragma unroll
-    for (int j = 1; j < 32; j++) m = pkmin(m, R[j]);
-    const uint32_t mu = asu(m);
+    for (int j = 0; j < 16; j++) t[j] = pkmin(R[j], R[j + 16]);
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; j++) t[j] = pkmin(t[j], t[j + w]);
+    const uint32_t mu = asu(t[0]);
     uint32_t lo = mu & 0xffffu, hi = mu >> 16;
     const uint32_t mn = lo < hi ? lo : hi;
     const u16x2 sub = splat(mn);
