@@ -8,7 +8,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/prof; rm -rf $O; mkdir -p $O
-BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt-schedule"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $BENCH > $O/stats.log 2>&1
 KR='k_demod|k_viterbi|k_msc_gather|k_cp_products|k_sync_find|k_sync_finish|k_fic_gather|k_rs_msc|k_superframe'
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
