@@ -145,7 +145,7 @@ def main():
     torch.cuda.synchronize()
 
     sched = int(os.environ.get("DABPHY_PIPELINE", "1"))
-    dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.path.join(PKG_DIR, "libdabphy_hip.so"),
+    dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so")),
                       want_constellation=False, want_impulse_response=False, disable_coarse=False, pipeline_sync=sched,
                       demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
     dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
@@ -228,7 +228,7 @@ def main():
             # the other pipelined schedule, measured the same way right after the timed region (reported, never `value`)
             dev.close(); dev = None
             alt = 3 - sched
-            dev2 = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.path.join(PKG_DIR, "libdabphy_hip.so"), want_constellation=False,
+            dev2 = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so")), want_constellation=False,
                                want_impulse_response=False, disable_coarse=False, pipeline_sync=alt, demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
             dev2.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
             dev2.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev2.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])

@@ -564,21 +564,14 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     HIPCHK(h, hipEventRecord(h->ev_sync_done, h->sync_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync_done, 0));
-    // Where the next batch's chain is queued: pipeline_sync = 1 behind this batch's demod kernel (the FFT stage then runs at its own
-    // speed -- 2.05 instead of 2.75 ms for 256 x 20 frames -- and the chain shares the device with the gather and Viterbi kernels);
-    // pipeline_sync = 2 at once (chain and demod share the device: ~7 % more frames per second)
-    const int chain_after = h->cfg.pipeline_sync == 2 ? 0 : 1;
-    bool chain_pending = false;
-    if (h->cfg.pipeline_sync) { if (chain_after == 0) launch_sync_chain(cur ^ 1); else chain_pending = true; h->presynced = F; h->desc_sel = cur ^ 1; }
+    // Pipelined mode: the chain of the NEXT batch (60 launches) is handed to the driver after this batch's decode kernels, so that the
+    // main stream never waits for the host, and starts on the device
+    //   pipeline_sync = 1: when this batch's demod kernel has finished (event gate).  The FFT stage then runs at its own speed and the
+    //                      chain shares the device with the gather / Viterbi / RS kernels;
+    //   pipeline_sync = 2: at once.  Chain and demod kernel share the device: the FFT stage is a third slower, the chain done earlier.
+    // DESIGN.md section 4.3 has the numbers.
+    if (h->cfg.pipeline_sync) { h->presynced = F; h->desc_sel = cur ^ 1; }
     else h->presynced = 0;
-    auto chain_here = [&](int point) -> int {
-        if (!chain_pending || chain_after != point) return 0;
-        HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
-        launch_sync_chain(cur ^ 1);
-        chain_pending = false;
-        return 0;
-    };
     FrameDesc* const d_desc = h->s_desc2[cur].as<FrameDesc>();
     h->last_desc = d_desc;
     h->cur_cir = h->cfg.want_impulse_response ? h->s_cir2[cur].as<float>() : nullptr;
@@ -591,7 +584,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
     mark(dabphy_handle::ST_DEMOD, true);
-    if ((r = chain_here(1))) return r;
+    if (h->cfg.pipeline_sync == 1) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
     mark(dabphy_handle::ST_SNR, false);
     launch_snr(sn, h->stream);
@@ -652,12 +645,15 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         const bool first_cls = (&cls == &h->classes.front());
         if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
         launch_msc_gather(g, h->stream);
-        if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); if ((r = chain_here(2))) return r; mark(dabphy_handle::ST_MSC_VITERBI, false); }
+        if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         launch_viterbi(v, h->stream);
         if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
     }
-    if (chain_pending) { HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream)); HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0)); launch_sync_chain(cur ^ 1); chain_pending = false; }
+    if (h->cfg.pipeline_sync) {
+        if (h->cfg.pipeline_sync == 1) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
+        launch_sync_chain(cur ^ 1);
+    }
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
     h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
     HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));

@@ -57,7 +57,8 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
 // previous batch that run concurrently on the main stream.
 __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b, const int frame)
 {
-    __shared__ __attribute__((aligned(16))) cf32 tile[2 * 4 * 512];      // per wave: 4-slot ring of product rows (504 used of 512)
+    __shared__ __attribute__((aligned(16))) cf32 tile[2 * 3 * 512];      // per wave: 3-slot ring of product rows (504 used of 512); 24 KiB: fits the
+                                                                          // hole one retiring k_msc_gather work-group (28 KiB) leaves on a full CU
     __shared__ float s_sum;
     const int t = threadIdx.x;
     // ------------------------------------------------------------------------------------------ finish frame-1
@@ -72,30 +73,30 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
             // Staging: all threads copy the products two symbols ahead from HBM/L2 into a 3-slot LDS ring (coalesced
             // 16-byte loads issued before the chains start on the current symbol, stored after), so the chains only
             // ever read LDS.
-            // Staging: every wave keeps its OWN 4-row ring of product rows in LDS, filled by LDS-DMA three rows ahead
-            // (4 x 1 KiB requests per row, no registers, and the wait is "all but the 8 youngest requests").  The two
+            // Staging: every wave keeps its OWN 3-row ring of product rows in LDS, filled by LDS-DMA two rows ahead
+            // (4 x 1 KiB requests per row, no registers, and the wait is "all but the 4 youngest requests").  The two
             // chains therefore never meet inside the 75-symbol loop: no barrier, no wave waiting for the other's SIMD.
             float acc = 0.0f;
             const int wv = t >> 6, lane = t & 63;
-            cf32* ring = tile + wv * (4 * 512);                                    // [4][512] cf32 per wave
+            cf32* ring = tile + wv * (3 * 512);                                    // [3][512] cf32 per wave
             const cf32* grow = A.prods + (size_t)b * 75 * 512;
             auto fetch_row = [&](int sy) {
-                const cf32* g = grow + (size_t)sy * 512 + 2 * lane; cf32* l = ring + (sy & 3) * 512;
+                const cf32* g = grow + (size_t)sy * 512 + 2 * lane; cf32* l = ring + (sy % 3) * 512;
                 lds_dma16<0>(g, l); lds_dma16<1024>(g, l); lds_dma16<2048>(g, l); lds_dma16<3072>(g, l);
             };
-            fetch_row(0); fetch_row(1); fetch_row(2);
+            fetch_row(0); fetch_row(1);
 #pragma unroll 1
             for (int sy = 0; sy < 75; sy++) {
-                if (sy < 73) lds_dma_wait_but<8>(); else lds_dma_wait();           // row sy has landed (rows sy+1, sy+2 may be in flight)
+                if (sy < 74) lds_dma_wait_but<4>(); else lds_dma_wait();           // row sy has landed (row sy+1 may be in flight)
                 {
                     // wave 0 adds the real parts, wave 1 the imaginary parts.  Lanes 0..15 each hold one product of a
                     // block of 16; lane 0 folds them in order with row_shl DPP reads (one instruction per addition).
-                    const float* q = reinterpret_cast<const float*>(ring + (sy & 3) * 512) + wv;   // +0: re, +1: im
+                    const float* q = reinterpret_cast<const float*>(ring + (sy % 3) * 512) + wv;   // +0: re, +1: im
                     const int l16 = t & 15;
                     float xs[32];
 #pragma unroll
                     for (int i = 0; i < 32; i++) xs[i] = (16 * i + l16 < T_G) ? q[2 * (16 * i + l16)] : 0.0f;
-                    if (sy + 3 < 75) fetch_row(sy + 3);                             // its slot held row sy-1: consumed an iteration ago
+                    if (sy + 2 < 75) fetch_row(sy + 2);                             // its slot held row sy-1: consumed an iteration ago
 #pragma unroll
                     for (int i = 0; i < 32; i++) {
                         const int nk = (i < 31) ? 16 : 8;                       // 504 = 31 * 16 + 8
@@ -403,7 +404,10 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
 
 // Cyclic-prefix products of one pending frame: grid (75 symbols, B ensembles).  prods[b][sym][j] =
 // buf[2048 + j] * conj(buf[j]), j < 504, both samples oscillator-corrected (ofdm-processor.cpp:211-214,440-441).
-__global__ void __launch_bounds__(FFT_THREADS, 2) k_sync_find(SyncArgs A)
+#ifndef SYNC_FIND_OCC
+#define SYNC_FIND_OCC 2
+#endif
+__global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find(SyncArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
     sync_find_body(A, blockIdx.x, A.frame);
@@ -460,6 +464,7 @@ __device__ __forceinline__ void cp_products_body(const SyncArgs& A, const int sy
 
 __global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
 {
+    __builtin_amdgcn_s_setprio(3);                                          // the chain is latency-critical: its waves issue ahead of the decode kernels'
     cp_products_body(A, blockIdx.x, blockIdx.y, A.frame);
 }
 
