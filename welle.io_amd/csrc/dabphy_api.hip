@@ -53,7 +53,7 @@ struct dabphy_handle {
     uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
     DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
     DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
-    DevBuf s_prods; DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
+    DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
     hipEvent_t ev_chain_beg[2]{}, ev_chain_end[2]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
@@ -196,7 +196,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_prods, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     { DevBuf* tb[] = {&h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
@@ -512,7 +512,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
     if ((r = ensure(h, h->s_soft, (size_t)B * ring_frames * SOFT_PER_FRAME))) return r;
-    if ((r = ensure(h, h->s_prods, (size_t)B * 75 * 512 * sizeof(cf32)))) return r;
     if ((r = ensure(h, h->s_mag, (size_t)B * F * T_U * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_snr, (size_t)B * F * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_fib, (size_t)B * F * 384))) return r;
@@ -535,7 +534,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
         sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse; sa.freqsync = h->cfg.freqsync_method;
         sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
-        sa.prods = h->s_prods.as<cf32>();
         { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
         for (uint32_t f = 0; f < F; f++) {
             // acquisition is only queued while some ensemble may be out of lock (start of a stream, or a failed
@@ -543,8 +541,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if (h->need_acquire) launch_acquire(sa, h->sync_stream);
             sa.frame = (int)f;
             launch_sync_find(sa, h->sync_stream);       // PRS window search of frame f
-            launch_cp_products(sa, h->sync_stream);     // its cyclic-prefix products (B x 75 work-groups)
-            launch_sync_finish(sa, h->sync_stream);     // ordered sums -> correctors -> state
+            launch_sync_finish(sa, h->sync_stream);     // cyclic-prefix products + their ordered sums -> correctors -> state
         }
         { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
     };

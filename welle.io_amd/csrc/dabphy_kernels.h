@@ -56,7 +56,6 @@ struct SyncArgs {
     RxState* state; const DecState* dec; FrameDesc* desc; int n_ens, n_frames, frame;
     int fft_placement, disable_coarse, freqsync;        // FFTPlacementMethod, disableCoarseCorrector, FreqsyncMethod (reference numbering)
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
-    cf32* prods;                                         // [B][75][512] cyclic-prefix products of the pending frame
 };
 
 struct DemodArgs {
@@ -199,6 +198,5 @@ void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
 void launch_sync_find(const SyncArgs& a, hipStream_t s);
 void launch_sync_finish(const SyncArgs& a, hipStream_t s);
 void launch_acquire(const SyncArgs& a, hipStream_t s);
-void launch_cp_products(const SyncArgs& a, hipStream_t s);
 
 } // namespace dabphy

@@ -48,92 +48,139 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
     return r;
 }
 
-// The frame chain, three launches per frame on the sync stream:
+// The frame chain, two launches per frame on the sync stream:
 //   k_sync_find(frame)      B work-groups: PRS window search (+ coarse corrector); leaves the descriptor "pending" (valid = 2)
-//   k_cp_products(frame)    B x 75 work-groups: cyclic-prefix products of the pending frame (throughput kernel)
-//   k_sync_finish(frame)    B work-groups: adds the products in the reference's order (two chains of 37 800 dependent
-//                           float additions), updates the fine/coarse correctors, consumes the null symbol, commits the state
-// Both serial kernels are kept small (<= 17 KiB LDS) so that they find room next to the decode kernels of the
-// previous batch that run concurrently on the main stream.
-__device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b, const int frame)
+//   k_sync_finish(frame)    B work-groups: forms the cyclic-prefix products of the pending frame and adds them in the reference's
+//                           order (two chains of 37 800 dependent float additions), updates the fine/coarse correctors, consumes
+//                           the null symbol, commits the state
+// Both kernels are kept small (<= 19 KiB LDS) so that they find room next to the decode kernels of the previous batch that run
+// concurrently on the main stream.
+// ofdm-processor.cpp:447-490: correctors, null symbol, state commit (one thread)
+__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, const float acc, const float acc_im)
 {
-    __shared__ __attribute__((aligned(16))) cf32 tile[2 * 3 * 512];      // per wave: 3-slot ring of product rows (504 used of 512); 24 KiB: fits the
-                                                                          // hole one retiring k_msc_gather work-group (28 KiB) leaves on a full CU
-    __shared__ float s_sum;
-    const int t = threadIdx.x;
-    // ------------------------------------------------------------------------------------------ finish frame-1
-    {
-        FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + frame];
-        const int pending = dfin.valid;
-        __syncthreads();
-        if (pending == 2) {
-            // ofdm-processor.cpp:435-442: FreqCorr += buf[i] * conj(buf[i - T_u]) over 75 x 504 products, one float chain
-            // for the real parts (thread 0) and one for the imaginary parts (thread 64, another SIMD); operands are
-            // fetched 8 products ahead so each chain is bounded by add latency only
-            // Staging: all threads copy the products two symbols ahead from HBM/L2 into a 3-slot LDS ring (coalesced
-            // 16-byte loads issued before the chains start on the current symbol, stored after), so the chains only
-            // ever read LDS.
-            // Staging: every wave keeps its OWN 3-row ring of product rows in LDS, filled by LDS-DMA two rows ahead
-            // (4 x 1 KiB requests per row, no registers, and the wait is "all but the 4 youngest requests").  The two
-            // chains therefore never meet inside the 75-symbol loop: no barrier, no wave waiting for the other's SIMD.
-            float acc = 0.0f;
-            const int wv = t >> 6, lane = t & 63;
-            cf32* ring = tile + wv * (3 * 512);                                    // [3][512] cf32 per wave
-            const cf32* grow = A.prods + (size_t)b * 75 * 512;
-            auto fetch_row = [&](int sy) {
-                const cf32* g = grow + (size_t)sy * 512 + 2 * lane; cf32* l = ring + (sy % 3) * 512;
-                lds_dma16<0>(g, l); lds_dma16<1024>(g, l); lds_dma16<2048>(g, l); lds_dma16<3072>(g, l);
-            };
-            fetch_row(0); fetch_row(1);
-#pragma unroll 1
-            for (int sy = 0; sy < 75; sy++) {
-                if (sy < 74) lds_dma_wait_but<4>(); else lds_dma_wait();           // row sy has landed (row sy+1 may be in flight)
-                {
-                    // wave 0 adds the real parts, wave 1 the imaginary parts.  Lanes 0..15 each hold one product of a
-                    // block of 16; lane 0 folds them in order with row_shl DPP reads (one instruction per addition).
-                    const float* q = reinterpret_cast<const float*>(ring + (sy % 3) * 512) + wv;   // +0: re, +1: im
-                    const int l16 = t & 15;
-                    float xs[32];
+    RxState& st = A.state[b];              // updated field by field (the struct carries the 64-entry envelope history)
+    FrameDesc d = dfin;
+    int32_t coarse = d.coarse_after;                                  // after the coarse corrector of this frame
+    // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
+    const float a = fdlibm_atan2f(acc_im, acc);
+    int32_t fine = (int32_t)(int16_t)((double)st.fine + 0.1 * (double)a / M_PI * (1000 / 2));
+    // null symbol (:462-463) is pulled with the new fine corrector
+    const int32_t J0 = d.start_index + T_U;
+    const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
+    const int32_t f_null = coarse + fine;
+    const int32_t L3 = mod_rate64((int64_t)L2 - (int64_t)T_NULL * f_null);
+    d.null_L = L2; d.null_f = f_null;
+    d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
+    if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
+    else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
+    d.valid = 1;
+    dfin = d;
+    st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
+    st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
+}
+
+// ---- finish with its own product stage: the same work-group forms the cyclic-prefix products (waves 2-3, two rows ahead,
+// through a shared 3-row LDS ring) while waves 0-1 fold them in the reference's order.  Replaces k_cp_products + the HBM round
+// trip of its 75 x 512 products per ensemble and frame + one launch per frame of the chain.
+struct CpRow { cf32 lo[4], hi[4]; };                 // raw samples buf[j], buf[T_u + j], j = tp + 128 k
+
+__device__ __forceinline__ void cp_row_fetch(const SyncArgs& A, const FrameDesc& d, const cf32* __restrict__ iq, int sy, int tp, CpRow& r)
+{
+    int64_t a = (d.pos + d.start_index + T_U + (int64_t)sy * T_S + tp) % A.ring;
 #pragma unroll
-                    for (int i = 0; i < 32; i++) xs[i] = (16 * i + l16 < T_G) ? q[2 * (16 * i + l16)] : 0.0f;
-                    if (sy + 2 < 75) fetch_row(sy + 2);                             // its slot held row sy-1: consumed an iteration ago
-#pragma unroll
-                    for (int i = 0; i < 32; i++) {
-                        const int nk = (i < 31) ? 16 : 8;                       // 504 = 31 * 16 + 8
-                        acc = chain16(acc, xs[i], nk);
-                    }
-                }
-            }
-            if (t == 64) s_sum = acc;
-            __syncthreads();
-            if (t == 0) {
-                RxState& st = A.state[b];              // updated field by field (the struct carries the 64-entry envelope history)
-                FrameDesc d = dfin;
-                const float acc_im = s_sum;
-                int32_t coarse = d.coarse_after;                                  // after the coarse corrector of this frame
-                // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
-                const float a = fdlibm_atan2f(acc_im, acc);
-                int32_t fine = (int32_t)(int16_t)((double)st.fine + 0.1 * (double)a / M_PI * (1000 / 2));
-                // null symbol (:462-463) is pulled with the new fine corrector
-                const int32_t J0 = d.start_index + T_U;
-                const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
-                const int32_t f_null = coarse + fine;
-                const int32_t L3 = mod_rate64((int64_t)L2 - (int64_t)T_NULL * f_null);
-                d.null_L = L2; d.null_f = f_null;
-                d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
-                if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
-                else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
-                d.valid = 1;
-                dfin = d;
-                st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
-                st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
-            }
-            __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        if (tp + 128 * k < T_G) {
+            int64_t a_hi = a + T_U; if (a_hi >= A.ring) a_hi -= A.ring;
+            r.lo[k] = iq[a]; r.hi[k] = iq[a_hi];
         }
+        a += 128; if (a >= A.ring) a -= A.ring;
     }
 }
 
-__global__ void __launch_bounds__(FFT_THREADS) k_sync_finish(SyncArgs A)
+// buf[i] * conj(buf[i - T_u]) of symbol sy (ofdm-processor.cpp:436-441), oscillator applied as getSamples does (:211-214)
+__device__ __forceinline__ void cp_row_emit(const SyncArgs& A, const FrameDesc& d, int sy, int tp, const CpRow& r, cf32* row)
+{
+    const cf32* __restrict__ nco = A.tab.nco;
+    const int64_t rel = (int64_t)sy * T_S + tp;
+    const int32_t stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
+    const int32_t ph0 = mod_rate64((int64_t)d.L1 - (rel + 1) * (int64_t)d.f_sym);
+    cf32 o[8];
+    uint32_t hard = 0;
+    {
+        dc64 e = osc_exp(ph0);
+        const dc64 d128 = osc_step(128, d.f_sym), dTU = osc_step(T_U, d.f_sym);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            hard |= osc_round(e, o[2 * k]) << (2 * k);
+            hard |= osc_round(osc_mul(e, dTU), o[2 * k + 1]) << (2 * k + 1);
+            if (k < 3) e = osc_mul(e, d128);
+        }
+    }
+    if (!wave_all(hard == 0)) {
+        int32_t ph = ph0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
+            if ((hard >> (2 * k)) & 1u) o[2 * k] = nco[ph];
+            if ((hard >> (2 * k + 1)) & 1u) o[2 * k + 1] = nco[ph_hi];
+            ph -= step128; if (ph < 0) ph += INPUT_RATE;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = tp + 128 * k;
+        if (j < T_G) row[j] = cmul(cmul(r.hi[k], o[2 * k + 1]), cconj(cmul(r.lo[k], o[2 * k])));
+    }
+}
+
+constexpr int FINISH_THREADS = 256;
+__device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b, const int frame)
+{
+    __shared__ __attribute__((aligned(16))) cf32 ring[3 * 512];          // product rows sy, sy+1, sy+2 (504 used of 512)
+    __shared__ float s_sum;
+    const int t = threadIdx.x;
+    FrameDesc& dfin = A.desc[(size_t)b * A.n_frames + frame];
+    const int pending = dfin.valid;
+    __syncthreads();
+    if (pending != 2) return;
+    const FrameDesc d = dfin;
+    const bool producer = t >= 128;
+    const int tp = t - 128, wv = t >> 6;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    float acc = 0.0f;
+    CpRow cur, nxt;
+    if (producer) {
+        cp_row_fetch(A, d, iq, 0, tp, cur); cp_row_fetch(A, d, iq, 1, tp, nxt);
+        cp_row_emit(A, d, 0, tp, cur, ring);
+        cp_row_emit(A, d, 1, tp, nxt, ring + 512);
+        cp_row_fetch(A, d, iq, 2, tp, nxt);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int sy = 0; sy < 75; sy++) {
+        if (!producer) {
+            // wave 0 adds the real parts, wave 1 the imaginary parts (ofdm-processor.cpp:435-442 in index order).  Lanes 0..15
+            // each hold one product of a block of 16; lane 0 folds them in order with row_shl DPP reads (one instruction per addition).
+            const float* q = reinterpret_cast<const float*>(ring + (sy % 3) * 512) + wv;       // +0: re, +1: im
+            const int l16 = t & 15;
+            float xs[32];
+#pragma unroll
+            for (int i = 0; i < 32; i++) xs[i] = (16 * i + l16 < T_G) ? q[2 * (16 * i + l16)] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; i++) acc = chain16(acc, xs[i], (i < 31) ? 16 : 8);         // 504 = 31 * 16 + 8
+        } else if (sy + 2 < 75) {
+            cur = nxt;
+            if (sy + 3 < 75) cp_row_fetch(A, d, iq, sy + 3, tp, nxt);                          // in flight while row sy+2 is formed
+            cp_row_emit(A, d, sy + 2, tp, cur, ring + ((sy + 2) % 3) * 512);                    // its slot held row sy-1, consumed an iteration ago
+        }
+        __syncthreads();
+    }
+    if (t == 64) s_sum = acc;
+    __syncthreads();
+    if (t == 0) sync_finish_commit(A, b, dfin, acc, s_sum);
+}
+
+__global__ void __launch_bounds__(FINISH_THREADS) k_sync_finish(SyncArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
     sync_finish_body(A, blockIdx.x, A.frame);
@@ -398,12 +445,10 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     }
     d.f_sym = coarse + st.fine;
     d.coarse_after = coarse;
-    d.valid = 2;                                   // pending: k_cp_products + the finish phase of the next launch complete it
+    d.valid = 2;                                   // pending: k_sync_finish completes it
     if (t == 0) dout = d;
 }
 
-// Cyclic-prefix products of one pending frame: grid (75 symbols, B ensembles).  prods[b][sym][j] =
-// buf[2048 + j] * conj(buf[j]), j < 504, both samples oscillator-corrected (ofdm-processor.cpp:211-214,440-441).
 #ifndef SYNC_FIND_OCC
 #define SYNC_FIND_OCC 2
 #endif
@@ -411,61 +456,6 @@ __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find(SyncAr
 {
     __builtin_amdgcn_s_setprio(3);
     sync_find_body(A, blockIdx.x, A.frame);
-}
-
-__device__ __forceinline__ void cp_products_body(const SyncArgs& A, const int sy, const int b, const int frame)
-{
-    const int t = threadIdx.x;
-    const FrameDesc d = A.desc[(size_t)b * A.n_frames + frame];
-    if (d.valid != 2) return;
-    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
-    const cf32* __restrict__ nco = A.tab.nco;
-    const int32_t J0 = d.start_index + T_U;
-    const int64_t rel = (int64_t)sy * T_S + t;                                   // index of buf[t] after the PRS
-    const int32_t stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
-    const int32_t ph0 = mod_rate64((int64_t)d.L1 - (rel + 1) * (int64_t)d.f_sym);
-    int64_t a = (d.pos + J0 + rel) % A.ring;
-    cf32* out = A.prods + ((size_t)b * 75 + sy) * 512;
-    // oscillator values of buf[j] (o[2k]) and buf[2048 + j] (o[2k+1]), j = t + 128k, computed (osc_exact.h)
-    cf32 o[8];
-    uint32_t hard = 0;
-    {
-        dc64 e = osc_exp(ph0);
-        const dc64 d128 = osc_step(128, d.f_sym), dTU = osc_step(T_U, d.f_sym);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            hard |= osc_round(e, o[2 * k]) << (2 * k);
-            hard |= osc_round(osc_mul(e, dTU), o[2 * k + 1]) << (2 * k + 1);
-            if (k < 3) e = osc_mul(e, d128);
-        }
-    }
-    if (!wave_all(hard == 0)) {
-        int32_t ph = ph0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
-            if ((hard >> (2 * k)) & 1u) o[2 * k] = nco[ph];
-            if ((hard >> (2 * k + 1)) & 1u) o[2 * k + 1] = nco[ph_hi];
-            ph -= step128; if (ph < 0) ph += INPUT_RATE;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int j = t + 128 * k;
-        if (j < T_G) {
-            int64_t a_hi = a + T_U; if (a_hi >= A.ring) a_hi -= A.ring;
-            const cf32 lo = cmul(iq[a], o[2 * k]);
-            const cf32 hi = cmul(iq[a_hi], o[2 * k + 1]);
-            out[j] = cmul(hi, cconj(lo));
-        }
-        a += 128; if (a >= A.ring) a -= A.ring;
-    }
-}
-
-__global__ void __launch_bounds__(128) k_cp_products(SyncArgs A)
-{
-    __builtin_amdgcn_s_setprio(3);                                          // the chain is latency-critical: its waves issue ahead of the decode kernels'
-    cp_products_body(A, blockIdx.x, blockIdx.y, A.frame);
 }
 
 // ---- acquisition: OFDMProcessor::run from "Initing" / notSynced to SyncOnPhase (ofdm-processor.cpp:249-319).
@@ -539,11 +529,7 @@ void launch_sync_find(const SyncArgs& a, hipStream_t s)
 }
 void launch_sync_finish(const SyncArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sync_finish, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
-}
-void launch_cp_products(const SyncArgs& a, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_cp_products, dim3(75, a.n_ens), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(k_sync_finish, dim3(a.n_ens), dim3(FINISH_THREADS), 0, s, a);
 }
 void launch_acquire(const SyncArgs& a, hipStream_t s)
 {
