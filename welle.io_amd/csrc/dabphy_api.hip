@@ -561,7 +561,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     HIPCHK(h, hipEventRecord(h->ev_sync_done, h->sync_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync_done, 0));
-    // Pipelined mode: the chain of the NEXT batch (60 launches) is handed to the driver after this batch's decode kernels, so that the
+    // Pipelined mode: the chain of the NEXT batch (40 launches) is handed to the driver after this batch's decode kernels, so that the
     // main stream never waits for the host, and starts on the device
     //   pipeline_sync = 1: when this batch's demod kernel has finished (event gate).  The FFT stage then runs at its own speed and the
     //                      chain shares the device with the gather / Viterbi / RS kernels;
