@@ -88,7 +88,12 @@ template <int I>
 __device__ __forceinline__ void bfly_pairs(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&BM)[4], uint32_t& accA, uint32_t& accB, uint32_t ones)
 {
     u16x2 D[32];
-#if VIT_INTERLEAVE
+#if VIT_INTERLEAVE == 2
+    bfly<I>(R, N, D, BM); bfly<I + 16>(R, N, D, BM); bfly<I + 1>(R, N, D, BM); bfly<I + 17>(R, N, D, BM);
+    bfly<I + 2>(R, N, D, BM); bfly<I + 18>(R, N, D, BM); bfly<I + 3>(R, N, D, BM); bfly<I + 19>(R, N, D, BM);
+    decide<I>(D, accA, accB, ones); decide<I + 1>(D, accA, accB, ones); decide<I + 2>(D, accA, accB, ones); decide<I + 3>(D, accA, accB, ones);
+    if constexpr (I + 4 < 16) bfly_pairs<I + 4>(R, N, BM, accA, accB, ones);
+#elif VIT_INTERLEAVE
     bfly<I>(R, N, D, BM);
     bfly<I + 16>(R, N, D, BM);
     bfly<I + 1>(R, N, D, BM);
@@ -136,7 +141,10 @@ __device__ __forceinline__ void renorm(u16x2 (&R)[32])
 
 // One wavefront per work-group; a work-group walks groups g, g + gridDim.x, ... of 64 codewords (launch_viterbi sizes the
 // grid to the device's wave slots, so very large batches do not queue tens of thousands of millisecond-long waves).
-__global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
+#ifndef VIT_OCC
+#define VIT_OCC 1
+#endif
+__global__ void __launch_bounds__(64, VIT_OCC) k_viterbi(VitArgs A)
 {
   const int lane = threadIdx.x;
 #pragma unroll 1
@@ -191,10 +199,15 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
     const int cw = g * 64 + lane;
     uint32_t* out = reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32);
     uint32_t T = 0, acc = 0;
-    for (int n = nbits - 1; n >= 0; n -= 8) {
-        uint2 dq[8];
+    uint2 dq[8], dn[8];                                           // this iteration's decision words and the next one's (already in flight)
 #pragma unroll
-        for (int k = 0; k < 8; k++) dq[k] = dec[(size_t)(n - k + 6) * 64];
+    for (int k = 0; k < 8; k++) dq[k] = dec[(size_t)(nbits - 1 - k + 6) * 64];
+    for (int n = nbits - 1; n >= 0; n -= 8) {
+        {
+            const int m = n >= 8 ? n - 8 : n;                     // the last iteration re-reads its own words
+#pragma unroll
+            for (int k = 0; k < 8; k++) dn[k] = dec[(size_t)(m - k + 6) * 64];
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int nn = n - k;                                 // n is 7 mod 8: nn & 7 = 7 - k
@@ -209,6 +222,8 @@ __global__ void __launch_bounds__(64) k_viterbi(VitArgs A)
             if (cw < A.c.n_cw) out[wi] = A.c.dedisperse ? acc ^ A.prbs_words[wi] : acc;
             acc = 0;
         }
+#pragma unroll
+        for (int k = 0; k < 8; k++) dq[k] = dn[k];
     }
   }
 }
