@@ -180,7 +180,10 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
     if (t == 0) sync_finish_commit(A, b, dfin, acc, s_sum);
 }
 
-__global__ void __launch_bounds__(FINISH_THREADS) k_sync_finish(SyncArgs A)
+#ifndef SYNC_FINISH_OCC
+#define SYNC_FINISH_OCC 1
+#endif
+__global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_OCC) k_sync_finish(SyncArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
     sync_finish_body(A, blockIdx.x, A.frame);
