@@ -135,6 +135,7 @@ static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned 
     return r;
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 // v_mov_b32 dpp row_shl:k (dpp_ctrl 0x101..0x10f): lane i reads lane i+k of its row of 16, 0 beyond the row (bound_ctrl)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
