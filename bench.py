@@ -152,6 +152,7 @@ def main():
     subchs = txs[0].subchs
     dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
     dev.set_profiling(True)
+    dev.set_auto_superframes(True)                         # the superframe filter rides in process()'s submission
 
     def step():
         dev.process(F)
@@ -232,7 +233,7 @@ def main():
                                want_impulse_response=False, disable_coarse=False, pipeline_sync=alt, demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
             dev2.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
             dev2.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev2.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
-            dev2.set_profiling(True)
+            dev2.set_profiling(True); dev2.set_auto_superframes(True)
             def step2():
                 dev2.process(F); dev2.superframes_stats(); return dev2.fibs()
             for _ in range(3):

@@ -234,6 +234,9 @@ int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* 
  * addition to, dabphy_superframes for this batch); nothing but totals leaves the device:
  * stats [n_ensembles][4] = synchronised superframes, corrected symbols, uncorrectable attempts, access units failing their CRC */
 int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats);
+/* on: every following dabphy_process queues that all-sub-channel filter pass itself, behind the MSC Viterbi kernels of the same
+ * submission (no host round trip between decode and filter); dabphy_superframes_stats then only fetches the totals of the batch. */
+int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on);
 
 /* ---- TIIDecoder (tii-decoder.cpp:189-383), fed by OFDMProcessor::run with the PRS and the trailing NULL symbol of every
  * frame (ofdm-processor.cpp:381-386,462-466) when RadioReceiverOptions::decodeTII is set (radio-receiver-options.h:75; welle-cli

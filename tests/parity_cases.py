@@ -284,23 +284,25 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
                 assert ns >= 1 and all(np.array_equal(got_sf[b][i][k], so[k]) for k in range(ns)), "corrected superframes differ"
     finally:
         d.close()
-    # the all-sub-channels variant: only totals leave the device
-    d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
-    try:
-        d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
-        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
-        tot = np.zeros((B, 4), np.int64)
-        for _ in range((nf + F - 1) // F):
-            d.process(F)
-            if not (d.frame_info()["valid"] == 1).any():
-                break
-            tot += d.superframes_stats()
-        for b in range(B):
-            ev = [e for i in range(len(subs)) for e in got[b][i]]
-            want = (sum(e[2] for e in ev), sum(e[0] for e in ev), sum(e[1] for e in ev), sum(e[4] - bin(e[6]).count("1") for e in ev if e[2]))
-            assert tuple(tot[b]) == want, (tuple(tot[b]), want)
-    finally:
-        d.close()
+    # the all-sub-channels variant: only totals leave the device -- launched by superframes_stats(), or by process() itself
+    for auto in (False, True):
+        d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
+        try:
+            d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
+            d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+            d.set_auto_superframes(auto)
+            tot = np.zeros((B, 4), np.int64)
+            for _ in range((nf + F - 1) // F):
+                d.process(F)
+                if not (d.frame_info()["valid"] == 1).any():
+                    break
+                tot += d.superframes_stats()
+            for b in range(B):
+                ev = [e for i in range(len(subs)) for e in got[b][i]]
+                want = (sum(e[2] for e in ev), sum(e[0] for e in ev), sum(e[1] for e in ev), sum(e[4] - bin(e[6]).count("1") for e in ev if e[2]))
+                assert tuple(tot[b]) == want, (auto, tuple(tot[b]), want)
+        finally:
+            d.close()
     return got
 
 

@@ -142,6 +142,10 @@ class DabPhy:
         self._chk(self.lib.dabphy_superframes(self.h, subch_index, _p(ev), _p(ne), _p(sf)))
         return ev, ne, sf
 
+    def set_auto_superframes(self, on=True):
+        """run the all-sub-channel superframe filter inside every process() call; superframes_stats() then only fetches the totals"""
+        self._chk(self.lib.dabphy_set_auto_superframes(self.h, int(on)))
+
     def superframes_stats(self):
         st = np.zeros((self.cfg.n_ensembles, 4), np.int32)
         self._chk(self.lib.dabphy_superframes_stats(self.h, _p(st)))

@@ -73,6 +73,7 @@ struct dabphy_handle {
     DevBuf rs_first, rs_result;
     // TII (RadioReceiverOptions::decodeTII): constants, per-batch scratch, per-ensemble sums that live across batches
     bool tii_on = false; bool tii_ran = false;
+    bool sf_auto = false, sf_stats_ready = false;   // dabphy_set_auto_superframes: the all-sub-channel filter rides in dabphy_process's submission
     DevBuf tii_rot, tii_rank, tii_pat, tii_err, tii_likely, tii_state, tii_events, tii_nev, tii_ovf;
     uint32_t tii_max_events = 0;
 };
@@ -499,6 +500,8 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
     return DABPHY_OK;
 }
 
+namespace { int launch_superframe_stats(dabphy_handle* h); }
+
 // One batch: acquisition where needed, n_frames frame steps of the synchroniser, then the fully parallel stages.
 int dabphy_process(dabphy_handle* h, uint32_t n_frames)
 {
@@ -647,6 +650,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         launch_viterbi(v, h->stream);
         if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
     }
+    h->last_frames = F;
+    h->sf_stats_ready = false;
+    if (h->sf_auto) { if ((r = launch_superframe_stats(h))) return r; h->sf_stats_ready = true; }
     if (h->cfg.pipeline_sync) {
         if (h->cfg.pipeline_sync == 1) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
         launch_sync_chain(cur ^ 1);
@@ -889,9 +895,10 @@ int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* 
     return DABPHY_ERR_INVALID;
 }
 
-int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
+namespace {
+// SuperframeFilter over every DAB+ sub-channel of every ensemble: one launch per protection class on the main stream, totals into sf_stats
+int launch_superframe_stats(dabphy_handle* h)
 {
-    if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles;
     int r;
     if ((r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
@@ -905,7 +912,24 @@ int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
         if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
         first_launch = false;
     }
-    HIPCHK(h, hipMemcpyAsync(stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+}
+
+int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    h->sf_auto = on != 0;
+    return DABPHY_OK;
+}
+
+int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
+{
+    if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
+    int r;
+    if (!h->sf_stats_ready) { if ((r = launch_superframe_stats(h))) return r; }
+    h->sf_stats_ready = false;                   // one filter pass per batch: a second call would feed the same frames again
+    HIPCHK(h, hipMemcpyAsync(stats, h->sf_stats.p, sizeof(int32_t) * 4 * h->cfg.n_ensembles, hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
 
