@@ -230,7 +230,7 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, a
 
 
 # ---- DAB+ superframe filter on the device vs the oracle's (itself pinned to the real SuperframeFilter)
-def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True):
+def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True, auto_modes=(False, True)):
     """superframes straddle the batches (12 logical frames per batch, 5 per superframe); the noise level makes the Viterbi
     output carry byte errors for Reed-Solomon to correct (no loss of lock: batch mode and the reference drop different
     frames then), and the transmitter damages some superframes beyond repair: a broken access unit, more byte errors than
@@ -285,7 +285,7 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
     finally:
         d.close()
     # the all-sub-channels variant: only totals leave the device -- launched by superframes_stats(), or by process() itself
-    for auto in (False, True):
+    for auto in auto_modes:
         d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
         try:
             d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))

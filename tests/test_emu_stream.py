@@ -44,7 +44,7 @@ def test_live_ring_raw_formats(emu, fmt):
 
 def test_superframe_filter(emu):
     """DAB+ superframe synchronisation, Reed-Solomon and AU CRCs on the device = SuperframeFilter::Feed, state carried over batches"""
-    got = P.check_superframes_vs_oracle(factory, nf=20)
+    got = P.check_superframes_vs_oracle(factory, nf=20, auto_modes=(True,))     # (the GPU run checks both launch paths)
     ev = got[0][0]
     assert any(e[0] > 0 for e in ev) and any(e[1] and e[2] and e[6] != 7 for e in ev) and any(not e[2] for e in ev[2:])   # corrections, a broken AU, a lost sync
 
