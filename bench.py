@@ -117,9 +117,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DABPHY_FORCE_DIST") == "1":    # (the env switch lets a 1-GPU box exercise the RCCL path: torchrun --nproc-per-node 1)
         import torch.distributed as dist
-        dist.init_process_group("nccl")          # RCCL
+        dist.init_process_group("nccl")          # RCCL (no device_id: eager RCCL initialisation prints to stdout, and stdout is one JSON line)
     load_package()
     from welle_io_amd import capi, synth
     from welle_io_amd.distributed import gather_fibs
