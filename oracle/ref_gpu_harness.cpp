@@ -134,7 +134,7 @@ int gpu_receiver_run(gpu_run_io* io)
 
 // ---- batch mode: n_ens ensembles (streams of equal length, [n_ens][n_samples] cf32), each with its own FIBProcessor;
 // out per ensemble: ensemble id, number of services listed, number of FIBs that passed the CRC, onServiceDetected calls
-int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected)
+int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii)
 {
     std::vector<std::unique_ptr<Rec>> recs;
     std::vector<RadioControllerInterface*> ctl;
@@ -142,13 +142,13 @@ int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_
     struct CountRec : Rec { int* ok; void onFIBDecodeSuccess(bool good, const uint8_t* bits) override { if (good) (*ok)++; Rec::onFIBDecodeSuccess(good, bits); } };
     for (int e = 0; e < n_ens; e++) { auto r = std::unique_ptr<CountRec>(new CountRec); r->ok = &fib_ok[e]; ctl.push_back(r.get()); recs.push_back(std::move(r)); }
     try {
-        RadioReceiverOptions rro; rro.decodeTII = false;
+        RadioReceiverOptions rro; rro.decodeTII = true;             // per-ensemble onTIIMeasurement calls are counted
         GpuBatchReceiver rx(ctl, (uint32_t)frames_per_step, rro);
         if (dabphy_stream_upload(rx.phy(), iq, (uint64_t)n_samples, 0) != DABPHY_OK) return -2;
         for (int k = 0; k < n_steps; k++) rx.process((uint32_t)frames_per_step);
         for (int e = 0; e < n_ens; e++) {
             eid[e] = rx.getEnsembleId(e); n_listed[e] = (int32_t)rx.getServiceList(e).size(); n_fib_ok[e] = fib_ok[e];
-            n_detected[e] = recs[e]->n_services;
+            n_detected[e] = recs[e]->n_services; n_tii[e] = recs[e]->n_tii;
         }
     } catch (const std::exception& ex) {
         fprintf(stderr, "gpu_batch_run: %s\n", ex.what());

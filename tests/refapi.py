@@ -458,8 +458,8 @@ def gpu_batch_run(iq, frames_per_step, n_steps, lib=GPU_EMU_SO):
     """GpuBatchReceiver (one reference FIBProcessor per ensemble) over [n_ens][n_samples] cf32 -> per-ensemble (eid, services listed, FIBs ok, onServiceDetected calls)"""
     L = C.CDLL(lib)
     iq = np.ascontiguousarray(iq, np.complex64); B, n = iq.shape
-    eid = np.zeros(B, np.int32); nl = np.zeros(B, np.int32); ok = np.zeros(B, np.int32); nd = np.zeros(B, np.int32)
-    L.gpu_batch_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    r = L.gpu_batch_run(_p(iq), n, B, frames_per_step, n_steps, _p(eid), _p(nl), _p(ok), _p(nd))
+    eid = np.zeros(B, np.int32); nl = np.zeros(B, np.int32); ok = np.zeros(B, np.int32); nd = np.zeros(B, np.int32); nt = np.zeros(B, np.int32)
+    L.gpu_batch_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = L.gpu_batch_run(_p(iq), n, B, frames_per_step, n_steps, _p(eid), _p(nl), _p(ok), _p(nd), _p(nt))
     assert r == 0, "gpu_batch_run failed (%d)" % r
-    return eid, nl, ok, nd
+    return eid, nl, ok, nd, nt

@@ -29,7 +29,7 @@ def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(gpu):
     streams, eids = [], [0x10A1, 0x20B2, 0x30C3]
     for e, (eid, cfo) in enumerate(zip(eids, (0, 120, -80))):
         streams.append(synth.make_stream(9, eid=eid, snr_db=20, cfo_hz=cfo, seed=40 + e))
-    eid, listed, ok, detected = R.gpu_batch_run(np.stack(streams), 4, 2, lib=R.GPU_HIP_SO)
+    eid, listed, ok, detected, n_tii = R.gpu_batch_run(np.stack(streams), 4, 2, lib=R.GPU_HIP_SO)
     assert list(eid) == eids and (listed == 18).all() and (ok >= 48).all() and (ok % 12 == 0).all()
 
 

@@ -83,11 +83,12 @@ def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(emu):
     nf = 9
     streams, want = [], []
     for e, (eid, cfo) in enumerate([(0x10A1, 0), (0x20B2, 120), (0x30C3, -80)]):
-        x = synth.make_stream(nf, eid=eid, snr_db=20, cfo_hz=cfo, seed=40 + e)
+        x = synth.make_stream(nf, eid=eid, snr_db=20, cfo_hz=cfo, seed=40 + e, tii=[(7, 33, 0, 1.0)] if e == 1 else None)
         streams.append(x)
         a = R.gpu_receiver_run(x, lib=R.GPU_EMU_SO)            # the single-ensemble facade (itself compared with the reference above)
         want.append((eid, a["n_services"]))
-    eid, listed, ok, detected = R.gpu_batch_run(np.stack(streams), 4, 2, lib=R.GPU_EMU_SO)
+    eid, listed, ok, detected, n_tii = R.gpu_batch_run(np.stack(streams), 4, 2, lib=R.GPU_EMU_SO)
+    assert list(n_tii) == [0, len([m for m in R.orc_receiver_run(streams[1], tii=True)["tii"] if m[0] < 8]), 0] and n_tii[1] >= 1   # decodeTII per ensemble
     for e in range(3):
         assert eid[e] == want[e][0]
         assert listed[e] == 18 and detected[e] == want[e][1]

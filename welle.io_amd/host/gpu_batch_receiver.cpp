@@ -20,6 +20,8 @@ GpuBatchReceiver::GpuBatchReceiver(const std::vector<RadioControllerInterface*>&
     cfg.freqsync_method = (int32_t)rro.freqsyncMethod;
     cfg.disable_coarse = rro.disableCoarseCorrector;
     if (dabphy_create(&cfg, &handle) != DABPHY_OK) throw std::runtime_error("GpuBatchReceiver: dabphy_create failed (no gfx950 device?)");
+    decode_tii = rro.decodeTII;
+    if (decode_tii && dabphy_set_tii(handle, 1) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
 }
 
 GpuBatchReceiver::~GpuBatchReceiver() { dabphy_destroy(handle); }
@@ -33,8 +35,13 @@ size_t GpuBatchReceiver::process(uint32_t n_frames)
     std::vector<uint8_t> fibs(B * n_frames * 12 * 32), ok(B * n_frames * 12);
     dabphy_get_frame_info(handle, info.data());
     dabphy_get_fibs(handle, fibs.data(), ok.data());
+    // RadioReceiverOptions::decodeTII: the measurements of the batch, ordered by frame (tii-decoder.cpp:371-377 -> onTIIMeasurement)
+    const uint32_t tii_cap = 9 * n_frames;
+    std::vector<dabphy_tii_measurement> tii; std::vector<int32_t> n_tii(B, 0);
+    if (decode_tii) { tii.resize(B * tii_cap); dabphy_get_tii(handle, tii.data(), n_tii.data(), tii_cap); }
     size_t decoded = 0;
-    for (size_t e = 0; e < B; e++)
+    for (size_t e = 0; e < B; e++) {
+        uint32_t next_tii = 0;
         for (uint32_t f = 0; f < n_frames; f++) {
             const dabphy_frame_info& fi = info[e * n_frames + f];
             if (fi.valid == 3) { if (synced[e]) { rci[e]->onSyncChange(false); synced[e] = 0; } continue; }   // ofdm-processor.cpp:347-350
@@ -50,6 +57,12 @@ size_t GpuBatchReceiver::process(uint32_t n_frames)
                 if (good) fib[e]->processFIB(bits, (uint16_t)(k / 3));                                           // :221-229
             }
             if (!std::isnan(fi.snr)) rci[e]->onSNR(fi.snr);
+            for (; next_tii < (uint32_t)n_tii[e] && next_tii < tii_cap && tii[e * tii_cap + next_tii].frame == (int32_t)f; next_tii++) {
+                const dabphy_tii_measurement& m = tii[e * tii_cap + next_tii];
+                tii_measurement_t t; t.comb = m.comb; t.pattern = m.pattern; t.delay_samples = m.delay_samples; t.error = m.error;
+                rci[e]->onTIIMeasurement(std::move(t));
+            }
         }
+    }
     return decoded;
 }

@@ -50,4 +50,5 @@ class GpuBatchReceiver {
         std::vector<char> synced;
         dabphy_handle* handle = nullptr;
         uint32_t max_frames;
+        bool decode_tii = false;
 };
