@@ -60,4 +60,7 @@ static inline void lds_dma4(const void* gptr, void* lds_wave_base) { memcpy((cha
 static inline void lds_dma_wait() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 template <int N> static inline void lds_dma_wait_but() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 
+// accumulate into a double in LDS from many threads (order irrelevant to its users)
+static inline void lds_add_f64(double* p, double v) { *p += v; }      // the fibers of a block take turns: no race in the model
+
 } // namespace dabphy

@@ -383,6 +383,30 @@ def check_tii_vs_oracle(d_factory, F=4, nf=17, snr_db=20, cfo=70, pipeline_sync=
         d.close()
 
 
+def check_fine_corrector_paths(d_factory):
+    """k_sync_finish settles the int16 fine-corrector step by an interval test on exact sums and falls back to the reference's
+    ordered float sums when the interval straddles a step: both paths must give the oracle's correctors, and both must be taken"""
+    seen_fast = seen_exact = 0
+    for snr, cfo, seed in ((25, 0, 3), (13, 137, 3), (14, -400, 3), (None, -1000, 4), (9, 30, 5)):
+        x = synth.make_stream(14, snr_db=snr, cfo_hz=cfo, delay=300, seed=seed)
+        o = R.orc_receiver_run(x)
+        d = d_factory(n_ensembles=1, max_frames=4, want_constellation=False)
+        try:
+            d.stream_upload(x[None, :])
+            corr = []
+            for _ in range(4):
+                d.process(4)
+                corr += [(int(i["fine"]), int(i["coarse"])) for i in d.frame_info()[0] if i["valid"] == 1]
+            lost, ex = d.sync_stats()
+        finally:
+            d.close()
+        n = min(len(corr), len(o["corr"]))
+        assert n >= 11 and corr[:n] == [tuple(c) for c in o["corr"][:n]], "correctors differ at snr %s cfo %s" % (snr, cfo)
+        assert lost[0] == 0 and 0 <= ex[0] <= len(corr)
+        seen_exact += int(ex[0]); seen_fast += len(corr) - int(ex[0])
+    assert seen_fast >= 30 and seen_exact >= 5, (seen_fast, seen_exact)
+
+
 def check_error_behaviour(d_factory):
     """signal problems never raise (they surface as valid = 0 / CRC false, like the reference's callbacks); programming errors
     come back as negative status codes with a message, never as a crash (the reference throws std::logic_error / out_of_range)"""

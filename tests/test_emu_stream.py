@@ -73,3 +73,7 @@ def test_live_ring_async_ingest(emu):
 def test_tii_side_path(emu):
     """TIIDecoder on the device: four ensembles with different transmitter sets, sums carried across batches"""
     P.check_tii_vs_oracle(factory)
+
+
+def test_fine_corrector_interval_and_exact_paths(emu):
+    P.check_fine_corrector_paths(factory)

@@ -92,3 +92,7 @@ def test_live_ring_async_ingest(gpu):
 def test_tii_side_path(gpu, pipelined):
     """TIIDecoder on the device: four ensembles with different transmitter sets, sums carried across batches"""
     P.check_tii_vs_oracle(factory, pipeline_sync=pipelined)
+
+
+def test_fine_corrector_interval_and_exact_paths(gpu):
+    P.check_fine_corrector_paths(factory)

@@ -142,6 +142,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_superframes(self.h, subch_index, _p(ev), _p(ne), _p(sf)))
         return ev, ne, sf
 
+    def sync_stats(self):
+        """(failed window searches, frames settled by the ordered float sums) per ensemble since reset"""
+        lost = np.zeros(self.cfg.n_ensembles, np.int32); ex = np.zeros(self.cfg.n_ensembles, np.int32)
+        self._chk(self.lib.dabphy_get_sync_stats(self.h, _p(lost), _p(ex)))
+        return lost, ex
+
     def set_auto_superframes(self, on=True):
         """run the all-sub-channel superframe filter inside every process() call; superframes_stats() then only fetches the totals"""
         self._chk(self.lib.dabphy_set_auto_superframes(self.h, int(on)))

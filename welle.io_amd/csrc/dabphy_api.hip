@@ -693,6 +693,17 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
     return sync(h);
 }
 
+int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) { if (lost) lost[i] = st[i].lost; if (exact_sums) exact_sums[i] = st[i].n_exact_sums; }
+    return DABPHY_OK;
+}
+
 int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
 {
     if (!h || !ratio_percent) return DABPHY_ERR_INVALID;

@@ -15,6 +15,7 @@ struct RxState {
     int32_t synced;         // 0: acquisition needed (notSynced), 1: tracking (SyncOnPhase loop)
     float s_level;          // OFDMProcessor::sLevel (maintained by the acquisition kernel only)
     int32_t lost;           // number of findIndex failures seen
+    int32_t n_exact_sums;   // frames whose fine corrector needed the ordered float sums (k_sync_finish's interval test was undecided)
     // acquisition state machine (survives a call that ran out of samples mid-search)
     int32_t acq_phase;      // 0 priming sLevel, 1 first 50 samples, 2 looking for the dip, 3 looking for the end of the null
     int32_t acq_counter, acq_idx, acq_left;

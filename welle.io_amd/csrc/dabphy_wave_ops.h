@@ -139,4 +139,7 @@ __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 // last N requests has landed")
 template <int N> __device__ __forceinline__ void lds_dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// accumulate into a double in LDS from many threads (order irrelevant to its users)
+__device__ __forceinline__ void lds_add_f64(double* p, double v) { atomicAdd(p, v); }
+
 } // namespace dabphy

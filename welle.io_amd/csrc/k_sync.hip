@@ -56,14 +56,65 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
 // Both kernels are kept small (<= 19 KiB LDS) so that they find room next to the decode kernels of the previous batch that run
 // concurrently on the main stream.
 // ofdm-processor.cpp:447-490: correctors, null symbol, state commit (one thread)
-__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, const float acc, const float acc_im)
+// ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
+__device__ __forceinline__ int32_t fine_from_arg(int32_t fine_old, float a)
+{
+    return (int32_t)(int16_t)((double)fine_old + 0.1 * (double)a / M_PI * (1000 / 2));
+}
+
+// next float towards +inf (up) or -inf
+__device__ __forceinline__ float f32_step(float x, bool up)
+{
+    union { float f; uint32_t u; } v; v.f = x;
+    if ((v.u & 0x7fffffffu) == 0) { v.u = up ? 1u : 0x80000001u; return v.f; }
+    const bool neg = (v.u >> 31) != 0;
+    v.u += (neg != up) ? 1u : 0xffffffffu;                  // away from zero when the step and the sign agree
+    return v.f;
+}
+__device__ __forceinline__ float f32_down(double x) { float f = (float)x; if ((double)f > x) f = f32_step(f, false); return f; }
+__device__ __forceinline__ float f32_up(double x) { float f = (float)x; if ((double)f < x) f = f32_step(f, true); return f; }
+
+// The only thing the reference takes from FreqCorr is the int16 it adds to the fine corrector.  The float sums it accumulates in
+// index order differ from the exact sums by at most E = u Q / (1 - (n + 1) u), Q >= sum over all prefixes |S_k|, u = 2^-24 (each
+// addition errs by at most u times its own result; Higham, "Accuracy and Stability of Numerical Algorithms", section 4.2, with the
+// computed prefixes bounded by the exact ones plus E).  Q comes from block sums: a prefix that ends inside block b is at most
+// |sum of the blocks before b| + sum of the magnitudes inside b.  atan2 is monotone along the edges of a box that avoids the
+// origin and the branch cut, atan2f is within 2 ulp of it, and the corrector expression is monotone in the angle.  So evaluating
+// it at the ends of the interval decides the int16 whenever both ends agree -- all but about one frame in 5000 -- and otherwise the
+// caller falls back to the ordered float sums.  blk[b][0..3] = sum re, sum im, sum |re|, sum |im| of block b (double precision, any
+// order), m[b] = products in block b.  Returns true when decided.
+constexpr int FIN_BLOCK_ROWS = 8, FIN_BLOCKS = (75 + FIN_BLOCK_ROWS - 1) / FIN_BLOCK_ROWS;
+__device__ __forceinline__ bool fine_decided(int32_t fine_old, const double (*blk)[4], int32_t& fine_new)
+{
+    constexpr double n = 75.0 * 504.0, u = 0x1p-24;
+    double sre = 0.0, sim = 0.0, are = 0.0, aim = 0.0, qre = 0.0, qim = 0.0;
+    for (int b = 0; b < FIN_BLOCKS; b++) {
+        const double m = 504.0 * ((b + 1) * FIN_BLOCK_ROWS <= 75 ? FIN_BLOCK_ROWS : 75 - b * FIN_BLOCK_ROWS);
+        qre += m * (fabs(sre) + blk[b][2]); qim += m * (fabs(sim) + blk[b][3]);
+        sre += blk[b][0]; sim += blk[b][1]; are += blk[b][2]; aim += blk[b][3];
+    }
+    constexpr double k = u / (1.0 - (n + 1.0) * u) * (1.0 + 0x1p-30);
+    constexpr double dsum = n * 0x1p-51;                              // this path's own (double precision) summation errors, generously
+    const double ere = k * qre * (1.0 + dsum) + dsum * are + 1e-30, eim = k * qim * (1.0 + dsum) + dsum * aim + 1e-30;
+    const double r_lo = sre - ere, r_hi = sre + ere, i_lo = sim - eim, i_hi = sim + eim;
+    if (!(r_lo > -1e30) || !(r_hi < 1e30) || !(i_lo > -1e30) || !(i_hi < 1e30)) return false;    // (also NaN)
+    const float xl = f32_down(r_lo), xh = f32_up(r_hi), yl = f32_down(i_lo), yh = f32_up(i_hi);
+    // the box must avoid the origin and the branch cut: then atan2 is monotone along every edge and its extremes sit in the corners
+    if (!(xl > 0.0f || yl > 0.0f || yh < 0.0f)) return false;
+    const float c0 = fdlibm_atan2f(yl, xl), c1 = fdlibm_atan2f(yl, xh), c2 = fdlibm_atan2f(yh, xl), c3 = fdlibm_atan2f(yh, xh);
+    float a_lo = fminf(fminf(c0, c1), fminf(c2, c3)), a_hi = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3));
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a_lo = f32_step(a_lo, false); a_hi = f32_step(a_hi, true); }    // atan2f's own error (< 2 ulp) at the corners and at the true point, with room for a binade change
+    const int32_t n_lo = fine_from_arg(fine_old, a_lo), n_hi = fine_from_arg(fine_old, a_hi);
+    fine_new = n_lo;
+    return n_lo == n_hi;
+}
+
+__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, int32_t fine)
 {
     RxState& st = A.state[b];              // updated field by field (the struct carries the 64-entry envelope history)
     FrameDesc d = dfin;
     int32_t coarse = d.coarse_after;                                  // after the coarse corrector of this frame
-    // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
-    const float a = fdlibm_atan2f(acc_im, acc);
-    int32_t fine = (int32_t)(int16_t)((double)st.fine + 0.1 * (double)a / M_PI * (1000 / 2));
     // null symbol (:462-463) is pulled with the new fine corrector
     const int32_t J0 = d.start_index + T_U;
     const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
@@ -84,9 +135,38 @@ __device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int 
 // trip of its 75 x 512 products per ensemble and frame + one launch per frame of the chain.
 struct CpRow { cf32 lo[4], hi[4]; };                 // raw samples buf[j], buf[T_u + j], j = tp + 128 k
 
-__device__ __forceinline__ void cp_row_fetch(const SyncArgs& A, const FrameDesc& d, const cf32* __restrict__ iq, int sy, int tp, CpRow& r)
+// Per-thread walk over the symbols of a frame: ring index and oscillator of buf[tp] of the current row, advanced by `stride`
+// symbols at a time.  The oscillator value is carried in double precision (osc_exact.h) and advanced by complex multiplication;
+// it is re-anchored with osc_exp every 8 rows, so no chain is longer than 8 + 3 + 1 multiplications (error < 6e-15, a twentieth
+// of osc_round's margin).  The step factors are the same for every thread: they live in SGPRs.
+struct CpSteps { dc64 d128, dTU, dRow; int32_t step128, stepTU, stepRow; int64_t aRow; };
+struct CpWalk { int64_t a; dc64 e; int32_t ph; int n; };
+
+__device__ __forceinline__ CpSteps cp_steps(const SyncArgs& A, const FrameDesc& d, int stride)
 {
-    int64_t a = (d.pos + d.start_index + T_U + (int64_t)sy * T_S + tp) % A.ring;
+    CpSteps c;
+    const dc64 x = osc_step(128, d.f_sym), y = osc_step(T_U, d.f_sym), z = osc_step((int64_t)stride * T_S, d.f_sym);
+    c.d128.re = uniform_f64(x.re); c.d128.im = uniform_f64(x.im); c.dTU.re = uniform_f64(y.re); c.dTU.im = uniform_f64(y.im);
+    c.dRow.re = uniform_f64(z.re); c.dRow.im = uniform_f64(z.im);
+    c.step128 = mod_rate64(128LL * d.f_sym); c.stepTU = mod_rate64((int64_t)T_U * d.f_sym); c.stepRow = mod_rate64((int64_t)stride * T_S * d.f_sym);
+    c.aRow = ((int64_t)stride * T_S) % A.ring;
+    return c;
+}
+
+// start at symbol sy0: buf[tp] sits J0 + sy0 T_s + tp samples behind the sync buffer start and carries phase L1 - (sy0 T_s + tp + 1) f
+__device__ __forceinline__ CpWalk cp_walk_begin(const SyncArgs& A, const FrameDesc& d, int sy0, int tp)
+{
+    CpWalk w;
+    w.a = (d.pos + d.start_index + T_U + (int64_t)sy0 * T_S + tp) % A.ring;
+    w.ph = mod_rate64((int64_t)d.L1 - ((int64_t)sy0 * T_S + tp + 1) * (int64_t)d.f_sym);
+    w.e = osc_exp(w.ph);
+    w.n = 0;
+    return w;
+}
+
+__device__ __forceinline__ void cp_row_fetch(const SyncArgs& A, const CpSteps& c, const cf32* __restrict__ iq, int64_t& a_row, int tp, CpRow& r)
+{
+    int64_t a = a_row;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (tp + 128 * k < T_G) {
@@ -95,42 +175,40 @@ __device__ __forceinline__ void cp_row_fetch(const SyncArgs& A, const FrameDesc&
         }
         a += 128; if (a >= A.ring) a -= A.ring;
     }
+    a_row += c.aRow; if (a_row >= A.ring) a_row -= A.ring;
 }
 
-// buf[i] * conj(buf[i - T_u]) of symbol sy (ofdm-processor.cpp:436-441), oscillator applied as getSamples does (:211-214)
-__device__ __forceinline__ void cp_row_emit(const SyncArgs& A, const FrameDesc& d, int sy, int tp, const CpRow& r, cf32* row)
+// buf[i] * conj(buf[i - T_u]) of the walk's current symbol (ofdm-processor.cpp:436-441), oscillator applied as getSamples does
+// (:211-214); p[k] = product j = tp + 128 k (zero beyond the 504 of the guard interval).  Advances the oscillator to the next row.
+__device__ __forceinline__ void cp_row_products(const SyncArgs& A, const CpSteps& c, CpWalk& w, int tp, const CpRow& r, cf32 (&p)[4])
 {
     const cf32* __restrict__ nco = A.tab.nco;
-    const int64_t rel = (int64_t)sy * T_S + tp;
-    const int32_t stepTU = mod_rate64((int64_t)T_U * d.f_sym), step128 = mod_rate64(128LL * d.f_sym);
-    const int32_t ph0 = mod_rate64((int64_t)d.L1 - (rel + 1) * (int64_t)d.f_sym);
-    cf32 o[8];
-    uint32_t hard = 0;
-    {
-        dc64 e = osc_exp(ph0);
-        const dc64 d128 = osc_step(128, d.f_sym), dTU = osc_step(T_U, d.f_sym);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            hard |= osc_round(e, o[2 * k]) << (2 * k);
-            hard |= osc_round(osc_mul(e, dTU), o[2 * k + 1]) << (2 * k + 1);
-            if (k < 3) e = osc_mul(e, d128);
-        }
-    }
-    if (!wave_all(hard == 0)) {
-        int32_t ph = ph0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int32_t ph_hi = ph - stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
-            if ((hard >> (2 * k)) & 1u) o[2 * k] = nco[ph];
-            if ((hard >> (2 * k + 1)) & 1u) o[2 * k + 1] = nco[ph_hi];
-            ph -= step128; if (ph < 0) ph += INPUT_RATE;
-        }
-    }
+    dc64 e = w.e;
+    int32_t ph = w.ph;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int j = tp + 128 * k;
-        if (j < T_G) row[j] = cmul(cmul(r.hi[k], o[2 * k + 1]), cconj(cmul(r.lo[k], o[2 * k])));
+        cf32 o_lo, o_hi;
+        const uint32_t hard_lo = osc_round(e, o_lo), hard_hi = osc_round(osc_mul(e, c.dTU), o_hi);
+        if (hard_lo | hard_hi) {                                            // about one sample in 10^5: the table decides
+            int32_t ph_hi = ph - c.stepTU; if (ph_hi < 0) ph_hi += INPUT_RATE;
+            if (hard_lo) o_lo = nco[ph];
+            if (hard_hi) o_hi = nco[ph_hi];
+        }
+        p[k].re = 0.0f; p[k].im = 0.0f;
+        if (tp + 128 * k < T_G) p[k] = cmul(cmul(r.hi[k], o_hi), cconj(cmul(r.lo[k], o_lo)));
+        if (k < 3) { e = osc_mul(e, c.d128); ph -= c.step128; if (ph < 0) ph += INPUT_RATE; }
     }
+    w.ph -= c.stepRow; if (w.ph < 0) w.ph += INPUT_RATE;
+    if (++w.n == 8) { w.e = osc_exp(w.ph); w.n = 0; }
+    else w.e = osc_mul(w.e, c.dRow);
+}
+
+__device__ __forceinline__ void cp_row_emit(const SyncArgs& A, const CpSteps& c, CpWalk& w, int tp, const CpRow& r, cf32* row)
+{
+    cf32 p[4];
+    cp_row_products(A, c, w, tp, r, p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (tp + 128 * k < T_G) row[tp + 128 * k] = p[k];
 }
 
 constexpr int FINISH_THREADS = 256;
@@ -144,16 +222,61 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
     __syncthreads();
     if (pending != 2) return;
     const FrameDesc d = dfin;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    {
+        // ---- fast path: all four waves form the products, sums in double precision, the int16 decided by interval (fine_decided)
+        __shared__ int s_decided, s_fine;
+        const int tq = t & 127, grp = t >> 7;                                     // the two halves take alternate symbols
+        __shared__ double s_blk[FIN_BLOCKS][4];
+        if (t < FIN_BLOCKS * 4) (&s_blk[0][0])[t] = 0.0;
+        __syncthreads();
+        double sre = 0.0, sim = 0.0, are = 0.0, aim = 0.0;
+        const CpSteps cs2 = cp_steps(A, d, 2);
+        CpWalk w = cp_walk_begin(A, d, grp, tq);
+        CpRow cur, nxt;
+        cp_row_fetch(A, cs2, iq, w.a, tq, cur);
+        int cur_blk = 0;
+#pragma unroll 1
+        for (int sy = grp; sy < 75; sy += 2) {
+            if (sy + 2 < 75) cp_row_fetch(A, cs2, iq, w.a, tq, nxt);
+            if ((sy / FIN_BLOCK_ROWS) != cur_blk) {
+                lds_add_f64(&s_blk[cur_blk][0], sre); lds_add_f64(&s_blk[cur_blk][1], sim); lds_add_f64(&s_blk[cur_blk][2], are); lds_add_f64(&s_blk[cur_blk][3], aim);
+                sre = sim = are = aim = 0.0; cur_blk = sy / FIN_BLOCK_ROWS;
+            }
+            cf32 p[4];
+            cp_row_products(A, cs2, w, tq, cur, p);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sre += (double)p[k].re; sim += (double)p[k].im; are += fabs((double)p[k].re); aim += fabs((double)p[k].im);
+            }
+            cur = nxt;
+        }
+        lds_add_f64(&s_blk[cur_blk][0], sre); lds_add_f64(&s_blk[cur_blk][1], sim); lds_add_f64(&s_blk[cur_blk][2], are); lds_add_f64(&s_blk[cur_blk][3], aim);
+        __syncthreads();
+        if (t == 0) {
+            int32_t fine_new = 0;
+            s_decided = fine_decided(A.state[b].fine, s_blk, fine_new) ? 1 : 0;
+            s_fine = fine_new;
+        }
+        __syncthreads();
+        if (s_decided) {
+            if (t == 0) sync_finish_commit(A, b, dfin, s_fine);
+            return;
+        }
+    }
+    // ---- exact path: the reference's ordered float sums (the interval straddled a multiple of pi/50, or the signal is too weak to bound)
     const bool producer = t >= 128;
     const int tp = t - 128, wv = t >> 6;
-    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     float acc = 0.0f;
     CpRow cur, nxt;
+    const CpSteps cs1 = cp_steps(A, d, 1);
+    CpWalk w1;
     if (producer) {
-        cp_row_fetch(A, d, iq, 0, tp, cur); cp_row_fetch(A, d, iq, 1, tp, nxt);
-        cp_row_emit(A, d, 0, tp, cur, ring);
-        cp_row_emit(A, d, 1, tp, nxt, ring + 512);
-        cp_row_fetch(A, d, iq, 2, tp, nxt);
+        w1 = cp_walk_begin(A, d, 0, tp);
+        cp_row_fetch(A, cs1, iq, w1.a, tp, cur); cp_row_fetch(A, cs1, iq, w1.a, tp, nxt);
+        cp_row_emit(A, cs1, w1, tp, cur, ring);
+        cp_row_emit(A, cs1, w1, tp, nxt, ring + 512);
+        cp_row_fetch(A, cs1, iq, w1.a, tp, nxt);
     }
     __syncthreads();
 #pragma unroll 1
@@ -170,14 +293,14 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
             for (int i = 0; i < 32; i++) acc = chain16(acc, xs[i], (i < 31) ? 16 : 8);         // 504 = 31 * 16 + 8
         } else if (sy + 2 < 75) {
             cur = nxt;
-            if (sy + 3 < 75) cp_row_fetch(A, d, iq, sy + 3, tp, nxt);                          // in flight while row sy+2 is formed
-            cp_row_emit(A, d, sy + 2, tp, cur, ring + ((sy + 2) % 3) * 512);                    // its slot held row sy-1, consumed an iteration ago
+            if (sy + 3 < 75) cp_row_fetch(A, cs1, iq, w1.a, tp, nxt);                          // row sy+3, in flight while row sy+2 is formed
+            cp_row_emit(A, cs1, w1, tp, cur, ring + ((sy + 2) % 3) * 512);                     // its slot held row sy-1, consumed an iteration ago
         }
         __syncthreads();
     }
     if (t == 64) s_sum = acc;
     __syncthreads();
-    if (t == 0) sync_finish_commit(A, b, dfin, acc, s_sum);
+    if (t == 0) { A.state[b].n_exact_sums += 1; sync_finish_commit(A, b, dfin, fine_from_arg(A.state[b].fine, fdlibm_atan2f(s_sum, acc))); }
 }
 
 #ifndef SYNC_FINISH_OCC
