@@ -185,10 +185,12 @@ int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out /* [n_ensembl
 /* onFIBDecodeSuccess: fib [n_ensembles][n_frames][12][32], crc_ok [n_ensembles][n_frames][12] */
 int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok);
 int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensembles] */);
-/* synchroniser counters since dabphy_reset (either pointer may be NULL), [n_ensembles] each: failed window searches
- * (PhaseReference::findIndex < 0, ofdm-processor.cpp:347) and frames whose fine corrector had to be settled by the ordered float
- * sums of ofdm-processor.cpp:435-442 because the interval test on the exact sums was undecided */
-int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums);
+/* synchroniser counters since dabphy_reset (any pointer may be NULL), [n_ensembles] each: failed window searches
+ * (PhaseReference::findIndex < 0, ofdm-processor.cpp:347); frames whose fine corrector had to be settled by the ordered float sums
+ * of ofdm-processor.cpp:435-442 because the interval test on the exact sums was undecided; re-acquisitions whose sLevel
+ * (ofdm-processor.cpp:216) could not be certified because the samples pulled since the last acquisition were no longer all
+ * available (more than 64 frames ago or out of the ring) and the two bracketing replays had not met (DESIGN.md sections 4.3, 7) */
+int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact);
 /* decoded logical frames of sub-channel `subch_index` (order of dabphy_set_subchannels):
  * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file;
  * first_valid[b] = number of leading CIF slots of this batch that carry no frame yet (the de-interleaver emits

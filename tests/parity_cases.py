@@ -407,6 +407,39 @@ def check_fine_corrector_paths(d_factory):
     assert seen_fast >= 30 and seen_exact >= 5, (seen_fast, seen_exact)
 
 
+def check_dropout_relock(d_factory, F=1):
+    """the signal disappears (samples squelched to zero) for 1.4 frames: the window search fails, the receiver searches for a null
+    symbol with the sLevel the reference has at that moment -- it was advanced by every sample pulled while tracking -- lands on
+    data symbols, fails again and re-locks; every attempt's position, window index, correctors and FIBs equal the oracle's"""
+    T_F = 196608
+    x = synth.make_stream(16, snr_db=18, cfo_hz=60, delay=200, seed=8).copy()
+    x[6 * T_F + 50000:7 * T_F + 120000] = 0
+    o = R.orc_receiver_run(x)
+    assert o["n_sync_false"] > 5 and o["n_frames"] >= 13
+    d = d_factory(n_ensembles=1, max_frames=F, want_constellation=False)
+    try:
+        d.stream_upload(x[None, :])
+        got = []
+        for _ in range(40 // F):
+            d.process(F)
+            info = d.frame_info(); fb, ok = d.fibs()
+            for f in range(F):
+                if info[0, f]["valid"] == 1:
+                    got.append((int(info[0, f]["pos"]), int(info[0, f]["start_index"]), int(info[0, f]["fine"]), int(info[0, f]["coarse"]), ok[0, f].copy(), fb[0, f].copy()))
+        lost, ex = d.sync_stats()
+        assert lost[0] >= 2 and d.relock_inexact[0] == 0
+    finally:
+        d.close()
+    n = len(got)
+    assert n >= o["n_frames"] - 1
+    ofib = o["fib"].reshape(-1, 12, 33)
+    for k in range(min(n, o["n_frames"])):
+        g = got[k]
+        assert (g[0], g[1]) == (int(o["frame_pos"][k]), int(o["start_index"][k])), "frame %d found at %s, the reference finds it at %s" % (k, g[:2], (o["frame_pos"][k], o["start_index"][k]))
+        assert (g[2], g[3]) == tuple(int(v) for v in o["corr"][k])
+        assert np.array_equal(g[4], ofib[k, :, 0]) and np.array_equal(g[5], ofib[k, :, 1:])
+
+
 def check_error_behaviour(d_factory):
     """signal problems never raise (they surface as valid = 0 / CRC false, like the reference's callbacks); programming errors
     come back as negative status codes with a message, never as a crash (the reference throws std::logic_error / out_of_range)"""

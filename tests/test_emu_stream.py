@@ -77,3 +77,7 @@ def test_tii_side_path(emu):
 
 def test_fine_corrector_interval_and_exact_paths(emu):
     P.check_fine_corrector_paths(factory)
+
+
+def test_dropout_and_relock(emu):
+    P.check_dropout_relock(factory)

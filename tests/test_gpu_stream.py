@@ -96,3 +96,7 @@ def test_tii_side_path(gpu, pipelined):
 
 def test_fine_corrector_interval_and_exact_paths(gpu):
     P.check_fine_corrector_paths(factory)
+
+
+def test_dropout_and_relock(gpu):
+    P.check_dropout_relock(factory)

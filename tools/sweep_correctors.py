@@ -45,5 +45,6 @@ for it in range(0, n, B):
             bad += 1
             print("MISMATCH stream", it + b, got[b][:k], [tuple(int(v) for v in c) for c in orc[b]["corr"][:k]])
         elif not same:
-            relock += 1                                   # lost lock and re-acquired: the documented sLevel gap
+            relock += 1                                   # differs after a loss of lock
+            print("MISMATCH after loss of lock, stream", it + b)
 print("streams %d  frames %d  frames settled by ordered sums %d  streams differing after a loss of lock %d  other mismatches %d" % (n, frames, exact, relock, bad))

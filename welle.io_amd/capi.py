@@ -145,7 +145,8 @@ class DabPhy:
     def sync_stats(self):
         """(failed window searches, frames settled by the ordered float sums) per ensemble since reset"""
         lost = np.zeros(self.cfg.n_ensembles, np.int32); ex = np.zeros(self.cfg.n_ensembles, np.int32)
-        self._chk(self.lib.dabphy_get_sync_stats(self.h, _p(lost), _p(ex)))
+        self.relock_inexact = np.zeros(self.cfg.n_ensembles, np.int32)
+        self._chk(self.lib.dabphy_get_sync_stats(self.h, _p(lost), _p(ex), _p(self.relock_inexact)))
         return lost, ex
 
     def set_auto_superframes(self, on=True):

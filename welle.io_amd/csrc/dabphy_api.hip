@@ -71,6 +71,7 @@ struct dabphy_handle {
     hipEvent_t ev_beg[ST_COUNT]{}, ev_end[ST_COUNT]{};
     bool ev_used[ST_COUNT]{};
     DevBuf rs_first, rs_result;
+    DevBuf s_hist;                          // [B][HIST_CAP] window searches since the last acquisition (sLevel replay in k_acquire)
     // TII (RadioReceiverOptions::decodeTII): constants, per-batch scratch, per-ensemble sums that live across batches
     bool tii_on = false; bool tii_ran = false;
     bool sf_auto = false, sf_stats_ready = false;   // dabphy_set_auto_superframes: the all-sub-channel filter rides in dabphy_process's submission
@@ -200,7 +201,7 @@ void dabphy_destroy(dabphy_handle* h)
     DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
-    { DevBuf* tb[] = {&h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* tb[] = {&h->s_hist, &h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
@@ -500,7 +501,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
     return DABPHY_OK;
 }
 
-namespace { int launch_superframe_stats(dabphy_handle* h); }
+namespace { int launch_superframe_stats(dabphy_handle* h); constexpr int HIST_CAP = 64; }
 
 // One batch: acquisition where needed, n_frames frame steps of the synchroniser, then the fully parallel stages.
 int dabphy_process(dabphy_handle* h, uint32_t n_frames)
@@ -515,6 +516,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
     if ((r = ensure(h, h->s_soft, (size_t)B * ring_frames * SOFT_PER_FRAME))) return r;
+    if ((r = ensure(h, h->s_hist, (size_t)B * HIST_CAP * sizeof(FrameDesc)))) return r;
     if ((r = ensure(h, h->s_mag, (size_t)B * F * T_U * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_snr, (size_t)B * F * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_fib, (size_t)B * F * 384))) return r;
@@ -537,6 +539,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
         sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse; sa.freqsync = h->cfg.freqsync_method;
         sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
+        sa.hist = h->s_hist.as<FrameDesc>(); sa.hist_cap = HIST_CAP;
         { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
         for (uint32_t f = 0; f < F; f++) {
             // acquisition is only queued while some ensemble may be out of lock (start of a stream, or a failed
@@ -693,14 +696,14 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
     return sync(h);
 }
 
-int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums)
+int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact)
 {
     if (!h) return DABPHY_ERR_INVALID;
     std::vector<RxState> st(h->cfg.n_ensembles);
     if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
     int r = sync(h); if (r) return r;
-    for (size_t i = 0; i < st.size(); i++) { if (lost) lost[i] = st[i].lost; if (exact_sums) exact_sums[i] = st[i].n_exact_sums; }
+    for (size_t i = 0; i < st.size(); i++) { if (lost) lost[i] = st[i].lost; if (exact_sums) exact_sums[i] = st[i].n_exact_sums; if (relock_inexact) relock_inexact[i] = st[i].n_relock_inexact; }
     return DABPHY_OK;
 }
 

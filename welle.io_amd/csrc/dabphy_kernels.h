@@ -13,9 +13,13 @@ struct RxState {
     int32_t coarse;         // coarseCorrector [Hz]
     int32_t fine;           // fineCorrector [Hz], int16 range
     int32_t synced;         // 0: acquisition needed (notSynced), 1: tracking (SyncOnPhase loop)
-    float s_level;          // OFDMProcessor::sLevel (maintained by the acquisition kernel only)
+    float s_level;          // OFDMProcessor::sLevel: advanced by the acquisition kernel sample by sample; the samples pulled while
+                            // tracking are replayed from `hist` when lock is lost (the level is only read by the acquisition)
     int32_t lost;           // number of findIndex failures seen
     int32_t n_exact_sums;   // frames whose fine corrector needed the ordered float sums (k_sync_finish's interval test was undecided)
+    int32_t hist_count, hist_head; // window searches since the last acquisition whose samples sLevel has not seen yet: ring entries head .. head+count-1 of `hist`
+    int32_t hist_dropped;   // 1: older entries were overwritten (or their samples have left the ring): the replay cannot start from an exact level
+    int32_t n_relock_inexact; // re-acquisitions that started from a level the replay could not certify
     // acquisition state machine (survives a call that ran out of samples mid-search)
     int32_t acq_phase;      // 0 priming sLevel, 1 first 50 samples, 2 looking for the dip, 3 looking for the end of the null
     int32_t acq_counter, acq_idx, acq_left;
@@ -57,6 +61,7 @@ struct SyncArgs {
     RxState* state; const DecState* dec; FrameDesc* desc; int n_ens, n_frames, frame;
     int fft_placement, disable_coarse, freqsync;        // FFTPlacementMethod, disableCoarseCorrector, FreqsyncMethod (reference numbering)
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
+    FrameDesc* hist; int hist_cap;                       // [B][hist_cap] ring of the window searches since the last acquisition (sLevel replay)
 };
 
 struct DemodArgs {

@@ -56,6 +56,20 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
 // Both kernels are kept small (<= 19 KiB LDS) so that they find room next to the decode kernels of the previous batch that run
 // concurrently on the main stream.
 // ofdm-processor.cpp:447-490: correctors, null symbol, state commit (one thread)
+// OFDMProcessor::sLevel is advanced by every sample getSample(s) hands out (ofdm-processor.cpp:174,216) but only ever read by the
+// null-symbol search after a loss of lock (:284,:303).  While tracking, the synchroniser therefore just records what was pulled
+// (one descriptor per window search); k_acquire replays those samples through the recurrence when it is next needed.
+__device__ __forceinline__ void hist_append(const SyncArgs& A, int b, RxState& st, const FrameDesc& d)
+{
+    if (!A.hist) return;
+    FrameDesc* h = A.hist + (size_t)b * A.hist_cap;
+    if (st.hist_count == A.hist_cap) {                       // full: forget the oldest
+        st.hist_head = (st.hist_head + 1) % A.hist_cap; st.hist_count--; st.hist_dropped = 1;
+    }
+    h[(st.hist_head + st.hist_count) % A.hist_cap] = d;
+    st.hist_count++;
+}
+
 // ofdm-processor.cpp:450-451: fineCorrector (int16) += 0.1 * arg(FreqCorr) / M_PI * (carrierDiff / 2)
 __device__ __forceinline__ int32_t fine_from_arg(int32_t fine_old, float a)
 {
@@ -126,6 +140,7 @@ __device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int 
     else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
     d.valid = 1;
     dfin = d;
+    hist_append(A, b, st, d);
     st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
     st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
 }
@@ -473,6 +488,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
             g.pos = st.pos + T_U;
             g.local_phase = mod_rate64((int64_t)d.L0 - (int64_t)T_U * d.f_prs);
             g.synced = 0; g.lost = g.lost + 1;
+            hist_append(A, b, g, d);                   // the T_u samples of the failed attempt were pulled too
         }
         return;
     }
@@ -600,6 +616,55 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
     if (t == 0) { s_st = A.state[b]; s_done = s_st.synced ? 1 : 0; }
     __syncthreads();
     if (s_done) return;
+
+    // ---- sLevel catches up with the samples that were pulled while tracking (ofdm-processor.cpp:216: once per sample, float result
+    // of a double expression).  Exact when the history reaches back to the last acquisition; otherwise two runs from the extremes
+    // of what the level can be bracket it (the update is monotone in the level): if they have met by the end, that is the level.
+    if (s_st.hist_count > 0 && A.hist) {
+        const FrameDesc* hist = A.hist + (size_t)b * A.hist_cap;
+        __shared__ float s_lo, s_hi;
+        __shared__ int s_first;
+        if (t == 0) {
+            int first = 0; bool dropped = s_st.hist_dropped != 0;
+            if (!A.loop)                                                         // samples that have left the ring cannot be replayed
+                for (int i = s_st.hist_count - 1; i >= 0; i--) if (hist[(s_st.hist_head + i) % A.hist_cap].pos < A.n_valid - A.ring) { first = i + 1; dropped = true; break; }
+            s_first = first;
+            s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? 3.0e38f : s_st.s_level;
+        }
+        __syncthreads();
+        for (int e = s_first; e < s_st.hist_count; e++) {
+            const FrameDesc d = hist[(s_st.hist_head + e) % A.hist_cap];
+            // what one window search pulled: T_u + start_index samples at f_prs; then, if it succeeded, 75 symbols at f_sym and the null
+            // symbol at null_f (ofdm-processor.cpp:337-344,371-374,432-434,462-463)
+            const int nseg = d.valid == 1 ? 3 : 1;
+            for (int sgm = 0; sgm < nseg; sgm++) {
+                const int64_t off0 = sgm == 0 ? 0 : sgm == 1 ? (int64_t)T_U + d.start_index : (int64_t)T_U + d.start_index + 75LL * T_S;
+                const int64_t n = sgm == 0 ? (int64_t)T_U + (d.valid == 1 ? d.start_index : 0) : sgm == 1 ? 75LL * T_S : T_NULL;
+                const int32_t L = sgm == 0 ? d.L0 : sgm == 1 ? d.L1 : d.null_L, f = sgm == 0 ? d.f_prs : sgm == 1 ? d.f_sym : d.null_f;
+                for (int64_t i0 = 0; i0 < n; i0 += TILE) {
+                    const int m = (int)((n - i0 < TILE) ? n - i0 : TILE);
+                    for (int i = t; i < m; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, d.pos, off0 + i0 + i, nco, L, f, i0 + i));
+                    __syncthreads();
+                    if (t == 0) {
+                        float lo = s_lo, hi = s_hi;
+                        for (int i = 0; i < m; i++) {
+                            const double a = 0.00001 * (double)l1[i];
+                            lo = (float)(a + (1 - 0.00001) * (double)lo);
+                            hi = (float)(a + (1 - 0.00001) * (double)hi);
+                        }
+                        s_lo = lo; s_hi = hi;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (t == 0) {
+            if (s_lo != s_hi) s_st.n_relock_inexact += 1;
+            s_st.s_level = s_hi;
+            s_st.hist_count = 0; s_st.hist_head = 0; s_st.hist_dropped = 0;
+        }
+        __syncthreads();
+    }
 
     for (;;) {
         const int64_t pos = s_st.pos; const int32_t L = s_st.local_phase;
