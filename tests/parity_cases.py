@@ -407,6 +407,33 @@ def check_fine_corrector_paths(d_factory):
     assert seen_fast >= 30 and seen_exact >= 5, (seen_fast, seen_exact)
 
 
+def check_relock_after_long_lock(d_factory, n_locked=70, F=1):       # one frame per call: the coarse corrector sees the FIC ratio as the reference does
+    """lock held for more than the 64 window searches the synchroniser remembers, then a dropout: k_acquire cannot replay sLevel
+    from the last acquisition and brackets it instead (runs from 0 and from 3e38 over the remembered 64 frames); the two runs must
+    have met, and the re-acquisition must land where the reference's does"""
+    T_F = 196608
+    nf = n_locked + 10
+    x = synth.make_stream(nf, snr_db=20, cfo_hz=-45, delay=150, seed=21, subchs=synth.default_subchannels(2)).copy()
+    x[n_locked * T_F + 30000:(n_locked + 1) * T_F + 90000] = 0
+    o = R.orc_receiver_run(x)
+    assert o["n_sync_false"] > 3
+    d = d_factory(n_ensembles=1, max_frames=F, want_constellation=False)
+    try:
+        d.stream_upload(x[None, :])
+        got = []
+        for _ in range((nf + 8) // F + 4):
+            d.process(F)
+            info = d.frame_info()
+            got += [(int(i["pos"]), int(i["start_index"]), int(i["fine"]), int(i["coarse"])) for i in info[0] if i["valid"] == 1]
+        lost, ex = d.sync_stats()
+        assert lost[0] >= 1 and d.relock_inexact[0] == 0, (lost, d.relock_inexact)
+    finally:
+        d.close()
+    want = [(int(o["frame_pos"][k]), int(o["start_index"][k]), int(o["corr"][k][0]), int(o["corr"][k][1])) for k in range(o["n_frames"])]
+    n = min(len(got), len(want))
+    assert n >= o["n_frames"] - 1 and got[:n] == want[:n]
+
+
 def check_dropout_relock(d_factory, F=1):
     """the signal disappears (samples squelched to zero) for 1.4 frames: the window search fails, the receiver searches for a null
     symbol with the sLevel the reference has at that moment -- it was advanced by every sample pulled while tracking -- lands on

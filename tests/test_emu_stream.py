@@ -81,3 +81,7 @@ def test_fine_corrector_interval_and_exact_paths(emu):
 
 def test_dropout_and_relock(emu):
     P.check_dropout_relock(factory)
+
+
+def test_relock_after_long_lock(emu):
+    P.check_relock_after_long_lock(factory)

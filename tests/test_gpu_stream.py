@@ -100,3 +100,7 @@ def test_fine_corrector_interval_and_exact_paths(gpu):
 
 def test_dropout_and_relock(gpu):
     P.check_dropout_relock(factory)
+
+
+def test_relock_after_long_lock(gpu):
+    P.check_relock_after_long_lock(factory)
