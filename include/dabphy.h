@@ -191,6 +191,11 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensemble
  * (ofdm-processor.cpp:216) could not be certified because the samples pulled since the last acquisition were no longer all
  * available (more than 64 frames ago or out of the ring) and the two bracketing replays had not met (DESIGN.md sections 4.3, 7) */
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact);
+/* OFDMProcessor::sLevel (ofdm-processor.cpp:216) is only read when lock has been lost; by default the library advances it then, over
+ * the samples pulled since the last acquisition (up to 64 frames back, as far as they are still in the ring).  on = 1: advance it
+ * after every frame instead (about 3 ms of one GPU lane per frame and ensemble): always exact, meant for the real-time
+ * single-ensemble receiver whose ring holds only a few frames. */
+int dabphy_set_track_slevel(dabphy_handle* h, int32_t on);
 /* decoded logical frames of sub-channel `subch_index` (order of dabphy_set_subchannels):
  * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file;
  * first_valid[b] = number of leading CIF slots of this batch that carry no frame yet (the de-interleaver emits

@@ -51,3 +51,19 @@ def test_facade_reports_tii_measurements(gpu):
     b = R.gpu_receiver_run(x, lib=R.GPU_HIP_SO, tii=True)
     nfr = len(b["nul"])
     assert b["tii"] == [e for e in o["tii"] if e[0] < nfr] and len(b["tii"]) >= 2
+
+
+def test_facade_through_a_dropout(gpu):
+    """the drop-in receiver on the device through a loss of lock: same FIBs, impulse responses and null symbols as the reference facade"""
+    import numpy as np
+    T_F = 196608
+    x = synth.make_stream(19, snr_db=18, cfo_hz=60, delay=200, seed=8).copy()
+    x[9 * T_F + 50000:10 * T_F + 120000] = 0
+    a = R.receiver_run(x)
+    b = R.gpu_receiver_run(x, lib=R.GPU_HIP_SO)
+    n = min(len(a["fib"]), len(b["fib"]))
+    assert a["n_sync_false"] > 3 and n >= len(a["fib"]) - 12 and n >= 12 * 14 and np.array_equal(a["fib"][:n], b["fib"][:n])
+    kk = min(len(a["cir"]), len(b["cir"]))
+    assert kk >= len(a["cir"]) - 1 and np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))
+    kn = min(len(a["nul"]), len(b["nul"]))
+    assert kn >= len(a["nul"]) - 1 and np.array_equal(a["nul"][:kn].view(np.uint32), b["nul"][:kn].view(np.uint32))

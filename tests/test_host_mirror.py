@@ -106,3 +106,21 @@ def test_facade_reports_tii_measurements(emu):
     nfr = len(b["nul"])
     assert b["tii"] == [e for e in o["tii"] if e[0] < nfr] and len(b["tii"]) >= 2
     assert R.gpu_receiver_run(x[:6 * 196608], lib=R.GPU_EMU_SO, tii=False)["tii"] == []
+
+
+def test_facade_through_a_dropout(emu):
+    """the drop-in receiver (small live ring, sLevel followed frame by frame) against the reference facade on a stream whose signal
+    disappears for 1.4 frames after 9 frames of lock: same FIBs, impulse responses (one per attempt, failed ones included), null
+    symbols and sync changes -- i.e. both lose lock, search, and re-lock on the same samples"""
+    T_F = 196608
+    x = synth.make_stream(19, snr_db=18, cfo_hz=60, delay=200, seed=8).copy()
+    x[9 * T_F + 50000:10 * T_F + 120000] = 0
+    a = R.receiver_run(x)
+    b = R.gpu_receiver_run(x, lib=R.GPU_EMU_SO)
+    assert a["n_sync_false"] > 3
+    n = min(len(a["fib"]), len(b["fib"]))
+    assert n >= len(a["fib"]) - 12 and n >= 12 * 14 and np.array_equal(a["fib"][:n], b["fib"][:n])
+    kk = min(len(a["cir"]), len(b["cir"]))
+    assert kk >= len(a["cir"]) - 1 and np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))
+    kn = min(len(a["nul"]), len(b["nul"]))
+    assert kn >= len(a["nul"]) - 1 and np.array_equal(a["nul"][:kn].view(np.uint32), b["nul"][:kn].view(np.uint32))

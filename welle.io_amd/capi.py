@@ -149,6 +149,9 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_sync_stats(self.h, _p(lost), _p(ex), _p(self.relock_inexact)))
         return lost, ex
 
+    def set_track_slevel(self, on=True):
+        self._chk(self.lib.dabphy_set_track_slevel(self.h, int(on)))
+
     def set_auto_superframes(self, on=True):
         """run the all-sub-channel superframe filter inside every process() call; superframes_stats() then only fetches the totals"""
         self._chk(self.lib.dabphy_set_auto_superframes(self.h, int(on)))

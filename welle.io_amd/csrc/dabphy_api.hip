@@ -74,6 +74,7 @@ struct dabphy_handle {
     DevBuf s_hist;                          // [B][HIST_CAP] window searches since the last acquisition (sLevel replay in k_acquire)
     // TII (RadioReceiverOptions::decodeTII): constants, per-batch scratch, per-ensemble sums that live across batches
     bool tii_on = false; bool tii_ran = false;
+    bool track_slevel = false;        // dabphy_set_track_slevel: sLevel follows every tracked frame instead of catching up at a loss of lock
     bool sf_auto = false, sf_stats_ready = false;   // dabphy_set_auto_superframes: the all-sub-channel filter rides in dabphy_process's submission
     DevBuf tii_rot, tii_rank, tii_pat, tii_err, tii_likely, tii_state, tii_events, tii_nev, tii_ovf;
     uint32_t tii_max_events = 0;
@@ -548,6 +549,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             sa.frame = (int)f;
             launch_sync_find(sa, h->sync_stream);       // PRS window search of frame f
             launch_sync_finish(sa, h->sync_stream);     // cyclic-prefix products + their ordered sums -> correctors -> state
+            if (h->track_slevel) launch_slevel_catchup(sa, h->sync_stream);
         }
         { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
     };
@@ -928,6 +930,13 @@ int launch_superframe_stats(dabphy_handle* h)
     }
     return 0;
 }
+}
+
+int dabphy_set_track_slevel(dabphy_handle* h, int32_t on)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    h->track_slevel = on != 0;
+    return DABPHY_OK;
 }
 
 int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on)

@@ -204,5 +204,6 @@ void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
 void launch_sync_find(const SyncArgs& a, hipStream_t s);
 void launch_sync_finish(const SyncArgs& a, hipStream_t s);
 void launch_acquire(const SyncArgs& a, hipStream_t s);
+void launch_slevel_catchup(const SyncArgs& a, hipStream_t s);
 
 } // namespace dabphy

@@ -600,6 +600,58 @@ __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find(SyncAr
     sync_find_body(A, blockIdx.x, A.frame);
 }
 
+// ---- sLevel catches up with the samples that were pulled while tracking (ofdm-processor.cpp:216: once per sample, float result
+// of a double expression).  Exact when the history reaches back to the last point at which the level was exact; otherwise two
+// runs from the extremes of what the level can be bracket it (the update is monotone in the level): if they have met by the end,
+// that is the level.  One work-group per ensemble; s_st = its state (LDS), l1 = a tile of |re| + |im| values (LDS).
+template <int TILE>
+__device__ __forceinline__ void slevel_replay(const SyncArgs& A, const int b, RxState& s_st, float* l1, const cf32* __restrict__ iq, const cf32* __restrict__ nco, const int t)
+{
+    const FrameDesc* hist = A.hist + (size_t)b * A.hist_cap;
+    __shared__ float s_lo, s_hi;
+    __shared__ int s_first;
+    if (t == 0) {
+        int first = 0; bool dropped = s_st.hist_dropped != 0;
+        if (!A.loop)                                                         // samples that have left the ring cannot be replayed
+            for (int i = s_st.hist_count - 1; i >= 0; i--) if (hist[(s_st.hist_head + i) % A.hist_cap].pos < A.n_valid - A.ring) { first = i + 1; dropped = true; break; }
+        s_first = first;
+        s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? 3.0e38f : s_st.s_level;
+    }
+    __syncthreads();
+    for (int e = s_first; e < s_st.hist_count; e++) {
+        const FrameDesc d = hist[(s_st.hist_head + e) % A.hist_cap];
+        // what one window search pulled: T_u + start_index samples at f_prs; then, if it succeeded, 75 symbols at f_sym and the null
+        // symbol at null_f (ofdm-processor.cpp:337-344,371-374,432-434,462-463)
+        const int nseg = d.valid == 1 ? 3 : 1;
+        for (int sgm = 0; sgm < nseg; sgm++) {
+            const int64_t off0 = sgm == 0 ? 0 : sgm == 1 ? (int64_t)T_U + d.start_index : (int64_t)T_U + d.start_index + 75LL * T_S;
+            const int64_t n = sgm == 0 ? (int64_t)T_U + (d.valid == 1 ? d.start_index : 0) : sgm == 1 ? 75LL * T_S : T_NULL;
+            const int32_t L = sgm == 0 ? d.L0 : sgm == 1 ? d.L1 : d.null_L, f = sgm == 0 ? d.f_prs : sgm == 1 ? d.f_sym : d.null_f;
+            for (int64_t i0 = 0; i0 < n; i0 += TILE) {
+                const int m = (int)((n - i0 < TILE) ? n - i0 : TILE);
+                for (int i = t; i < m; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, d.pos, off0 + i0 + i, nco, L, f, i0 + i));
+                __syncthreads();
+                if (t == 0) {
+                    float lo = s_lo, hi = s_hi;
+                    for (int i = 0; i < m; i++) {
+                        const double a = 0.00001 * (double)l1[i];
+                        lo = (float)(a + (1 - 0.00001) * (double)lo);
+                        hi = (float)(a + (1 - 0.00001) * (double)hi);
+                    }
+                    s_lo = lo; s_hi = hi;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (t == 0) {
+        if (s_lo != s_hi) s_st.n_relock_inexact += 1;
+        s_st.s_level = s_hi;
+        s_st.hist_count = 0; s_st.hist_head = 0; s_st.hist_dropped = 0;
+    }
+    __syncthreads();
+}
+
 // ---- acquisition: OFDMProcessor::run from "Initing" / notSynced to SyncOnPhase (ofdm-processor.cpp:249-319).
 // A strictly per-sample recurrence (sLevel IIR evaluated in double, 50-sample moving sum); one work-group per
 // ensemble stages |re|+|im| of the oscillator-corrected samples in LDS, lane 0 walks the state machine.
@@ -617,54 +669,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
     __syncthreads();
     if (s_done) return;
 
-    // ---- sLevel catches up with the samples that were pulled while tracking (ofdm-processor.cpp:216: once per sample, float result
-    // of a double expression).  Exact when the history reaches back to the last acquisition; otherwise two runs from the extremes
-    // of what the level can be bracket it (the update is monotone in the level): if they have met by the end, that is the level.
-    if (s_st.hist_count > 0 && A.hist) {
-        const FrameDesc* hist = A.hist + (size_t)b * A.hist_cap;
-        __shared__ float s_lo, s_hi;
-        __shared__ int s_first;
-        if (t == 0) {
-            int first = 0; bool dropped = s_st.hist_dropped != 0;
-            if (!A.loop)                                                         // samples that have left the ring cannot be replayed
-                for (int i = s_st.hist_count - 1; i >= 0; i--) if (hist[(s_st.hist_head + i) % A.hist_cap].pos < A.n_valid - A.ring) { first = i + 1; dropped = true; break; }
-            s_first = first;
-            s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? 3.0e38f : s_st.s_level;
-        }
-        __syncthreads();
-        for (int e = s_first; e < s_st.hist_count; e++) {
-            const FrameDesc d = hist[(s_st.hist_head + e) % A.hist_cap];
-            // what one window search pulled: T_u + start_index samples at f_prs; then, if it succeeded, 75 symbols at f_sym and the null
-            // symbol at null_f (ofdm-processor.cpp:337-344,371-374,432-434,462-463)
-            const int nseg = d.valid == 1 ? 3 : 1;
-            for (int sgm = 0; sgm < nseg; sgm++) {
-                const int64_t off0 = sgm == 0 ? 0 : sgm == 1 ? (int64_t)T_U + d.start_index : (int64_t)T_U + d.start_index + 75LL * T_S;
-                const int64_t n = sgm == 0 ? (int64_t)T_U + (d.valid == 1 ? d.start_index : 0) : sgm == 1 ? 75LL * T_S : T_NULL;
-                const int32_t L = sgm == 0 ? d.L0 : sgm == 1 ? d.L1 : d.null_L, f = sgm == 0 ? d.f_prs : sgm == 1 ? d.f_sym : d.null_f;
-                for (int64_t i0 = 0; i0 < n; i0 += TILE) {
-                    const int m = (int)((n - i0 < TILE) ? n - i0 : TILE);
-                    for (int i = t; i < m; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, d.pos, off0 + i0 + i, nco, L, f, i0 + i));
-                    __syncthreads();
-                    if (t == 0) {
-                        float lo = s_lo, hi = s_hi;
-                        for (int i = 0; i < m; i++) {
-                            const double a = 0.00001 * (double)l1[i];
-                            lo = (float)(a + (1 - 0.00001) * (double)lo);
-                            hi = (float)(a + (1 - 0.00001) * (double)hi);
-                        }
-                        s_lo = lo; s_hi = hi;
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        if (t == 0) {
-            if (s_lo != s_hi) s_st.n_relock_inexact += 1;
-            s_st.s_level = s_hi;
-            s_st.hist_count = 0; s_st.hist_head = 0; s_st.hist_dropped = 0;
-        }
-        __syncthreads();
-    }
+    if (s_st.hist_count > 0 && A.hist) slevel_replay<TILE>(A, b, s_st, l1, iq, nco, t);
 
     for (;;) {
         const int64_t pos = s_st.pos; const int32_t L = s_st.local_phase;
@@ -712,6 +717,28 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
         if (s_done) break;
     }
     if (t == 0) A.state[b] = s_st;
+}
+
+// Continuous mode (dabphy_set_track_slevel): the level follows the tracked frames one by one (3 ms per frame on one lane: meant for
+// the single-ensemble real-time receiver, where it is 3 % of a frame's 96 ms) instead of catching up when lock is lost.
+__global__ void __launch_bounds__(256) k_slevel_catchup(SyncArgs A)
+{
+    constexpr int TILE = 1024;
+    __shared__ float l1[TILE];
+    __shared__ RxState s_st;
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (t == 0) s_st = A.state[b];
+    __syncthreads();
+    if (s_st.hist_count == 0 || !A.hist) return;
+    slevel_replay<TILE>(A, b, s_st, l1, A.iq + (size_t)b * A.iq_stride, A.tab.nco, t);
+    if (t == 0) {
+        RxState& g = A.state[b];
+        g.s_level = s_st.s_level; g.hist_count = 0; g.hist_head = 0; g.hist_dropped = 0; g.n_relock_inexact = s_st.n_relock_inexact;
+    }
+}
+void launch_slevel_catchup(const SyncArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_slevel_catchup, dim3(a.n_ens), dim3(256), 0, s, a);
 }
 
 void launch_sync_find(const SyncArgs& a, hipStream_t s)

@@ -41,6 +41,7 @@ GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterfac
     cfg.want_constellation = 1; cfg.want_impulse_response = 1;
     const int r = dabphy_create(&cfg, &phy);
     if (r != DABPHY_OK) throw std::runtime_error("GpuRadioReceiver: dabphy_create failed (no gfx950 device?)");
+    dabphy_set_track_slevel(phy, 1);                                    // real-time receiver, small ring: keep sLevel exact frame by frame
 }
 
 GpuRadioReceiver::~GpuRadioReceiver()
