@@ -633,11 +633,27 @@ __device__ __forceinline__ void slevel_replay(const SyncArgs& A, const int b, Rx
                 __syncthreads();
                 if (t == 0) {
                     float lo = s_lo, hi = s_hi;
-                    for (int i = 0; i < m; i++) {
+                    const bool one = lo == hi;                                   // exact start: a single chain
+                    int i = 0;
+                    for (; i + 16 <= m; i += 16) {                               // operands fetched 16 at a time, off the dependent chain
+                        const float4 q0 = *reinterpret_cast<const float4*>(l1 + i), q1 = *reinterpret_cast<const float4*>(l1 + i + 4),
+                                     q2 = *reinterpret_cast<const float4*>(l1 + i + 8), q3 = *reinterpret_cast<const float4*>(l1 + i + 12);
+                        const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                        double a[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) a[k] = 0.00001 * (double)v[k];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            lo = (float)(a[k] + (1 - 0.00001) * (double)lo);
+                            if (!one) hi = (float)(a[k] + (1 - 0.00001) * (double)hi);
+                        }
+                    }
+                    for (; i < m; i++) {
                         const double a = 0.00001 * (double)l1[i];
                         lo = (float)(a + (1 - 0.00001) * (double)lo);
-                        hi = (float)(a + (1 - 0.00001) * (double)hi);
+                        if (!one) hi = (float)(a + (1 - 0.00001) * (double)hi);
                     }
+                    if (one) hi = lo;
                     s_lo = lo; s_hi = hi;
                 }
                 __syncthreads();
@@ -658,7 +674,7 @@ __device__ __forceinline__ void slevel_replay(const SyncArgs& A, const int b, Rx
 __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
 {
     constexpr int TILE = 1024;
-    __shared__ float l1[TILE];
+    __shared__ __attribute__((aligned(16))) float l1[TILE];
     __shared__ RxState s_st;
     __shared__ int s_done;
 
@@ -724,7 +740,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
 __global__ void __launch_bounds__(256) k_slevel_catchup(SyncArgs A)
 {
     constexpr int TILE = 1024;
-    __shared__ float l1[TILE];
+    __shared__ __attribute__((aligned(16))) float l1[TILE];
     __shared__ RxState s_st;
     const int t = threadIdx.x, b = blockIdx.x;
     if (t == 0) s_st = A.state[b];
