@@ -407,6 +407,34 @@ def check_fine_corrector_paths(d_factory):
     assert seen_fast >= 30 and seen_exact >= 5, (seen_fast, seen_exact)
 
 
+def check_fine_corrector_on_the_edge(d_factory):
+    """carrier offsets that leave the residual right at the fine corrector's step (a step is taken when the measured angle exceeds
+    pi/50, i.e. a residual of about 10 Hz): the decision hangs on the last bits of FreqCorr -- the interval test must decline when it
+    has to, and the ordered sums must give the reference's step.  (The offsets were found by scanning: two bands 0.08 Hz wide.)"""
+    cfos = [10.09 + 0.01 * b for b in range(10)] + [10.59 + 0.01 * b for b in range(10)]
+    B = len(cfos)
+    base = synth.make_stream(9, snr_db=None, cfo_hz=0.0, delay=100, seed=60)
+    n = np.arange(len(base))
+    xs = [(base * np.exp(2j * np.pi * c * n / 2048000.0)).astype(np.complex64) for c in cfos]
+    want = [R.orc_receiver_run(x, disable_coarse=True) for x in xs]
+    d = d_factory(n_ensembles=B, max_frames=4, want_constellation=False, disable_coarse=True)
+    try:
+        d.stream_upload(np.stack(xs))
+        got = [[] for _ in range(B)]
+        for _ in range(2):
+            d.process(4)
+            info = d.frame_info()
+            for b in range(B):
+                got[b] += [(int(i["fine"]), int(i["coarse"])) for i in info[b] if i["valid"] == 1]
+        lost, ex = d.sync_stats()
+    finally:
+        d.close()
+    for b in range(B):
+        k = min(len(got[b]), len(want[b]["corr"]))
+        assert k >= 7 and got[b][:k] == [tuple(int(v) for v in c) for c in want[b]["corr"][:k]], (b, cfos[b], got[b][:k], want[b]["corr"][:k].tolist())
+    assert (ex > 0).sum() >= 10 and (ex == 0).sum() >= 1, ex                    # the edge was really met, and not everywhere
+
+
 def check_relock_after_long_lock(d_factory, n_locked=70, F=1):       # one frame per call: the coarse corrector sees the FIC ratio as the reference does
     """lock held for more than the 64 window searches the synchroniser remembers, then a dropout: k_acquire cannot replay sLevel
     from the last acquisition and brackets it instead (runs from 0 and from 3e38 over the remembered 64 frames); the two runs must

@@ -85,3 +85,7 @@ def test_dropout_and_relock(emu):
 
 def test_relock_after_long_lock(emu):
     P.check_relock_after_long_lock(factory)
+
+
+def test_fine_corrector_on_the_edge(emu):
+    P.check_fine_corrector_on_the_edge(factory)

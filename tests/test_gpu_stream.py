@@ -104,3 +104,7 @@ def test_dropout_and_relock(gpu):
 
 def test_relock_after_long_lock(gpu):
     P.check_relock_after_long_lock(factory)
+
+
+def test_fine_corrector_on_the_edge(gpu):
+    P.check_fine_corrector_on_the_edge(factory)
