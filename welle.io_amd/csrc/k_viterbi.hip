@@ -211,7 +211,9 @@ __global__ void __launch_bounds__(64, VIT_OCC) k_viterbi(VitArgs A)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int nn = n - k;                                 // n is 7 mod 8: nn & 7 = 7 - k
-            const uint32_t wsel = (T & 16) ? dq[k].y : dq[k].x;
+            const uint32_t dx = dq[k].x, dy = dq[k].y;
+            const uint32_t wsel = dx ^ ((dx ^ dy) & (0u - ((T >> 4) & 1u)));   // (T & 16) ? dy : dx as a bitwise blend: a select of two array
+                                                                                 // elements would turn dq[] into an indexed LDS array
             const uint32_t bit = ((T >> 1) & 7) + 8 * (2 * (T & 1) + (T >> 5));
             const uint32_t kk = (wsel >> bit) & 1;
             T = (T >> 1) | (kk << 5);
