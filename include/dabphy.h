@@ -72,6 +72,15 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out);      /* RadioR
 void dabphy_destroy(dabphy_handle* h);
 const char* dabphy_last_error(const dabphy_handle* h);
 const char* dabphy_device_name(const dabphy_handle* h);
+/* the configuration in effect (defaults resolved: e.g. demod_chunk = 25 when n_ensembles * max_frames >= 1024, else 15; the
+ * synchroniser options as last set by dabphy_set_options) */
+int dabphy_get_config(const dabphy_handle* h, dabphy_config* out);
+/* RadioReceiver::setReceiverOptions -> OFDMProcessor::setReceiverOptions (ofdm-processor.cpp:518-529) at run time: the FFT placement
+ * and frequency-sync methods apply from the next frame on (the reference calls phaseRef.selectFFTWindowPlacement and reads
+ * freqsyncMethod per frame, :399); a CHANGE of disable_coarse restarts the receiver exactly like the reference does (:523-528
+ * resetCoarseCorrector + restart: dabphy_reset semantics, the stream position is kept).  In pipelined mode frames that were already
+ * synchronised ahead keep the old options.  *restarted (may be NULL) tells whether the restart happened. */
+int dabphy_set_options(dabphy_handle* h, int32_t fft_placement, int32_t freqsync_method, int32_t disable_coarse, int32_t* restarted);
 
 /* protection helpers (pure host) */
 int dabphy_protection_fic(dabphy_protection* p);
@@ -184,6 +193,9 @@ typedef struct {
 int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out /* [n_ensembles][n_frames] */);
 /* onFIBDecodeSuccess: fib [n_ensembles][n_frames][12][32], crc_ok [n_ensembles][n_frames][12] */
 int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok);
+/* the same buffers where they lie in HBM (DEVICE pointers, valid until the next dabphy_process / dabphy_destroy; complete when
+ * dabphy_process has returned): for consumers on the device, e.g. the multi-GPU gather of the FIC over RCCL */
+int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_t** d_crc_ok);
 int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensembles] */);
 /* synchroniser counters since dabphy_reset (any pointer may be NULL), [n_ensembles] each: failed window searches
  * (PhaseReference::findIndex < 0, ofdm-processor.cpp:347); frames whose fine corrector had to be settled by the ordered float sums
@@ -191,16 +203,24 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensemble
  * (ofdm-processor.cpp:216) could not be certified because the samples pulled since the last acquisition were no longer all
  * available (more than 64 frames ago or out of the ring) and the two bracketing replays had not met (DESIGN.md sections 4.3, 7) */
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact);
+/* Scan mode (RadioReceiver::restart(doScan = true) -> OFDMProcessor::set_scanMode, ofdm-processor.cpp:256-262,351-355), [n_ensembles]
+ * each, since dabphy_reset: attempts = entries into the notSynced state (after the sLevel priming, after every hopeless null search,
+ * after every failed window search) -- the reference reports onSignalPresence(false) when this exceeds 5 before a lock;
+ * attempts_at_first_lock = that count when the first window search succeeded (-1: none yet) -- onSignalPresence(true) if <= 5. */
+int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts_at_first_lock);
 /* OFDMProcessor::sLevel (ofdm-processor.cpp:216) is only read when lock has been lost; by default the library advances it then, over
  * the samples pulled since the last acquisition (up to 64 frames back, as far as they are still in the ring).  on = 1: advance it
  * after every frame instead (about 3 ms of one GPU lane per frame and ensemble): always exact, meant for the real-time
  * single-ensemble receiver whose ring holds only a few frames. */
 int dabphy_set_track_slevel(dabphy_handle* h, int32_t on);
 /* decoded logical frames of sub-channel `subch_index` (order of dabphy_set_subchannels):
- * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file;
- * first_valid[b] = number of leading CIF slots of this batch that carry no frame yet (the de-interleaver emits
- * its first frame on the 17th CIF, dab-audio.cpp:146-149). */
-int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t* first_valid);
+ * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file (out_capacity = size of
+ * `out` in bytes; DABPHY_ERR_INVALID when it is too small).  Row layout: the logical frames of an ensemble are packed in CIF order
+ * from row 0 on, whatever slots of the batch its demodulated frames occupied (a slot that failed its window search leaves no gap):
+ * rows [first_valid[b], n_rows[b]) are this batch's frames, n_rows[b] = 4 x (frames of ensemble b with valid == 1), rows beyond it
+ * are undefined.  first_valid[b] = number of leading rows that carry no frame yet (the de-interleaver emits its first frame on the
+ * 17th CIF, dab-audio.cpp:146-149).  first_valid / n_rows may be NULL. */
+int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
 int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_frames][2048] */);      /* onNewImpulseResponse */
 /* onNewNullSymbol (ofdm-processor.cpp:462-469): the 2656 oscillator-corrected samples of the null symbol that follows each
  * demodulated frame of the last batch, out[n_ensembles][n_frames][2656][2] (zeros where valid != 1).  Computed on request. */

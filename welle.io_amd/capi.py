@@ -272,10 +272,42 @@ class DabPhy:
         return r
 
     def msc(self, idx):
+        """-> (out [B][4F][bytes], first_valid [B]); rows [first_valid[b], self.msc_rows[b]) are the batch's logical frames"""
         B, F = self.cfg.n_ensembles, self._last
-        out = np.zeros((B, 4 * F, self._sub_bytes[idx]), np.uint8); fv = np.zeros(B, np.int32)
-        self._chk(self.lib.dabphy_get_msc(self.h, idx, _p(out), _p(fv)))
+        out = np.zeros((B, 4 * F, self._sub_bytes[idx]), np.uint8); fv = np.zeros(B, np.int32); self.msc_rows = np.zeros(B, np.int32)
+        self._chk(self.lib.dabphy_get_msc(self.h, idx, _p(out), C.c_size_t(out.nbytes), _p(fv), _p(self.msc_rows)))
         return out, fv
+
+    def config(self):
+        c = Config(); self._chk(self.lib.dabphy_get_config(self.h, C.byref(c))); return c
+
+    def demod_chunk(self):
+        return self.config().demod_chunk
+
+    def set_options(self, fft_placement=2, freqsync_method=2, disable_coarse=False):
+        """RadioReceiver::setReceiverOptions at run time; returns True when the change restarted the synchroniser"""
+        r = C.c_int32(0)
+        self._chk(self.lib.dabphy_set_options(self.h, fft_placement, freqsync_method, int(disable_coarse), C.byref(r)))
+        return bool(r.value)
+
+    def scan_stats(self):
+        a = np.zeros(self.cfg.n_ensembles, np.int32); f = np.zeros(self.cfg.n_ensembles, np.int32)
+        self._chk(self.lib.dabphy_get_scan_stats(self.h, _p(a), _p(f)))
+        return a, f
+
+    def fibs_device(self):
+        """(fib [B][F][12][32], crc_ok [B][F][12]) as torch uint8 tensors aliasing the library's HBM buffers (valid until the next
+        process()); for device-side consumers such as the RCCL gather of the multi-GPU bench"""
+        import torch
+        B, F = self.cfg.n_ensembles, self._last
+        pf = C.c_void_p(); po = C.c_void_p()
+        self._chk(self.lib.dabphy_get_fibs_device(self.h, C.byref(pf), C.byref(po)))
+
+        class _Dev:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "|u1", "data": (ptr, False), "version": 2}
+        dev = "cuda:%d" % self.cfg.device
+        return (torch.as_tensor(_Dev(pf.value, (B, F, 12, 32)), device=dev), torch.as_tensor(_Dev(po.value, (B, F, 12)), device=dev))
 
     def impulse_response(self):
         B, F = self.cfg.n_ensembles, self._last

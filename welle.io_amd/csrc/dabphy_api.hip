@@ -213,6 +213,26 @@ void dabphy_destroy(dabphy_handle* h)
 const char* dabphy_last_error(const dabphy_handle* h) { return h ? h->err.c_str() : "null handle"; }
 const char* dabphy_device_name(const dabphy_handle* h) { return h ? h->devname : ""; }
 
+int dabphy_get_config(const dabphy_handle* h, dabphy_config* out)
+{
+    if (!h || !out) return DABPHY_ERR_INVALID;
+    *out = h->cfg;
+    return DABPHY_OK;
+}
+
+static int reset_synchroniser(dabphy_handle* h, bool decoder_too);
+
+int dabphy_set_options(dabphy_handle* h, int32_t fft_placement, int32_t freqsync_method, int32_t disable_coarse, int32_t* restarted)
+{
+    if (!h || fft_placement < 0 || fft_placement > 2 || freqsync_method < 0 || freqsync_method > 2) return DABPHY_ERR_INVALID;
+    const bool need_reset = (h->cfg.disable_coarse != 0) != (disable_coarse != 0);      // ofdm-processor.cpp:521
+    h->cfg.fft_placement = fft_placement; h->cfg.freqsync_method = freqsync_method; h->cfg.disable_coarse = disable_coarse != 0;
+    if (restarted) *restarted = need_reset ? 1 : 0;
+    // :523-528 -> OFDMProcessor::restart (:115-132): correctors, phase, sLevel and the sync state start over; the decoders (FIC
+    // counter, SNR filter, time de-interleaver, superframe windows) are not touched by this path
+    return (need_reset && h->s_iq) ? reset_synchroniser(h, false) : DABPHY_OK;
+}
+
 int dabphy_protection_fic(dabphy_protection* p) { return p ? protection_fic(p) : DABPHY_ERR_INVALID; }
 int dabphy_protection_eep(dabphy_protection* p, int bitrate, int profile_b, int level)
 {
@@ -319,17 +339,42 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
 
 // =================================================================================== streaming receiver
 
+// OFDMProcessor::restart (ofdm-processor.cpp:115-132) + the start of run(): correctors, phase and sync state zero, sLevel primed over
+// the next T_F/2 samples (:252-255).  decoder_too (dabphy_reset: a freshly bound stream) also rewinds the stream to sample 0 and
+// clears the frame counter; without it (setReceiverOptions on a running receiver) the stream goes on where the DECODED frames end:
+// frames that pipelined mode had synchronised ahead are handed back, so the time de-interleavers see every CIF exactly once.
+static int reset_synchroniser(dabphy_handle* h, bool decoder_too)
+{
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t B = h->cfg.n_ensembles;
+    std::vector<RxState> init(B);
+    std::vector<FrameDesc> ahead;
+    if (!decoder_too) {
+        HIPCHK(h, hipMemcpy(init.data(), h->d_state, init.size() * sizeof(RxState), hipMemcpyDeviceToHost));
+        if (h->presynced && h->s_desc2[h->desc_sel].p) {
+            ahead.resize((size_t)B * h->presynced);
+            HIPCHK(h, hipMemcpy(ahead.data(), h->s_desc2[h->desc_sel].p, ahead.size() * sizeof(FrameDesc), hipMemcpyDeviceToHost));
+        }
+    }
+    for (uint32_t b = 0; b < B; b++) {
+        RxState& s = init[b];
+        int64_t frame_no = decoder_too ? 0 : s.frame_no, pos = decoder_too ? 0 : s.pos;
+        if (!ahead.empty()) { frame_no = ahead[(size_t)b * h->presynced].frame_no; pos = ahead[(size_t)b * h->presynced].pos; }
+        memset(&s, 0, sizeof s);
+        s.acq_phase = 0; s.acq_left = T_F / 2; s.first_lock_attempts = -1; s.frame_no = frame_no; s.pos = pos;
+    }
+    h->presynced = 0;
+    HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
+    return sync(h);
+}
+
 int dabphy_reset(dabphy_handle* h)
 {
     if (!h) return DABPHY_ERR_INVALID;
-    // OFDMProcessor::restart + the start of run(): everything zero, sLevel primed over the first T_F/2 samples (:252-255)
-    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
-    h->presynced = 0; h->desc_sel = 0; h->need_acquire = true;
+    int r = reset_synchroniser(h, true); if (r) return r;
+    h->desc_sel = 0;
     HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
-    std::vector<RxState> init(h->cfg.n_ensembles);
-    memset(init.data(), 0, init.size() * sizeof(RxState));
-    for (auto& s : init) { s.acq_phase = 0; s.acq_left = T_F / 2; }
-    HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
     for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
     if (h->tii_state.p) HIPCHK(h, hipMemsetAsync(h->tii_state.p, 0, h->tii_state.cap, h->stream));      // a new OFDMProcessor owns a new TIIDecoder
@@ -469,6 +514,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         (void)e;
     }
     h->classes.clear();
+    h->last_frames = 0; h->last_desc = nullptr; h->sf_stats_ready = false;     // the class outputs of the last batch are gone with the classes
     h->subch.assign(list, list + n);
     for (uint32_t i = 0; i < n; i++) {
         dabphy_handle::MscClass* cls = nullptr;
@@ -502,7 +548,27 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
     return DABPHY_OK;
 }
 
-namespace { int launch_superframe_stats(dabphy_handle* h); constexpr int HIST_CAP = 64; }
+namespace {
+int launch_superframe_stats(dabphy_handle* h); constexpr int HIST_CAP = 64;
+// device buffers of the superframe filter for one class and F frames per batch (the window state is zeroed when it is (re)allocated)
+int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F)
+{
+    const uint32_t B = h->cfg.n_ensembles;
+    const int fb = cls.prot.nbits / 8, M = (int)cls.members.size();
+    if ((cls.prot.nbits / 24) % 8 || fb < 10) return 0;                  // not a DAB+ rate: the filter never runs on this class
+    const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+    const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
+    int r;
+    if (cls.sf_state.cap < stride * B * M) {
+        if ((r = ensure(h, cls.sf_state, stride * B * M))) return r;
+        HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
+    }
+    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * M * n_cif))) return r;
+    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B * M))) return r;
+    if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
+    return 0;
+}
+}
 
 // One batch: acquisition where needed, n_frames frame steps of the synchroniser, then the fully parallel stages.
 int dabphy_process(dabphy_handle* h, uint32_t n_frames)
@@ -523,6 +589,29 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     if ((r = ensure(h, h->s_fib, (size_t)B * F * 384))) return r;
     if ((r = ensure(h, h->s_ok, (size_t)B * F * 12))) return r;
     if (h->cfg.want_constellation && (r = ensure(h, h->s_con, (size_t)B * F * 1200 * sizeof(cf32)))) return r;
+    // every allocation this call may need happens here, before any kernel is queued or any pipeline state advances: a failed
+    // hipMalloc leaves the handle as it was
+    VitClass fic_c{};
+    {
+        fic_c.nbits = 768; fic_c.nsteps = 774; fic_c.n_cw = (int)(B * F * 4); fic_c.n_groups = (fic_c.n_cw + 63) / 64; fic_c.dedisperse = 1;
+        const size_t cells = (size_t)fic_c.n_groups * fic_c.nsteps * 64;
+        if ((r = ensure(h, h->fsym, cells * sizeof(uint32_t)))) return r;
+        if ((r = ensure(h, h->fdec, cells * sizeof(uint2)))) return r;
+        if ((r = ensure(h, h->s_fib, (size_t)fic_c.n_groups * 64 * 96))) return r;      // the class output holds whole groups of 64 codewords
+        if (h->tii_on) {
+            if ((r = ensure(h, h->tii_err, (size_t)B * F * TII_MAX_LIKELY * TII_NERR * sizeof(float)))) return r;
+            if ((r = ensure(h, h->tii_likely, (size_t)B * F * (1 + TII_MAX_LIKELY) * sizeof(int32_t)))) return r;
+            if ((r = ensure(h, h->tii_events, (size_t)B * TII_MAX_LIKELY * h->cfg.max_frames * sizeof(TiiEvent)))) return r;
+            if ((r = ensure(h, h->tii_nev, (size_t)B * sizeof(int32_t)))) return r;
+        }
+        for (auto& cls : h->classes) {
+            VitClass c{};
+            if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * cls.members.size()), 1))) return r;
+            if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
+            if (h->sf_auto && (r = prepare_superframes(h, cls, F))) return r;
+        }
+        if (h->sf_auto && (r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
+    }
     h->soft_ring = ring_frames;
 
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) h->ev_used[i] = false;
@@ -543,9 +632,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         sa.hist = h->s_hist.as<FrameDesc>(); sa.hist_cap = HIST_CAP;
         { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
         for (uint32_t f = 0; f < F; f++) {
-            // acquisition is only queued while some ensemble may be out of lock (start of a stream, or a failed
-            // window search seen in the last finished batch); tracking ensembles skip it inside the kernel anyway
-            if (h->need_acquire) launch_acquire(sa, h->sync_stream);
+            // acquisition is queued in front of every frame step, as the reference falls back to it after any failed window search
+            // (ofdm-processor.cpp:347-350): an ensemble that loses lock in slot f re-acquires before slot f + 1.  Tracking ensembles
+            // leave the kernel after one load.
+            launch_acquire(sa, h->sync_stream);
             sa.frame = (int)f;
             launch_sync_find(sa, h->sync_stream);       // PRS window search of frame f
             launch_sync_finish(sa, h->sync_stream);     // cyclic-prefix products + their ordered sums -> correctors -> state
@@ -598,12 +688,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     // FIC: 4 codewords per frame.  Only B*F/16 wavefronts of 774 serial trellis steps: it runs on its own stream beside the
     // MSC classes (own Viterbi scratch), filling execution slots instead of holding the whole device for a latency-bound tail.
     {
-        VitClass c{};
-        c.nbits = 768; c.nsteps = 774; c.n_cw = (int)(B * F * 4); c.n_groups = (c.n_cw + 63) / 64; c.dedisperse = 1;
-        const size_t cells = (size_t)c.n_groups * c.nsteps * 64;
-        if ((r = ensure(h, h->fsym, cells * sizeof(uint32_t)))) return r;
-        if ((r = ensure(h, h->fdec, cells * sizeof(uint2)))) return r;
-        if ((r = ensure(h, h->s_fib, (size_t)c.n_groups * 64 * 96))) return r;      // the class output holds whole groups of 64 codewords
+        VitClass c = fic_c;
         c.sym = h->fsym.as<uint32_t>(); c.dec = h->fdec.as<uint2>(); c.out = h->s_fib.as<uint8_t>();
         FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
@@ -622,11 +707,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->tii_on) {
             // TII side path (ofdm-processor.cpp:462-466 -> TIIDecoder): needs only the samples and the frame descriptors, rides behind
             // the FIC on the auxiliary stream
-            if ((r = ensure(h, h->tii_err, (size_t)B * F * TII_MAX_LIKELY * TII_NERR * sizeof(float)))) return r;
-            if ((r = ensure(h, h->tii_likely, (size_t)B * F * (1 + TII_MAX_LIKELY) * sizeof(int32_t)))) return r;
             h->tii_max_events = TII_MAX_LIKELY * h->cfg.max_frames;
-            if ((r = ensure(h, h->tii_events, (size_t)B * h->tii_max_events * sizeof(TiiEvent)))) return r;
-            if ((r = ensure(h, h->tii_nev, (size_t)B * sizeof(int32_t)))) return r;
             TiiArgs ta{};
             ta.tab = h->tab; ta.iq = h->s_iq; ta.iq_stride = h->s_stride; ta.ring = (int64_t)h->s_ring; ta.desc = d_desc; ta.n_ens = (int)B; ta.n_frames = (int)F;
             ta.rot = h->tii_rot.as<cf32>(); ta.rank = h->tii_rank.as<int32_t>(); ta.pattern = h->tii_pat.as<uint8_t>();
@@ -698,6 +779,24 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
     return sync(h);
 }
 
+int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_t** d_crc_ok)
+{
+    if (!h || !d_fib || !d_crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
+    *d_fib = h->s_fib.as<uint8_t>(); *d_crc_ok = h->s_ok.as<uint8_t>();
+    return DABPHY_OK;
+}
+
+int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts_at_first_lock)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) { if (attempts) attempts[i] = st[i].attempts; if (attempts_at_first_lock) attempts_at_first_lock[i] = st[i].first_lock_attempts; }
+    return DABPHY_OK;
+}
+
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact)
 {
     if (!h) return DABPHY_ERR_INVALID;
@@ -719,9 +818,10 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
     return DABPHY_OK;
 }
 
-int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t* first_valid)
+int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows)
 {
     if (!h || !out || subch_index >= h->subch.size() || !h->last_frames) return DABPHY_ERR_INVALID;
+    if (out_capacity < (size_t)h->cfg.n_ensembles * 4 * h->last_frames * (h->subch[subch_index].prot.nbits / 8)) { h->err = "dabphy_get_msc: output buffer too small"; return DABPHY_ERR_INVALID; }
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
     for (auto& cls : h->classes) {
         for (size_t m = 0; m < cls.members.size(); m++) {
@@ -737,6 +837,12 @@ int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, int32_t
                     // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149)
                     const int64_t c0 = 4 * h->h_desc[(size_t)b * F].frame_no;
                     first_valid[b] = c0 >= 16 ? 0 : (int32_t)(16 - c0);
+                }
+            if (n_rows)
+                for (uint32_t b = 0; b < B; b++) {
+                    int nv = 0;
+                    for (uint32_t f = 0; f < F; f++) nv += h->h_desc[(size_t)b * F + f].valid == 1 ? 1 : 0;
+                    n_rows[b] = 4 * nv;
                 }
             return DABPHY_OK;
         }
@@ -870,13 +976,7 @@ int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, 
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
     const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
     int r;
-    if (cls.sf_state.cap < stride * B * M) {
-        if ((r = ensure(h, cls.sf_state, stride * B * M))) return r;
-        HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
-    }
-    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * M * n_cif))) return r;
-    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B * M))) return r;
-    if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
+    if ((r = prepare_superframes(h, cls, F))) return r;
     SfArgs a{};
     a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = M; a.frame_bytes = fb;
     a.s = bitrate / 8; a.member = member; a.desc = h->last_desc; a.n_frames = (int)F;

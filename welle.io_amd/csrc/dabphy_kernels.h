@@ -20,6 +20,8 @@ struct RxState {
     int32_t hist_count, hist_head; // window searches since the last acquisition whose samples sLevel has not seen yet: ring entries head .. head+count-1 of `hist`
     int32_t hist_dropped;   // 1: older entries were overwritten (or their samples have left the ring): the replay cannot start from an exact level
     int32_t n_relock_inexact; // re-acquisitions that started from a level the replay could not certify
+    int32_t attempts;       // entries into the notSynced state since reset (ofdm-processor.cpp:256-262: what scan mode counts)
+    int32_t first_lock_attempts; // `attempts` when the first window search succeeded (:351-355 onSignalPresence(true)); -1 = not yet
     // acquisition state machine (survives a call that ran out of samples mid-search)
     int32_t acq_phase;      // 0 priming sLevel, 1 first 50 samples, 2 looking for the dip, 3 looking for the end of the null
     int32_t acq_counter, acq_idx, acq_left;

@@ -235,11 +235,15 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
     int ne = 0, slot = 0;
     SfEvent* ev = A.events + bm * A.n_cif;
     int tot_sync = 0, tot_corr = 0, tot_unc = 0;
-    for (int r = 0; r < A.n_cif; r++) {
-        const FrameDesc& d = A.desc[(size_t)b * A.n_frames + (r >> 2)];
-        // frames the reference's DabAudio would have emitted: synchronised transmission frames, after the 16-CIF fill of
-        // the time de-interleaver (dab-audio.cpp:146-149)
-        if (d.valid != 1 || 4 * d.frame_no + (r & 3) < 16) continue;
+    // Rows of the class output are packed: k_msc_gather lays the logical frames of an ensemble out in CIF order from the first frame
+    // number of the batch (c_glob = 4 * desc[b][0].frame_no + r), whatever slots the demodulated frames occupied -- rows
+    // [0, 4 * nv) are real, nv = frames with valid == 1; a slot whose window search failed leaves no gap.
+    int nv = 0;
+    for (int f = 0; f < A.n_frames; f++) nv += A.desc[(size_t)b * A.n_frames + f].valid == 1 ? 1 : 0;
+    const long long c0 = 4 * A.desc[(size_t)b * A.n_frames].frame_no;
+    for (int r = 0; r < 4 * nv; r++) {
+        // frames the reference's DabAudio would have emitted: after the 16-CIF fill of the time de-interleaver (dab-audio.cpp:146-149)
+        if (c0 + r < 16) continue;
         const uint8_t* src = A.out + (bm * A.n_cif + r) * fb;
         __syncthreads();
         int dst_slot;

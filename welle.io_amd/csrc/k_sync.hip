@@ -487,12 +487,13 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
             RxState& g = A.state[b];
             g.pos = st.pos + T_U;
             g.local_phase = mod_rate64((int64_t)d.L0 - (int64_t)T_U * d.f_prs);
-            g.synced = 0; g.lost = g.lost + 1;
+            g.synced = 0; g.lost = g.lost + 1; g.attempts = g.attempts + 1;                  // goto notSynced (:347-350 -> :256-262)
             hist_append(A, b, g, d);                   // the T_u samples of the failed attempt were pulled too
         }
         return;
     }
     d.start_index = startIndex;
+    if (t == 0 && A.state[b].first_lock_attempts < 0) A.state[b].first_lock_attempts = A.state[b].attempts;    // ofdm-processor.cpp:351-355
     const int32_t J0 = startIndex + T_U;
     d.L1 = mod_rate64((int64_t)d.L0 - (int64_t)J0 * d.f_prs);
 
@@ -681,9 +682,9 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
     const int t = threadIdx.x, b = blockIdx.x;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
-    if (t == 0) { s_st = A.state[b]; s_done = s_st.synced ? 1 : 0; }
+    if (A.state[b].synced) return;                   // tracking (uniform per work-group): the kernel is queued in front of every frame step
+    if (t == 0) { s_st = A.state[b]; s_done = 0; }
     __syncthreads();
-    if (s_done) return;
 
     if (s_st.hist_count > 0 && A.hist) slevel_replay<TILE>(A, b, s_st, l1, iq, nco, t);
 
@@ -709,7 +710,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
                 const float a = l1[i++];
                 sLevel = (float)(0.00001 * (double)a + (1 - 0.00001) * (double)sLevel);         // :174
                 if (ph == 0) {                                                                  // :252-255
-                    if (--left <= 0) { ph = 1; idx = 0; cs = 0.0f; }
+                    if (--left <= 0) { ph = 1; idx = 0; cs = 0.0f; st.attempts += 1; }                  // falls through into notSynced (:256)
                 } else if (ph == 1) {                                                           // :268-273
                     st.env[idx & 63] = a; cs += a; idx++;
                     if (idx == 50) { ph = 2; counter = 0; break; }                              // oscillator changes -> new tile
@@ -719,7 +720,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
                     idx = (idx + 1) & 32767;
                     counter++;
                     if ((ph == 2 && counter > T_F) || (ph == 3 && counter > T_NULL + 50)) {     // hopeless -> notSynced
-                        ph = 1; idx = 0; cs = 0.0f; break;
+                        ph = 1; idx = 0; cs = 0.0f; st.attempts += 1; break;
                     }
                 }
             }

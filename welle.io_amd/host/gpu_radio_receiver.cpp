@@ -1,10 +1,9 @@
 // welle.io_amd/host/gpu_radio_receiver.cpp -- see gpu_radio_receiver.h.
 //
-// Thread model: one worker thread replaces the reference's threads A (OFDMProcessor::run), B (OfdmDecoder) and C
-// (DabAudio): it pulls samples from InputInterface exactly like OFDMProcessor::getSamples (non-blocking count, then
-// read, is_ok() while starving: ofdm-processor.cpp:186-207), appends them to the HBM ring and decodes frame by frame
-// (dabphy_process(h, 1): with one frame per call the coarse-corrector feedback of ofdm-processor.cpp:397 is exact).
-// Callbacks are issued in the reference's order on this thread; callees must be thread-safe as before.
+// The worker pulls samples from InputInterface exactly like OFDMProcessor::getSamples (non-blocking count, then read, is_ok()
+// while starving: ofdm-processor.cpp:186-207), appends them to the HBM ring and decodes frame by frame (dabphy_process(h, 1):
+// with one frame per call the coarse-corrector feedback of ofdm-processor.cpp:397 is exact).  Callbacks are issued in the
+// reference's order on this thread; callees must be thread-safe as before.
 #include "gpu_radio_receiver.h"
 #include "../../include/dabphy.h"
 
@@ -17,16 +16,86 @@ namespace {
 constexpr uint64_t kRing = 8ull * 196608;           // 8 transmission frames of sample ring in HBM
 constexpr int kPull = 65536;                         // samples per InputInterface::getSamples call
 
-dabphy_protection protection_of(const Subchannel& sub)
+bool protection_of(const Subchannel& sub, dabphy_protection* p)
 {
-    dabphy_protection p;
+    memset(p, 0, sizeof *p);
     const auto& ps = sub.protectionSettings;
-    if (ps.shortForm) dabphy_protection_uep(&p, sub.bitrate(), ps.uepLevel);
-    else dabphy_protection_eep(&p, sub.bitrate(), ps.eepProfile == EEPProtectionProfile::EEP_B, (int)ps.eepLevel);
-    return p;
+    const int r = ps.shortForm ? dabphy_protection_uep(p, sub.bitrate(), ps.uepLevel)
+                               : dabphy_protection_eep(p, sub.bitrate(), ps.eepProfile == EEPProtectionProfile::EEP_B, (int)ps.eepLevel);
+    return r == DABPHY_OK;
+}
+
+int placement_code(FFTPlacementMethod m)
+{
+    return m == FFTPlacementMethod::StrongestPeak ? 0 : m == FFTPlacementMethod::EarliestPeakWithBinning ? 1 : 2;
 }
 }
 
+#ifndef DABPHY_NO_TOSTRING           // radio-receiver.cpp:36-62 (that translation unit is not part of a GPU build)
+const char* fftPlacementMethodToString(FFTPlacementMethod fft_placement)
+{
+    switch (fft_placement) {
+        case FFTPlacementMethod::StrongestPeak: return "StrongestPeak";
+        case FFTPlacementMethod::EarliestPeakWithBinning: return "EarliestPeakWithBinning";
+        case FFTPlacementMethod::ThresholdBeforePeak: return "ThresholdBeforePeak";
+    }
+    throw std::logic_error("Unhandled FFT placement");
+}
+
+const char* freqSyncMethodToString(FreqsyncMethod method)
+{
+    switch (method) {
+        case FreqsyncMethod::GetMiddle: return "GetMiddle";
+        case FreqsyncMethod::CorrelatePRS: return "CorrelatePRS";
+        case FreqsyncMethod::PatternOfZeros: return "PatternOfZeros";
+    }
+    throw std::logic_error("Unhandled freqsyncMethod placement");
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------ one selected sub-channel
+GpuRadioReceiver::Stream::Stream(ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& s) :
+    sub(s), frame_bytes(3 * s.bitrate()), adapter(handler, (int16_t)s.bitrate(), ascty, dumpFileName)
+{
+    thread = std::thread(&Stream::run, this);
+}
+
+GpuRadioReceiver::Stream::~Stream()
+{
+    {
+        std::lock_guard<std::mutex> lock(m);
+        closing = true;
+    }
+    cv.notify_all();
+    if (thread.joinable()) thread.join();           // frames already queued are still delivered (a file ends with its last frames decoded)
+}
+
+void GpuRadioReceiver::Stream::push(const uint8_t* p)
+{
+    {
+        std::lock_guard<std::mutex> lock(m);
+        q.emplace_back(p, p + frame_bytes);
+    }
+    cv.notify_one();
+}
+
+void GpuRadioReceiver::Stream::run()
+{
+    std::vector<uint8_t> bits(8 * (size_t)frame_bytes);
+    for (;;) {
+        std::vector<uint8_t> f;
+        {
+            std::unique_lock<std::mutex> lock(m);
+            cv.wait(lock, [&] { return closing || !q.empty(); });
+            if (q.empty()) return;
+            f = std::move(q.front()); q.pop_front();
+        }
+        for (int i = 0; i < 8 * frame_bytes; i++) bits[i] = (f[i >> 3] >> (7 - (i & 7))) & 1;     // DabAudio hands over one bit per byte
+        adapter.addtoFrame(bits.data());                                                          // dab-audio.cpp:157
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ facade
 GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterface& input_, RadioReceiverOptions rro, int transmission_mode) :
     fibProcessor(rci_), params(transmission_mode), rci(rci_), input(input_), options(rro)
 {
@@ -34,8 +103,7 @@ GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterfac
     dabphy_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.n_ensembles = 1; cfg.max_frames = 1; cfg.device = 0;
-    cfg.fft_placement = rro.fftPlacementMethod == FFTPlacementMethod::StrongestPeak ? 0
-                      : rro.fftPlacementMethod == FFTPlacementMethod::EarliestPeakWithBinning ? 1 : 2;
+    cfg.fft_placement = placement_code(rro.fftPlacementMethod);
     cfg.freqsync_method = (int32_t)rro.freqsyncMethod;                  // GetMiddle = 0, CorrelatePRS = 1, PatternOfZeros = 2
     cfg.disable_coarse = rro.disableCoarseCorrector;
     cfg.want_constellation = 1; cfg.want_impulse_response = 1;
@@ -47,18 +115,19 @@ GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterfac
 GpuRadioReceiver::~GpuRadioReceiver()
 {
     stop();
+    clearSubchannels();
     if (phy) dabphy_destroy(phy);
 }
 
 void GpuRadioReceiver::restart(bool doScan)
 {
-    (void)doScan;       // scan mode only paces onSignalPresence in the reference (ofdm-processor.cpp:258-262,352-356)
     stop();
+    scan_mode = doScan;                                                 // radio-receiver.cpp:82-88
     clearSubchannels();
     fibProcessor.clearEnsemble();
     input.restart();
     if (dabphy_stream_open(phy, kRing) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
-    was_synced = false; sample_count = 0;
+    sample_count = 0;
     running = true;
     worker = std::thread(&GpuRadioReceiver::run, this);
 }
@@ -78,7 +147,15 @@ void GpuRadioReceiver::stop()
 void GpuRadioReceiver::setReceiverOptions(const RadioReceiverOptions rro)
 {
     std::lock_guard<std::mutex> lock(mutex);
-    options = rro;      // placement / coarse settings are fixed at construction on the GPU path; decodeTII is consulted per frame
+    options = rro;              // applied by the worker before its next frame (the handle is not thread-safe): OFDMProcessor::setReceiverOptions,
+    options_dirty = true;       // ofdm-processor.cpp:518-529, incl. the restart when disableCoarseCorrector changes; decodeTII is read per frame
+}
+
+RadioReceiverStats GpuRadioReceiver::getReceiverStats() const
+{
+    RadioReceiverStats s;
+    s.timeLastFCT0Frame = fibProcessor.getTimeLastFCT0Frame();
+    return s;
 }
 
 bool GpuRadioReceiver::serviceHasAudioComponent(const Service& s) const
@@ -101,13 +178,23 @@ bool GpuRadioReceiver::addServiceToDecode(ProgrammeHandlerInterface& handler, co
 
 bool GpuRadioReceiver::removeServiceToDecode(const Service& s)
 {
+    // radio-receiver.cpp:130-144
     for (const auto& sc : fibProcessor.getComponents(s)) {
         if (sc.transportMode() != TransportMode::Audio) continue;
         const auto subch = fibProcessor.getSubchannel(sc);
         if (!subch.valid()) continue;
-        std::lock_guard<std::mutex> lock(mutex);
-        for (auto it = streams.begin(); it != streams.end(); ++it)
-            if (it->sub.subChId == subch.subChId) { streams.erase(it); subchannels_dirty = true; return true; }
+        std::shared_ptr<Stream> gone;
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            for (auto it = streams.begin(); it != streams.end(); ++it)
+                if ((*it)->sub.subChId == subch.subChId) { gone = *it; streams.erase(it); subchannels_dirty = true; break; }
+        }
+        if (!gone) return false;
+        // the caller may destroy its ProgrammeHandler as soon as this returns (MscHandler::removeSubchannel joins the DabAudio
+        // thread): wait until the worker has let go of the stream, then end its decoder thread here
+        while (running && gone.use_count() > 1) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        gone.reset();
+        return true;
     }
     return false;
 }
@@ -129,13 +216,14 @@ bool GpuRadioReceiver::playProgramme(ProgrammeHandlerInterface& handler, const S
 bool GpuRadioReceiver::addSubchannel(ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty,
                                      const std::string& dumpFileName, const Subchannel& sub)
 {
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        for (const auto& st : streams) if (st->sub.subChId == sub.subChId) return true;      // msc-handler.cpp:69-74
+    }
+    dabphy_protection p;
+    if (!protection_of(sub, &p)) return false;          // no such protection profile: nothing the channel decoder could do with it
+    auto st = std::make_shared<Stream>(handler, ascty, dumpFileName, sub);      // may throw like DecoderAdapter does (unknown component type)
     std::lock_guard<std::mutex> lock(mutex);
-    for (const auto& st : streams) if (st.sub.subChId == sub.subChId) return true;      // msc-handler.cpp:69-74
-    Stream st;
-    st.sub = sub;
-    AudioServiceComponentType a = ascty;
-    st.adapter = std::make_unique<DecoderAdapter>(handler, (int16_t)sub.bitrate(), a, dumpFileName);
-    st.frame_bytes = 3 * sub.bitrate();
     streams.push_back(std::move(st));
     subchannels_dirty = true;
     return true;
@@ -143,48 +231,72 @@ bool GpuRadioReceiver::addSubchannel(ProgrammeHandlerInterface& handler, AudioSe
 
 void GpuRadioReceiver::clearSubchannels()
 {
-    std::lock_guard<std::mutex> lock(mutex);
-    streams.clear();
-    subchannels_dirty = true;
+    std::list<std::shared_ptr<Stream>> gone;
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        gone.swap(streams);
+        subchannels_dirty = true;
+    }
+    // as in removeServiceToDecode: the handlers may go away once this returns
+    for (auto& g : gone) while (running && g.use_count() > 1) std::this_thread::sleep_for(std::chrono::microseconds(200));
 }
 
-void GpuRadioReceiver::push_subchannels_locked()
+// Pending changes from other threads (options, sub-channel selection) are applied here, on the worker: the handle is not thread-safe,
+// and its sub-channel list and `active` must change together.
+void GpuRadioReceiver::apply_pending()
 {
-    std::vector<dabphy_subchannel> list;
-    for (const auto& st : streams) {
-        dabphy_subchannel d;
-        d.subch_id = st.sub.subChId; d.start_cu = st.sub.startAddr; d.size_cu = st.sub.length; d.prot = protection_of(st.sub);
-        list.push_back(d);
+    std::lock_guard<std::mutex> lock(mutex);
+    if (options_dirty) {
+        if (dabphy_set_options(phy, placement_code(options.fftPlacementMethod), (int32_t)options.freqsyncMethod,
+                               options.disableCoarseCorrector, nullptr) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
+        options_dirty = false;
     }
-    dabphy_set_subchannels(phy, list.data(), (uint32_t)list.size());
-    subchannels_dirty = false;
+    if (subchannels_dirty) {
+        std::vector<dabphy_subchannel> list;
+        std::vector<std::shared_ptr<Stream>> now;
+        for (const auto& st : streams) {
+            dabphy_subchannel d;
+            d.subch_id = st->sub.subChId; d.start_cu = st->sub.startAddr; d.size_cu = st->sub.length;
+            if (!protection_of(st->sub, &d.prot)) continue;
+            list.push_back(d); now.push_back(st);
+        }
+        if (dabphy_set_subchannels(phy, list.data(), (uint32_t)list.size()) != DABPHY_OK) {
+            // (a sub-channel the library refuses, e.g. one that runs past the CIF: decode none rather than the wrong ones)
+            dabphy_set_subchannels(phy, nullptr, 0);
+            now.clear();
+        }
+        active.swap(now);
+        subchannels_dirty = false;
+    }
+    tii_now = options.decodeTII;                                        // read once per frame, ofdm-processor.cpp:376-380
 }
 
 // One dabphy_process(1) + the reference's callbacks for that frame slot.  Returns false when nothing was decoded.
-bool GpuRadioReceiver::decode_one_frame(uint64_t written)
+bool GpuRadioReceiver::decode_one_frame()
 {
-    (void)written;
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        if (subchannels_dirty) push_subchannels_locked();
-    }
-    bool tii;
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        tii = options.decodeTII;                                        // read once per frame, ofdm-processor.cpp:376-380
-    }
+    apply_pending();
+    const bool tii = tii_now;
     if (dabphy_set_tii(phy, tii) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
     if (dabphy_process(phy, 1) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
     dabphy_frame_info info;
     dabphy_get_frame_info(phy, &info);
+    bool signal_found = false;
+    if (scan_mode) {
+        // ofdm-processor.cpp:256-262: the sixth entry into notSynced without a lock reports "no signal" and ends the scan; :351-355:
+        // the first successful window search reports the signal (after that attempt's impulse response, below)
+        int32_t attempts = 0, at_lock = -1;
+        dabphy_get_scan_stats(phy, &attempts, &at_lock);
+        if (at_lock >= 0 && at_lock <= 5) signal_found = true;
+        else if (attempts > 5) { rci.onSignalPresence(false); scan_mode = false; }
+    }
     if (info.valid == 3 || info.valid == 1) {
         std::vector<float> cir(2048);
         dabphy_get_impulse_response(phy, cir.data());
         rci.onNewImpulseResponse(std::move(cir));                       // ofdm-processor.cpp:344
     }
-    if (info.valid == 3) { rci.onSyncChange(false); was_synced = false; return true; }      // :347-350 -> notSynced (:282)
+    if (info.valid == 3) { rci.onSyncChange(false); return true; }      // :347-350 -> notSynced (:282)
     if (info.valid != 1) return false;
-    if (!was_synced) was_synced = true;
+    if (signal_found) { rci.onSignalPresence(true); scan_mode = false; }       // :351-355
     rci.onSyncChange(true);                                             // :369
     // thread B of the reference: FIBs in FIC order (fic-handler.cpp:215-229)
     uint8_t fib[12][32], ok[12];
@@ -215,21 +327,14 @@ bool GpuRadioReceiver::decode_one_frame(uint64_t written)
                 rci.onTIIMeasurement(std::move(t));                     // tii-decoder.cpp:371-377
             }
     }
-    // thread C: decoded logical frames, 4 per transmission frame, in CIF order (dab-audio.cpp:151-160)
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        uint32_t idx = 0;
-        for (auto& st : streams) {
-            std::vector<uint8_t> out(4 * (size_t)st.frame_bytes);
-            int32_t first_valid = 0;
-            if (dabphy_get_msc(phy, idx++, out.data(), &first_valid) != DABPHY_OK) continue;
-            std::vector<uint8_t> bits(8 * (size_t)st.frame_bytes);
-            for (int c = first_valid; c < 4; c++) {
-                const uint8_t* p = out.data() + (size_t)c * st.frame_bytes;
-                for (int i = 0; i < 8 * st.frame_bytes; i++) bits[i] = (p[i >> 3] >> (7 - (i & 7))) & 1;
-                st.adapter->addtoFrame(bits.data());
-            }
-        }
+    // thread C: decoded logical frames, 4 per transmission frame, in CIF order (dab-audio.cpp:151-160), handed to the sub-channel's
+    // own decoder thread.  `active` is exactly the list the handle decoded this frame with.
+    for (size_t idx = 0; idx < active.size(); idx++) {
+        Stream& st = *active[idx];
+        std::vector<uint8_t> out(4 * (size_t)st.frame_bytes);
+        int32_t first_valid = 0, n_rows = 0;
+        if (dabphy_get_msc(phy, (uint32_t)idx, out.data(), out.size(), &first_valid, &n_rows) != DABPHY_OK) continue;
+        for (int c = first_valid; c < n_rows; c++) st.push(out.data() + (size_t)c * st.frame_bytes);
     }
     // onFrequencyCorrectorChange every INPUT_RATE/5 samples (ofdm-processor.cpp:218-223)
     sample_count += 196608;
@@ -244,6 +349,7 @@ void GpuRadioReceiver::run()
     const uint64_t frame_need = 2048 + 2047 + 75ull * 2552 + 2656;       // what one SyncOnPhase pass may touch
     bool input_done = false;
     while (running) {
+        apply_pending();                 // also while starving: a removed sub-channel's stream must be let go of
         // --- fill the ring like OFDMProcessor::getSamples pulls (count, then read; is_ok() while starving)
         uint64_t consumed = dabphy_stream_consumed(phy);
         bool pulled = false;
@@ -265,7 +371,7 @@ void GpuRadioReceiver::run()
         consumed = dabphy_stream_consumed(phy);
         bool progressed = false;
         while (running && written - consumed >= frame_need) {
-            const bool did = decode_one_frame(written);
+            const bool did = decode_one_frame();
             const uint64_t c2 = dabphy_stream_consumed(phy);
             progressed |= did || c2 != consumed;
             if (c2 == consumed && !did) break;
@@ -278,4 +384,5 @@ void GpuRadioReceiver::run()
         }
         if (!pulled && !progressed) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
+    active.clear();
 }

@@ -1,20 +1,29 @@
 // welle.io_amd/host/gpu_radio_receiver.h -- the reference's RadioReceiver facade on top of libdabphy_hip.so.
 //
-// Same constructor and public methods as RadioReceiver (src/backend/radio-receiver.h:52-116): welle-cli / the
-// GUI compile against it unchanged once `using RadioReceiver = GpuRadioReceiver;` (or a rename) is in place --
-// see INTEGRATION.md.  It is written against the reference's OWN headers (radio-controller.h, fib-processor.h,
-// decoder_adapter.h, dab-constants.h); only the PHY hot path behind them is replaced:
+// Same constructor and public methods as RadioReceiver (src/backend/radio-receiver.h:52-116).  welle-cli compiles against it
+// UNCHANGED: welle.io_amd/host/dropin/ holds a `radio-receiver.h` that shadows the reference's header and gives this class the
+// name RadioReceiver (oracle/Makefile builds welle-cli both ways).  It is written against the reference's OWN
+// headers (radio-controller.h, fib-processor.h, decoder_adapter.h, dab-constants.h); only the PHY hot path behind them is replaced:
 //
 //   reference object                      replaced by
-//   OFDMProcessor (+PhaseReference)       dabphy_process: k_acquire, k_sync_find, k_cp_products, k_sync_finish
+//   OFDMProcessor (+PhaseReference)       dabphy_process: k_acquire, k_sync_find, k_sync_finish
 //   OfdmDecoder                           k_demod, k_snr*
 //   FicHandler (depuncture/Viterbi/CRC)   k_fic_gather, k_viterbi, k_fib_crc        -> FIBProcessor::processFIB stays
 //   MscHandler + DabAudio + Protection    k_msc_gather, k_viterbi                   -> DecoderAdapter::addtoFrame stays
 //
 // What stays on the host, unchanged: FIBProcessor (FIG parsing, service database), DecoderAdapter and the audio /
 // PAD decoders behind it, every front-end.
+//
+// Threads.  The reference runs thread A (OFDMProcessor::run), thread B (OfdmDecoder) and one thread C per selected
+// sub-channel (DabAudio::run).  Here one worker replaces A + B (pull samples, dabphy_process(1), the per-frame callbacks in the
+// reference's order) and every selected sub-channel keeps its own thread C: the worker queues the decoded logical frames, the
+// sub-channel's thread feeds DecoderAdapter::addtoFrame -- audio decoding never holds up the PHY or another caller, and
+// removeServiceToDecode returns only after that thread has ended (as MscHandler::removeSubchannel joins DabAudio).
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -30,7 +39,14 @@
 
 struct dabphy_handle;
 
-struct RadioReceiverStats;      // radio-receiver.h defines it when the facade replaces that header; see .cpp
+#ifndef DABPHY_HAVE_RECEIVER_STATS                  // radio-receiver.h:48-50 (the drop-in header replaces that file)
+#define DABPHY_HAVE_RECEIVER_STATS
+struct RadioReceiverStats {
+    std::chrono::system_clock::time_point timeLastFCT0Frame;
+};
+const char* fftPlacementMethodToString(FFTPlacementMethod fft_placement);
+const char* freqSyncMethodToString(FreqsyncMethod method);
+#endif
 
 class GpuRadioReceiver {
     public:
@@ -58,6 +74,7 @@ class GpuRadioReceiver {
         bool serviceHasAudioComponent(const Service& s) const;
         Subchannel getSubchannel(const ServiceComponent& sc) const { return fibProcessor.getSubchannel(sc); }
         DABParams& getParams() { return params; }
+        RadioReceiverStats getReceiverStats() const;                    // radio-receiver.cpp:225-229
         std::chrono::system_clock::time_point getTimeLastFCT0Frame() const { return fibProcessor.getTimeLastFCT0Frame(); }
 
         // MscHandler::addSubchannel / removeSubchannel (msc-handler.cpp:61-122), used by playProgramme
@@ -68,26 +85,39 @@ class GpuRadioReceiver {
         FIBProcessor fibProcessor;      // public like FicHandler::fibProcessor (fic-handler.h:47)
 
     private:
+        // one selected sub-channel: DabAudio's role after the channel decoder (dab-audio.cpp:151-160), on its own thread
         struct Stream {
+            Stream(ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& sub);
+            ~Stream();
+            void push(const uint8_t* frame_bytes_msb_first);            // one logical frame (3 * bitrate bytes)
             Subchannel sub;
-            std::unique_ptr<DecoderAdapter> adapter;
-            int frame_bytes = 0;
+            int frame_bytes;
+          private:
+            void run();
+            DecoderAdapter adapter;
+            std::mutex m; std::condition_variable cv;
+            std::deque<std::vector<uint8_t>> q;
+            bool closing = false;
+            std::thread thread;
         };
         bool playProgramme(ProgrammeHandlerInterface& handler, const Service& s, const std::string& dumpFileName, bool unique);
         void run();
-        void push_subchannels_locked();
-        bool decode_one_frame(uint64_t written);
+        bool decode_one_frame();
+        void apply_pending();
 
         DABParams params;
         RadioControllerInterface& rci;
         InputInterface& input;
-        RadioReceiverOptions options;
         dabphy_handle* phy = nullptr;
         std::thread worker;
         std::atomic<bool> running{false};
-        std::mutex mutex;                 // guards streams / subchannels_dirty / options
-        std::list<Stream> streams;
+        std::mutex mutex;                 // guards streams / subchannels_dirty / options / options_dirty
+        RadioReceiverOptions options;
+        bool options_dirty = false;
+        std::list<std::shared_ptr<Stream>> streams;
         bool subchannels_dirty = false;
-        bool was_synced = false;
+        std::vector<std::shared_ptr<Stream>> active;   // worker thread only: the streams whose sub-channels the handle currently decodes, in its order
+        std::atomic<bool> scan_mode{false};            // OFDMProcessor::scanMode (ofdm-processor.h:110)
+        bool tii_now = false;
         int sample_count = 0;             // OFDMProcessor::sampleCnt (onFrequencyCorrectorChange pacing)
 };

@@ -1,0 +1,64 @@
+"""The throughput workload of BASELINE.json config 4/5 ("batch of 256 synthetic Mode-I ensembles per GPU"), built ONCE here so
+that bench.py and the parity test of the benchmarked configuration (tests/test_gpu_bench_config.py) decode the very same signal
+with the very same handle configuration.
+
+Signal: `n_distinct` looping recordings of REC = 20 frames of the canonical ensemble (18 x 64 kbit/s DAB+ EEP-3A, RS-valid
+payload; 80 CIFs = a whole number of superframes and of interleaver periods, transmitter run for one period first so that the loop
+point is seamless), each ensemble = recording b % n_distinct with its own carrier offset (a multiple of RATE/N, so the loop stays
+phase-continuous) and its own AWGN (sigma 0.02 per axis, SURVEY 8d throughput setting).  torch is used for the arithmetic only
+(device "cuda" in bench.py, "cpu" in the GPU-less tests)."""
+import numpy as np
+
+from . import synth
+
+REC_FRAMES = 20
+RATE = 2048000.0
+
+
+def make_base_streams(n_distinct, n_frames=REC_FRAMES, seed0=0, subchs=None):
+    out, txs = [], []
+    for e in range(n_distinct):
+        tx = synth.EnsembleTx(eid=0x1000 + seed0 + e, subchs=subchs, seed=seed0 + e, payload_fn=synth.dabplus_payload_fn(4 * n_frames, seed0 + e))
+        for _ in range(n_frames):
+            tx.next_frame()
+        frames = [tx.next_frame() for _ in range(n_frames)]
+        out.append(np.concatenate(frames).astype(np.complex64))
+        txs.append(tx)
+    return np.stack(out), txs
+
+
+def make_batch(B, rank=0, n_distinct=4, cfo_max_hz=60.0, sigma=0.02, device="cuda", base=None):
+    """-> (iq [B][N] complex64 torch tensor on `device`, per-ensemble carrier offsets in Hz, base recordings, their transmitters)"""
+    import torch
+    if base is None:
+        base = make_base_streams(n_distinct, REC_FRAMES, seed0=100 * rank)
+    base_np, txs = base
+    N = base_np.shape[1]
+    gbase = torch.from_numpy(base_np).to(device)
+    gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
+    iq = torch.empty((B, N), dtype=torch.complex64, device=device)
+    rs = np.random.RandomState(4321 + rank)
+    cfo_hz = np.round(rs.uniform(-cfo_max_hz, cfo_max_hz, B) * N / RATE) * RATE / N
+    n_idx = torch.arange(N, device=device, dtype=torch.float64)
+    for b in range(B):
+        noise = torch.randn((N, 2), generator=gen, device=device, dtype=torch.float32) * sigma
+        rot = torch.polar(torch.ones_like(n_idx), n_idx * (2.0 * np.pi * cfo_hz[b] / RATE)).to(torch.complex64)
+        iq[b] = gbase[b % base_np.shape[0]] * rot + torch.view_as_complex(noise)
+    return iq, cfo_hz, base_np, txs
+
+
+def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demod_chunk=0, profiling=True):
+    """the handle bench.py times: batch geometry B x F, looping HBM-resident ring, coarse corrector enabled, no constellation / CIR
+    taps, all sub-channels decoded, superframe filter inside process()"""
+    B, N = iq.shape
+    dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=device, lib_path=lib_path, want_constellation=False, want_impulse_response=False,
+                      disable_coarse=False, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk)
+    if iq.is_cuda:
+        dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
+    else:
+        dev.stream_upload(iq.numpy(), loop=True)
+    dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
+    if profiling:
+        dev.set_profiling(True)
+    dev.set_auto_superframes(True)
+    return dev
