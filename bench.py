@@ -1,19 +1,22 @@
 #!/usr/bin/env python
-"""bench.py -- DAB Mode-I PHY hot path on MI355X: whole-job throughput, FFT-stage HBM roofline, CPU baseline.
+"""bench.py -- DAB Mode-I PHY hot path on MI355X: whole-job throughput, FFT-stage HBM roofline, Viterbi issue roofline, CPU baseline.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  For N > 1 the
-driver starts one process per GPU with torch.distributed.run; every rank decodes its own block of ensembles (the
-path shards by ensemble, no data-path collective) and the decoded FIBs are gathered to rank 0 over RCCL per step.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  Started without a
+torch.distributed environment and N > 1 it launches the N ranks itself (torch.distributed.run, 127.0.0.1); started by the driver's
+own torch.distributed.run it is one of the ranks.  Every rank decodes its own block of ensembles (the path shards by ensemble, no
+data-path collective); the decoded FIBs + CRC flags are gathered to rank 0 over RCCL per step, device buffer to device buffer.
 
-A "step" is one pass of the whole hot path (time/frequency sync, NCO, 2048-pt FFT, DQPSK demap, de-interleavers,
-depuncture, Viterbi, energy dispersal, FIB CRC, Reed-Solomon) over one batch of B ensembles x F transmission frames
-of synthetic 2.048 Msps complex-float IQ that is already resident in HBM (BASELINE.json config
-"1xMI355X: batch of 256 synthetic Mode-I ensembles").  value = ensembles decoded in real time (x real-time) summed
-over all GPUs = N*B*F*0.096 s / step time.
+A "step" is one pass of the whole hot path (time/frequency sync, NCO, 2048-pt FFT, DQPSK demap, de-interleavers, depuncture,
+Viterbi, energy dispersal, FIB CRC, superframe filter with Reed-Solomon) over one batch of B ensembles x F transmission frames of
+synthetic 2.048 Msps complex-float IQ that is already resident in HBM (BASELINE.json config "1xMI355X: batch of 256 synthetic Mode-I
+ensembles"; welle_io_amd/workload.py builds signal and handle, tests/test_gpu_bench_config.py checks exactly this configuration
+against the oracle).  value = ensembles decoded in real time (x real-time) summed over all GPUs = N*B*F*0.096 s / step time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,28 +31,14 @@ T_F = 196608
 ALG_BYTES_DEMOD_PER_FRAME = 76 * 2048 * 8 + 75 * 3072      # IQ useful parts read once + int8 soft bits written once
 ALG_BYTES_FFT_CLASSIC_PER_FRAME = 76 * 2 * 2048 * 8          # SURVEY 8(d) c2c accounting (read + write of each FFT)
 HBM_PEAK_GBPS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
+CLOCK_HZ = 2.4e9                                             # MI355X_MICROARCH.md: peak engine clock
+PARITY_SUBCH = (0, 7, 17)                                    # sub-channels whose MSC bytes the parity leg compares
 
 
-def make_base_streams(n_distinct, n_frames, seed0):
-    """n_distinct looping recordings of n_frames frames each: canonical ensemble (18 x 64 kbit/s DAB+ EEP-3A), RS-valid
-    payload periodic in 4*n_frames CIFs, transmitter run for one extra period first so the loop point is seamless"""
-    from welle_io_amd import synth
-    out, txs = [], []
-    for e in range(n_distinct):
-        tx = synth.EnsembleTx(eid=0x1000 + seed0 + e, seed=seed0 + e, payload_fn=synth.dabplus_payload_fn(4 * n_frames, seed0 + e))
-        for _ in range(n_frames):
-            tx.next_frame()
-        frames = [tx.next_frame() for _ in range(n_frames)]
-        out.append(np.concatenate(frames).astype(np.complex64))
-        txs.append(tx)
-    return np.stack(out), txs
-
-
-def _run_receivers(rec, n_proc, n_loops, mode, env):
-    """n_proc concurrent receiver processes over the same recording; returns their result records"""
-    import subprocess
-    args = [sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py"), rec, str(n_loops)]
-    procs = [subprocess.Popen(args + [str(7 + i)] + (["reference"] if mode == "reference" else []),
+def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir):
+    """n_proc concurrent receiver processes, receiver i over recording recs[i % len(recs)]; returns their result records"""
+    args = [sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py")]
+    procs = [subprocess.Popen(args + [recs[i % len(recs)], str(n_loops), mode, os.path.join(out_dir, "%s_%d.npz" % (mode, i)) if i < len(recs) else "-"],
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(n_proc)]
     for p in procs:
         if p.stdout.readline().strip() != "READY":
@@ -62,42 +51,85 @@ def _run_receivers(rec, n_proc, n_loops, mode, env):
     return res
 
 
-def cpu_baseline(base_stream, n_loops):
-    """The CPU side of the same workload on this host, a bounded sample (one canonical ensemble with all 18 sub-channels per
-    receiver; the reference's own concurrency model is one receiver per ensemble):
+def cpu_baseline(rows, n_loops, gpu_logs):
+    """The CPU side of the same workload on this host, a bounded sample: the very rows of the GPU batch named in `rows` (ensemble index
+    -> looping recording incl. its noise and carrier offset), one receiver per ensemble as the reference runs them, all 18 sub-channels:
       * kind "reference": the REAL reference backend (oracle/_ref, built from /root/reference where that exists) -- RadioReceiver
         with its own 2-3 threads and SSE Viterbi; it also runs the layers above the PHY (FIG parsing, superframe filter, AAC).
         cores/2 receivers run concurrently so that every core is busy.
       * the oracle (C restatement of the PHY only, single-threaded), one receiver per core, as a second figure (or as the
-        baseline, kind "port", where oracle/_ref is absent)."""
+        baseline, kind "port", where oracle/_ref is absent).
+    The receivers' outputs for the first frames are also the PARITY CHECK of this very run: FIB bytes + CRC flags and the MSC bytes of
+    three sub-channels of those ensembles, GPU (logged during warm-up) vs CPU, byte for byte."""
     import tempfile
     cores = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    ens = sorted(rows)
     with tempfile.TemporaryDirectory() as td:
-        rec = os.path.join(td, "rec.npy"); np.save(rec, base_stream)
+        recs = []
+        for e in ens:
+            path = os.path.join(td, "rec%d.npy" % e); np.save(path, rows[e]); recs.append(path)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        res = _run_receivers(rec, cores, n_loops, "port", env)
+        res = _run_receivers(recs, cores, n_loops, "port", env, td)
         ref = None
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref.so")):
             try:
-                ref = _run_receivers(rec, max(1, cores // 2), max(1, n_loops // 2), "reference", env)
+                ref = _run_receivers(recs, max(len(recs), cores // 2), max(1, n_loops // 2), "reference", env, td)
             except Exception:
                 ref = None
+        # ---- parity of this run: GPU log vs CPU receivers on the same rows
+        parity = {"ensembles": ens, "sub_channels": list(PARITY_SUBCH), "against": []}
+        for mode in (["reference"] if ref else []) + ["port"]:
+            for i, e in enumerate(ens):
+                z = np.load(os.path.join(td, "%s_%d.npz" % (mode, i)))
+                g = gpu_logs[e]
+                n = min(len(g["fib"]), len(z["fib"]) // 12)
+                assert n >= len(g["fib"]) - 1 and n > 0, (mode, e, n, len(g["fib"]))
+                zf = z["fib"][:12 * n].reshape(n, 12, 33)
+                ok = np.array_equal(np.array(g["ok"][:n]), zf[:, :, 0]) and np.array_equal(np.array(g["fib"][:n]), zf[:, :, 1:])
+                if not ok:
+                    raise AssertionError("parity: FIBs of ensemble %d differ from the %s receiver's" % (e, mode))
+                for k, i_sub in enumerate(PARITY_SUBCH):
+                    got = b"".join(g["msc"][k]); want = z["msc%d" % i_sub].tobytes()
+                    m = min(len(got), len(want))
+                    if m == 0 or got[:m] != want[:m]:
+                        raise AssertionError("parity: MSC bytes of ensemble %d sub-channel %d differ from the %s receiver's" % (e, i_sub, mode))
+                parity["frames"] = n; parity["msc_bytes_per_sub_channel"] = m
+            parity["against"].append("reference backend (oracle/_ref)" if mode == "reference" else "oracle (C restatement)")
+        parity["fib_equal"] = True; parity["msc_equal"] = True
     port_value = sum(r["frames"] for r in res) * FRAME_S / max(r["seconds"] for r in res)
     port = dict(value=port_value, per_core=res[0]["frames"] * FRAME_S / res[0]["seconds"], receivers=cores,
                 fib_ok=sum(r["fib_ok"] for r in res), fibs=sum(r["fibs"] for r in res))
     if ref:
         slowest = max(r["seconds"] for r in ref)
-        return dict(value=sum(r["frames"] for r in ref) * FRAME_S / slowest, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores,
+        base = dict(value=sum(r["frames"] for r in ref) * FRAME_S / slowest, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores,
                     kind="reference", per_receiver=ref[0]["frames"] * FRAME_S / ref[0]["seconds"],
                     sample="%d concurrent RadioReceivers of the reference backend (each 2-3 threads; PHY + FIG parsing + superframe filter + AAC; lock-step input so that no frame is dropped) x %d frames "
-                           "(%.1f s of IQ each) of the canonical ensemble, 18 sub-channels, slowest receiver %.1f s"
-                           % (len(ref), ref[0]["frames"], ref[0]["frames"] * FRAME_S, slowest),
+                           "(%.1f s of IQ each) of ensembles %s of this batch, 18 sub-channels, slowest receiver %.1f s"
+                           % (len(ref), ref[0]["frames"], ref[0]["frames"] * FRAME_S, ens, slowest),
                     fib_ok=sum(r["fib_ok"] for r in ref), fibs=sum(r["fibs"] for r in ref), oracle_port=port)
-    return dict(value=port_value, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
-                per_core=port["per_core"],
-                sample="%d receivers x %d frames (%.1f s of IQ each) of the canonical ensemble, 18 sub-channels, oracle C restatement, slowest receiver %.1f s"
-                       % (cores, res[0]["frames"], res[0]["frames"] * FRAME_S, max(r["seconds"] for r in res)),
-                fib_ok=port["fib_ok"], fibs=port["fibs"])
+    else:
+        base = dict(value=port_value, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
+                    per_core=port["per_core"],
+                    sample="%d receivers x %d frames (%.1f s of IQ each) of ensembles %s of this batch, 18 sub-channels, oracle C restatement, slowest receiver %.1f s"
+                           % (cores, res[0]["frames"], res[0]["frames"] * FRAME_S, ens, max(r["seconds"] for r in res)),
+                    fib_ok=port["fib_ok"], fibs=port["fibs"])
+    return base, parity
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _static_profile(name, B, F):
+    """counter figures collected by tools/make_profiles.sh in their own rocprofv3 passes (NOT measured by this run; keyed by batch geometry)"""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        pj = json.load(open(path))
+    except Exception:
+        return None
+    return pj if pj.get("ensembles") == B and pj.get("frames") == F else None
 
 
 def main():
@@ -108,66 +140,79 @@ def main():
     ap.add_argument("--ensembles", type=int, default=256, help="ensembles per GPU")
     ap.add_argument("--frames", type=int, default=20, help="transmission frames per ensemble and step")
     ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and with it the parity check of this run)")
     ap.add_argument("--no-alt-schedule", action="store_true", help="skip the extra (untimed) pass with the other pipelined schedule")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the N ranks ourselves, one process per GPU; rank 0's JSON line is this process's output
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    assert world == args.gpus or "WORLD_SIZE" in os.environ, (world, args.gpus)
+    if os.environ.get("DABPHY_SHARE_GPU") == "1":            # TEST ONLY (1-GPU box): several ranks on one device; RCCL refuses that, so the
+        local = local % torch.cuda.device_count()            # collective then runs over gloo (DABPHY_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or os.environ.get("DABPHY_FORCE_DIST") == "1":    # (the env switch lets a 1-GPU box exercise the RCCL path: torchrun --nproc-per-node 1)
+    dist = None; backend = None
+    if world > 1 or os.environ.get("DABPHY_FORCE_DIST") == "1":    # (the env switch lets a 1-GPU box exercise the RCCL path with one rank)
         import torch.distributed as dist
-        dist.init_process_group("nccl")          # RCCL (no device_id: eager RCCL initialisation prints to stdout, and stdout is one JSON line)
+        backend = os.environ.get("DABPHY_DIST_BACKEND", "nccl")
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group(backend)         # "nccl" = RCCL (no device_id: eager RCCL initialisation prints to stdout, and stdout is one JSON line)
     load_package()
-    from welle_io_amd import capi, synth
+    from welle_io_amd import capi, workload
     from welle_io_amd.distributed import gather_fibs
 
     B, F = args.ensembles, args.frames
-    REC = 20            # frames per looping recording: 80 CIFs = a whole number of superframes (5 CIFs) and interleaver periods (16)
-    n_distinct = 4
-    base, txs = make_base_streams(n_distinct, REC, seed0=100 * rank)
-    N = base.shape[1]
-    gbase = torch.from_numpy(base).cuda()
-    gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
-    iq = torch.empty((B, N), dtype=torch.complex64, device="cuda")
-    # per-ensemble carrier frequency offset (a multiple of RATE/N so that the looping recording stays phase-continuous) and
-    # AWGN, sigma = 0.02 per axis (SURVEY 8d throughput setting): every ensemble runs its own coarse/fine correctors
-    rs = np.random.RandomState(4321 + rank)
-    cfo_hz = np.round(rs.uniform(-args.cfo_max_hz, args.cfo_max_hz, B) * N / 2048000.0) * 2048000.0 / N
-    n_idx = torch.arange(N, device="cuda", dtype=torch.float64)
-    for b in range(B):
-        noise = torch.randn((N, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.02
-        rot = torch.polar(torch.ones_like(n_idx), n_idx * (2.0 * np.pi * cfo_hz[b] / 2048000.0)).to(torch.complex64)
-        iq[b] = gbase[b % n_distinct] * rot + torch.view_as_complex(noise)
-    del gbase, n_idx, rot
+    iq, cfo_hz, base, txs = workload.make_batch(B, rank=rank, cfo_max_hz=args.cfo_max_hz, device="cuda")
+    N = iq.shape[1]
     torch.cuda.synchronize()
-
-    sched = int(os.environ.get("DABPHY_PIPELINE", "1"))
-    dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so")),
-                      want_constellation=False, want_impulse_response=False, disable_coarse=False, pipeline_sync=sched,
-                      demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
-    dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
     subchs = txs[0].subchs
-    dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
-    dev.set_profiling(True)
-    dev.set_auto_superframes(True)                         # the superframe filter rides in process()'s submission
+    lib_path = os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so"))
+    chunk = int(os.environ.get("DABPHY_DEMOD_CHUNK", "0"))
+    sched = int(os.environ.get("DABPHY_PIPELINE", "1"))
+    dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=sched, demod_chunk=chunk)
 
     def step():
         dev.process(F)
         sf = dev.superframes_stats()                       # DAB+ superframe filter of all 18 sub-channels on the device: Fire-code sync, RS, AU CRCs
-        fib, ok = dev.fibs()                               # decoded FIBs + CRC flags to the host of this rank
-        if dist is not None:                               # final FIC gather to rank 0 over RCCL/xGMI
-            gather_fibs(dist, fib, ok, rank, world, device="cuda")
+        if dist is not None:                               # final FIC gather to rank 0 over RCCL/xGMI, straight from the library's HBM buffers
+            d_fib, d_ok = dev.fibs_device()
+            if backend != "nccl":                          # (gloo, test only: host tensors)
+                d_fib, d_ok = d_fib.cpu(), d_ok.cpu()
+            got = gather_fibs(dist, d_fib, d_ok, rank, world)
+            fib, ok = got[0] if rank == 0 else (None, None)     # rank 0 now holds every rank's FIBs on its host
+        else:
+            fib, ok = dev.fibs()                           # decoded FIBs + CRC flags to the host
         return fib, ok, sf
 
-    # warm-up: acquisition, time-de-interleaver fill, superframe synchronisation
+    # warm-up: acquisition, time-de-interleaver fill, superframe synchronisation.  Rank 0 logs what two ensembles of the batch (first
+    # and last) deliver from the very first frame on: the parity leg below compares it with CPU receivers decoding the same rows.
+    check = sorted({0, B - 1}) if rank == 0 else []
+    logs = {e: dict(fib=[], ok=[], msc=[[] for _ in PARITY_SUBCH]) for e in check}
     for W in range(max(2, args.warmup)):
-        step()
+        fib, ok, sf = step()
+        if check and not args.no_cpu_baseline:
+            info = dev.frame_info()
+            mscs = [dev.msc(i) for i in PARITY_SUBCH]
+            for e in check:
+                valid = [f for f in range(F) if info[e, f]["valid"] == 1]
+                for f in valid:
+                    logs[e]["fib"].append(np.array(fib[e, f])); logs[e]["ok"].append(np.array(ok[e, f]))
+                for k in range(len(PARITY_SUBCH)):
+                    m, fv = mscs[k]
+                    logs[e]["msc"][k].append(m[e, fv[e]:4 * len(valid)].tobytes())
     fib, ok, sf = step()
     # sanity outside the timed region: all FIBs pass CRC; every sub-channel of every ensemble delivers its 4F/5 superframes per
     # step, none uncorrectable, every access unit passes its CRC; the FIBs of ensemble 0 are the transmitted ones
+    if rank != 0:
+        fib, ok = dev.fibs()
+    fib = np.asarray(fib); ok = np.asarray(ok)
     assert ok.all(), "FIB CRC failures in the benchmark signal"
     assert (sf[:, 0] >= len(subchs) * (4 * F // 5)).all() and (sf[:, 0] <= len(subchs) * ((4 * F + 4) // 5)).all(), "superframe filter: %s" % sf[:4]
     assert (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all(), "superframe filter: %s" % sf[:4]
@@ -188,52 +233,65 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     if rank == 0:
+        n_simd = 4 * torch.cuda.get_device_properties(local).multi_processor_count
         ms_step = dt / args.steps * 1e3
         value = world * B * F * FRAME_S / (dt / args.steps)
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         demod_ms = stages["demod"]
         ach = B * F * ALG_BYTES_DEMOD_PER_FRAME / (demod_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "demod_hbm_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                if pj.get("ensembles") == B and pj.get("frames") == F:
-                    traffic = pj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pj = _static_profile("demod_hbm_traffic.json", B, F)
         n_cw_steps = B * F * (4 * 774 + 72 * 1542)
         line = {
             "metric": "DAB Mode-I ensembles/s (x real-time)", "value": value, "unit": "x real-time (ensembles decoded concurrently)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 (FFT/demap) + u16 (Viterbi metrics) + u8 (GF(256))", "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of %d synthetic Mode-I ensembles x %d frames (2.048 Msps cf32, HBM-resident, 18 x 64 kbit/s DAB+ EEP-3A sub-channels each), full chain incl. Viterbi + Reed-Solomon" % (B, F),
-                       "ensembles_per_gpu": B, "frames_per_step": F, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B},
+                       "ensembles_per_gpu": B, "frames_per_step": F, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B,
+                       "demod_chunk": dev.demod_chunk(), "parity_test": "tests/test_gpu_bench_config.py decodes this configuration against the oracle"},
+            "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
             "roofline": {"kernel": "k_demod (NCO + 2048-pt FFT + DQPSK demap + freq de-interleave)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": pj.get("hbm_bytes_per_launch") if pj else None,
+                         "traffic_source": ("static: profiles/demod_hbm_traffic.json (FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh on this command; not measured by this run)" if pj else None),
                          "algorithmic_bytes_per_launch": B * F * ALG_BYTES_DEMOD_PER_FRAME, "kernel_ms": demod_ms,
                          "classic_c2c_GBps": B * F * ALG_BYTES_FFT_CLASSIC_PER_FRAME / (demod_ms * 1e-3) / 1e9,
                          "survey_8d_fused_GBps": B * F * (196608 * 8 + 75 * 3072) / (demod_ms * 1e-3) / 1e9},
             "stages_ms": stages,
-            "viterbi": {"codeword_steps_per_s": n_cw_steps / ((stages["fic"] + stages["msc_viterbi"]) * 1e-3) if stages["msc_viterbi"] > 0 else None,
-                        "bound": "VALU int16 (v_pk_add/min_u16), metrics in VGPRs: no LDS traffic"},
         }
+        # ---- Viterbi stage: VALU issue roofline (the kernel holds its path metrics in VGPRs; no LDS traffic to be efficient with)
+        vit_ms = stages.get("msc_viterbi", 0.0)
+        vj = _static_profile("viterbi_counters.json", B, F)
+        ub = None
+        try:
+            ub = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
+        except Exception:
+            ub = None
+        rv = {"kernel": "k_viterbi, MSC class (lane = codeword, 64 states in 32 VGPRs of packed u16)", "bound": "valu",
+              "kernel_ms": vit_ms, "codeword_steps_per_s": B * F * 72 * 1542 / (vit_ms * 1e-3) if vit_ms > 0 else None,
+              "algorithmic_bytes": B * F * 72 * (4 * 1542 + 1536 // 8), "hbm_bytes": vj.get("hbm_bytes_per_launch") if vj else None,
+              "valu_insts_per_launch": vj.get("valu_insts_per_launch") if vj else None,
+              "counter_source": "static: profiles/viterbi_counters.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh; not measured by this run)" if vj else None}
+        if vj and vit_ms > 0:
+            ips = vj["valu_insts_per_launch"] / (vit_ms * 1e-3)
+            rv.update(unit="wave-instructions/s", achieved=ips, peak=n_simd * CLOCK_HZ / 2.0, frac=ips / (n_simd * CLOCK_HZ / 2.0),
+                      peak_note="MI355X_MICROARCH.md: one plain wave64 VALU instruction per SIMD every 2 cycles at 2.4 GHz")
+            if ub:
+                cyc = ub["cycles_per_instruction_kernel_mix"]
+                rv.update(peak_measured_mix=n_simd * CLOCK_HZ / cyc, frac_of_measured_mix=ips / (n_simd * CLOCK_HZ / cyc),
+                          measured_mix_note="profiles/valu_rate.json: issue cost of this kernel's instruction mix from tools/ubench/valu_rate.hip (packed 16-bit ops %.2f cycles, plain %.2f)" % (ub["cycles_packed"], ub["cycles_plain"]))
+        line["roofline_viterbi"] = rv
         line["config"]["schedule"] = {0: "serial synchroniser", 1: "pipelined: the next batch's synchroniser starts behind this batch's demod kernel",
                                       2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)"}[sched]
         if world == 1 and sched in (1, 2) and not args.no_alt_schedule:
             # the other pipelined schedule, measured the same way right after the timed region (reported, never `value`)
             dev.close(); dev = None
             alt = 3 - sched
-            dev2 = capi.DabPhy(n_ensembles=B, max_frames=F, device=local, lib_path=os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so")), want_constellation=False,
-                               want_impulse_response=False, disable_coarse=False, pipeline_sync=alt, demod_chunk=int(os.environ.get("DABPHY_DEMOD_CHUNK", "0")))
-            dev2.stream_bind_device(iq.data_ptr(), N, N, N, loop=True)
-            dev2.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev2.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
-            dev2.set_profiling(True); dev2.set_auto_superframes(True)
+            dev2 = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=alt, demod_chunk=chunk)
+
             def step2():
                 dev2.process(F); dev2.superframes_stats(); return dev2.fibs()
             for _ in range(3):
@@ -247,11 +305,13 @@ def main():
                                     "roofline_frac": B * F * ALG_BYTES_DEMOD_PER_FRAME / (dm * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             dev2.close()
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(base[0], n_loops=12)
-        print(json.dumps(line))
+            rows = {e: iq[e].cpu().numpy() for e in check}
+            line["cpu_baseline"], line["parity_check"] = cpu_baseline(rows, n_loops=12, gpu_logs=logs)
+        print(json.dumps(line), flush=True)
     if dev is not None:
         dev.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

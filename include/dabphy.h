@@ -157,6 +157,10 @@ int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_sampl
 int dabphy_stream_write_raw_async(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format);
 int dabphy_stream_commit(dabphy_handle* h);
 
+/* diagnostics: n samples of ensemble `ensemble` starting at absolute sample index `pos`, as they lie in the ring (cf32), e.g. to
+ * compare the device's format conversion with CRAWFile::convertSamples */
+int dabphy_stream_read(dabphy_handle* h, uint32_t ensemble, uint64_t pos, uint64_t n_samples, float* out);
+
 /* Page-locked host memory for the buffers handed to dabphy_stream_write / _write_raw (DMA at PCIe rate instead of a
  * staged copy); plain malloc'ed buffers work too. */
 int dabphy_host_alloc(size_t bytes, void** out);

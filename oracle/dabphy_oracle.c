@@ -533,6 +533,14 @@ static const int16_t UEP_TAB[64][11] = {
     {320,5,160, 11,26,200,3, 8,5,2,6}, {320,4,208, 11,25,201,3, 13,9,5,10}, {320,2,280, 11,26,200,3, 24,17,9,17},
     {384,5,192, 11,27,247,3, 8,6,2,7}, {384,3,280, 11,24,250,3, 16,9,7,10}, {384,1,416, 12,28,245,3, 24,20,14,23}};
 
+/* row `idx` of the short-form table (dab-constants.cpp:45-109): what FIG 0/1's 6-bit table index selects */
+int orc_uep_table(int idx, int* bitrate, int* level, int* size_cu)
+{
+    if (idx < 0 || idx >= 64) return -1;
+    *bitrate = UEP_TAB[idx][0]; *level = UEP_TAB[idx][1]; *size_cu = UEP_TAB[idx][2];
+    return 0;
+}
+
 /* uep-protection.cpp:120-167 (unknown pair falls back to row 1 like the reference) */
 int orc_prot_uep(orc_prot* p, int bitRate, int level)
 {

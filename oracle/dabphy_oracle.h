@@ -72,6 +72,7 @@ typedef struct {
 } orc_prot;
 int orc_prot_fic(orc_prot* p);
 int orc_prot_eep(orc_prot* p, int bitrate, int profile_b, int level);     /* eep-protection.cpp:32-113 */
+int orc_uep_table(int idx, int* bitrate, int* level, int* size_cu);         /* dab-constants.cpp:45-109 */
 int orc_prot_uep(orc_prot* p, int bitrate, int level);                    /* uep-protection.cpp:27-167 */
 void orc_depuncture(const orc_prot* p, const int8_t* in, int8_t* out /* 4*nbits+24 */);
 

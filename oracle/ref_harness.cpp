@@ -43,6 +43,7 @@
 #define private public
 #define protected public
 #include "radio-receiver.h"
+#include "raw_file.h"
 #include "dabplus_decoder.h"
 #undef private
 #undef protected
@@ -384,6 +385,29 @@ int ref_tii_run(const float* nulls, const float* prss, int n_pairs, ref_tii_even
         }
     }
     return rec.n;
+}
+
+// ---- CRAWFile (input/raw_file.cpp): the reference's own file reader, reading `path` in `format` ("u8", "s8", "s16le", "s16be",
+// "cf32", "auto") without throttling or rewind; out = the first `cap` samples CRAWFile::getSamples -> convertSamples
+// (raw_file.cpp:203-214,324-366) hands over.  Pins the device's ingest conversion (k_ingest) to the real class.
+int ref_rawfile_read(const char* path, const char* format, float* out /* cap x (re, im) */, int cap)
+{
+    Recorder rec;
+    CRAWFile f(rec, false, false);
+    f.setFileName(path, format);
+    if (!f.restart()) return -1;
+    int n = 0;
+    for (int idle = 0; n < cap && idle < 2000;) {
+        int32_t avail = f.getSamplesToRead();
+        if (avail <= 0) { idle++; std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+        if (avail > cap - n) avail = cap - n;
+        if (avail > 8192) avail = 8192;
+        const int32_t got = f.getSamples(reinterpret_cast<DSPCOMPLEX*>(out) + n, avail);
+        if (got <= 0) { idle++; continue; }
+        n += got; idle = 0;
+    }
+    f.stop();
+    return n;
 }
 
 } // extern "C"

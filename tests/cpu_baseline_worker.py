@@ -1,5 +1,8 @@
-"""Not a test: one single-threaded CPU receiver (the oracle = CPU restatement of the reference algorithm) over a recording,
-timed; bench.py starts one of these per host core for its `cpu_baseline` leg.  argv: recording.npy n_loops seed"""
+"""Not a test: one CPU receiver over a looping recording, timed; bench.py starts one of these per host core for its `cpu_baseline`
+leg and compares what the first ones decoded with the GPU's output for the same rows (the run's parity check).
+argv: recording.npy n_loops mode(port|reference) out.npz|-
+  port       the oracle = single-threaded C restatement of the reference's PHY
+  reference  the real reference backend (oracle/_ref): RadioReceiver with its own threads, FIBProcessor, DecoderAdapter (incl. AAC)"""
 import json
 import os
 import sys
@@ -14,25 +17,25 @@ load_package()
 import refapi as R  # noqa: E402
 from welle_io_amd import synth  # noqa: E402
 
-base = np.load(sys.argv[1]); n_loops = int(sys.argv[2]); seed = int(sys.argv[3])
-use_reference = len(sys.argv) > 4 and sys.argv[4] == "reference"      # the real reference backend (oracle/_ref) instead of the restatement
+rec = np.load(sys.argv[1]); n_loops = int(sys.argv[2]); mode = sys.argv[3]; out = sys.argv[4]
 subchs = synth.EnsembleTx(eid=0x1000, seed=0).subchs          # the canonical 18 x 64 kbit/s EEP-3A layout
-x = np.tile(base, n_loops)
-rng = np.random.RandomState(seed)
-xv = x.view(np.float32)
-for i in range(0, len(xv), 1 << 22):
-    xv[i:i + (1 << 22)] += (0.02 * rng.randn(len(xv[i:i + (1 << 22)]))).astype(np.float32)
-if use_reference:
+x = np.tile(rec, n_loops)                                     # the looping ring as the device sees it, noise and carrier offset included
+if mode == "reference":
     R.ref()
 else:
     R.orc(); R.orc_nco_table()                                 # load + build tables outside the timed region
 print("READY", flush=True)
 sys.stdin.readline()                                           # all receivers start together
 t0 = time.time()
-if use_reference:
-    a = R.receiver_run(x, subchs=subchs)                        # RadioReceiver + its own threads, FIBProcessor, DecoderAdapter (incl. AAC)
+if mode == "reference":
+    a = R.receiver_run(x, subchs=subchs)
     dt = time.time() - t0
-    print(json.dumps({"frames": len(a["fib"]) // 12, "seconds": dt, "fib_ok": int(a["fib"][:, 0].sum()), "fibs": int(len(a["fib"]))}), flush=True)
+    fib, msc, frames = a["fib"], a["msc"], len(a["fib"]) // 12
 else:
     o = R.orc_receiver_run(x, subchs=subchs)
-    print(json.dumps({"frames": int(o["n_frames"]), "seconds": time.time() - t0, "fib_ok": int(o["fib"][:, 0].sum()), "fibs": int(len(o["fib"]))}), flush=True)
+    dt = time.time() - t0
+    fib, msc, frames = o["fib"], o["msc"], int(o["n_frames"])
+if out != "-":
+    keep = 64                                                  # frames of output kept for the parity comparison
+    np.savez(out, fib=fib[:12 * keep], **{"msc%d" % i: np.frombuffer(bytes(msc[i])[:4 * keep * 192], np.uint8) for i in range(len(subchs))})
+print(json.dumps({"frames": frames, "seconds": dt, "fib_ok": int(fib[:, 0].sum()), "fibs": int(len(fib))}), flush=True)

@@ -101,16 +101,21 @@ def check_demod_degenerate(d, seed=21):
         assert np.array_equal(soft, so), "%d of %d soft bits differ" % ((soft != so).sum(), soft.size)
 
 
+def dev_prot(d, s):
+    """device protection record of a synth.SubchannelCfg (dabphy_protection_eep / _uep)"""
+    return d.protection_uep(s.bitrate, s.level) if getattr(s, "uep", None) is not None else d.protection_eep(s.bitrate, s.profile_b, s.level)
+
+
 def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2):
     """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
     from welle_io_amd import capi  # noqa: F401
     d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
-        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subs])
         logs = [dict(fib=[], ok=[], info=[], con=[], soft=[], nul=[], msc=[[] for _ in subs]) for _ in range(B)]
         done = 0
-        while done < n_frames_total:
+        while done < n_frames_total + 2 * F:
             d.process(F)
             info = d.frame_info(); fb, ok = d.fibs(); cn = d.constellation() if con else np.zeros((B, F, 1200), np.complex64)
             nl = d.null_symbols()
@@ -127,7 +132,8 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
                 for i in range(len(subs)):
                     m, fv = mscs[i]
                     logs[b]["msc"][i].append(m[b, fv[b]:4 * nv].tobytes())
-            if not (info["valid"] == 1).any():
+                assert len(subs) == 0 or d.msc_rows[b] == 4 * nv
+            if (info["valid"] == 0).all():              # starved: the stream has ended (a failed window search is valid = 3 and goes on)
                 break
             done += F
         return logs
@@ -135,7 +141,22 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
         d.close()
 
 
-def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True, fft_placement=2, freqsync=2):
+def fic_ratio_before(ok_flags):
+    """FicHandler's saturating success counter (fic-handler.cpp:219-229) x 10 as it stands BEFORE each frame: what
+    OFDMProcessor::run consults for that frame's coarse corrector (ofdm-processor.cpp:397)"""
+    r = 0; out = []
+    for frame in ok_flags:
+        out.append(10 * r)
+        for k in frame:
+            r = min(10, r + 1) if k else max(0, r - 1)
+    return out
+
+
+def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True, fft_placement=2, freqsync=2,
+                           ratio_lag_ok=False):
+    """ratio_lag_ok: batch mode's documented deviation (include/dabphy.h, dabphy_process) is tolerated and PINNED: the frames must
+    equal the oracle's up to the first frame before which the FIC ratio crossed the 50 % line within the last F (2F when pipelined)
+    frames -- only there may a batch have consulted a stale ratio; what comes before is compared bit for bit, returns that frame"""
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
     o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse, fft_placement=fft_placement, freqsync=freqsync)
@@ -143,7 +164,21 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
     for b in range(B):
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)
-        assert n >= o["n_frames"] - (1 if lockstep else F) * (2 if pipeline_sync else 1), (n, o["n_frames"])
+        if ratio_lag_ok:
+            ofib = o["fib"][:12 * n].reshape(n, 12, 33)
+            inf = np.array(L["info"][:n])
+            same = [np.array_equal(L["ok"][k], ofib[k, :, 0]) and np.array_equal(L["fib"][k], ofib[k, :, 1:]) and
+                    (int(inf["fine"][k]), int(inf["coarse"][k])) == tuple(int(v) for v in o["corr"][k]) for k in range(n)]
+            if not all(same):
+                k = same.index(False)
+                rb = fic_ratio_before(o["fib"].reshape(-1, 12, 33)[:, :, 0])
+                lag = F * (2 if pipeline_sync else 1)
+                crossed = [f for f in range(max(1, k - lag), k + 1) if any((rb[f] < 50) != (rb[g] < 50) for g in range(max(0, f - lag), f))]
+                assert crossed, "frame %d differs from the oracle although the FIC ratio did not cross 50 %% in the %d frames before it: %s" % (k, lag, rb[max(0, k - lag):k + 1])
+                n = k                                   # everything before the tolerated divergence is compared below
+                assert n >= 4, n
+        else:
+            assert n >= o["n_frames"] - (1 if lockstep else F) * (2 if pipeline_sync else 1), (n, o["n_frames"])
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
         assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]), "CRC flags differ"
         assert np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:]), "FIB bytes differ"
@@ -159,6 +194,8 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
         assert np.array_equal(rep, o["snr"][:len(rep)])      # same libm-free arithmetic up to log10: equal here, 1e-5 by contract
         for i in range(len(subs)):
             got = b"".join(L["msc"][i])
+            if ratio_lag_ok:
+                got = got[:max(0, 4 * n - 16) * subs[i].frame_bytes]
             assert len(got) > 0 or n < 5
             assert got == o["msc"][i][:len(got)], "MSC bytes of sub-channel %d differ" % i
     return logs, o, tx
@@ -314,6 +351,10 @@ def check_mixed_ensemble(d_factory, F=4, nf=11, snr_db=12, seed=31):
     subchs = []; cu = 0
     for sid, br, pb, lvl in cfgs:
         sc = synth.SubchannelCfg(sid, cu, br, pb, lvl, dabplus=False); subchs.append(sc); cu += sc.size_cu
+    # short-form (UEP) sub-channels through the streaming path: 80 kbit/s level 1 (the reference's table row with PI2 = 7,
+    # uep-protection.cpp:66) and the longest code word there is, 384 kbit/s (9216 bits, level 5)
+    for sid, br, lvl in ((8, 80, 1), (9, 384, 5)):
+        sc = R.uep_subchannel(synth, sid, cu, br, lvl); subchs.append(sc); cu += sc.size_cu
     assert cu <= 864
     x, tx = synth.make_stream(nf, subchs=subchs, snr_db=snr_db, cfo_hz=-55, delay=123, return_tx=True, seed=seed)
     o = R.orc_receiver_run(x, subchs=subchs)
@@ -600,3 +641,82 @@ def check_demod_chunks(d_factory, chunks=(7, 25, 75), snr_db=13, seed=2, early=1
             assert np.array_equal(con.view(np.uint32), co.view(np.uint32)), "demod_chunk %d: constellation points differ" % ch
         finally:
             d.close()
+
+
+def check_ingest_vs_rawfile(d_factory, fmt, tmp_path, n_bytes=3 * 32768 + 4001, seed=77):
+    """k_ingest against the reference's own CRAWFile reading the same bytes from a file: every byte value occurs, the byte count is
+    odd (and not a multiple of the sample size), the file spans several of the reader's 32 KiB blocks, and the write wraps the ring"""
+    rng = np.random.RandomState(seed)
+    raw = rng.randint(0, 256, n_bytes).astype(np.uint8)
+    raw[:512] = np.repeat(np.arange(256, dtype=np.uint8), 2)           # I = Q = every value
+    raw[512:1024] = np.tile(np.array([0x80, 0x00, 0x7f, 0xff, 0x00, 0x80, 0xff, 0x7f], np.uint8), 64)   # extremes, both byte orders
+    path = str(tmp_path / ("blob.%s.iq" % fmt))
+    raw.tofile(path)
+    bps = 2 if fmt in ("u8", "s8") else 4
+    # without rewind the reference drops the file's last partial 32 KiB block (raw_file.cpp:307-325: a short read returns 0), so the
+    # odd tail never reaches convertSamples: whole blocks are compared
+    n = n_bytes // 32768 * 32768 // bps
+    want = R.ref_rawfile_read(path, fmt, n)
+    d = d_factory(n_ensembles=2, max_frames=1, want_constellation=False)
+    try:
+        ring = 4 * 196608
+        d.stream_open(ring)
+        pre = ring - n // 3                                              # fill up to n/3 samples before the wrap point
+        d.stream_write_raw(np.zeros((2, pre, 2), np.uint8) + 128, "u8")
+        body = raw[:n * bps].reshape(n, bps)
+        both = np.stack([body, body[::-1]])                              # ensemble 1: the same samples in reverse order
+        d.stream_write_raw(both, fmt)
+        got0 = d.stream_read(0, pre, n); got1 = d.stream_read(1, pre, n)
+    finally:
+        d.close()
+    assert np.array_equal(got0.view(np.uint32), want.view(np.uint32)), "%s: %d samples differ from CRAWFile::convertSamples" % (fmt, (got0 != want).sum())
+    assert np.array_equal(got1.view(np.uint32), np.ascontiguousarray(want[::-1]).view(np.uint32))
+
+
+def check_dropout_batch(d_factory, F=4):
+    """the dropout of check_dropout_relock, four frames per call (an invalid slot in front of valid ones inside a batch).
+    Positions, window indices and FIBs of every frame equal the oracle's as long as the coarse corrector's view of the FIC ratio agrees
+    (it is disabled here: the stale-ratio deviation is pinned elsewhere); the logical frames of both sub-channels come out gap-free
+    and equal the oracle's; the superframe filter's events equal the restated SuperframeFilter fed with those frames."""
+    T_F = 196608
+    x, tx = synth.make_stream(20, snr_db=18, cfo_hz=60, delay=200, seed=8, return_tx=True, payload_fn=synth.dabplus_payload_fn(80, 8))
+    x = x.copy()
+    x[6 * T_F + 50000:7 * T_F + 120000] = 0
+    subs = [tx.subchs[1], tx.subchs[4]]
+    o = R.orc_receiver_run(x, subchs=subs, disable_coarse=True)
+    assert o["n_sync_false"] > 5 and o["n_frames"] >= 16
+    d = d_factory(n_ensembles=1, max_frames=F, want_constellation=False, disable_coarse=True)
+    try:
+        d.stream_upload(x[None, :])
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subs])
+        got = []; msc = [[] for _ in subs]; sf_ev = [[] for _ in subs]; patterns = []
+        for _ in range(12):
+            d.process(F)
+            info = d.frame_info(); fb, ok = d.fibs()
+            if (info["valid"] == 0).all():
+                break
+            patterns.append(tuple(int(v) for v in info[0]["valid"]))
+            for f in range(F):
+                if info[0, f]["valid"] == 1:
+                    got.append((int(info[0, f]["pos"]), int(info[0, f]["start_index"]), ok[0, f].copy(), fb[0, f].copy()))
+            for i, sc in enumerate(subs):
+                m, fv = d.msc(i)
+                msc[i].append(m[0, fv[0]:d.msc_rows[0]].tobytes())
+                ev, ne, sf = d.superframes(i, sc.bitrate)
+                sf_ev[i] += [(int(e["corrected"]), int(e["uncorrectable"]), int(e["sync"])) for e in ev[0, :ne[0]]]
+    finally:
+        d.close()
+    assert any(p.index(1) > 0 and p[0] != 1 for p in patterns if 1 in p) or any(3 in p and 1 in p[p.index(3):] for p in patterns), patterns   # an invalid slot in FRONT of valid ones
+    n = len(got)
+    assert n >= o["n_frames"] - F
+    ofib = o["fib"].reshape(-1, 12, 33)
+    for k in range(min(n, o["n_frames"])):
+        g = got[k]
+        assert (g[0], g[1]) == (int(o["frame_pos"][k]), int(o["start_index"][k])), "frame %d found at %s, the reference finds it at %s" % (k, g[:2], (o["frame_pos"][k], o["start_index"][k]))
+        assert np.array_equal(g[2], ofib[k, :, 0]) and np.array_equal(g[3], ofib[k, :, 1:])
+    for i, sc in enumerate(subs):
+        b = b"".join(msc[i])
+        assert len(b) == (4 * n - 16) * sc.frame_bytes and b == o["msc"][i][:len(b)], "MSC bytes of sub-channel %d differ" % i
+        fr = np.frombuffer(b, np.uint8).reshape(-1, sc.frame_bytes)
+        eo, _ = R.orc_superframe_run(fr)
+        assert sf_ev[i] == [(e[1], e[2], e[3]) for e in eo], "superframe events of sub-channel %d differ" % i

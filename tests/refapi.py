@@ -70,6 +70,8 @@ def receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_place
     for i, s in enumerate(subchs):
         arr[i].subChId = s.subch_id; arr[i].startAddr = s.start_cu; arr[i].length = s.size_cu
         arr[i].shortForm = 0; arr[i].eepProfileB = int(s.profile_b); arr[i].eepLevel = s.level
+        if getattr(s, "uep", None) is not None:
+            arr[i].shortForm = 1; arr[i].uepTableIndex = s.uep[0]; arr[i].uepLevel = s.level
         arr[i].dabplus = int(s.dabplus)
         path = os.path.join(dump_dir, "refdump_%d_%d.msc" % (os.getpid(), s.subch_id))
         if os.path.exists(path):
@@ -92,6 +94,14 @@ def receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_place
     return dict(fib=fib[:io.n_fib], cir=cir[:io.n_cir], con=con[:io.n_con], nul=nul[:io.n_nul], snr=snr[:io.n_snr],
                 corr=corr[:io.n_nul], n_sync_true=io.n_sync_true, n_sync_false=io.n_sync_false, msc=msc,
                 rs_calls=list(io.rs_calls), rs_uncorr=list(io.rs_uncorr), rs_corr=list(io.rs_corr))
+
+
+def ref_rawfile_read(path, fmt, n_samples):
+    """the reference's CRAWFile (input/raw_file.cpp) reading `path` as `fmt`: the first n_samples it hands to getSamples()"""
+    out = np.zeros(n_samples, np.complex64)
+    n = ref().ref_rawfile_read(path.encode(), fmt.encode(), _p(out), n_samples)
+    assert n == n_samples, (n, n_samples)
+    return out
 
 
 def ref_fft2048(x, inverse=False):
@@ -250,6 +260,29 @@ def orc_prot_fic():
     p = OrcProt(); orc().orc_prot_fic(C.byref(p)); return p
 
 
+def orc_uep_row(bitrate, level):
+    """(table index, size in CU) of the short-form table row for (bitrate, level)"""
+    b = C.c_int(); l = C.c_int(); sz = C.c_int()
+    for i in range(64):
+        assert orc().orc_uep_table(i, C.byref(b), C.byref(l), C.byref(sz)) == 0
+        if b.value == bitrate and l.value == level:
+            return i, sz.value
+    raise ValueError("no UEP row for %d kbit/s level %d" % (bitrate, level))
+
+
+def orc_prot_of(s):
+    """oracle protection record of a synth.SubchannelCfg (EEP long form or UEP short form)"""
+    return orc_prot_uep(s.bitrate, s.level) if getattr(s, "uep", None) is not None else orc_prot_eep(s.bitrate, s.profile_b, s.level)
+
+
+def uep_subchannel(synth, subch_id, start_cu, bitrate, level, dabplus=False):
+    """a synth.SubchannelCfg in short form, its segments and size taken from the oracle's table (itself pinned to the reference's)"""
+    p = orc_prot_uep(bitrate, level)
+    idx, size = orc_uep_row(bitrate, level)
+    segs = [(p.L[i], p.PI[i]) for i in range(4) if p.PI[i] > 0 and p.L[i] > 0]
+    return synth.SubchannelCfg(subch_id, start_cu, bitrate, level=level, dabplus=dabplus, uep=(idx, size, segs))
+
+
 def orc_prot_eep(bitrate, profile_b, level):
     p = OrcProt(); r = orc().orc_prot_eep(C.byref(p), bitrate, int(profile_b), level); assert r == 0; return p
 
@@ -340,7 +373,7 @@ def orc_receiver_run(iq, subchs=(), disable_coarse=False, fft_placement=2, want_
     bufs = []; ptrs = (C.c_void_p * max(1, len(subchs)))(); caps = (C.c_int64 * max(1, len(subchs)))(); lens = (C.c_int64 * max(1, len(subchs)))()
     for i, s in enumerate(subchs):
         cfg[i].subch_id = s.subch_id; cfg[i].start_cu = s.start_cu; cfg[i].length_cu = s.size_cu
-        cfg[i].prot = orc_prot_eep(s.bitrate, s.profile_b, s.level)
+        cfg[i].prot = orc_prot_of(s)
         b = np.zeros(nf * 4 * s.frame_bytes, np.uint8); bufs.append(b); ptrs[i] = b.ctypes.data; caps[i] = len(b)
     io.n_subch = len(subchs); io.subch = cfg; io.msc = ptrs; io.msc_cap = caps; io.msc_len = lens
     fib = np.zeros((nf * 12, 33), np.uint8); io.fib = _p(fib); io.fib_cap = nf * 12

@@ -39,3 +39,9 @@ def test_error_behaviour(emu):
     from welle_io_amd import capi
     import conftest
     P.check_error_behaviour(lambda **kw: capi.DabPhy(lib_path=conftest.EMU_LIB, **kw))
+
+
+def test_demod_chunk_sizes(emu):
+    from welle_io_amd import capi
+    import conftest
+    P.check_demod_chunks(lambda **kw: capi.DabPhy(lib_path=conftest.EMU_LIB, **kw))

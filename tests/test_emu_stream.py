@@ -89,3 +89,32 @@ def test_relock_after_long_lock(emu):
 
 def test_fine_corrector_on_the_edge(emu):
     P.check_fine_corrector_on_the_edge(factory)
+
+
+def test_benchmark_handle_configuration_small(emu):
+    """the handle bench.py opens (looping ring, coarse corrector on, pipelined synchroniser, all 18 sub-channels, superframe filter
+    inside process(), 25-symbol demod chunks), at a size the execution model finishes: against the oracle on the same samples"""
+    from welle_io_amd import workload
+    P.check_bench_config(capi, EMU_LIB, 3, 3, 1, check_ens=[0, 1, 2], n_steps=5, demod_chunk=25, device="cpu", subs_idx=(0, 7, 17),
+                         base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=0), expect_chunk=25)
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
+def test_ingest_vs_reference_crawfile(emu, fmt, tmp_path):
+    """k_ingest pinned to the real CRAWFile::convertSamples (input/raw_file.cpp:324-366, compiled into oracle/_ref)"""
+    import refapi as R
+    if not R.have_ref():
+        pytest.skip("oracle/_ref not built")
+    P.check_ingest_vs_rawfile(factory, fmt, tmp_path)
+
+
+@pytest.mark.parametrize("snr,cfo,F,seed", [(4, 300, 4, 3), (3, -1000, 4, 5), (5, 2300, 6, 7), (2, 40, 4, 9)])
+def test_low_snr_batches_with_coarse_corrector(emu, snr, cfo, F, seed):
+    """batch mode (F > 1) with the coarse corrector enabled while the FIC decodes badly (ratio around / below 50): the corrector then
+    consults the previous batch's ratio (include/dabphy.h, dabphy_process); these streams, including losses of lock inside a batch,
+    either give the oracle's frames bit for bit or part from them exactly where the ratio crossed the 50 % line inside a batch"""
+    P.check_stream_vs_oracle(factory, snr, cfo, 150, 21, False, F=F, seed=seed, ratio_lag_ok=True)
+
+
+def test_dropout_in_batch_mode(emu):
+    P.check_dropout_batch(factory)

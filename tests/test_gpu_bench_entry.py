@@ -1,0 +1,48 @@
+"""bench.py's own entry points on the device, small sizes: the line's contract fields, the parity leg (GPU vs CPU receivers on the same
+rows), the RCCL gather of device buffers with one rank, and `--gpus 2` starting its two ranks itself (on a 1-GPU box the two ranks
+share the device and the collective falls back to gloo -- RCCL refuses two ranks on one GPU; with >= 2 GPUs it is the real thing)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_and_parity_leg(gpu):
+    j = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "2", "--ensembles", "8", "--frames", "10", "--no-alt-schedule"])
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 0 and j["value"] > 0 and j["higher_is_better"] is True
+    for k in ("roofline", "roofline_viterbi", "cpu_baseline", "parity_check", "stages_ms"):
+        assert k in j, k
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["parity_check"]["fib_equal"] and j["parity_check"]["msc_equal"] and j["parity_check"]["frames"] >= 15
+    assert j["cpu_baseline"]["kind"] in ("reference", "port") and j["cpu_baseline"]["value"] > 0
+
+
+def test_rccl_gather_of_device_buffers_one_rank(gpu):
+    j = run_bench(["--gpus", "1", "--steps", "2", "--ensembles", "8", "--frames", "10", "--no-alt-schedule", "--no-cpu-baseline"], {"DABPHY_FORCE_DIST": "1"})
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["value"] > 0
+
+
+def test_gpus_2_starts_its_ranks(gpu):
+    import torch
+    env = {} if torch.cuda.device_count() >= 2 else {"DABPHY_SHARE_GPU": "1", "DABPHY_DIST_BACKEND": "gloo"}
+    env = dict(env, **{k: "" for k in ()})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    j = run_bench(["--gpus", "2", "--steps", "1", "--ensembles", "4", "--frames", "10", "--no-alt-schedule", "--no-cpu-baseline"], env)
+    assert j["n_gpus"] == 2 and j["config"]["ensembles_per_gpu"] == 4
+    assert j["rccl_ranks"] == (2 if torch.cuda.device_count() >= 2 else 0)

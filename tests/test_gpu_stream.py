@@ -108,3 +108,26 @@ def test_relock_after_long_lock(gpu):
 
 def test_fine_corrector_on_the_edge(gpu):
     P.check_fine_corrector_on_the_edge(factory)
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
+def test_ingest_vs_reference_crawfile(gpu, fmt, tmp_path):
+    """k_ingest pinned to the real CRAWFile::convertSamples (input/raw_file.cpp:324-366, compiled into oracle/_ref)"""
+    import refapi as R
+    if not R.have_ref():
+        pytest.skip("oracle/_ref not built")
+    P.check_ingest_vs_rawfile(factory, fmt, tmp_path)
+
+
+@pytest.mark.parametrize("snr,cfo,F,seed", [(4, 300, 4, 3), (3, -1000, 4, 5), (5, 2300, 6, 7), (2, 40, 4, 9), (3, -1000, 8, 11), (4, 17400, 5, 13)])
+def test_low_snr_batches_with_coarse_corrector(gpu, snr, cfo, F, seed):
+    """batch mode (F > 1) with the coarse corrector enabled while the FIC decodes badly (ratio around / below 50): the corrector then
+    consults the previous batch's ratio (include/dabphy.h, dabphy_process); these streams, including losses of lock inside a batch,
+    either give the oracle's frames bit for bit or part from them exactly where the ratio crossed the 50 % line inside a batch"""
+    P.check_stream_vs_oracle(factory, snr, cfo, 150, 25, False, F=F, seed=seed, ratio_lag_ok=True)
+
+
+def test_dropout_in_batch_mode(gpu):
+    """a dropout decoded four frames per call: the slot after the failed window search re-acquires at once (k_acquire is queued before
+    every frame step), MSC rows stay packed, the superframe filter walks the frames that exist"""
+    P.check_dropout_batch(factory)

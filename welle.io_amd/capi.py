@@ -238,6 +238,11 @@ class DabPhy:
         bps = 2 if code <= 2 else 4
         self._chk(self.lib.dabphy_stream_write_raw_async(self.h, _p(data), C.c_uint64(data.nbytes // (self.cfg.n_ensembles * bps)), code))
 
+    def stream_read(self, ensemble, pos, n):
+        out = np.zeros(n, np.complex64)
+        self._chk(self.lib.dabphy_stream_read(self.h, ensemble, C.c_uint64(pos), C.c_uint64(n), _p(out)))
+        return out
+
     def stream_commit(self):
         self._chk(self.lib.dabphy_stream_commit(self.h))
 

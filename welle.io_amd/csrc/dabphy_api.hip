@@ -448,6 +448,17 @@ int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_sampl
     return sync(h);
 }
 
+int dabphy_stream_read(dabphy_handle* h, uint32_t ensemble, uint64_t pos, uint64_t n_samples, float* out)
+{
+    if (!h || !out || !h->s_iq || ensemble >= h->cfg.n_ensembles || n_samples == 0 || n_samples > h->s_ring) return DABPHY_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    const cf32* src = h->s_iq + (size_t)ensemble * h->s_stride;
+    const uint64_t w = pos % h->s_ring, first = std::min<uint64_t>(n_samples, h->s_ring - w);
+    HIPCHK(h, hipMemcpyAsync(out, src + w, first * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
+    if (first < n_samples) HIPCHK(h, hipMemcpyAsync(out + 2 * first, src, (n_samples - first) * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
 int dabphy_stream_write_raw_async(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format)
 {
     if (!h || !data || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring ||

@@ -178,17 +178,26 @@ def prs_freq():
 class SubchannelCfg:
     """EEP sub-channel (long form).  size in CUs derived like Subchannel::bitrate (dab-constants.cpp:404)."""
 
-    def __init__(self, subch_id, start_cu, bitrate, profile_b=False, level=3, dabplus=True):
+    def __init__(self, subch_id, start_cu, bitrate, profile_b=False, level=3, dabplus=True, uep=None):
+        """uep = (table_index, size_cu, segments): short-form (UEP) sub-channel, `level` then is the UEP protection level and the
+        (L_i, PI_i) segments / the size come from the caller (the tests take them from the oracle's table)"""
         self.subch_id, self.start_cu, self.bitrate = subch_id, start_cu, bitrate
         self.profile_b, self.level, self.dabplus = profile_b, level, dabplus
-        self.segments = eep_segments(bitrate, profile_b, level)
+        self.uep = uep
+        self.segments = eep_segments(bitrate, profile_b, level) if uep is None else list(uep[2])
         nb = 24 * bitrate
         self.n_coded = int(puncture_mask(self.segments, nb).sum())
-        assert self.n_coded % 64 == 0
-        self.size_cu = self.n_coded // 64
+        if uep is None:
+            assert self.n_coded % 64 == 0
+            self.size_cu = self.n_coded // 64
+        else:
+            self.size_cu = uep[1]                       # short form: the table's size; the punctured bits may fall short of it (padding)
+            assert self.n_coded <= 64 * self.size_cu
         self.frame_bytes = 3 * bitrate
 
     def fig0_1(self):
+        if self.uep is not None:                        # short form: table switch 0, 6-bit table index
+            return bytes([(self.subch_id << 2) | (self.start_cu >> 8), self.start_cu & 0xFF, self.uep[0] & 0x3F])
         opt = 1 if self.profile_b else 0
         prot = self.level - 1
         return bytes([(self.subch_id << 2) | (self.start_cu >> 8), self.start_cu & 0xFF,
