@@ -39,10 +39,13 @@ def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir):
     """n_proc concurrent receiver processes, receiver i over recording recs[i % len(recs)]; returns their result records"""
     args = [sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py")]
     procs = [subprocess.Popen(args + [recs[i % len(recs)], str(n_loops), mode, os.path.join(out_dir, "%s_%d.npz" % (mode, i)) if i < len(recs) else "-"],
-                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(n_proc)]
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=open(os.path.join(out_dir, "%s_err.txt" % mode), "w") if i == 0 else subprocess.DEVNULL, text=True, env=env) for i in range(n_proc)]
     for p in procs:
         if p.stdout.readline().strip() != "READY":
-            raise RuntimeError("CPU baseline worker did not start")
+            err = open(os.path.join(out_dir, "%s_err.txt" % mode)).read()[-400:]
+            for q in procs:
+                q.kill()
+            raise RuntimeError("CPU baseline worker did not start " + err)
     for p in procs:
         p.stdin.write("go\n"); p.stdin.flush()            # all receivers start together
     res = [json.loads(p.stdout.readline()) for p in procs]
@@ -70,12 +73,12 @@ def cpu_baseline(rows, n_loops, gpu_logs):
             path = os.path.join(td, "rec%d.npy" % e); np.save(path, rows[e]); recs.append(path)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         res = _run_receivers(recs, cores, n_loops, "port", env, td)
-        ref = None
+        ref = None; ref_error = None
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref.so")):
             try:
                 ref = _run_receivers(recs, max(len(recs), cores // 2), max(1, n_loops // 2), "reference", env, td)
-            except Exception:
-                ref = None
+            except Exception as ex:                        # reported in the line (kind falls back to "port")
+                ref = None; ref_error = "%s: %s" % (type(ex).__name__, ex)
         # ---- parity of this run: GPU log vs CPU receivers on the same rows
         parity = {"ensembles": ens, "sub_channels": list(PARITY_SUBCH), "against": []}
         for mode in (["reference"] if ref else []) + ["port"]:
@@ -112,7 +115,7 @@ def cpu_baseline(rows, n_loops, gpu_logs):
                     per_core=port["per_core"],
                     sample="%d receivers x %d frames (%.1f s of IQ each) of ensembles %s of this batch, 18 sub-channels, oracle C restatement, slowest receiver %.1f s"
                            % (cores, res[0]["frames"], res[0]["frames"] * FRAME_S, ens, max(r["seconds"] for r in res)),
-                    fib_ok=port["fib_ok"], fibs=port["fibs"])
+                    fib_ok=port["fib_ok"], fibs=port["fibs"], reference_error=ref_error)
     return base, parity
 
 

@@ -62,6 +62,11 @@ def gpu():
     """the product library on a real device; fails loudly if it is missing"""
     from welle_io_amd import capi
     assert os.path.exists(GPU_LIB), "libdabphy_hip.so not built: run __graft_entry__.build()"
+    # torch's bundled HIP runtime must come up BEFORE the library brings up the system one: the other order leaves torch without
+    # devices ("No HIP GPUs are available"), and tests/test_gpu_bench_config.py builds its batch with torch on the device
+    import torch
+    assert torch.cuda.is_available(), "no GPU visible to torch"
+    torch.cuda.init()
     d = capi.DabPhy(lib_path=GPU_LIB)
     assert "gfx950" in d.device_name
     yield d

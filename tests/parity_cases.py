@@ -176,7 +176,7 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
                 crossed = [f for f in range(max(1, k - lag), k + 1) if any((rb[f] < 50) != (rb[g] < 50) for g in range(max(0, f - lag), f))]
                 assert crossed, "frame %d differs from the oracle although the FIC ratio did not cross 50 %% in the %d frames before it: %s" % (k, lag, rb[max(0, k - lag):k + 1])
                 n = k                                   # everything before the tolerated divergence is compared below
-                assert n >= 4, n
+                assert n >= 1, n
         else:
             assert n >= o["n_frames"] - (1 if lockstep else F) * (2 if pipeline_sync else 1), (n, o["n_frames"])
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
