@@ -48,6 +48,10 @@ typedef struct {
                                        feedback then lags one more batch).  1: the next batch's synchroniser is queued behind this
                                        batch's demod kernel; 2: at once (it then competes with the demod kernel: more frames per
                                        second in total, a slower FFT stage) */
+    int32_t msc_parts;              /* decode every MSC protection class in this many parts (whole ensembles each): part p's Viterbi kernel
+                                       (VALU-bound) runs on a side stream while part p + 1 is gathered (HBM-bound).  0 or 1 = one gather and
+                                       one decode launch per class, which is also what measures best on MI355X: parts that are not
+                                       resident together leave the Viterbi kernel below its five waves per SIMD */
 } dabphy_config;
 
 /* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)

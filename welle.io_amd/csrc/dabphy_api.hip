@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <algorithm>
 
@@ -56,6 +57,10 @@ struct dabphy_handle {
     DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
+    hipStream_t vit_stream[2] = {nullptr, nullptr};      // the MSC class is decoded in parts: part p's Viterbi (+ superframe filter) runs here while part p + 1 is gathered
+    static constexpr int MAX_PARTS = 8;
+    hipEvent_t ev_part[MAX_PARTS]{}, ev_vit_done[2]{};
+    int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
     hipEvent_t ev_chain_beg[2]{}, ev_chain_end[2]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
     bool need_acquire = true;         // queue k_acquire in front of every frame step
@@ -115,7 +120,7 @@ int sync(dabphy_handle* h)
 // Fill a VitClass for n_cw codewords of nbits and make sure its device buffers exist.
 int prepare_class(dabphy_handle* h, VitClass& c, int nbits, int n_cw, int dedisperse)
 {
-    c.nbits = nbits; c.nsteps = nbits + 6; c.n_cw = n_cw; c.n_groups = (n_cw + 63) / 64; c.dedisperse = dedisperse;
+    c.nbits = nbits; c.nsteps = nbits + 6; c.n_cw = n_cw; c.n_groups = (n_cw + 63) / 64; c.dedisperse = dedisperse; c.g_begin = 0; c.g_end = c.n_groups;
     const size_t cells = (size_t)c.n_groups * c.nsteps * 64;
     int r;
     if ((r = ensure(h, h->vsym, cells * sizeof(uint32_t)))) return r;
@@ -177,6 +182,11 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipEventCreateWithFlags(&h->ev_chain_gate, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < 2; i++) if (hipStreamCreateWithFlags(&h->vit_stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_vit_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    h->msc_parts = cfg->msc_parts;
+    if (const char* e = getenv("DABPHY_MSC_PARTS")) h->msc_parts = atoi(e);          // (experiments: overrides the configuration)
+    if (h->msc_parts < 0) return fail(DABPHY_ERR_INVALID);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
@@ -196,6 +206,8 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->ev_chain_gate) e = hipEventDestroy(h->ev_chain_gate);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < 2; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
+    for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
+    for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (h->ev_part[i]) e = hipEventDestroy(h->ev_part[i]);
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
@@ -561,6 +573,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
 
 namespace {
 int launch_superframe_stats(dabphy_handle* h); constexpr int HIST_CAP = 64;
+int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st = nullptr, int ens0 = 0, int ens_count = 0);
 // device buffers of the superframe filter for one class and F frames per batch (the window state is zeroed when it is (re)allocated)
 int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F)
 {
@@ -604,7 +617,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     // hipMalloc leaves the handle as it was
     VitClass fic_c{};
     {
-        fic_c.nbits = 768; fic_c.nsteps = 774; fic_c.n_cw = (int)(B * F * 4); fic_c.n_groups = (fic_c.n_cw + 63) / 64; fic_c.dedisperse = 1;
+        fic_c.nbits = 768; fic_c.nsteps = 774; fic_c.n_cw = (int)(B * F * 4); fic_c.n_groups = (fic_c.n_cw + 63) / 64; fic_c.dedisperse = 1; fic_c.g_begin = 0; fic_c.g_end = fic_c.n_groups;
         const size_t cells = (size_t)fic_c.n_groups * fic_c.nsteps * 64;
         if ((r = ensure(h, h->fsym, cells * sizeof(uint32_t)))) return r;
         if ((r = ensure(h, h->fdec, cells * sizeof(uint2)))) return r;
@@ -730,26 +743,72 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         }
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
-    // MSC: one launch pair per protection class (stage events bracket the first class only: one class in the canonical ensemble)
+    // MSC: one gather + decode per protection class (stage events bracket the first class only: one class in the canonical ensemble).
+    // A big class is decoded in PARTS (whole ensembles each): the parts are gathered back to back on the main stream and part p's
+    // Viterbi kernel -- VALU-bound -- runs on a side stream while part p + 1 is gathered -- HBM / LDS-DMA-bound --, and with auto
+    // superframes the filter of part p follows its Viterbi on the same side stream.  The stage times then overlap (they are spans).
+    h->last_frames = F;
+    h->sf_stats_ready = false;
+    bool sf_done_in_parts = false;
+    // parts of a class: whole ensembles, whole 64-codeword groups, and (automatic choice) enough groups per part to fill the device
+    auto parts_of = [&](const dabphy_handle::MscClass& cls) {
+        const int M = (int)cls.members.size();
+        const int n_groups = (int)(((int64_t)B * 4 * F * M + 63) / 64);
+        const int want = h->msc_parts > 0 ? h->msc_parts : 1;
+        for (int q = std::min(want, (int)dabphy_handle::MAX_PARTS); q > 1; q--)
+            if (B % q == 0 && ((int64_t)(B / q) * 4 * F * M) % 64 == 0) return q;
+        return 1;
+    };
+    auto is_dabplus_rate = [](const dabphy_handle::MscClass& cls) { return (cls.prot.nbits / 24) % 8 == 0 && cls.prot.nbits / 8 >= 10; };
     for (auto& cls : h->classes) {
         VitClass c{};
-        const int n_cw = (int)(B * 4 * F * cls.members.size());
+        const int M = (int)cls.members.size();
+        const int n_cw = (int)(B * 4 * F * M);
         if ((r = prepare_class(h, c, cls.prot.nbits, n_cw, 1))) return r;
         if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
         c.out = cls.out.as<uint8_t>();
         MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
-        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = (int)cls.members.size(); g.desc = d_desc; g.c = c;
+        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
         const bool first_cls = (&cls == &h->classes.front());
+        const int parts = parts_of(cls);
+        if (parts == 1) {
+            if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
+            launch_msc_gather(g, h->stream);
+            if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
+            VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+            launch_viterbi(v, h->stream);
+            if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
+            continue;
+        }
+        const bool sf_here = h->sf_auto && is_dabplus_rate(cls);
+        if (h->sf_auto && !sf_done_in_parts) HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));   // before the first part's gather: ordered before every filter launch
+        sf_done_in_parts = sf_done_in_parts || h->sf_auto;
+        const int ens_per = (int)B / parts, grp_per = c.n_groups / parts;
         if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
-        launch_msc_gather(g, h->stream);
-        if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
-        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
-        launch_viterbi(v, h->stream);
-        if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
+        for (int p = 0; p < parts; p++) {
+            hipStream_t vs = h->vit_stream[p & 1];
+            MscGatherArgs gp = g; gp.c.g_begin = p * grp_per; gp.c.g_end = (p + 1) * grp_per;
+            launch_msc_gather(gp, h->stream);
+            HIPCHK(h, hipEventRecord(h->ev_part[p], h->stream));
+            HIPCHK(h, hipStreamWaitEvent(vs, h->ev_part[p], 0));
+            if (first_cls && p == 0) { mark(dabphy_handle::ST_MSC_VITERBI, false, vs); if (sf_here) mark(dabphy_handle::ST_RS, false, vs); }
+            VitArgs v{}; v.c = gp.c; v.prbs_words = h->d_prbs_words;
+            launch_viterbi(v, vs);
+            if (sf_here && (r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>(), vs, p * ens_per, ens_per))) return r;
+        }
+        if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, true);
+        for (int i = 0; i < 2; i++) { HIPCHK(h, hipEventRecord(h->ev_vit_done[i], h->vit_stream[i])); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_vit_done[i], 0)); }
+        if (first_cls) { mark(dabphy_handle::ST_MSC_VITERBI, true); if (sf_here) mark(dabphy_handle::ST_RS, true); }
     }
-    h->last_frames = F;
-    h->sf_stats_ready = false;
-    if (h->sf_auto) { if ((r = launch_superframe_stats(h))) return r; h->sf_stats_ready = true; }
+    if (h->sf_auto) {
+        if (!sf_done_in_parts) { if ((r = launch_superframe_stats(h))) return r; }
+        else {
+            // classes that were decoded in one piece while another was decoded in parts: filter them now, into the same totals
+            for (auto& cls : h->classes)
+                if (parts_of(cls) == 1 && is_dabplus_rate(cls) && (r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>()))) return r;
+        }
+        h->sf_stats_ready = true;
+    }
     if (h->cfg.pipeline_sync) {
         if (h->cfg.pipeline_sync == 1) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
         launch_sync_chain(cur ^ 1);
@@ -980,7 +1039,7 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
 
 namespace {
 // launches k_superframe for one class: member >= 0 -> that member only, -1 -> all members
-int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats)
+int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st, int ens0, int ens_count)
 {
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
     const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
@@ -992,8 +1051,8 @@ int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, 
     a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = M; a.frame_bytes = fb;
     a.s = bitrate / 8; a.member = member; a.desc = h->last_desc; a.n_frames = (int)F;
     a.state = cls.sf_state.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
-    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats;
-    launch_superframe(a, h->stream);
+    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats; a.ens0 = ens0; a.ens_count = ens_count;
+    launch_superframe(a, st ? st : h->stream);
     return 0;
 }
 }

@@ -91,6 +91,7 @@ struct VitClass {
     int nsteps;             // nbits + 6
     int n_cw;               // codewords in the class
     int n_groups;           // ceil(n_cw / 64)
+    int g_begin, g_end;     // groups [g_begin, g_end) are handled by this launch (a class can be decoded in several parts on different streams)
     uint32_t* sym;          // [n_groups][nsteps][64]
     uint2* dec;             // [n_groups][nsteps][64] decision words (scratch)
     uint8_t* out;           // [n_cw][nbits/8] decoded bytes, energy dispersal removed when prbs != 0
@@ -188,6 +189,7 @@ struct SfArgs {
     SfEvent* events; int32_t* n_events;           // [B][members][n_cif], [B][members]
     uint8_t* sf; int n_slots;                     // [B][members][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
     int32_t* stats;                               // optional [B][4]: synchronised superframes, corrected symbols, uncorrectable attempts, AUs failing their CRC
+    int ens0, ens_count;                          // this launch walks ensembles [ens0, ens0 + ens_count); ens_count = 0: all of them
 };
 void launch_superframe(const SfArgs& a, hipStream_t s);
 void launch_rs_superframes(const RsArgs& a, hipStream_t s);

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
     __shared__ int s_corr, s_unc, s_sync, s_au_start[8], s_aubad;
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
     if (threadIdx.x == 0) s_aubad = 0;
-    const int t = threadIdx.x, b = blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
+    const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb;
     uint8_t* const s_raw = s_dyn;
     uint8_t* const s_sf = s_dyn + SF_MAX;
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
 
 void launch_superframe(const SfArgs& a, hipStream_t s)
 {
-    const dim3 grid(a.member >= 0 ? 1 : a.n_members, a.n_ens);
+    const dim3 grid(a.member >= 0 ? 1 : a.n_members, a.ens_count > 0 ? a.ens_count : a.n_ens - a.ens0);
     const int sf_len = 5 * a.frame_bytes;
     if (sf_len <= 960) hipLaunchKernelGGL(k_superframe<960>, grid, dim3(64), 0, s, a);            // <= 64 kbit/s
     else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe<2880>, grid, dim3(64), 0, s, a);     // <= 192 kbit/s

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64, VIT_OCC) k_viterbi(VitArgs A)
 {
   const int lane = threadIdx.x;
 #pragma unroll 1
-  for (int g = blockIdx.x; g < A.c.n_groups; g += gridDim.x) {
+  for (int g = A.c.g_begin + blockIdx.x; g < A.c.g_end; g += gridDim.x) {
     const int nsteps = A.c.nsteps, nbits = A.c.nbits;
     const uint32_t* __restrict__ sym = A.c.sym + (size_t)g * nsteps * 64 + lane;
     uint2* __restrict__ dec = A.c.dec + (size_t)g * nsteps * 64 + lane;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
     __shared__ int s_nrows;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int g = blockIdx.x;
+    const int g = A.c.g_begin + blockIdx.x;
     const int cw = g * 64 + lane;
     const int nsteps = A.c.nsteps, R = 4 * A.n_frames;
     const bool live = cw < A.c.n_cw;
@@ -461,8 +461,10 @@ void launch_viterbi(const VitArgs& a, hipStream_t s)
     }
     // equal work per work-group: `per` groups each, chosen so that the grid never exceeds the 8 wave slots per SIMD (the
     // decoder needs ~6 resident waves per SIMD to keep the VALU busy: 3 per SIMD measured 30 % slower)
-    const int per = (a.c.n_groups + 8 * n_simd - 1) / (8 * n_simd);
-    const int grid = (a.c.n_groups + per - 1) / per;
+    const int n = a.c.g_end - a.c.g_begin;
+    if (n <= 0) return;
+    const int per = (n + 8 * n_simd - 1) / (8 * n_simd);
+    const int grid = (n + per - 1) / per;
     hipLaunchKernelGGL(k_viterbi, dim3(grid), dim3(64), 0, s, a);
 }
 void launch_fic_gather(const FicGatherArgs& a, hipStream_t s)
@@ -471,7 +473,7 @@ void launch_fic_gather(const FicGatherArgs& a, hipStream_t s)
 }
 void launch_msc_gather(const MscGatherArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_msc_gather, dim3(a.c.n_groups), dim3(256), 0, s, a);
+    if (a.c.g_end > a.c.g_begin) hipLaunchKernelGGL(k_msc_gather, dim3(a.c.g_end - a.c.g_begin), dim3(256), 0, s, a);
 }
 void launch_lin_gather(const LinGatherArgs& a, hipStream_t s)
 {
