@@ -134,7 +134,13 @@ int gpu_receiver_run(gpu_run_io* io)
 
 // ---- batch mode: n_ens ensembles (streams of equal length, [n_ens][n_samples] cf32), each with its own FIBProcessor;
 // out per ensemble: ensemble id, number of services listed, number of FIBs that passed the CRC, onServiceDetected calls
+int gpu_batch_run2(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int signal_clock, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii);
 int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii)
+{
+    return gpu_batch_run2(iq, n_samples, n_ens, frames_per_step, n_steps, 1, eid, n_listed, n_fib_ok, n_detected, n_tii);
+}
+// signal_clock = 0: FIBProcessor ages its service counters by wall clock, as the reference does (for the contrast test)
+int gpu_batch_run2(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int signal_clock, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii)
 {
     std::vector<std::unique_ptr<Rec>> recs;
     std::vector<RadioControllerInterface*> ctl;
@@ -144,6 +150,7 @@ int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_
     try {
         RadioReceiverOptions rro; rro.decodeTII = true;             // per-ensemble onTIIMeasurement calls are counted
         GpuBatchReceiver rx(ctl, (uint32_t)frames_per_step, rro);
+        rx.setSignalClock(signal_clock != 0);
         if (dabphy_stream_upload(rx.phy(), iq, (uint64_t)n_samples, 0) != DABPHY_OK) return -2;
         for (int k = 0; k < n_steps; k++) rx.process((uint32_t)frames_per_step);
         for (int e = 0; e < n_ens; e++) {

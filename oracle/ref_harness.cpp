@@ -410,4 +410,41 @@ int ref_rawfile_read(const char* path, const char* format, float* out /* cap x (
     return n;
 }
 
+// ---- the reference's RadioReceiver over a stream, optionally PACED IN REAL TIME (2.048 Msps of wall clock, like a live front end
+// or welle-cli's throttled file input): number of services FIBProcessor lists at the end and of onServiceDetected calls.
+// FIBProcessor ages its service-repeat counters by wall clock (fib-processor.cpp:290-309), so what it lists depends on the pace.
+namespace {
+struct ServiceRecorder : Recorder { std::atomic<int> n_detected{0}; void onServiceDetected(uint32_t) override { n_detected++; } };
+struct PacedInput : MemInput {
+    bool realtime; std::chrono::steady_clock::time_point start;
+    PacedInput(const float* iq, int64_t n_, Recorder* r, bool rt) : MemInput(iq, n_, r), realtime(rt), start(std::chrono::steady_clock::now()) {}
+    int32_t getSamplesToRead() override {
+        const int32_t k = MemInput::getSamplesToRead();
+        if (!realtime || k <= 0) return k;
+        const double due = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() * 2048000.0;
+        return (double)(pos + k) <= due ? k : 0;
+    }
+};
+}
+int ref_service_list_run(const float* iq, int64_t n_samples, int realtime, int32_t* n_listed, int32_t* n_detected)
+{
+    ServiceRecorder rec;
+    PacedInput in(iq, n_samples, &rec, realtime != 0);
+    RadioReceiverOptions rro; rro.decodeTII = false;
+    {
+        RadioReceiver rx(rec, in, rro);
+        rec.rx = &rx;
+        in.start = std::chrono::steady_clock::now();
+        rx.restart(false);
+        in.armed = true;
+        while (!rec.failed) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        *n_listed = (int32_t)rx.getServiceList().size();
+        rx.stop();
+        rec.rx = nullptr;
+    }
+    *n_detected = rec.n_detected;
+    return 0;
+}
+
 } // extern "C"

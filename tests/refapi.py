@@ -487,6 +487,26 @@ def ref_superframe_run(frames):
     return [_ev_tuple(ev[i]) for i in range(ne)], [out[i].copy() for i in range(ne) if ev[i].sync]
 
 
+def ref_service_list_run(iq, realtime):
+    """the real reference RadioReceiver over a stream, paced in real time or not -> (services listed at the end, onServiceDetected calls)"""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    nl = C.c_int32(0); nd = C.c_int32(0)
+    ref().ref_service_list_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    ref().ref_service_list_run(_p(iq), len(iq), int(realtime), C.byref(nl), C.byref(nd))
+    return nl.value, nd.value
+
+
+def gpu_batch_services(iq, frames_per_step, n_steps, signal_clock=True, lib=GPU_EMU_SO):
+    """GpuBatchReceiver with / without its signal-time clock -> per-ensemble (services listed, onServiceDetected calls)"""
+    L = C.CDLL(lib)
+    iq = np.ascontiguousarray(iq, np.complex64); B, n = iq.shape
+    eid = np.zeros(B, np.int32); nl = np.zeros(B, np.int32); ok = np.zeros(B, np.int32); nd = np.zeros(B, np.int32); nt = np.zeros(B, np.int32)
+    L.gpu_batch_run2.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = L.gpu_batch_run2(_p(iq), n, B, frames_per_step, n_steps, int(signal_clock), _p(eid), _p(nl), _p(ok), _p(nd), _p(nt))
+    assert r == 0, "gpu_batch_run2 failed (%d)" % r
+    return nl, nd
+
+
 def gpu_batch_run(iq, frames_per_step, n_steps, lib=GPU_EMU_SO):
     """GpuBatchReceiver (one reference FIBProcessor per ensemble) over [n_ens][n_samples] cf32 -> per-ensemble (eid, services listed, FIBs ok, onServiceDetected calls)"""
     L = C.CDLL(lib)

@@ -6,12 +6,17 @@
 #include <stdexcept>
 
 #include "../../include/dabphy.h"
+#include "signal_clock.h"
 
 GpuBatchReceiver::GpuBatchReceiver(const std::vector<RadioControllerInterface*>& controllers, uint32_t max_frames_, RadioReceiverOptions rro, int device) :
     rci(controllers), synced(controllers.size(), 0), max_frames(max_frames_)
 {
     if (controllers.empty() || max_frames == 0) throw std::logic_error("GpuBatchReceiver: needs at least one ensemble and one frame");
-    for (auto* c : rci) fib.emplace_back(new FIBProcessor(*c));
+    t0 = std::chrono::steady_clock::now();
+    {
+        dabphy_signal_clock::Scope at(t0);                 // FIBProcessor's constructor reads the clock (fib-processor.cpp:1271)
+        for (auto* c : rci) fib.emplace_back(new FIBProcessor(*c));
+    }
     dabphy_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.n_ensembles = (uint32_t)rci.size(); cfg.max_frames = max_frames; cfg.device = device;
@@ -48,6 +53,9 @@ size_t GpuBatchReceiver::process(uint32_t n_frames)
             if (fi.valid != 1) continue;
             if (!synced[e]) { rci[e]->onSyncChange(true); synced[e] = 1; }                                      // :369
             decoded++;
+            // signal time of this frame: its last sample's position in the ensemble's stream
+            const auto t_sig = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>((double)(fi.sample_pos + 196608) / 2048000.0));
+            std::unique_ptr<dabphy_signal_clock::Scope> at(use_signal_clock ? new dabphy_signal_clock::Scope(t_sig) : nullptr);
             for (int k = 0; k < 12; k++) {
                 const uint8_t* p = &fibs[((e * n_frames + f) * 12 + k) * 32];
                 uint8_t bits[256];

@@ -9,9 +9,13 @@
 // The per-ensemble RadioControllerInterface receives that ensemble's control-plane callbacks (onServiceDetected,
 // onNewEnsemble, onSetEnsembleLabel, onDateTimeUpdate) and its FIB / SNR / sync callbacks.
 //
-// Note: FIBProcessor ages services by wall clock (fib-processor.cpp:290-319).  A batch decoded at thousands of
-// times real time passes hours of signal per second, so that ageing never fires here -- services stay listed.
+// Service ageing: FIBProcessor decrements its service-repeat counters once per second of steady_clock
+// (fib-processor.cpp:290-309).  A batch decoded at thousands of times real time passes hours of signal per wall-clock second, so
+// every ensemble gets a SIGNAL clock instead: while its FIBs are processed, `steady_clock` inside fib-processor.cpp reads
+// t0 + (samples of that ensemble consumed so far) / 2.048 MHz (signal_clock.h; fib-processor.cpp is compiled with that header
+// force-included, unmodified).  The counters then age exactly as they do in a receiver running in real time, at any decode speed.
 #pragma once
+#include <chrono>
 #include <memory>
 #include <vector>
 
@@ -51,4 +55,8 @@ class GpuBatchReceiver {
         dabphy_handle* handle = nullptr;
         uint32_t max_frames;
         bool decode_tii = false;
+        std::chrono::steady_clock::time_point t0;         // signal time 0 of every ensemble (construction time)
+        bool use_signal_clock = true;
+    public:
+        void setSignalClock(bool on) { use_signal_clock = on; }   // off: FIBProcessor ages by wall clock as in the reference (tests)
 };

@@ -216,8 +216,8 @@ def default_subchannels(n=18, bitrate=64):
     return out
 
 
-def build_fibs(eid, subchs, cif_count):
-    """12 FIBs for one frame: FIG0/0, FIG0/1 (all sub-channels), FIG0/2, FIG1/0, FIG1/1, rest padding."""
+def build_fibs(eid, subchs, cif_count, extra_figs=()):
+    """12 FIBs for one frame: FIG0/0, FIG0/1 (all sub-channels), FIG0/2, FIG1/0, FIG1/1, `extra_figs` (raw FIG bytes), rest padding."""
     figs = []
     figs.append(bytes([0x05, 0x00, eid >> 8, eid & 0xFF, (cif_count // 250) % 20, cif_count % 250]))
     for i in range(0, len(subchs), 6):
@@ -234,6 +234,7 @@ def build_fibs(eid, subchs, cif_count):
     for s in subchs[:2]:
         sid = 0x1000 + s.subch_id
         figs.append(bytes([0x35, 0x01, sid >> 8, sid & 0xFF]) + ("SERVICE %02d" % s.subch_id).ljust(16).encode() + b"\xff\x00")
+    figs += list(extra_figs)
     fibs = []
     for f in figs:          # first-fit packing
         for i in range(len(fibs)):
@@ -264,8 +265,9 @@ def tii_carriers(comb, pattern):
 class EnsembleTx:
     """Generates consecutive Mode-I transmission frames (cf64 numpy arrays of T_F samples)."""
 
-    def __init__(self, eid=0x1000, subchs=None, seed=0, payload_fn=None, amplitude=0.25, tii=None, tii_gain=1.0):
+    def __init__(self, eid=0x1000, subchs=None, seed=0, payload_fn=None, amplitude=0.25, tii=None, tii_gain=1.0, extra_figs_fn=None):
         self.eid = eid
+        self.extra_figs_fn = extra_figs_fn   # frame number -> list of extra FIGs (raw bytes) for that frame's FIC
         self.tii = tii                  # (comb 0..23, pattern 0..69): fills the null symbol (EN 300 401 clause 14.8)
         self.tii_gain = tii_gain
         self.subchs = default_subchannels() if subchs is None else subchs
@@ -303,7 +305,8 @@ class EnsembleTx:
         return cif
 
     def next_frame_bits(self):
-        fibs = build_fibs(self.eid, self.subchs, self.cif_no)
+        extra = self.extra_figs_fn(len(self.fib_log)) if self.extra_figs_fn else ()
+        fibs = build_fibs(self.eid, self.subchs, self.cif_no, extra)
         self.fib_log.append(fibs)
         fic = np.concatenate([fic_encode(fibs[3 * i:3 * i + 3]) for i in range(4)])
         msc = np.concatenate([self._next_cif() for _ in range(4)])
@@ -335,11 +338,11 @@ class EnsembleTx:
 
 
 def make_stream(n_frames, eid=0x1000, subchs=None, seed=0, snr_db=None, cfo_hz=0.0, delay=0,
-                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False, tii=None):
+                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False, tii=None, extra_figs_fn=None):
     """cf32 interleaved stream of n_frames frames (+ `delay` leading noise/zero samples).
     tii: None, or a list of transmitters (comb, pattern, delay_samples, gain) of a single-frequency network: identical
     frames, each with its own TII in the null symbol, summed with their relative delays."""
-    tx = EnsembleTx(eid, subchs, seed, payload_fn, amplitude, tii=tii[0][:2] if tii else None)
+    tx = EnsembleTx(eid, subchs, seed, payload_fn, amplitude, tii=tii[0][:2] if tii else None, extra_figs_fn=extra_figs_fn)
     x = np.concatenate([tx.next_frame() for _ in range(n_frames)])
     if tii:
         x = np.concatenate([np.zeros(tii[0][2], np.complex128), x])[:len(x)] * tii[0][3]
