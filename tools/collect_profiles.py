@@ -9,8 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
-B, F = 256, 20
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+B, F = int(os.environ.get("PROF_B", "256")), int(os.environ.get("PROF_F", "20"))
 
 shutil.copy(os.path.join(SRC, "stats_kernel_stats.csv"), os.path.join(DST, TAG + "_bench_kernel_stats.csv"))
 
@@ -71,3 +71,46 @@ json.dump({
 print(open(os.path.join(DST, "demod_hbm_traffic.json")).read())
 for k in sorted(fetch):
     print("%-60s fetch %10.0f KB  write %10.0f KB" % (k[:60], sorted(fetch[k])[len(fetch[k]) // 2], sorted(write.get(k, [0]))[len(write.get(k, [0])) // 2]))
+
+
+# ---- Viterbi stage: instruction counts and HBM traffic of the MSC launch (grid = B*F*72/64 one-wave work-groups), for bench.py's
+# roofline_viterbi block; the ubench's issue costs
+vit_grid = B * F * 72            # work-items of the MSC launch (64 per group)
+if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
+    shutil.copy(os.path.join(SRC, "pmc_vit_counter_collection.csv"), os.path.join(DST, TAG + "_pmc_sq_viterbi_gather.csv"))
+    acc = {}
+    for r in rows("pmc_vit_counter_collection.csv"):
+        if "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    med = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
+    fv = [float(r["Counter_Value"]) for r in rows("pmc_fetch_counter_collection.csv") if r["Counter_Name"] == "FETCH_SIZE" and "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid]
+    wv = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid]
+    fg = [float(r["Counter_Value"]) for r in rows("pmc_fetch_counter_collection.csv") if r["Counter_Name"] == "FETCH_SIZE" and "k_msc_gather" in r["Kernel_Name"]]
+    wg = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and "k_msc_gather" in r["Kernel_Name"]]
+    mid = lambda v: sorted(v)[len(v) // 2] if v else 0.0
+    json.dump({
+        "kernel": "dabphy::k_viterbi (MSC class launch)", "ensembles": B, "frames": F,
+        "valu_insts_per_launch": med.get("SQ_INSTS_VALU"), "lds_insts_per_launch": med.get("SQ_INSTS_LDS"), "vmem_insts_per_launch": med.get("SQ_INSTS_VMEM"),
+        "waves": med.get("SQ_WAVES"), "lds_bank_conflict_cycles": med.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": med.get("SQ_LDS_IDX_ACTIVE"),
+        "fetch_size_kb_raw": mid(fv), "write_size_kb_raw": mid(wv),
+        "hbm_bytes_per_launch": int(mid(fv) * 1024 * 2 + mid(wv) * 1024),
+        "gather_fetch_size_kb_raw": mid(fg), "gather_write_size_kb_raw": mid(wg), "gather_hbm_bytes_per_launch": int(mid(fg) * 1024 * 2 + mid(wg) * 1024),
+        "algorithmic_bytes_per_launch": B * F * 72 * (4 * 1542 + 1536 // 8),
+        "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported; median launch",
+        "source": "profiles/%s_pmc_sq_viterbi_gather.csv, profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv" % (TAG, TAG, TAG),
+    }, open(os.path.join(DST, "viterbi_counters.json"), "w"), indent=1)
+    print(open(os.path.join(DST, "viterbi_counters.json")).read())
+if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
+    shutil.copy(os.path.join(SRC, "valu_rate.txt"), os.path.join(DST, TAG + "_ubench_valu_rate.txt"))
+    cyc = {}
+    for line in open(os.path.join(SRC, "valu_rate.txt")):
+        if "waves/SIMD 5:" in line:
+            name = line.split("waves/SIMD")[0].strip(); cyc[name] = float(line.split("->")[1].split()[0])
+    if cyc:
+        packed = [cyc[k] for k in ("v_pk_add_u16", "v_pk_min_u16", "v_pk_sub_i16", "v_perm_b32 (vgpr sel)", "v_and_or_b32", "v_pk_add_u16 op_sel") if k in cyc]
+        cp = sum(packed) / len(packed); cl = cyc.get("v_add_u32", 2.4)
+        # instruction mix of one trellis step: 128 packed 16-bit operations, 32 decision-extraction operations (v_perm_b32 /
+        # v_and_or_b32), about 35 plain 32-bit ones (branch metrics, addresses, loop)
+        json.dump({"cycles_packed": cp, "cycles_plain": cl, "cycles_per_instruction_kernel_mix": (160 * cp + 35 * cl) / 195, "at_waves_per_simd": 5, "per_instruction": cyc,
+                   "source": "profiles/%s_ubench_valu_rate.txt (tools/ubench/valu_rate.hip on the GPU box, 2.4 GHz assumed)" % TAG},
+                  open(os.path.join(DST, "valu_rate.json"), "w"), indent=1)

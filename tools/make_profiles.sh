@@ -3,16 +3,20 @@
 #   gpurun_out/prof/stats_*          --kernel-trace --stats of the default bench command
 #   gpurun_out/prof/pmc_fetch_*      --pmc FETCH_SIZE   (own pass)
 #   gpurun_out/prof/pmc_write_*      --pmc WRITE_SIZE   (own pass)
+#   gpurun_out/prof/pmc_vit_*        SQ instruction / LDS counters of k_viterbi and k_msc_gather (own pass)
 #   gpurun_out/prof/pmc_sq{1,2}_*    SQ issue / wait / LDS counters of k_demod (own passes, demod-only driver)
-# The summaries are then copied into profiles/ by tools/collect_profiles.py.
+#   gpurun_out/prof/valu_rate.txt    tools/ubench/valu_rate.hip: issue cost of the instructions the Viterbi kernel is made of
+# The summaries are then copied into profiles/ by tools/collect_profiles.py <tag>.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/prof; rm -rf $O; mkdir -p $O
-BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt-schedule"
+BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt-schedule $BENCH_EXTRA"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $BENCH > $O/stats.log 2>&1
-KR='k_demod|k_viterbi|k_msc_gather|k_cp_products|k_sync_find|k_sync_finish|k_fic_gather|k_rs_msc|k_superframe'
+KR='k_demod|k_viterbi|k_msc_gather|k_sync_find|k_sync_finish|k_fic_gather|k_rs_msc|k_superframe|k_acquire'
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_write -- $BENCH > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-include-regex 'k_viterbi|k_msc_gather' --output-format csv -d $O -o pmc_vit -- $BENCH > $O/pmc_vit.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --kernel-include-regex k_demod --output-format csv -d $O -o pmc_sq1 -- python tools/prof_demod.py > $O/pmc_sq1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAVES GRBM_GUI_ACTIVE --kernel-include-regex k_demod --output-format csv -d $O -o pmc_sq2 -- python tools/prof_demod.py > $O/pmc_sq2.log 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o /tmp/valu_rate && timeout 120 /tmp/valu_rate > $O/valu_rate.txt 2>&1
 find $O -name "*.csv" | xargs ls -la

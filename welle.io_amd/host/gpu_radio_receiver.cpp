@@ -13,7 +13,13 @@
 #include <stdexcept>
 
 namespace {
-constexpr uint64_t kRing = 8ull * 196608;           // 8 transmission frames of sample ring in HBM
+// The sample ring in HBM holds 80 transmission frames (126 MB of a 288 GB device) although the worker only writes kAhead = 8 frames
+// ahead of the synchroniser: the 72 frames behind it are the memory OFDMProcessor::sLevel needs.  The reference advances that level
+// with every sample it pulls (ofdm-processor.cpp:174,216) -- a serial recurrence, 3 ms of one GPU lane per frame -- but reads it
+// only after a loss of lock.  So nothing is spent on it while tracking; at a loss of lock k_acquire replays the samples pulled
+// since the last acquisition (exactly; up to 64 frames back, beyond that two bracketing replays that meet: DESIGN.md section 7).
+constexpr uint64_t kRing = 80ull * 196608;
+constexpr uint64_t kAhead = 8ull * 196608;
 constexpr int kPull = 65536;                         // samples per InputInterface::getSamples call
 
 bool protection_of(const Subchannel& sub, dabphy_protection* p)
@@ -109,7 +115,6 @@ GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterfac
     cfg.want_constellation = 1; cfg.want_impulse_response = 1;
     const int r = dabphy_create(&cfg, &phy);
     if (r != DABPHY_OK) throw std::runtime_error("GpuRadioReceiver: dabphy_create failed (no gfx950 device?)");
-    dabphy_set_track_slevel(phy, 1);                                    // real-time receiver, small ring: keep sLevel exact frame by frame
 }
 
 GpuRadioReceiver::~GpuRadioReceiver()
@@ -353,7 +358,7 @@ void GpuRadioReceiver::run()
         // --- fill the ring like OFDMProcessor::getSamples pulls (count, then read; is_ok() while starving)
         uint64_t consumed = dabphy_stream_consumed(phy);
         bool pulled = false;
-        while (running && !input_done && written - consumed + kPull <= kRing) {
+        while (running && !input_done && written - consumed + kPull <= kAhead) {
             int32_t avail = input.getSamplesToRead();
             if (avail <= 0) {
                 if (!input.is_ok()) { input_done = true; break; }
