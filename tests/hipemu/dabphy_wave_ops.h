@@ -57,6 +57,11 @@ template <int OFF> static inline void lds_dma16(const void* gptr, void* lds_wave
 static inline void lds_dma4(const void* gptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu_lane(), gptr, 4); }
 // the hardware executes a wave's DMA requests for all lanes at once; the fibers of the model do not run in lock-step, so
 // "the data has landed" must also mean "every lane of the wave has issued its part": a wave-wide rendezvous
+static inline uint32_t opaque_vgpr(uint32_t x) { return x; }
+#define DABPHY_CONST_AS
+template <typename T> static inline const T* as_constant(const T* p) { return p; }
+static inline uint32_t u32_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+static inline void wave_converge() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 static inline void lds_dma_wait() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 template <int N> static inline void lds_dma_wait_but() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 

@@ -68,7 +68,13 @@ def test_superframe_filter(gpu):
 
 
 def test_mixed_protection_classes(gpu):
-    P.check_mixed_ensemble(factory)
+    P.check_mixed_ensemble(factory, expect_fused=False)
+
+
+def test_mixed_protection_classes_fused_decode(gpu):
+    """16 / 20 frames per call: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel (k_viterbi_msc)"""
+    P.check_mixed_ensemble(factory, F=16, nf=36, expect_fused=True)
+    P.check_mixed_ensemble(factory, F=20, nf=45, seed=32, snr_db=9, expect_fused=True)
 
 
 @pytest.mark.parametrize("method,snr,cfo", [(1, 15, 90), (1, None, -300), (0, 12, 40)])

@@ -42,6 +42,7 @@ struct dabphy_handle {
         dabphy_protection prot{};
         std::vector<int> members;     // indices into subch
         DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
+        DevBuf steps; int n_windows = 0;     // fused decode (k_viterbi_msc): per-step window-ring descriptors, 16-byte windows of the punctured stream
         DevBuf sf_state;                     // SuperframeFilter window of every (ensemble, member)
     };
     const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
@@ -61,6 +62,7 @@ struct dabphy_handle {
     static constexpr int MAX_PARTS = 8;
     hipEvent_t ev_part[MAX_PARTS]{}, ev_vit_done[2]{};
     int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
+    bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     hipEvent_t ev_chain_beg[2]{}, ev_chain_end[2]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
     bool need_acquire = true;         // queue k_acquire in front of every frame step
@@ -187,6 +189,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     h->msc_parts = cfg->msc_parts;
     if (const char* e = getenv("DABPHY_MSC_PARTS")) h->msc_parts = atoi(e);          // (experiments: overrides the configuration)
     if (h->msc_parts < 0) return fail(DABPHY_ERR_INVALID);
+    if (const char* e = getenv("DABPHY_FUSED_MSC")) h->fused_msc = atoi(e) != 0;
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
@@ -215,7 +218,7 @@ void dabphy_destroy(dabphy_handle* h)
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     { DevBuf* tb[] = {&h->s_hist, &h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
-    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); }
+    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); if (c.steps.p) e = hipFree(c.steps.p); }
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
     (void)e;
@@ -534,6 +537,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         if (c.tiles.p) e = hipFree(c.tiles.p);
         if (c.sf_state.p) e = hipFree(c.sf_state.p);
         if (c.out.p) e = hipFree(c.out.p);
+        if (c.steps.p) e = hipFree(c.steps.p);
         (void)e;
     }
     h->classes.clear();
@@ -567,6 +571,53 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         }
         if ((r = ensure(h, c.tiles, tl.size() * sizeof(int32_t)))) return r;
         HIPCHK(h, hipMemcpy(c.tiles.p, tl.data(), tl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        // fused decode: what every trellis step reads, in terms of the wave's window ring (k_viterbi_msc).  Source byte u sits in
+        // window u >> 4 (slot (u >> 4) & 1), column u & 15, map16[u & 15] rows below the lane's row base.
+        {
+            static const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+            constexpr int ROWS = 96, SLOT = ROWS * 16, ZERO = 2 * SLOT;
+            std::vector<MscStep> st((size_t)nsteps + 2);      // (+2: the kernel requests descriptors one pair of steps ahead)
+            std::vector<int> wlo((size_t)nsteps, -1), whi((size_t)nsteps, -1);
+            for (int q = 0; q < nsteps; q++) {
+                uint32_t off[4];
+                for (int j = 0; j < 4; j++) {
+                    const int u = m[4 * q + j];
+                    if (u < 0) { off[j] = ZERO; continue; }
+                    const int w = u >> 4, col = u & 15;
+                    off[j] = (uint32_t)((w & 1) * SLOT + map16[col] * 16 + col);
+                    if (wlo[q] < 0) wlo[q] = w;
+                    whi[q] = w;
+                }
+                st[q].off01 = off[0] | (off[1] << 16); st[q].off23 = off[2] | (off[3] << 16);
+            }
+            st[(size_t)nsteps].off01 = st[(size_t)nsteps + 1].off01 = ZERO | (ZERO << 16); st[(size_t)nsteps].off23 = st[(size_t)nsteps + 1].off23 = ZERO | (ZERO << 16);
+            const int n_in = protection_input_bits(&c.prot);
+            c.n_windows = (n_in + 15) / 16;
+            // lowest window any LATER step reads: when it moves up, the window below it has died and its slot takes the window after the next
+            std::vector<int> low_after((size_t)nsteps, c.n_windows);
+            for (int q = nsteps - 2, low = c.n_windows; q >= 0; q--) { if (wlo[q + 1] >= 0) low = wlo[q + 1]; low_after[q] = low; }
+            int seen = 1, prev_low = 0;
+            std::vector<int> load_step((size_t)c.n_windows + 2, -10);
+            bool ok = true; int why = 0;
+            for (int q = 0; q < nsteps; q++) {
+                if (whi[q] > seen) {
+                    st[q].off01 |= MSC_FIRST_USE; seen = whi[q];
+                    // the step BEFORE q waits for the window with s_waitcnt vmcnt(2): its load must be older than two decision stores
+                    if (q - 1 - load_step[seen] < 2) { ok = false; why |= 1; }
+                }
+                if (whi[q] >= 0 && whi[q] - wlo[q] > 1) { ok = false; why |= 2; }
+                if (low_after[q] > prev_low) {
+                    if (low_after[q] != prev_low + 1 && low_after[q] < c.n_windows) { ok = false; why |= 4; }
+                    prev_low = low_after[q];
+                    if (prev_low + 1 < c.n_windows) { st[q].off01 |= MSC_LOAD_NEXT; load_step[prev_low + 1] = q; }
+                }
+            }
+            if (!ok && getenv("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class nbits %d: no fused decode (window schedule, reason %d)\n", c.prot.nbits, why);
+            if (!ok) c.n_windows = 0;             // (never for the profiles of EN 300 401; the two-kernel path decodes such a class)
+            if ((r = ensure(h, c.steps, st.size() * sizeof(MscStep)))) return r;
+            HIPCHK(h, hipMemcpy(c.steps.p, st.data(), st.size() * sizeof(MscStep), hipMemcpyHostToDevice));
+
+        }
     }
     return DABPHY_OK;
 }
@@ -606,7 +657,13 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
-    if ((r = ensure(h, h->s_soft, (size_t)B * ring_frames * SOFT_PER_FRAME))) return r;
+    {   // + a tail of zeros (one sub-channel's worth: 864 CU x 64 bits) that the fused MSC decode loads for CIFs that do not exist yet
+        const size_t ring_bytes = (size_t)B * ring_frames * SOFT_PER_FRAME, tail = 864 * 64 + 64;
+        if (h->s_soft.cap < ring_bytes + tail) {
+            if ((r = ensure(h, h->s_soft, ring_bytes + tail))) return r;
+            HIPCHK(h, hipMemsetAsync(h->s_soft.as<int8_t>() + ring_bytes, 0, tail, h->stream));
+        }
+    }
     if ((r = ensure(h, h->s_hist, (size_t)B * HIST_CAP * sizeof(FrameDesc)))) return r;
     if ((r = ensure(h, h->s_mag, (size_t)B * F * T_U * sizeof(float)))) return r;
     if ((r = ensure(h, h->s_snr, (size_t)B * F * sizeof(float)))) return r;
@@ -656,10 +713,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         sa.hist = h->s_hist.as<FrameDesc>(); sa.hist_cap = HIST_CAP;
         { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
         for (uint32_t f = 0; f < F; f++) {
-            // acquisition is queued in front of every frame step, as the reference falls back to it after any failed window search
-            // (ofdm-processor.cpp:347-350): an ensemble that loses lock in slot f re-acquires before slot f + 1.  Tracking ensembles
-            // leave the kernel after one load.
-            launch_acquire(sa, h->sync_stream);
+            // (acquisition runs at the head of k_sync_find for an ensemble that is not synchronised -- start of a stream, or after a
+            // failed window search in whatever slot of a batch, as the reference falls back to notSynced, ofdm-processor.cpp:347-350)
             sa.frame = (int)f;
             launch_sync_find(sa, h->sync_stream);       // PRS window search of frame f
             launch_sync_finish(sa, h->sync_stream);     // cyclic-prefix products + their ordered sums -> correctors -> state
@@ -771,6 +826,17 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
         const bool first_cls = (&cls == &h->classes.front());
         const int parts = parts_of(cls);
+        if (parts == 1 && h->fused_msc && cls.n_windows > 0 && 4 * F >= 64) {
+            // fused: the gather happens inside the Viterbi kernel (needs >= 64 CIFs per sub-channel and batch: a wave then spans at
+            // most two (ensemble, sub-channel) pairs)
+            FusedMscArgs fa{}; fa.soft = da.soft; fa.soft_ring = ring_frames; fa.n_ens = (int)B; fa.n_frames = (int)F;
+            fa.steps = cls.steps.as<MscStep>(); fa.n_windows = cls.n_windows; fa.start_bit = cls.start_bits.as<int32_t>(); fa.n_members = M; fa.desc = d_desc; fa.zero_off16 = (uint32_t)(((size_t)B * ring_frames * SOFT_PER_FRAME) >> 4);
+            fa.c = c; fa.prbs_words = h->d_prbs_words;
+            if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, false);
+            launch_viterbi_msc(fa, h->stream);
+            if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
+            continue;
+        }
         if (parts == 1) {
             if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
             launch_msc_gather(g, h->stream);

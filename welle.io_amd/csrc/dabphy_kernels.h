@@ -120,6 +120,23 @@ struct MscGatherArgs {
     VitClass c;
 };
 
+// Fused MSC decode (k_viterbi_msc): the MSC gather inside the Viterbi kernel.  MscStep = what one trellis step needs, identical for
+// all code words of a class: byte offsets of its four soft bits in the wave's LDS window ring (relative to the lane's row base;
+// an erasure points into the zero slot), whether it is the first step to read a window, and which window to load once it has read.
+// (8 bytes per step: off0 | off1 << 16, off2 | off3 << 16 with two flags in the spare top bits -- bit 15 of off01: first step to read
+// a new window, wait for its load; bit 31 of off01: once this step has read, load the next window (they are loaded in order 2, 3, ...))
+struct MscStep { uint32_t off01, off23; };
+constexpr uint32_t MSC_FIRST_USE = 1u << 15, MSC_LOAD_NEXT = 1u << 31, MSC_OFF_MASK = 0x7fffu;
+struct FusedMscArgs {
+    const int8_t* soft; int soft_ring; int n_ens, n_frames;
+    const MscStep* steps;     // [nsteps]
+    int n_windows;            // 16-byte windows of the punctured bit stream
+    const int32_t* start_bit; int n_members; const FrameDesc* desc;
+    uint32_t zero_off16;      // (byte offset / 16) of >= 16 * n_windows zero bytes behind the soft-bit ring: what a row without a source CIF loads
+    VitClass c; const uint32_t* prbs_words;
+};
+void launch_viterbi_msc(const FusedMscArgs& a, hipStream_t s);
+
 struct CrcArgs {
     const uint8_t* fib;     // [B][F][12][32]
     uint8_t* ok;            // [B][F][12]

@@ -87,6 +87,18 @@ __device__ __forceinline__ double uniform_f64(double x)
 }
 // a wave-uniform constant the compiler must keep in a scalar register instead of folding it into literals
 __device__ __forceinline__ uint32_t opaque_sgpr(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+// A read-only table as the CONSTANT address space sees it: hipcc turns a wave-uniform load from ordinary global memory that the
+// kernel also writes elsewhere into a VECTOR load + s_waitcnt vmcnt(0) + v_readfirstlane (the scalar cache is not coherent with
+// vector stores), which drains every store in flight; loads through a constant-address-space pointer become s_load_dword*.
+#define DABPHY_CONST_AS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const DABPHY_CONST_AS T* as_constant(const T* p)
+{
+    return (const DABPHY_CONST_AS T*)(unsigned long long)p;
+}
+
+// a per-lane value the compiler must treat as new at this point (keeps loop-invariant address arithmetic from being hoisted into
+// registers that then have to live across a register-bound loop)
+__device__ __forceinline__ uint32_t opaque_vgpr(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 // (x & wave-uniform mask) | acc in one instruction
 __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t acc)
 {
@@ -138,6 +150,12 @@ __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 // ... until at most N of the wave's memory operations are still in flight (they complete in order: "everything but the
 // last N requests has landed")
 template <int N> __device__ __forceinline__ void lds_dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+__device__ __forceinline__ uint32_t u32_max(uint32_t a, uint32_t b) { return __builtin_elementwise_max(a, b); }     // one v_max_u32
+
+// The lanes of a wavefront run in lock step: what one lane wrote to LDS before this point is visible to the others after it without
+// any instruction (a scheduling fence for the compiler).  tests/hipemu runs lanes as fibres and switches them here.
+__device__ __forceinline__ void wave_converge() { __builtin_amdgcn_wave_barrier(); }
 
 // accumulate into a double in LDS from many threads (order irrelevant to its users)
 __device__ __forceinline__ void lds_add_f64(double* p, double v) { atomicAdd(p, v); }

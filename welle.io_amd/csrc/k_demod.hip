@@ -34,14 +34,16 @@ constexpr uint32_t NCO_BYTES = (uint32_t)INPUT_RATE * 8u;      // the oscillator
 
 // The oscillator of one thread: exp(j 2 pi phase / RATE) of its sample t of the current symbol, and the factors that
 // advance it by 128 / 256 / T_s samples (osc_exact.h).
-struct OscChain { dc64 base, d128, d256, dts; };
+struct OscChain { dc64 base, d128, d256, d512, d1024, dts; };
 
 __device__ __forceinline__ void osc_chain_steps(OscChain& k, int32_t f_hz)
 {
     // the same in every lane (f_hz is per frame): kept in scalar registers, 24 VGPRs less
-    const dc64 a = osc_step(128, f_hz), b = osc_step(256, f_hz), c = osc_step(T_S, f_hz);
+    const dc64 a = osc_step(128, f_hz), b = osc_step(256, f_hz), c = osc_step(T_S, f_hz), b2 = osc_step(512, f_hz), b4 = osc_step(1024, f_hz);
     k.d128.re = uniform_f64(a.re); k.d128.im = uniform_f64(a.im);
     k.d256.re = uniform_f64(b.re); k.d256.im = uniform_f64(b.im);
+    k.d512.re = uniform_f64(b2.re); k.d512.im = uniform_f64(b2.im);
+    k.d1024.re = uniform_f64(b4.re); k.d1024.im = uniform_f64(b4.im);
     k.dts.re = uniform_f64(c.re); k.dts.im = uniform_f64(c.im);
 }
 
@@ -51,13 +53,16 @@ __device__ __forceinline__ void osc_chain_steps(OscChain& k, int32_t f_hz)
 __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const cf32* __restrict__ nco, const SymCursor& c,
                                          const MixSteps& st, int h)
 {
-    dc64 e = h ? osc_mul(k.base, k.d128) : k.base;
+    // e[j] = base * exp(-j 2 pi (128 h + 256 j) f / RATE) as a tree of depth 3 (steps of 256, 512, 1024 samples) instead of a chain of
+    // seven dependent double-precision complex multiplications: same operation count, no latency chain (and a shorter error chain)
+    dc64 e[8];
+    e[0] = h ? osc_mul(k.base, k.d128) : k.base;
+    e[1] = osc_mul(e[0], k.d256);
+    e[2] = osc_mul(e[0], k.d512); e[3] = osc_mul(e[1], k.d512);
+    e[4] = osc_mul(e[0], k.d1024); e[5] = osc_mul(e[1], k.d1024); e[6] = osc_mul(e[2], k.d1024); e[7] = osc_mul(e[3], k.d1024);
     uint32_t hard = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        hard |= osc_round(e, o[j]) << j;
-        if (j < 7) e = osc_mul(e, k.d256);
-    }
+    for (int j = 0; j < 8; j++) hard |= osc_round(e[j], o[j]) << j;
     if (!wave_all(hard == 0)) {
         int32_t ph = c.ph; if (h) { ph -= st.s128; if (ph < 0) ph += INPUT_RATE; }
         uint32_t pb = (uint32_t)ph * 8u;

@@ -327,6 +327,152 @@ __global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_OCC) k_sync_finish
     sync_finish_body(A, blockIdx.x, A.frame);
 }
 
+// ---- sLevel catches up with the samples that were pulled while tracking (ofdm-processor.cpp:216: once per sample, float result
+// of a double expression).  Exact when the history reaches back to the last point at which the level was exact; otherwise two
+// runs from the extremes of what the level can be bracket it (the update is monotone in the level): if they have met by the end,
+// that is the level.  One work-group per ensemble; s_st = its state (LDS), l1 = a tile of |re| + |im| values (LDS).
+template <int TILE, int NT>
+__device__ __forceinline__ void slevel_replay(const SyncArgs& A, const int b, RxState& s_st, float* l1, const cf32* __restrict__ iq, const cf32* __restrict__ nco, const int t)
+{
+    const FrameDesc* hist = A.hist + (size_t)b * A.hist_cap;
+    __shared__ float s_lo, s_hi;
+    __shared__ int s_first;
+    if (t == 0) {
+        int first = 0; bool dropped = s_st.hist_dropped != 0;
+        if (!A.loop)                                                         // samples that have left the ring cannot be replayed
+            for (int i = s_st.hist_count - 1; i >= 0; i--) if (hist[(s_st.hist_head + i) % A.hist_cap].pos < A.n_valid - A.ring) { first = i + 1; dropped = true; break; }
+        s_first = first;
+        s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? 3.0e38f : s_st.s_level;
+    }
+    __syncthreads();
+    for (int e = s_first; e < s_st.hist_count; e++) {
+        const FrameDesc d = hist[(s_st.hist_head + e) % A.hist_cap];
+        // what one window search pulled: T_u + start_index samples at f_prs; then, if it succeeded, 75 symbols at f_sym and the null
+        // symbol at null_f (ofdm-processor.cpp:337-344,371-374,432-434,462-463)
+        const int nseg = d.valid == 1 ? 3 : 1;
+        for (int sgm = 0; sgm < nseg; sgm++) {
+            const int64_t off0 = sgm == 0 ? 0 : sgm == 1 ? (int64_t)T_U + d.start_index : (int64_t)T_U + d.start_index + 75LL * T_S;
+            const int64_t n = sgm == 0 ? (int64_t)T_U + (d.valid == 1 ? d.start_index : 0) : sgm == 1 ? 75LL * T_S : T_NULL;
+            const int32_t L = sgm == 0 ? d.L0 : sgm == 1 ? d.L1 : d.null_L, f = sgm == 0 ? d.f_prs : sgm == 1 ? d.f_sym : d.null_f;
+            for (int64_t i0 = 0; i0 < n; i0 += TILE) {
+                const int m = (int)((n - i0 < TILE) ? n - i0 : TILE);
+                for (int i = t; i < m; i += NT) l1[i] = l1norm(mixed_sample(iq, A.ring, d.pos, off0 + i0 + i, nco, L, f, i0 + i));
+                __syncthreads();
+                if (t == 0) {
+                    float lo = s_lo, hi = s_hi;
+                    const bool one = lo == hi;                                   // exact start: a single chain
+                    int i = 0;
+                    for (; i + 16 <= m; i += 16) {                               // operands fetched 16 at a time, off the dependent chain
+                        const float4 q0 = *reinterpret_cast<const float4*>(l1 + i), q1 = *reinterpret_cast<const float4*>(l1 + i + 4),
+                                     q2 = *reinterpret_cast<const float4*>(l1 + i + 8), q3 = *reinterpret_cast<const float4*>(l1 + i + 12);
+                        const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                        double a[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) a[k] = 0.00001 * (double)v[k];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            lo = (float)(a[k] + (1 - 0.00001) * (double)lo);
+                            if (!one) hi = (float)(a[k] + (1 - 0.00001) * (double)hi);
+                        }
+                    }
+                    for (; i < m; i++) {
+                        const double a = 0.00001 * (double)l1[i];
+                        lo = (float)(a + (1 - 0.00001) * (double)lo);
+                        if (!one) hi = (float)(a + (1 - 0.00001) * (double)hi);
+                    }
+                    if (one) hi = lo;
+                    s_lo = lo; s_hi = hi;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (t == 0) {
+        if (s_lo != s_hi) s_st.n_relock_inexact += 1;
+        s_st.s_level = s_hi;
+        s_st.hist_count = 0; s_st.hist_head = 0; s_st.hist_dropped = 0;
+    }
+    __syncthreads();
+}
+
+// ---- acquisition: OFDMProcessor::run from "Initing" / notSynced to SyncOnPhase (ofdm-processor.cpp:249-319).
+// A strictly per-sample recurrence (sLevel IIR evaluated in double, 50-sample moving sum); the work-group stages |re|+|im| of the
+// oscillator-corrected samples in LDS (l1: TILE floats, s_st: the ensemble's state), lane 0 walks the state machine.
+// Runs at the head of k_sync_find for an ensemble that is not synchronised -- after the start of a stream and after every failed
+// window search, in whatever slot of a batch that happens, like the reference falls back to notSynced (:347-350) -- so the frame
+// chain stays at two launches per frame and a tracking ensemble pays one load for it.
+constexpr int ACQ_TILE = 1024;
+template <int NT>
+__device__ __forceinline__ void acquire_body(const SyncArgs& A, const int b, float* l1, RxState& s_st, int& s_done, const int t)
+{
+    constexpr int TILE = ACQ_TILE;
+    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    const cf32* __restrict__ nco = A.tab.nco;
+    if (t == 0) { s_st = A.state[b]; s_done = 0; }
+    __syncthreads();
+
+    if (s_st.hist_count > 0 && A.hist) slevel_replay<TILE, NT>(A, b, s_st, l1, iq, nco, t);
+
+    for (;;) {
+        const int64_t pos = s_st.pos; const int32_t L = s_st.local_phase;
+        // getSample(0) while priming / taking the first 50 samples, getSample(coarse+fine) while searching (:254,:269,:286,:305)
+        const int32_t f = (s_st.acq_phase >= 2) ? s_st.coarse + s_st.fine : 0;
+        int64_t avail = A.loop ? TILE : A.n_valid - pos;
+        if (avail > TILE) avail = TILE;
+        if (avail <= 0) break;                                       // starved: state is kept for the next call
+        for (int i = t; i < (int)avail; i += NT) l1[i] = l1norm(mixed_sample(iq, A.ring, pos, i, nco, L, f, i));
+        __syncthreads();
+        if (t == 0) {
+            RxState& st = s_st;
+            float sLevel = st.s_level, cs = st.acq_cs;
+            int ph = st.acq_phase, idx = st.acq_idx, counter = st.acq_counter, left = st.acq_left;
+            int i = 0; bool done = false;
+            for (;;) {
+                // loop conditions are evaluated before a sample is pulled (:284, :303)
+                if (ph == 2 && !((double)(cs / 50) > 0.50 * (double)sLevel)) { ph = 3; counter = 0; }
+                if (ph == 3 && !((double)(cs / 50) < 0.75 * (double)sLevel)) { done = true; break; }
+                if (i >= (int)avail) break;
+                const float a = l1[i++];
+                sLevel = (float)(0.00001 * (double)a + (1 - 0.00001) * (double)sLevel);         // :174
+                if (ph == 0) {                                                                  // :252-255
+                    if (--left <= 0) { ph = 1; idx = 0; cs = 0.0f; st.attempts += 1; }                  // falls through into notSynced (:256)
+                } else if (ph == 1) {                                                           // :268-273
+                    st.env[idx & 63] = a; cs += a; idx++;
+                    if (idx == 50) { ph = 2; counter = 0; break; }                              // oscillator changes -> new tile
+                } else {                                                                        // :285-297 / :304-316
+                    st.env[idx & 63] = a;
+                    cs += a - st.env[(idx - 50) & 63];
+                    idx = (idx + 1) & 32767;
+                    counter++;
+                    if ((ph == 2 && counter > T_F) || (ph == 3 && counter > T_NULL + 50)) {     // hopeless -> notSynced
+                        ph = 1; idx = 0; cs = 0.0f; st.attempts += 1; break;
+                    }
+                }
+            }
+            st.s_level = sLevel; st.acq_cs = cs; st.acq_phase = ph; st.acq_idx = idx; st.acq_counter = counter; st.acq_left = left;
+            st.pos = pos + i;
+            st.local_phase = (f == 0) ? L : mod_rate64((int64_t)L - (int64_t)i * f);
+            if (done) { st.synced = 1; st.acq_phase = 1; st.acq_idx = 0; st.acq_cs = 0.0f; st.acq_counter = 0; }
+            s_done = done ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (t == 0) A.state[b] = s_st;
+    __threadfence();
+    __syncthreads();                                     // the caller re-reads the state from memory
+}
+
+// stand-alone acquisition launch (no longer part of the frame chain; kept for diagnostics)
+__global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float l1[ACQ_TILE];
+    __shared__ RxState s_st;
+    __shared__ int s_done;
+    if (A.state[blockIdx.x].synced) return;
+    acquire_body<256>(A, blockIdx.x, l1, s_st, s_done, threadIdx.x);
+}
+
 __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, const int frame)
 {
     // 17 KiB of LDS, reused phase by phase (FFT tile -> |IFFT| + window maxima)
@@ -340,6 +486,13 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     const int t = threadIdx.x;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
+    if (!A.state[b].synced) {
+        // notSynced: null-symbol search first (the FFT tile is free until the window search: it holds the sample tile and the state)
+        static_assert(sizeof(tile) >= ACQ_TILE * sizeof(float) + sizeof(RxState) + 16, "acquisition scratch must fit the FFT tile");
+        float* const l1 = reinterpret_cast<float*>(tile);
+        RxState& s_st = *reinterpret_cast<RxState*>(l1 + ACQ_TILE);
+        acquire_body<FFT_THREADS>(A, b, l1, s_st, redi[0], t);
+    }
     struct { int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced; } st;
     {
         const RxState& g = A.state[b];
@@ -601,141 +754,6 @@ __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find(SyncAr
     sync_find_body(A, blockIdx.x, A.frame);
 }
 
-// ---- sLevel catches up with the samples that were pulled while tracking (ofdm-processor.cpp:216: once per sample, float result
-// of a double expression).  Exact when the history reaches back to the last point at which the level was exact; otherwise two
-// runs from the extremes of what the level can be bracket it (the update is monotone in the level): if they have met by the end,
-// that is the level.  One work-group per ensemble; s_st = its state (LDS), l1 = a tile of |re| + |im| values (LDS).
-template <int TILE>
-__device__ __forceinline__ void slevel_replay(const SyncArgs& A, const int b, RxState& s_st, float* l1, const cf32* __restrict__ iq, const cf32* __restrict__ nco, const int t)
-{
-    const FrameDesc* hist = A.hist + (size_t)b * A.hist_cap;
-    __shared__ float s_lo, s_hi;
-    __shared__ int s_first;
-    if (t == 0) {
-        int first = 0; bool dropped = s_st.hist_dropped != 0;
-        if (!A.loop)                                                         // samples that have left the ring cannot be replayed
-            for (int i = s_st.hist_count - 1; i >= 0; i--) if (hist[(s_st.hist_head + i) % A.hist_cap].pos < A.n_valid - A.ring) { first = i + 1; dropped = true; break; }
-        s_first = first;
-        s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? 3.0e38f : s_st.s_level;
-    }
-    __syncthreads();
-    for (int e = s_first; e < s_st.hist_count; e++) {
-        const FrameDesc d = hist[(s_st.hist_head + e) % A.hist_cap];
-        // what one window search pulled: T_u + start_index samples at f_prs; then, if it succeeded, 75 symbols at f_sym and the null
-        // symbol at null_f (ofdm-processor.cpp:337-344,371-374,432-434,462-463)
-        const int nseg = d.valid == 1 ? 3 : 1;
-        for (int sgm = 0; sgm < nseg; sgm++) {
-            const int64_t off0 = sgm == 0 ? 0 : sgm == 1 ? (int64_t)T_U + d.start_index : (int64_t)T_U + d.start_index + 75LL * T_S;
-            const int64_t n = sgm == 0 ? (int64_t)T_U + (d.valid == 1 ? d.start_index : 0) : sgm == 1 ? 75LL * T_S : T_NULL;
-            const int32_t L = sgm == 0 ? d.L0 : sgm == 1 ? d.L1 : d.null_L, f = sgm == 0 ? d.f_prs : sgm == 1 ? d.f_sym : d.null_f;
-            for (int64_t i0 = 0; i0 < n; i0 += TILE) {
-                const int m = (int)((n - i0 < TILE) ? n - i0 : TILE);
-                for (int i = t; i < m; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, d.pos, off0 + i0 + i, nco, L, f, i0 + i));
-                __syncthreads();
-                if (t == 0) {
-                    float lo = s_lo, hi = s_hi;
-                    const bool one = lo == hi;                                   // exact start: a single chain
-                    int i = 0;
-                    for (; i + 16 <= m; i += 16) {                               // operands fetched 16 at a time, off the dependent chain
-                        const float4 q0 = *reinterpret_cast<const float4*>(l1 + i), q1 = *reinterpret_cast<const float4*>(l1 + i + 4),
-                                     q2 = *reinterpret_cast<const float4*>(l1 + i + 8), q3 = *reinterpret_cast<const float4*>(l1 + i + 12);
-                        const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                        double a[16];
-#pragma unroll
-                        for (int k = 0; k < 16; k++) a[k] = 0.00001 * (double)v[k];
-#pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            lo = (float)(a[k] + (1 - 0.00001) * (double)lo);
-                            if (!one) hi = (float)(a[k] + (1 - 0.00001) * (double)hi);
-                        }
-                    }
-                    for (; i < m; i++) {
-                        const double a = 0.00001 * (double)l1[i];
-                        lo = (float)(a + (1 - 0.00001) * (double)lo);
-                        if (!one) hi = (float)(a + (1 - 0.00001) * (double)hi);
-                    }
-                    if (one) hi = lo;
-                    s_lo = lo; s_hi = hi;
-                }
-                __syncthreads();
-            }
-        }
-    }
-    if (t == 0) {
-        if (s_lo != s_hi) s_st.n_relock_inexact += 1;
-        s_st.s_level = s_hi;
-        s_st.hist_count = 0; s_st.hist_head = 0; s_st.hist_dropped = 0;
-    }
-    __syncthreads();
-}
-
-// ---- acquisition: OFDMProcessor::run from "Initing" / notSynced to SyncOnPhase (ofdm-processor.cpp:249-319).
-// A strictly per-sample recurrence (sLevel IIR evaluated in double, 50-sample moving sum); one work-group per
-// ensemble stages |re|+|im| of the oscillator-corrected samples in LDS, lane 0 walks the state machine.
-__global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
-{
-    constexpr int TILE = 1024;
-    __shared__ __attribute__((aligned(16))) float l1[TILE];
-    __shared__ RxState s_st;
-    __shared__ int s_done;
-
-    const int t = threadIdx.x, b = blockIdx.x;
-    const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
-    const cf32* __restrict__ nco = A.tab.nco;
-    if (A.state[b].synced) return;                   // tracking (uniform per work-group): the kernel is queued in front of every frame step
-    if (t == 0) { s_st = A.state[b]; s_done = 0; }
-    __syncthreads();
-
-    if (s_st.hist_count > 0 && A.hist) slevel_replay<TILE>(A, b, s_st, l1, iq, nco, t);
-
-    for (;;) {
-        const int64_t pos = s_st.pos; const int32_t L = s_st.local_phase;
-        // getSample(0) while priming / taking the first 50 samples, getSample(coarse+fine) while searching (:254,:269,:286,:305)
-        const int32_t f = (s_st.acq_phase >= 2) ? s_st.coarse + s_st.fine : 0;
-        int64_t avail = A.loop ? TILE : A.n_valid - pos;
-        if (avail > TILE) avail = TILE;
-        if (avail <= 0) break;                                       // starved: state is kept for the next call
-        for (int i = t; i < (int)avail; i += 256) l1[i] = l1norm(mixed_sample(iq, A.ring, pos, i, nco, L, f, i));
-        __syncthreads();
-        if (t == 0) {
-            RxState& st = s_st;
-            float sLevel = st.s_level, cs = st.acq_cs;
-            int ph = st.acq_phase, idx = st.acq_idx, counter = st.acq_counter, left = st.acq_left;
-            int i = 0; bool done = false;
-            for (;;) {
-                // loop conditions are evaluated before a sample is pulled (:284, :303)
-                if (ph == 2 && !((double)(cs / 50) > 0.50 * (double)sLevel)) { ph = 3; counter = 0; }
-                if (ph == 3 && !((double)(cs / 50) < 0.75 * (double)sLevel)) { done = true; break; }
-                if (i >= (int)avail) break;
-                const float a = l1[i++];
-                sLevel = (float)(0.00001 * (double)a + (1 - 0.00001) * (double)sLevel);         // :174
-                if (ph == 0) {                                                                  // :252-255
-                    if (--left <= 0) { ph = 1; idx = 0; cs = 0.0f; st.attempts += 1; }                  // falls through into notSynced (:256)
-                } else if (ph == 1) {                                                           // :268-273
-                    st.env[idx & 63] = a; cs += a; idx++;
-                    if (idx == 50) { ph = 2; counter = 0; break; }                              // oscillator changes -> new tile
-                } else {                                                                        // :285-297 / :304-316
-                    st.env[idx & 63] = a;
-                    cs += a - st.env[(idx - 50) & 63];
-                    idx = (idx + 1) & 32767;
-                    counter++;
-                    if ((ph == 2 && counter > T_F) || (ph == 3 && counter > T_NULL + 50)) {     // hopeless -> notSynced
-                        ph = 1; idx = 0; cs = 0.0f; st.attempts += 1; break;
-                    }
-                }
-            }
-            st.s_level = sLevel; st.acq_cs = cs; st.acq_phase = ph; st.acq_idx = idx; st.acq_counter = counter; st.acq_left = left;
-            st.pos = pos + i;
-            st.local_phase = (f == 0) ? L : mod_rate64((int64_t)L - (int64_t)i * f);
-            if (done) { st.synced = 1; st.acq_phase = 1; st.acq_idx = 0; st.acq_cs = 0.0f; st.acq_counter = 0; }
-            s_done = done ? 1 : 0;
-        }
-        __syncthreads();
-        if (s_done) break;
-    }
-    if (t == 0) A.state[b] = s_st;
-}
-
 // Continuous mode (dabphy_set_track_slevel): the level follows the tracked frames one by one (3 ms per frame on one lane: meant for
 // the single-ensemble real-time receiver, where it is 3 % of a frame's 96 ms) instead of catching up when lock is lost.
 __global__ void __launch_bounds__(256) k_slevel_catchup(SyncArgs A)
@@ -747,7 +765,7 @@ __global__ void __launch_bounds__(256) k_slevel_catchup(SyncArgs A)
     if (t == 0) s_st = A.state[b];
     __syncthreads();
     if (s_st.hist_count == 0 || !A.hist) return;
-    slevel_replay<TILE>(A, b, s_st, l1, A.iq + (size_t)b * A.iq_stride, A.tab.nco, t);
+    slevel_replay<TILE, 256>(A, b, s_st, l1, A.iq + (size_t)b * A.iq_stride, A.tab.nco, t);
     if (t == 0) {
         RxState& g = A.state[b];
         g.s_level = s_st.s_level; g.hist_count = 0; g.hist_head = 0; g.hist_dropped = 0; g.n_relock_inexact = s_st.n_relock_inexact;

@@ -19,6 +19,7 @@
 // "m0 > m1" evaluated on the true integers, ties keep the m0/m2 branch -- the reference's own
 // renormalisation schedule (viterbi.cpp:104-120) changes no decision, so none of it is mimicked.
 #include "dabphy_kernels.h"
+#include <cstdlib>
 #include <dabphy_wave_ops.h>
 
 namespace dabphy {
@@ -382,6 +383,212 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------ fused MSC decode
+// k_viterbi_msc = k_msc_gather + k_viterbi in one kernel: the step-word array (4 bytes per trellis step and code word written by the
+// gather and read back by the decoder: 2 x 2.27 GB per 256 x 20 batch) never exists.  A wavefront (64 code words = consecutive CIFs of
+// at most two (ensemble, sub-channel) pairs) keeps in LDS a sliding WINDOW of the soft-bit rows it decodes from:
+//   rows    the source CIFs of its code words, 64 + 15 per (b, m) segment (time de-interleaver: byte u of the frame emitted at CIF c
+//           comes from CIF c - 16 + map16[u & 15], dab-audio.cpp:113,138-143), <= 94;
+//   columns 16-byte windows of the sub-channel's punctured bit stream: window w = bytes [16 w, 16 w + 16).  Two windows are resident
+//           (slot w & 1), the next one travels HBM -> LDS by LDS-DMA (6 requests of 64 x 4 bytes, no VGPRs) while the current ones are
+//           consumed; u & 15 is the column inside a window, so the de-interleaver's row skew is a function of the column.
+// Everything that depends only on the step -- which of the 4 mother-code bits are punctured, where the others lie in the window ring,
+// when a window dies -- is the same for all lanes and comes from a per-class table (MscStep, built on the host from the depuncturing
+// map) through scalar loads.  Per step a lane adds its row base to four uniform offsets, reads four bytes from LDS (an erasure
+// reads a zero from a third, never written slot) and forms the branch metrics; the trellis and the traceback are k_viterbi's.
+constexpr int FM_ROWS = 96;                       // 16-row blocks of the LDS-DMA requests; 64 + 2 * 15 = 94 rows used at most
+constexpr int FM_SLOT = FM_ROWS * 16;             // bytes per window slot: [row][16]
+constexpr int FM_ZERO = 2 * FM_SLOT;              // third slot: zeros (erasures, viterbi.cpp:233-238 maps soft value 0 to symbol 127)
+constexpr int FM_ROWPTR = 3 * FM_SLOT;            // then the rows' sources: byte offset / 16 into the soft-bit ring (rows without a source CIF point at the zeros behind the ring)
+constexpr int FM_LDS = FM_ROWPTR + FM_ROWS * 4;
+
+// branch metrics straight from the four soft values v_j (signed; symbol s_j = v_j + 127, viterbi.cpp:233-236 -- the clamp at 0 only
+// matters for v = -128, which the demapper never produces: |v| <= 127 by construction, ofdm-decoder.cpp:208-212, asserted by the tests)
+__device__ __forceinline__ void bm_from_soft(u16x2 (&BM)[4], int v0, int v1, int v2, int v3)
+{
+    // viterbi.cpp:259-261 with outputs 0 and 3 sharing a generator: bm(0) = s0+s3+s1+s2, bm(1) = 510-(s0+s3)+s1+s2, bm(p|2) = bm(p) + 255 - 2 s1
+    const int a = v0 + v3, b = v1 + v2;
+    const uint32_t m0 = (uint32_t)(a + b + 508), m1 = (uint32_t)((b - a) + 510);
+    const uint32_t c = (uint32_t)(1 - 2 * v1);      // 255 - 2 (v1 + 127); added modulo 2^32
+    const uint32_t m2 = m0 + c, m3 = m1 + c;
+    // BM[p] = (bm(p), bm(p ^ 7))
+    BM[0] = asv(m0 | ((1020u - m0) << 16)); BM[1] = asv(m1 | ((1020u - m1) << 16));
+    BM[2] = asv(m2 | ((1020u - m2) << 16)); BM[3] = asv(m3 | ((1020u - m3) << 16));
+}
+
+__global__ void __launch_bounds__(64, 5) k_viterbi_msc(FusedMscArgs A)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[FM_LDS];
+  const int lane = threadIdx.x;
+  const int nsteps = A.c.nsteps, nbits = A.c.nbits, R = 4 * A.n_frames;
+  const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  (void)map16;
+#pragma unroll 1
+  for (int g = A.c.g_begin + blockIdx.x; g < A.c.g_end; g += gridDim.x) {
+    // ---- which rows this wave needs: segments = runs of lanes with the same (b, m) (their CIFs are consecutive by construction)
+    const int cw = g * 64 + lane;
+    const bool live = cw < A.c.n_cw;
+    const int pair = live ? cw / R : -1, r = live ? cw % R : 0;
+    const int b = live ? pair / A.n_members : 0, m = live ? pair % A.n_members : 0;
+    const long long c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;         // CIF whose arrival emits this logical frame
+    const int pair0 = __shfl(pair, 0);
+    const unsigned long long in0 = __ballot(pair == pair0);                              // segment 0 = the leading lanes of pair0
+    const int n0 = __popcll(in0);
+    const int seg = (pair == pair0) ? 0 : 1;                                             // (dead lanes ride in segment 1: their output is dropped)
+    const int rb = lane + 15 * seg;                                                      // row of CIF c_glob - 16
+    const int first1 = n0 < 64 ? n0 : 63;
+    const int pair1 = __shfl(pair, first1);
+    const long long c_a0 = 4 * A.desc[(size_t)__shfl(b, 0) * A.n_frames].frame_no + __shfl(r, 0);            // first CIF of segment 0 ...
+    const long long c_a1 = 4 * A.desc[(size_t)__shfl(b, first1) * A.n_frames].frame_no + __shfl(r, first1);  // ... and of segment 1
+    (void)c_glob;
+    const int nrows = (n0 < 64 && pair1 >= 0) ? 64 + 30 : n0 + 15;
+    __syncthreads();                                                                     // (one wave per work-group: orders the LDS reuse between groups)
+    // zero the window slots and the erasure slot; row pointers
+    for (int i = lane; i < FM_ROWPTR / 16; i += 64) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int row = lane; row < FM_ROWS; row += 64) {
+        uint32_t src = A.zero_off16;                   // no such CIF yet (start of a stream) / row not used by this wave
+        if (row < nrows) {
+            const bool s1 = row >= n0 + 15;
+            const int pr = s1 ? pair1 : pair0;
+            const long long c_src = (s1 ? c_a1 : c_a0) - 16 + (s1 ? row - (n0 + 15) : row);
+            if (pr >= 0 && c_src >= 0) {
+                const int pb = pr / A.n_members, pm = pr % A.n_members;
+                src = (uint32_t)(((long long)pb * A.soft_ring * SOFT_PER_FRAME + A.start_bit[pm] +
+                                  ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM) >> 4);     // (start_bit is a multiple of 64)
+            }
+        }
+        reinterpret_cast<uint32_t*>(lds + FM_ROWPTR)[row] = src;
+    }
+    __syncthreads();
+    // window w -> slot w & 1: 6 requests, lane l of request k moves dword (l & 3) of row 16 k + (l >> 2).  All six row addresses
+    // are read first, then the six requests go out back to back: no branch, no LDS round trip between them.
+    auto load_window = [&](int w) {
+        uint8_t* slot = lds + (w & 1) * FM_SLOT;
+        const uint32_t l = opaque_vgpr((uint32_t)lane);             // (nothing of this may be hoisted out of the step loop)
+        uint32_t src[FM_ROWS / 16];
+#pragma unroll
+        for (int k = 0; k < FM_ROWS / 16; k++) src[k] = reinterpret_cast<const uint32_t*>(lds + FM_ROWPTR)[16 * k + (l >> 2)];
+        const int8_t* col = A.soft + (16 * w + 4 * (l & 3));
+#pragma unroll
+        for (int k = 0; k < FM_ROWS / 16; k++) lds_dma4(col + ((size_t)src[k] << 4), slot + 256 * k);
+    };
+    load_window(0);
+    if (A.n_windows > 1) load_window(1);
+
+    // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
+    uint2* __restrict__ const dec_g = A.c.dec + (size_t)g * nsteps * 64;
+    const uint32_t ones = opaque_sgpr(0x01010101u);
+    u16x2 Rm[32], Nm[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) Rm[j] = splat(63);
+    Rm[0] = asv(63u << 16);
+#ifdef FM_EXP_BROADCAST          // (timing experiment only: every lane reads the same bytes -- no bank conflicts, wrong results)
+    const uint32_t lane_base = 0u; (void)rb;
+#else
+    const uint32_t lane_base = (uint32_t)rb * 16u;
+#endif
+    const int8_t* lds_c = reinterpret_cast<const int8_t*>(lds);        // (sign-extending byte reads)
+    auto fetch = [&](const MscStep& d, int (&y)[4]) {
+        y[0] = lds_c[lane_base + (d.off01 & MSC_OFF_MASK)]; y[1] = lds_c[lane_base + ((d.off01 >> 16) & MSC_OFF_MASK)];
+        y[2] = lds_c[lane_base + (d.off23 & 0xffffu)]; y[3] = lds_c[lane_base + (d.off23 >> 16)];
+    };
+    lds_dma_wait();                                                  // windows 0 and 1 have landed
+    int cur[4];
+    int next_window = 2;
+    // Per step: branch metrics from this step's bytes; then the bytes of step s + 1 are requested into the same registers (after
+    // waiting for its window, if it is the first step to read a new one) and travel while the 32 butterflies run; then -- this
+    // step's own reads have been consumed -- the window after the next is requested into the slot this step was the last to read.
+    // The wait is s_waitcnt vmcnt(2): memory operations complete in order, the load is older than the last two decision stores
+    // (the host checks that when it builds the table), so the newest stores stay in flight.
+    // The descriptors of steps s + 2, s + 3 are requested (scalar loads) while steps s, s + 1 run.
+    // (two halves: between them the loop requests the descriptors of the next pair of steps -- scalar loads share the LDS counter
+    // and return out of order, so any wait for LDS bytes also waits for them: they are issued right AFTER such a wait and have a
+    // whole step to arrive)
+    u16x2 BM[4];
+    auto step_a = [&]() { bm_from_soft(BM, cur[0], cur[1], cur[2], cur[3]); };
+    auto step_b_nofetch = [&](int s, const MscStep& d_cur, const u16x2 (&Rin)[32], u16x2 (&Nout)[32]) {
+        if (d_cur.off01 & MSC_LOAD_NEXT) { wave_converge(); load_window(next_window); next_window++; }     // every lane has consumed its reads of the dying window
+        uint32_t accA = 0, accB = 0;
+        bfly_pairs<0>(Rin, Nout, BM, accA, accB, ones);
+        dec_g[(uint32_t)(s * 64 + lane)] = make_uint2(accA, accB);
+    };
+    auto fetch_for = [&](const MscStep& d_next) {                     // the bytes of the step that follows (after the butterflies: four registers less while they run)
+#ifndef FM_EXP_NOWAIT            // (timing experiment only)
+        if (d_next.off01 & MSC_FIRST_USE) lds_dma_wait_but<2>();
+#endif
+        fetch(d_next, cur);
+    };
+    // descriptors through the constant address space (scalar loads), one pair of steps ahead (two entries of padding end the table)
+    const DABPHY_CONST_AS MscStep* steps = as_constant(A.steps);
+    auto desc_at = [&](int i) { MscStep d; d.off01 = steps[i].off01; d.off23 = steps[i].off23; return d; };
+    MscStep d0 = desc_at(0), d1 = desc_at(1);
+    fetch(d0, cur);
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        step_a();                                                    // (waits for the LDS bytes of step s: nothing scalar is in flight here)
+        const MscStep e0 = desc_at(s + 2), e1 = desc_at(s + 3);
+        step_b_nofetch(s, d0, Rm, Nm);
+        fetch_for(d1);
+        step_a();
+        step_b_nofetch(s + 1, d1, Nm, Rm);
+        fetch_for(e0);
+        if ((s & 30) == 30) renorm(Rm);                              // every 32 steps: 6120 + 32 * 1020 < 65536
+        d0 = e0; d1 = e1;
+    }
+    if (s < nsteps) { step_a(); step_b_nofetch(s, d0, Rm, Nm); }
+    lds_dma_wait();                                                  // (no load may still be in flight when the next group reuses the slots)
+
+    // traceback: as in k_viterbi
+    const int cw_out = g * 64 + lane;                                // (recomputed: nothing but the trellis lives across the step loop)
+    const bool live_out = cw_out < A.c.n_cw;
+    uint32_t* out = reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw_out * (nbits / 32);
+    uint32_t T = 0, acc = 0;
+    uint2 dq[8], dn[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) dq[k] = dec_g[(uint32_t)((nbits - 1 - k + 6) * 64 + lane)];
+    for (int n = nbits - 1; n >= 0; n -= 8) {
+        {
+            const int mm = n >= 8 ? n - 8 : n;
+#pragma unroll
+            for (int k = 0; k < 8; k++) dn[k] = dec_g[(uint32_t)((mm - k + 6) * 64 + lane)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int nn = n - k;
+            const uint32_t dx = dq[k].x, dy = dq[k].y;
+            const uint32_t wsel = dx ^ ((dx ^ dy) & (0u - ((T >> 4) & 1u)));
+            const uint32_t bit = ((T >> 1) & 7) + 8 * (2 * (T & 1) + (T >> 5));
+            const uint32_t kk = (wsel >> bit) & 1;
+            T = (T >> 1) | (kk << 5);
+            acc |= kk << (8 * ((nn >> 3) & 3) + k);
+        }
+        if (((n - 7) & 31) == 0) {
+            const int wi = (n - 7) >> 5;
+            if (live_out) out[wi] = A.c.dedisperse ? acc ^ A.prbs_words[wi] : acc;
+            acc = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) dq[k] = dn[k];
+    }
+  }
+}
+
+void launch_viterbi_msc(const FusedMscArgs& a, hipStream_t s)
+{
+    static int n_simd = 0;
+    if (!n_simd) {
+        int dev = 0; hipDeviceProp_t p;
+        n_simd = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? 4 * p.multiProcessorCount : 1024;
+    }
+    const int n = a.c.g_end - a.c.g_begin;
+    if (n <= 0) return;
+    const int per = (n + 8 * n_simd - 1) / (8 * n_simd);
+    // (experiments: extra dynamic LDS per wave caps the kernel's occupancy and leaves registers to the synchroniser's kernels)
+    static int pad = -1;
+    if (pad < 0) { const char* e = getenv("DABPHY_VIT_LDS_PAD"); pad = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k_viterbi_msc, dim3((n + per - 1) / per), dim3(64), (size_t)pad, s, a);
 }
 
 // ------------------------------------------------------------------------------------------ linear gather
