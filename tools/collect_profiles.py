@@ -80,7 +80,7 @@ if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
     shutil.copy(os.path.join(SRC, "pmc_vit_counter_collection.csv"), os.path.join(DST, TAG + "_pmc_sq_viterbi_gather.csv"))
     acc = {}
     for r in rows("pmc_vit_counter_collection.csv"):
-        if "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid:
+        if "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid:        # k_viterbi_msc (fused) or k_viterbi (two-kernel path)
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     med = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
     fv = [float(r["Counter_Value"]) for r in rows("pmc_fetch_counter_collection.csv") if r["Counter_Name"] == "FETCH_SIZE" and "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid]
@@ -89,7 +89,7 @@ if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
     wg = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and "k_msc_gather" in r["Kernel_Name"]]
     mid = lambda v: sorted(v)[len(v) // 2] if v else 0.0
     json.dump({
-        "kernel": "dabphy::k_viterbi (MSC class launch)", "ensembles": B, "frames": F,
+        "kernel": "dabphy::k_viterbi_msc (MSC class launch: gather fused into the Viterbi kernel)", "ensembles": B, "frames": F,
         "valu_insts_per_launch": med.get("SQ_INSTS_VALU"), "lds_insts_per_launch": med.get("SQ_INSTS_LDS"), "vmem_insts_per_launch": med.get("SQ_INSTS_VMEM"),
         "waves": med.get("SQ_WAVES"), "lds_bank_conflict_cycles": med.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": med.get("SQ_LDS_IDX_ACTIVE"),
         "fetch_size_kb_raw": mid(fv), "write_size_kb_raw": mid(wv),
