@@ -132,6 +132,22 @@ int gpu_receiver_run(gpu_run_io* io)
     return 0;
 }
 
+// ---- scan mode (RadioReceiver::restart(true)): the onSignalPresence calls the facade makes over a stream, in order (1 = true, 0 = false)
+int gpu_scan_run(const float* iq, int64_t n_samples, int32_t* calls, int cap)
+{
+    struct ScanRec : Rec { int32_t* calls; int cap; std::atomic<int> n{0}; void onSignalPresence(bool v) override { int k = n++; if (k < cap) calls[k] = v ? 1 : 0; } };
+    ScanRec rec; rec.calls = calls; rec.cap = cap;
+    MemInput in(iq, n_samples);
+    RadioReceiverOptions rro; rro.decodeTII = false;
+    try {
+        GpuRadioReceiver rx(rec, in, rro);
+        rx.restart(true);
+        while (!rec.failed) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        rx.stop();
+    } catch (const std::exception& e) { fprintf(stderr, "gpu_scan_run: %s\n", e.what()); return -1; }
+    return rec.n;
+}
+
 // ---- batch mode: n_ens ensembles (streams of equal length, [n_ens][n_samples] cf32), each with its own FIBProcessor;
 // out per ensemble: ensemble id, number of services listed, number of FIBs that passed the CRC, onServiceDetected calls
 int gpu_batch_run2(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int signal_clock, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii);

@@ -447,4 +447,24 @@ int ref_service_list_run(const float* iq, int64_t n_samples, int realtime, int32
     return 0;
 }
 
+// ---- scan mode of the reference (RadioReceiver::restart(true), ofdm-processor.cpp:256-262,351-355): its onSignalPresence calls in order
+int ref_scan_run(const float* iq, int64_t n_samples, int32_t* calls, int cap)
+{
+    struct ScanRec : Recorder { int32_t* calls; int cap; std::atomic<int> n{0}; void onSignalPresence(bool v) override { int k = n++; if (k < cap) calls[k] = v ? 1 : 0; } };
+    ScanRec rec; rec.calls = calls; rec.cap = cap;
+    MemInput in(iq, n_samples, &rec);
+    RadioReceiverOptions rro; rro.decodeTII = false;
+    {
+        RadioReceiver rx(rec, in, rro);
+        rec.rx = &rx;
+        rx.restart(true);
+        in.armed = true;
+        while (!rec.failed) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        rx.stop();
+        rec.rx = nullptr;
+    }
+    return rec.n;
+}
+
 } // extern "C"

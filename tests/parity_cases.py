@@ -731,3 +731,46 @@ def check_dropout_batch(d_factory, F=4):
         fr = np.frombuffer(b, np.uint8).reshape(-1, sc.frame_bytes)
         eo, _ = R.orc_superframe_run(fr)
         assert sf_ev[i] == [(e[1], e[2], e[3]) for e in eo], "superframe events of sub-channel %d differ" % i
+
+
+def check_runtime_options(d_factory):
+    """dabphy_set_options = OFDMProcessor::setReceiverOptions at run time (ofdm-processor.cpp:518-529): method changes apply from
+    the next frame on without a restart; a change of disableCoarseCorrector restarts the synchroniser (correctors, phase, sLevel,
+    acquisition) while the decoders keep their state; the stream goes on where the decoded frames ended"""
+    x, tx = synth.make_stream(48, snr_db=18, cfo_hz=2060, delay=100, return_tx=True, seed=23, subchs=synth.default_subchannels(2))
+    sent = [b"".join(f) for f in tx.fib_log]
+    d = d_factory(n_ensembles=1, max_frames=3, want_constellation=False)
+    try:
+        d.stream_upload(x[None, :])
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in tx.subchs[:1]])
+        frames = []
+
+        def run(k):
+            for _ in range(k):
+                d.process(3)
+                info = d.frame_info(); fb, ok = d.fibs()
+                for f in range(3):
+                    if info[0, f]["valid"] == 1:
+                        frames.append((int(info[0, f]["frame_no"]), int(info[0, f]["coarse"]), bool(ok[0, f].all()), fb[0, f].tobytes()))
+        run(3)
+        assert d.config().fft_placement == 2 and d.config().disable_coarse == 0
+        assert frames[-1][1] == 2000 and frames[-1][2]                    # the coarse corrector has pulled the 2.06 kHz offset in
+        assert d.set_options(fft_placement=1, freqsync_method=1, disable_coarse=False) is False      # methods only: no restart
+        assert d.config().fft_placement == 1 and d.config().freqsync_method == 1
+        n0 = len(frames); run(2)
+        assert len(frames) == n0 + 6 and all(f[2] for f in frames[n0:])   # goes on without losing a frame
+        assert d.set_options(fft_placement=1, freqsync_method=1, disable_coarse=True) is True       # restart (resetCoarseCorrector + restart)
+        assert d.config().disable_coarse == 1
+        n1 = len(frames); run(4)
+        after = frames[n1:]
+        assert len(after) >= 8, len(after)
+        assert all(f[1] == 0 for f in after)                             # coarse corrector reset to 0 and, disabled, never moved again
+        assert [f[0] for f in frames] == list(range(len(frames)))        # the frame counter (CIF count of the de-interleavers) went on
+        # without coarse correction the 2.06 kHz offset (two carrier spacings + 60 Hz) stays: FIBs no longer pass their CRC
+        assert not any(f[2] for f in after[2:])
+        assert d.set_options(fft_placement=2, freqsync_method=2, disable_coarse=False) is True
+        n2 = len(frames); run(4)
+        good = [f for f in frames[n2:] if f[2]]
+        assert len(good) >= 6 and all(f[3] in sent for f in good)        # decodes the transmitted FIBs again
+    finally:
+        d.close()

@@ -496,6 +496,23 @@ def ref_service_list_run(iq, realtime):
     return nl.value, nd.value
 
 
+def ref_scan_run(iq):
+    """onSignalPresence calls (1 / 0, in order) of the reference's RadioReceiver restarted in scan mode over a stream"""
+    iq = np.ascontiguousarray(iq, np.complex64); calls = np.zeros(8, np.int32)
+    ref().ref_scan_run.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    n = ref().ref_scan_run(_p(iq), len(iq), _p(calls), 8)
+    return [int(v) for v in calls[:min(n, 8)]]
+
+
+def gpu_scan_run(iq, lib=GPU_EMU_SO):
+    L = C.CDLL(lib)
+    iq = np.ascontiguousarray(iq, np.complex64); calls = np.zeros(8, np.int32)
+    L.gpu_scan_run.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    n = L.gpu_scan_run(_p(iq), len(iq), _p(calls), 8)
+    assert n >= 0
+    return [int(v) for v in calls[:min(n, 8)]]
+
+
 def gpu_batch_services(iq, frames_per_step, n_steps, signal_clock=True, lib=GPU_EMU_SO):
     """GpuBatchReceiver with / without its signal-time clock -> per-ensemble (services listed, onServiceDetected calls)"""
     L = C.CDLL(lib)

@@ -132,3 +132,7 @@ def test_mixed_protection_classes_fused_decode(emu):
     """16 frames per call = 64 CIFs per sub-channel: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel -- the MSC
     gather inside the Viterbi kernel (k_viterbi_msc: LDS window ring fed by LDS-DMA, per-step descriptors from the depuncturing map)"""
     P.check_mixed_ensemble(factory, F=16, nf=36, expect_fused=True)
+
+
+def test_receiver_options_at_run_time(emu):
+    P.check_runtime_options(factory)

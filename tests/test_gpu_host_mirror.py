@@ -67,3 +67,10 @@ def test_facade_through_a_dropout(gpu):
     assert kk >= len(a["cir"]) - 1 and np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))
     kn = min(len(a["nul"]), len(b["nul"]))
     assert kn >= len(a["nul"]) - 1 and np.array_equal(a["nul"][:kn].view(np.uint32), b["nul"][:kn].view(np.uint32))
+
+
+def test_scan_mode_signal_presence(gpu):
+    from test_host_mirror import scan_streams
+    good, noise = scan_streams()
+    assert R.gpu_scan_run(good, lib=R.GPU_HIP_SO) == [1]
+    assert R.gpu_scan_run(noise, lib=R.GPU_HIP_SO) == [0]

@@ -137,3 +137,7 @@ def test_dropout_in_batch_mode(gpu):
     """a dropout decoded four frames per call: the slot after the failed window search re-acquires at once (k_acquire is queued before
     every frame step), MSC rows stay packed, the superframe filter walks the frames that exist"""
     P.check_dropout_batch(factory)
+
+
+def test_receiver_options_at_run_time(gpu):
+    P.check_runtime_options(factory)

@@ -124,3 +124,18 @@ def test_facade_through_a_dropout(emu):
     assert kk >= len(a["cir"]) - 1 and np.array_equal(a["cir"][:kk].view(np.uint32), b["cir"][:kk].view(np.uint32))
     kn = min(len(a["nul"]), len(b["nul"]))
     assert kn >= len(a["nul"]) - 1 and np.array_equal(a["nul"][:kn].view(np.uint32), b["nul"][:kn].view(np.uint32))
+
+
+def scan_streams():
+    good = synth.make_stream(6, snr_db=20, cfo_hz=30, delay=500, seed=11)
+    rng = np.random.RandomState(5)
+    noise = (0.05 * (rng.randn(9 * 196608) + 1j * rng.randn(9 * 196608))).astype(np.complex64)      # no DAB signal: every null search is hopeless
+    return good, noise
+
+
+def test_scan_mode_signal_presence(emu):
+    """restart(doScan = true): onSignalPresence(true) on the first successful window search, onSignalPresence(false) after the sixth
+    entry into notSynced without one (ofdm-processor.cpp:256-262,351-355) -- exactly once each, like the reference"""
+    good, noise = scan_streams()
+    assert R.ref_scan_run(good) == [1] and R.gpu_scan_run(good, lib=R.GPU_EMU_SO) == [1]
+    assert R.ref_scan_run(noise) == [0] and R.gpu_scan_run(noise, lib=R.GPU_EMU_SO) == [0]
