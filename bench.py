@@ -280,8 +280,9 @@ def main():
             ub = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
         except Exception:
             ub = None
-        rv = {"kernel": "k_viterbi, MSC class (lane = codeword, 64 states in 32 VGPRs of packed u16)", "bound": "valu",
-              "kernel_ms": vit_ms, "codeword_steps_per_s": B * F * 72 * 1542 / (vit_ms * 1e-3) if vit_ms > 0 else None,
+        rv = {"kernel": "k_viterbi_msc, MSC class (lane = codeword, 64 states in 32 VGPRs of packed u16; de-interleave + depuncture gather fused in through an LDS window ring)", "bound": "valu",
+              "kernel_ms": vit_ms, "kernel_ms_note": "HIP events around the launch inside the pipelined step: the FIC class and the next batch's synchroniser run beside it",
+              "codeword_steps_per_s": B * F * 72 * 1542 / (vit_ms * 1e-3) if vit_ms > 0 else None,
               "algorithmic_bytes": B * F * 72 * (4 * 1542 + 1536 // 8), "hbm_bytes": vj.get("hbm_bytes_per_launch") if vj else None,
               "valu_insts_per_launch": vj.get("valu_insts_per_launch") if vj else None,
               "counter_source": "static: profiles/viterbi_counters.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh; not measured by this run)" if vj else None}
