@@ -296,25 +296,28 @@ def main():
                           measured_mix_note="profiles/valu_rate.json: issue cost of this kernel's instruction mix from tools/ubench/valu_rate.hip (packed 16-bit ops %.2f cycles, plain %.2f)" % (ub["cycles_packed"], ub["cycles_plain"]))
         line["roofline_viterbi"] = rv
         line["config"]["schedule"] = {0: "serial synchroniser", 1: "pipelined: the next batch's synchroniser starts behind this batch's demod kernel",
-                                      2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)"}[sched]
-        if world == 1 and sched in (1, 2) and not args.no_alt_schedule:
-            # the other pipelined schedule, measured the same way right after the timed region (reported, never `value`)
+                                      2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)",
+                                      3: "pipelined two batches ahead: the synchroniser of batch k + 2 starts behind batch k's demod kernel"}[sched]
+        if world == 1 and sched in (1, 2, 3) and not args.no_alt_schedule:
+            # the other pipelined schedules, measured the same way right after the timed region (reported, never `value`)
             dev.close(); dev = None
-            alt = 3 - sched
-            dev2 = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=alt, demod_chunk=chunk)
+            line["alt_schedules"] = []
+            for alt in [m for m in (1, 2, 3) if m != sched]:
+                dev2 = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=alt, demod_chunk=chunk)
 
-            def step2():
-                dev2.process(F); dev2.superframes_stats(); return dev2.fibs()
-            for _ in range(3):
-                step2()
-            torch.cuda.synchronize(); t1 = time.perf_counter(); dm = 0.0
-            for _ in range(args.steps):
-                step2(); dm += dev2.stage_times()["demod"]
-            torch.cuda.synchronize(); dt2 = (time.perf_counter() - t1) / args.steps
-            dm /= args.steps
-            line["alt_schedule"] = {"pipeline_sync": alt, "value": B * F * FRAME_S / dt2, "ms_per_step": dt2 * 1e3, "demod_kernel_ms": dm,
-                                    "roofline_frac": B * F * ALG_BYTES_DEMOD_PER_FRAME / (dm * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-            dev2.close()
+                def step2():
+                    dev2.process(F); dev2.superframes_stats(); return dev2.fibs()
+                for _ in range(4):
+                    step2()
+                torch.cuda.synchronize(); t1 = time.perf_counter(); dm = 0.0
+                for _ in range(args.steps):
+                    step2(); dm += dev2.stage_times()["demod"]
+                torch.cuda.synchronize(); dt2 = (time.perf_counter() - t1) / args.steps
+                dm /= args.steps
+                line["alt_schedules"].append({"pipeline_sync": alt, "value": B * F * FRAME_S / dt2, "ms_per_step": dt2 * 1e3, "demod_kernel_ms": dm,
+                                              "roofline_frac": B * F * ALG_BYTES_DEMOD_PER_FRAME / (dm * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+                dev2.close()
+            line["alt_schedule"] = line["alt_schedules"][0]
         if world == 1 and not args.no_cpu_baseline:
             rows = {e: iq[e].cpu().numpy() for e in check}
             line["cpu_baseline"], line["parity_check"] = cpu_baseline(rows, n_loops=12, gpu_logs=logs)

@@ -43,11 +43,12 @@ typedef struct {
     int32_t want_impulse_response;  /* keep the 2048-float CIR per frame (onNewImpulseResponse) */
     int32_t demod_chunk;            /* data symbols per work-group of the demod kernel; 0 = default */
     int32_t freqsync_method;        /* FreqsyncMethod of the coarse corrector: 2 = PatternOfZeros (default), 1 = CorrelatePRS, 0 = GetMiddle */
-    int32_t pipeline_sync;          /* 1 or 2: synchronise batch k+1 on a second stream while batch k is decoded (throughput mode:
+    int32_t pipeline_sync;          /* 1, 2 or 3: synchronise batch k+1 on a second stream while batch k is decoded (throughput mode:
                                        constant n_frames, samples of the next batch already in the ring; the coarse-corrector
                                        feedback then lags one more batch).  1: the next batch's synchroniser is queued behind this
                                        batch's demod kernel; 2: at once (it then competes with the demod kernel: more frames per
-                                       second in total, a slower FFT stage) */
+                                       second in total, a slower FFT stage); 3: queued like 1 but TWO batches ahead (the samples of
+                                       the next two batches must be in the ring; the coarse-corrector feedback lags one batch more) */
     int32_t msc_parts;              /* decode every MSC protection class in this many parts (whole ensembles each): part p's Viterbi kernel
                                        (VALU-bound) runs on a side stream while part p + 1 is gathered (HBM-bound).  0 or 1 = one gather and
                                        one decode launch per class, which is also what measures best on MI355X: parts that are not

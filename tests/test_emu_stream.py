@@ -26,7 +26,7 @@ def test_big_batch_tiled_gather(emu):
     P.check_stream_vs_oracle(factory, 14, 30, 200, 43, False, F=20)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_pipelined_sync(emu, mode):
     """throughput mode: batch k+1 synchronised ahead of batch k's decode gives the same bytes (coarse corrector off)"""
     P.check_stream_vs_oracle(factory, 16, -20, 50, 14, False, F=3, pipeline_sync=mode, disable_coarse=True)

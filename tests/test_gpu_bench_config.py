@@ -24,7 +24,7 @@ def base_streams():
     return _base
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_benchmarked_configuration(gpu, mode):
     P.check_bench_config(capi, GPU_LIB, 256, 20, mode, check_ens=[0, 1, 2, 77, 128, 129, 191, 254, 255], n_steps=3, base=base_streams(), expect_chunk=25)
 

@@ -42,7 +42,7 @@ def test_big_batch_tiled_gather(gpu):
     P.check_stream_vs_oracle(factory, 14, 30, 200, 43, False, F=20)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_pipelined_sync(gpu, mode):
     """batch k+1 is synchronised on a second stream while batch k is decoded (queued behind the demod kernel, or at once): same
     bytes as the serial order"""

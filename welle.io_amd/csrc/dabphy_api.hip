@@ -55,7 +55,8 @@ struct dabphy_handle {
     uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
     DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
     DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
-    DevBuf s_desc2[2], s_cir2[2], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
+    static constexpr int N_DESC = 3;    // descriptor buffers: the batch being decoded + up to two synchronised ahead
+    DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
     hipStream_t vit_stream[2] = {nullptr, nullptr};      // the MSC class is decoded in parts: part p's Viterbi (+ superframe filter) runs here while part p + 1 is gathered
@@ -63,9 +64,9 @@ struct dabphy_handle {
     hipEvent_t ev_part[MAX_PARTS]{}, ev_vit_done[2]{};
     int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
     bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
-    hipEvent_t ev_chain_beg[2]{}, ev_chain_end[2]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
+    hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
-    bool need_acquire = true;         // queue k_acquire in front of every frame step
+    int ahead = 0;                    // batches whose chain has been queued but which have not been decoded yet (pipelined modes: 1 or 2 between calls)
     uint32_t presynced = 0;           // frames already synchronised ahead into s_desc2[desc_sel] (pipelined mode)
     int soft_ring = 0;
     uint32_t last_frames = 0;         // n_frames of the last dabphy_process
@@ -153,7 +154,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
-    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 2) return fail(DABPHY_ERR_INVALID);
+    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3) return fail(DABPHY_ERR_INVALID);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
@@ -183,7 +184,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_ingest[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_chain_gate, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
-    for (int i = 0; i < 2; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipStreamCreateWithFlags(&h->vit_stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_vit_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     h->msc_parts = cfg->msc_parts;
@@ -208,13 +209,13 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);
     if (h->ev_chain_gate) e = hipEventDestroy(h->ev_chain_gate);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
-    for (int i = 0; i < 2; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
     for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (h->ev_part[i]) e = hipEventDestroy(h->ev_part[i]);
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
-    DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
+    DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_desc2[2], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_cir2[2], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     { DevBuf* tb[] = {&h->s_hist, &h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
@@ -367,7 +368,7 @@ static int reset_synchroniser(dabphy_handle* h, bool decoder_too)
     std::vector<FrameDesc> ahead;
     if (!decoder_too) {
         HIPCHK(h, hipMemcpy(init.data(), h->d_state, init.size() * sizeof(RxState), hipMemcpyDeviceToHost));
-        if (h->presynced && h->s_desc2[h->desc_sel].p) {
+        if (h->presynced && h->ahead > 0 && h->s_desc2[h->desc_sel].p) {          // the earliest batch synchronised ahead starts where the decoded frames end
             ahead.resize((size_t)B * h->presynced);
             HIPCHK(h, hipMemcpy(ahead.data(), h->s_desc2[h->desc_sel].p, ahead.size() * sizeof(FrameDesc), hipMemcpyDeviceToHost));
         }
@@ -379,7 +380,7 @@ static int reset_synchroniser(dabphy_handle* h, bool decoder_too)
         memset(&s, 0, sizeof s);
         s.acq_phase = 0; s.acq_left = T_F / 2; s.first_lock_attempts = -1; s.frame_no = frame_no; s.pos = pos;
     }
-    h->presynced = 0;
+    h->presynced = 0; h->ahead = 0;
     HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
     return sync(h);
 }
@@ -653,7 +654,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     const uint32_t B = h->cfg.n_ensembles, F = n_frames;
     const int ring_frames = (int)h->cfg.max_frames + 5;
     int r;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < dabphy_handle::N_DESC; k++) {
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
@@ -730,22 +731,25 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ingest[h->commit_slot], 0));
         h->commit_slot = -1;
     }
+    const int ND = dabphy_handle::N_DESC;
+    const int depth = h->cfg.pipeline_sync == 3 ? 2 : (h->cfg.pipeline_sync ? 1 : 0);     // batches the synchroniser runs ahead of the decoder
     const int cur = h->desc_sel;
-    if (h->presynced == 0) {
+    if (h->ahead == 0) {
         // the previous batch's decoder results (FIC ratio) must be final before the chain consults them
         HIPCHK(h, hipStreamSynchronize(h->stream));
         launch_sync_chain(cur);
+        h->ahead = 1;
     }
-    HIPCHK(h, hipEventRecord(h->ev_sync_done, h->sync_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync_done, 0));
-    // Pipelined mode: the chain of the NEXT batch (40 launches) is handed to the driver after this batch's decode kernels, so that the
-    // main stream never waits for the host, and starts on the device
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_chain_end[cur], 0));      // this batch's chain only: later ones may still be running
+    // Pipelined modes: the chains of the NEXT batch(es) (40 launches each) are handed to the driver after this batch's decode kernels, so
+    // that the main stream never waits for the host, and start on the device
     //   pipeline_sync = 1: when this batch's demod kernel has finished (event gate).  The FFT stage then runs at its own speed and the
-    //                      chain shares the device with the gather / Viterbi / RS kernels;
-    //   pipeline_sync = 2: at once.  Chain and demod kernel share the device: the FFT stage is a third slower, the chain done earlier.
+    //                      chain shares the device with the Viterbi / RS kernels;
+    //   pipeline_sync = 2: at once.  Chain and demod kernel share the device: the FFT stage is slower, the chain done earlier;
+    //   pipeline_sync = 3: gated like 1, but TWO batches ahead: the chain of batch k + 2 is queued while batch k is decoded, so the one
+    //                      placement stall it meets per step is off the decoder's critical path.
     // DESIGN.md section 4.3 has the numbers.
-    if (h->cfg.pipeline_sync) { h->presynced = F; h->desc_sel = cur ^ 1; }
-    else h->presynced = 0;
+    h->presynced = depth ? F : 0;
     FrameDesc* const d_desc = h->s_desc2[cur].as<FrameDesc>();
     h->last_desc = d_desc;
     h->cur_cir = h->cfg.want_impulse_response ? h->s_cir2[cur].as<float>() : nullptr;
@@ -758,7 +762,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
     mark(dabphy_handle::ST_DEMOD, true);
-    if (h->cfg.pipeline_sync == 1) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
+    if (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
     mark(dabphy_handle::ST_SNR, false);
     launch_snr(sn, h->stream);
@@ -875,10 +879,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         }
         h->sf_stats_ready = true;
     }
-    if (h->cfg.pipeline_sync) {
-        if (h->cfg.pipeline_sync == 1) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
-        launch_sync_chain(cur ^ 1);
+    if (depth) {
+        if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
+        for (; h->ahead < 1 + depth; h->ahead++) launch_sync_chain((cur + h->ahead) % ND);
     }
+    h->desc_sel = (cur + 1) % ND; h->ahead--;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
     h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
     HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
@@ -886,11 +891,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     h->last_frames = F;
     if ((r = sync(h))) return r;
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }
-    {   // every ensemble locked through the whole batch -> no acquisition launches for the next chain
-        bool all_locked = true;
-        for (const FrameDesc& d : h->h_desc) if (d.valid != 1) { all_locked = false; break; }
-        h->need_acquire = !all_locked;
-    }
     return DABPHY_OK;
 }
 
