@@ -187,6 +187,12 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
  * last finished batch is used for the whole batch -- identical once the ratio is >= 50 (normal tracking) or
  * with disable_coarse. */
 int dabphy_process(dabphy_handle* h, uint32_t n_frames);
+/* ... and the library tells exactly when that matters: stale_frames[b] = frames of ensemble b (since dabphy_reset) for which the
+ * synchroniser, running ahead of the decoder, consulted the coarse corrector although the reference -- which knows the ratio after the
+ * previous frame -- would not have, or the other way round; first_stale_frame[b] = frame number of the first one (-1: none).  Up to
+ * that frame the ensemble's output is the reference's bit for bit; from it on it is unless the corrector's step differed.  Always 0
+ * with one frame per call, with disable_coarse, and while the ratio stays on one side of 50 %.  [n_ensembles] each, may be NULL. */
+int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first_stale_frame);
 
 typedef struct {
     int64_t sample_pos;             /* absolute index of the sync buffer start (ofdm-processor.cpp:337) */

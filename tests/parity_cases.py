@@ -141,6 +141,9 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
             if (info["valid"] == 0).all():              # starved: the stream has ended (a failed window search is valid = 3 and goes on)
                 break
             done += F
+        stale, first = d.ratio_lag()
+        for b in range(B):
+            logs[b]["ratio_lag"] = (int(stale[b]), int(first[b]))
         return logs
     finally:
         d.close()
@@ -174,6 +177,12 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
             inf = np.array(L["info"][:n])
             same = [np.array_equal(L["ok"][k], ofib[k, :, 0]) and np.array_equal(L["fib"][k], ofib[k, :, 1:]) and
                     (int(inf["fine"][k]), int(inf["coarse"][k])) == tuple(int(v) for v in o["corr"][k]) for k in range(n)]
+            stale, first_stale = L["ratio_lag"]
+            if all(same):
+                pass                                    # (a stale decision need not change anything: the corrector's step may have been zero)
+            else:
+                # the library knows exactly where its synchroniser consulted a stale ratio: nothing may differ before that frame
+                assert stale > 0 and 0 <= first_stale <= same.index(False), "frame %d differs from the oracle, the first stale coarse decision is reported at frame %d" % (same.index(False), first_stale)
             if not all(same):
                 k = same.index(False)
                 rb = fic_ratio_before(o["fib"].reshape(-1, 12, 33)[:, :, 0])
@@ -184,6 +193,8 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
                 assert n >= 1, n
         else:
             assert n >= o["n_frames"] - (1 if lockstep else F) * (1 + {0: 0, 1: 1, 2: 1, 3: 2}[int(pipeline_sync)]), (n, o["n_frames"])
+            if lockstep or disable_coarse:
+                assert L["ratio_lag"] == (0, -1), L["ratio_lag"]      # one frame per call / no coarse corrector: never a stale decision
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
         assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]), "CRC flags differ"
         assert np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:]), "FIB bytes differ"

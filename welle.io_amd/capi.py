@@ -295,6 +295,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_set_options(self.h, fft_placement, freqsync_method, int(disable_coarse), C.byref(r)))
         return bool(r.value)
 
+    def ratio_lag(self):
+        """(frames whose coarse-corrector decision used a stale FIC ratio, frame number of the first one or -1) per ensemble"""
+        n = np.zeros(self.cfg.n_ensembles, np.int32); f = np.zeros(self.cfg.n_ensembles, np.int64)
+        self._chk(self.lib.dabphy_get_ratio_lag(self.h, _p(n), _p(f)))
+        return n, f
+
     def scan_stats(self):
         a = np.zeros(self.cfg.n_ensembles, np.int32); f = np.zeros(self.cfg.n_ensembles, np.int32)
         self._chk(self.lib.dabphy_get_scan_stats(self.h, _p(a), _p(f)))

@@ -341,7 +341,7 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
     launch_fic_gather(g, h->stream);
     VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
     launch_viterbi(v, h->stream);
-    CrcArgs k{}; k.fib = c.out; k.ok = h->ok.as<uint8_t>(); k.state = h->d_dec; k.desc = g.desc; k.n_ens = 1; k.n_frames = (int)n_frames;
+    CrcArgs k{}; k.fib = c.out; k.ok = h->ok.as<uint8_t>(); k.state = h->d_dec; k.desc = g.desc; k.n_ens = 1; k.n_frames = (int)n_frames; k.disable_coarse = 1;   // (no synchroniser behind this seam)
     launch_fib_crc(k, h->stream);
     launch_fic_ratio(k, h->stream);
     HIPCHK(h, hipMemcpyAsync(fib, c.out, (size_t)n_frames * 384, hipMemcpyDeviceToHost, h->stream));
@@ -782,7 +782,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         launch_fic_gather(g, fs);
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         launch_viterbi(v, fs);
-        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F;
+        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
         launch_fib_crc(k, fs);
         launch_fic_ratio(k, fs);
         mark(dabphy_handle::ST_FIC, true, fs);
@@ -919,6 +919,19 @@ int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_
 {
     if (!h || !d_fib || !d_crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
     *d_fib = h->s_fib.as<uint8_t>(); *d_crc_ok = h->s_ok.as<uint8_t>();
+    return DABPHY_OK;
+}
+
+int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first_stale_frame)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<DecState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) {
+        if (stale_frames) stale_frames[i] = st[i].stale_ratio_frames;
+        if (first_stale_frame) first_stale_frame[i] = st[i].stale_ratio_frames ? st[i].first_stale_frame : -1;
+    }
     return DABPHY_OK;
 }
 

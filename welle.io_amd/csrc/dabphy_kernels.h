@@ -36,7 +36,10 @@ struct DecState {
     int32_t fic_ratio;      // saturating 0..10 FIB CRC success counter
     int32_t snr_count;      // OfdmDecoder::snrCount
     float snr;              // OfdmDecoder::snr
-    int32_t pad;
+    int32_t stale_ratio_frames;   // frames (since reset) whose coarse-corrector decision -- made by the synchroniser ahead of the decoder from
+                                  // the ratio of an earlier batch -- differs from the one the reference makes with the ratio after the
+                                  // previous frame (ofdm-processor.cpp:397): from the first such frame on this ensemble may deviate
+    int64_t first_stale_frame;    // its frame number, -1: none
 };
 
 // Where one transmission frame sits in the sample stream and which oscillator settings were in force while
@@ -50,6 +53,7 @@ struct FrameDesc {
     int32_t L1;             // localPhase after the PRS (before the first sample of symbol 1)
     int32_t f_sym;          // coarse+fine while symbols 1..75 were pulled
     int32_t valid;          // 0: no frame (not synchronised / not enough samples), 1: demodulated, 2: pending (inside the chain), 3: window search failed
+    int32_t coarse_ran;     // 1: the coarse corrector was consulted for this frame (FIC ratio as the synchroniser knew it was < 50)
     int32_t fine_after, coarse_after;   // correctors after the frame (reported like onFrequencyCorrectorChange)
     int32_t null_L, null_f;             // oscillator state while the trailing null symbol was pulled (onNewNullSymbol)
 };
@@ -141,6 +145,7 @@ struct CrcArgs {
     const uint8_t* fib;     // [B][F][12][32]
     uint8_t* ok;            // [B][F][12]
     DecState* state; const FrameDesc* desc; int n_ens, n_frames;
+    int disable_coarse;     // RadioReceiverOptions::disableCoarseCorrector as the synchroniser used it (k_fic_ratio checks the ratio it saw)
 };
 
 // Gather from a plain [n_cw][in_stride] array of soft bits (the Viterbi::deconvolve / Protection::deconvolve seams)

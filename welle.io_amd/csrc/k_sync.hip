@@ -501,7 +501,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     FrameDesc& dout = A.desc[(size_t)b * A.n_frames + frame];
     FrameDesc d;
     d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
-    d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0;
+    d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0; d.coarse_ran = 0;
 
     // a whole frame (with the largest possible window index) must be available
     const int64_t need = (int64_t)T_U + (T_U - 1) + 75 * (int64_t)T_S + T_NULL;
@@ -653,6 +653,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     // ---- coarse frequency corrector (ofdm-processor.cpp:397-409, processPRS :537-616 PatternOfZeros)
     int32_t coarse = st.coarse;
     if (!A.disable_coarse && A.dec[b].fic_ratio * 10 < 50) {
+        d.coarse_ran = 1;
         load_mix2048(v, iq, A.ring, st.pos, startIndex, nco, d.L0, d.f_prs, startIndex, t);
         fft2048_wg<false>(v, tile, w, t);
         __syncthreads();

@@ -648,7 +648,13 @@ __global__ void k_fic_ratio(CrcArgs A)
     if (b >= A.n_ens) return;
     int r = A.state[b].fic_ratio;
     for (int f = 0; f < A.n_frames; f++) {
-        if (A.desc[(size_t)b * A.n_frames + f].valid != 1) continue;
+        const FrameDesc& d = A.desc[(size_t)b * A.n_frames + f];
+        if (d.valid != 1) continue;
+        // what the reference's synchroniser sees before this frame (ofdm-processor.cpp:397) against what ours saw when it ran ahead
+        if ((int)(!A.disable_coarse && r * 10 < 50) != d.coarse_ran) {
+            if (A.state[b].stale_ratio_frames == 0) A.state[b].first_stale_frame = d.frame_no;
+            A.state[b].stale_ratio_frames += 1;
+        }
         for (int k = 0; k < 12; k++) {
             if (A.ok[((size_t)b * A.n_frames + f) * 12 + k]) { if (r < 10) r++; }
             else if (r > 0) r--;
