@@ -295,6 +295,21 @@ def main():
                 rv.update(peak_measured_mix=n_simd * CLOCK_HZ / cyc, frac_of_measured_mix=ips / (n_simd * CLOCK_HZ / cyc),
                           measured_mix_note="profiles/valu_rate.json: issue cost of this kernel's instruction mix from tools/ubench/valu_rate.hip (packed 16-bit ops %.2f cycles, plain %.2f)" % (ub["cycles_packed"], ub["cycles_plain"]))
         line["roofline_viterbi"] = rv
+        # what a plain device-to-device copy moves on this box (read + write), for scale next to the 8 TB/s specification the fraction is
+        # taken against ("measure the denominator"); never used as `peak`
+        try:
+            src = iq[: max(1, B // 2)]; dst = torch.empty_like(src)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            dst.copy_(src); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                dst.copy_(src)
+            e1.record(); torch.cuda.synchronize()
+            line["roofline"]["measured_copy_GBps"] = 3 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            line["roofline"]["frac_of_measured_copy"] = ach / line["roofline"]["measured_copy_GBps"]
+            del dst
+        except Exception:
+            pass
         line["config"]["schedule"] = {0: "serial synchroniser", 1: "pipelined: the next batch's synchroniser starts behind this batch's demod kernel",
                                       2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)",
                                       3: "pipelined two batches ahead: the synchroniser of batch k + 2 starts behind batch k's demod kernel"}[sched]

@@ -785,3 +785,27 @@ def check_runtime_options(d_factory):
         assert len(good) >= 6 and all(f[3] in sent for f in good)        # decodes the transmitted FIBs again
     finally:
         d.close()
+
+
+def check_rs_random(d, n_sf=300, seed=77, s_per_sf=8):
+    """RS(120,110): valid superframes with 0 .. 12 byte errors per code word at random positions (<= 5: corrected; more: the decoder
+    gives up or miscorrects) -- corrected bytes, corrected-symbol totals and the uncorrectable verdict equal the oracle's, which is
+    pinned to the reference's decode_rs_char (test_oracle_vs_ref.py::test_rs), word for word"""
+    rng = np.random.RandomState(seed)
+    sfs = np.stack([synth.make_superframe(8 * s_per_sf, rng, header=False) for _ in range(n_sf)])      # [n][120 * s]
+    weights = []
+    for k in range(n_sf):
+        v = sfs[k].reshape(120, s_per_sf)
+        for c in range(s_per_sf):
+            w = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 5, 6, 6, 7, 8, 10, 12]))
+            pos = rng.choice(120, w, replace=False)
+            v[pos, c] ^= rng.randint(1, 256, w).astype(np.uint8)
+            weights.append(w)
+    out, corr, unc = d.rs_superframes(sfs, s_per_sf)
+    n_unc = 0
+    for k in range(n_sf):
+        o, c, u = R.orc_rs_superframe(sfs[k])
+        assert np.array_equal(out[k], o), "superframe %d: corrected bytes differ" % k
+        assert (int(corr[k]), bool(unc[k])) == (int(c), bool(u)), (k, int(corr[k]), int(unc[k]), c, u)
+        n_unc += bool(u)
+    assert n_unc > n_sf // 4 and max(weights) == 12          # the beyond-capacity paths were really taken

@@ -45,3 +45,7 @@ def test_demod_chunk_sizes(emu):
     from welle_io_amd import capi
     import conftest
     P.check_demod_chunks(lambda **kw: capi.DabPhy(lib_path=conftest.EMU_LIB, **kw))
+
+
+def test_reed_solomon_random_error_patterns(emu):
+    P.check_rs_random(emu, n_sf=120)

@@ -7,10 +7,10 @@
 //
 // A superframe of a sub-channel with s = bitrate/8 holds s column-interleaved codewords: codeword i consists of
 // bytes sf[pos*s + i], pos = 0..119.  Consecutive threads take consecutive i, so every syndrome step reads s
-// consecutive bytes.  The decoder is the reference's algorithm statement by statement (syndromes ->
-// Berlekamp-Massey -> Chien -> Forney) with its uint8 index arithmetic, so corrected bytes, the corrected-symbol
-// count and the "uncorrectable" verdict match it also for words beyond the correction capacity (miscorrections
-// included).  GF tables live in LDS; the rare non-zero-syndrome path works on per-thread arrays.
+// consecutive bytes.  Syndromes -> locator (Massey) -> roots -> values, register-resident (rs_correct120); corrected
+// bytes, the corrected-symbol count and the "uncorrectable" verdict equal the reference's also for words beyond the
+// correction capacity (miscorrections included: tests/golden rs vectors, random error patterns of weight 0 .. 12 against
+// the oracle, which is pinned to decode_rs_char itself).  GF tables live in LDS.
 #include "dabphy_kernels.h"
 
 namespace dabphy {
@@ -31,10 +31,10 @@ struct RsIo {                         // byte `pos` of codeword i
 
 // returns the number of corrected symbols, -1 when uncorrectable (decode_rs.h:71-298, no_eras = 0)
 template <typename IO>
-__device__ __forceinline__ int rs_correct120(const IO& io, const uint32_t (&syn)[RS_NROOTS], const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of);
+__device__ __forceinline__ int rs_correct120(const IO& io, const uint32_t (&syn)[RS_NROOTS], const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of, uint8_t* ws);
 
 template <typename IO>
-__device__ __forceinline__ int rs_decode120(const IO& io, const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
+__device__ __forceinline__ int rs_decode120(const IO& io, const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of, uint8_t* ws)
 {
     // the syndromes of the common case live in registers: `syn` is only ever indexed by unrolled constants (the array the
     // Berlekamp-Massey iteration indexes dynamically is a copy made on the error path -- sharing one array sent every
@@ -60,79 +60,108 @@ __device__ __forceinline__ int rs_decode120(const IO& io, const uint8_t* __restr
             syn[i] = (syn[i] == 0) ? dj : (dj ^ a);
         }
     }
-    return rs_correct120(io, syn, alpha_to, index_of);
+    return rs_correct120(io, syn, alpha_to, index_of, ws);
 }
 
-// Errors from the ten syndromes (polynomial form) on: Berlekamp-Massey, Chien, Forney (decode_rs.h:117-298)
-template <typename IO>
-__device__ __forceinline__ int rs_correct120(const IO& io, const uint32_t (&syn)[RS_NROOTS], const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
+// Errors from the ten syndromes on.  The polynomials are field VALUES (not logarithms) in a small per-thread LDS workspace -- the
+// path is rare and serial, what matters is that it costs the callers' hot loops neither registers nor scratch memory (a fully
+// unrolled register-resident version spilled the superframe filter's syndrome loop; the first version indexed per-thread arrays in
+// scratch) -- and every data-dependent choice is a select.
+// What has to equal the reference (decode_rs.h:117-298, no erasures) is the mathematics, including what it does beyond the
+// correction capacity -- a decoder that "detects" more or fewer uncorrectable words, or applies different wrong corrections,
+// would not give the reference's bytes:
+//   * Massey's iteration in the form that multiplies the auxiliary polynomial by x every round: the locator after ten rounds
+//     is the same whatever representation is used;
+//   * the word is given up (-1) exactly when the locator's degree differs from the number of its roots among alpha^1 .. alpha^255;
+//   * roots at positions inside the 135 bytes of padding are counted but not applied; a zero evaluator value is not applied;
+//   * a zero derivative is NOT treated as a failure (the reference checks that only in DEBUG builds): its logarithm reads 255
+//     from the table and the division degenerates into a multiplication by one.
+constexpr int RS_WS_BYTES = 64;                      // per-thread workspace: lam[11] aux[11] term[11] omega[10] root[10]
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b, const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
 {
-    uint32_t syn_error = 0;
-#pragma unroll
-    for (int i = 0; i < RS_NROOTS; i++) syn_error |= syn[i];
-    if (!syn_error) return 0;
-    uint8_t s[RS_NROOTS];
-#pragma unroll
-    for (int i = 0; i < RS_NROOTS; i++) s[i] = index_of[syn[i]];
+    uint32_t e = (uint32_t)index_of[a] + index_of[b];            // <= 254 + 254 when both are non-zero
+    e = e >= RS_NN ? e - RS_NN : e;
+    const uint32_t v = alpha_to[e >= RS_NN ? e - RS_NN : e];      // (index_of[0] = 255 can push e to 510: folded twice, result discarded)
+    return (a != 0 && b != 0) ? v : 0u;
+}
+// a * alpha^k, k in 0 .. 254
+__device__ __forceinline__ uint32_t gf_scale(uint32_t a, uint32_t k, const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of)
+{
+    uint32_t e = (uint32_t)index_of[a] + k;
+    e = e >= RS_NN ? e - RS_NN : e;
+    return a != 0 ? (uint32_t)alpha_to[e >= RS_NN ? e - RS_NN : e] : 0u;
+}
 
-    uint8_t lambda[RS_NROOTS + 1], b[RS_NROOTS + 1], t[RS_NROOTS + 1], omega[RS_NROOTS + 1], root[RS_NROOTS], reg[RS_NROOTS + 1], loc[RS_NROOTS];
-    for (int i = 1; i <= RS_NROOTS; i++) lambda[i] = 0;
-    lambda[0] = 1;
-    for (int i = 0; i <= RS_NROOTS; i++) b[i] = index_of[lambda[i]];
-    int r = 0, el = 0;
-    while (++r <= RS_NROOTS) {                                   // Berlekamp-Massey
-        uint8_t discr = 0;
-        for (int i = 0; i < r; i++)
-            if (lambda[i] != 0 && s[r - i - 1] != RS_A0) discr ^= alpha_to[rs_modnn(index_of[lambda[i]] + s[r - i - 1])];
-        discr = index_of[discr];
-        if (discr == RS_A0) {
-            for (int i = RS_NROOTS; i > 0; i--) b[i] = b[i - 1];
-            b[0] = RS_A0;
-        } else {
-            t[0] = lambda[0];
-            for (int i = 0; i < RS_NROOTS; i++)
-                t[i + 1] = (b[i] != RS_A0) ? (uint8_t)(lambda[i + 1] ^ alpha_to[rs_modnn(discr + b[i])]) : lambda[i + 1];
-            if (2 * el <= r - 1) {
-                el = r - el;
-                for (int i = 0; i <= RS_NROOTS; i++) b[i] = (lambda[i] == 0) ? (uint8_t)RS_A0 : (uint8_t)rs_modnn(index_of[lambda[i]] - discr + RS_NN);
-            } else {
-                for (int i = RS_NROOTS; i > 0; i--) b[i] = b[i - 1];
-                b[0] = RS_A0;
+template <typename IO>
+__device__ __forceinline__ int rs_correct120(const IO& io, const uint32_t (&syn_regs)[RS_NROOTS], const uint8_t* __restrict__ alpha_to, const uint8_t* __restrict__ index_of,
+                                             uint8_t* ws /* RS_WS_BYTES of LDS owned by this thread */)
+{
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < RS_NROOTS; i++) any |= syn_regs[i];
+    if (!any) return 0;
+    constexpr int T2 = RS_NROOTS;                    // 2t = 10 syndromes, locator degree <= 10
+    uint8_t* const lam = ws; uint8_t* const aux = ws + 11; uint8_t* const term = ws + 22; uint8_t* const omega = ws + 33; uint8_t* const root = ws + 43;
+    uint8_t* const syn = ws + 53;                    // (a dynamically indexed copy: the register array is only indexed by unrolled constants)
+#pragma unroll
+    for (int i = 0; i < T2; i++) syn[i] = (uint8_t)syn_regs[i];
+    // ---- locator polynomial: Massey's iteration, aux <- x aux every round
+    for (int i = 0; i <= T2; i++) { lam[i] = i == 0; aux[i] = i == 0; }
+    int L = 0;
+#pragma unroll 1
+    for (int r = 0; r < T2; r++) {
+        uint32_t d = 0;                              // discrepancy: sum lam[i] S[r - i]
+        for (int i = 0; i <= r; i++) d ^= gf_mul(lam[i], syn[r - i], alpha_to, index_of);
+        for (int i = T2; i > 0; i--) aux[i] = aux[i - 1];
+        aux[0] = 0;
+        if (d != 0) {
+            const bool grow = 2 * L <= r;
+            const uint32_t ld = index_of[d];
+            const uint32_t dinv = alpha_to[ld == 0 ? 0 : RS_NN - ld];            // 1 / d
+            for (int i = 0; i <= T2; i++) {
+                const uint32_t li = lam[i];
+                const uint32_t next = li ^ gf_mul(d, aux[i], alpha_to, index_of);
+                if (grow) aux[i] = (uint8_t)gf_mul(li, dinv, alpha_to, index_of);
+                lam[i] = (uint8_t)next;
             }
-            for (int i = 0; i <= RS_NROOTS; i++) lambda[i] = t[i];
+            if (grow) L = r + 1 - L;
         }
     }
-    int deg_lambda = 0;
-    for (int i = 0; i <= RS_NROOTS; i++) { lambda[i] = index_of[lambda[i]]; if (lambda[i] != RS_A0) deg_lambda = i; }
-    for (int i = 1; i <= RS_NROOTS; i++) reg[i] = lambda[i];
+    int deg = 0;
+    for (int i = 1; i <= T2; i++) if (lam[i] != 0) deg = i;
+    // ---- roots: Lambda(alpha^i) for i = 1 .. 255, terms advanced by alpha^j per step; position of a root: i - 1 (of the padded word)
+    for (int j = 1; j <= T2; j++) term[j] = lam[j];
     int count = 0;
-    for (int i = 1, k = 0; i <= RS_NN; i++, k = rs_modnn(k + 1)) {       // Chien search, IPRIM = 1
-        uint8_t q = 1;
-        for (int j = deg_lambda; j > 0; j--)
-            if (reg[j] != RS_A0) { reg[j] = (uint8_t)rs_modnn(reg[j] + j); q ^= alpha_to[reg[j]]; }
-        if (q != 0) continue;
-        root[count] = (uint8_t)i; loc[count] = (uint8_t)k;
-        if (++count == deg_lambda) break;
+#pragma unroll 1
+    for (int i = 1; i <= RS_NN && count < deg; i++) {
+        uint32_t q = 1;
+        for (int j = 1; j <= deg; j++) { const uint32_t t = gf_scale(term[j], (uint32_t)j, alpha_to, index_of); term[j] = (uint8_t)t; q ^= t; }
+        if (q == 0) root[count++] = (uint8_t)i;
     }
-    if (deg_lambda != count) return -1;
-    const int deg_omega = deg_lambda - 1;
-    for (int i = 0; i <= deg_omega; i++) {
-        uint8_t tmp = 0;
-        for (int j = i; j >= 0; j--)
-            if (s[i - j] != RS_A0 && lambda[j] != RS_A0) tmp ^= alpha_to[rs_modnn(s[i - j] + lambda[j])];
-        omega[i] = index_of[tmp];
+    if (count != deg) return -1;
+    // ---- evaluator: omega = S Lambda mod x^deg
+    for (int k = 0; k < deg; k++) {
+        uint32_t v = 0;
+        for (int j = 0; j <= k; j++) v ^= gf_mul(syn[k - j], lam[j], alpha_to, index_of);
+        omega[k] = (uint8_t)v;
     }
-    for (int j = count - 1; j >= 0; j--) {                                 // Forney
-        uint8_t num1 = 0;
-        for (int i = deg_omega; i >= 0; i--)
-            if (omega[i] != RS_A0) num1 ^= alpha_to[rs_modnn(omega[i] + i * root[j])];
-        const uint8_t num2 = alpha_to[rs_modnn(root[j] * (0 - 1) + RS_NN)];
-        uint8_t den = 0;
-        for (int i = (deg_lambda < RS_NROOTS - 1 ? deg_lambda : RS_NROOTS - 1) & ~1; i >= 0; i -= 2)
-            if (lambda[i + 1] != RS_A0) den ^= alpha_to[rs_modnn(lambda[i + 1] + i * root[j])];
-        if (num1 != 0 && loc[j] >= RS_PAD) {
-            const int p = loc[j] - RS_PAD;
-            io.put(p, (uint8_t)(io.get(p) ^ alpha_to[rs_modnn(index_of[num1] + index_of[num2] + RS_NN - index_of[den])]));
+    // ---- values: omega(alpha^i) alpha^(-i) / Lambda'(alpha^i), applied where the position lies in the 120 transmitted bytes
+#pragma unroll 1
+    for (int n = 0; n < count; n++) {
+        const uint32_t i = root[n];
+        uint32_t num = 0, den = 0, p = 0;            // p = (k i) mod 255
+        for (int k = 0; k < T2; k++) {
+            if (k < deg) num ^= gf_scale(omega[k], p, alpha_to, index_of);
+            if ((k & 1) == 0) den ^= gf_scale(lam[k + 1], p, alpha_to, index_of);    // formal derivative: the odd coefficients
+            p += i; p = p >= RS_NN ? p - RS_NN : p;
+        }
+        const int pos = (int)i - 1 - RS_PAD;
+        if (num != 0 && pos >= 0) {
+            const uint32_t xinv = i == RS_NN ? 0u : RS_NN - i;                       // log of alpha^(-i)
+            const uint32_t lden = index_of[den];                                      // 255 for den = 0 (see above)
+            uint32_t e = (uint32_t)index_of[num] + xinv + RS_NN - lden;               // <= 254 + 254 + 255
+            e = e >= 2 * RS_NN ? e - 2 * RS_NN : e; e = e >= RS_NN ? e - RS_NN : e;
+            io.put(pos, (uint8_t)(io.get(pos) ^ alpha_to[e]));
         }
     }
     return count;
@@ -156,13 +185,14 @@ __device__ __forceinline__ void rs_tables(uint8_t* alpha_to, uint8_t* index_of, 
 __global__ void __launch_bounds__(256) k_rs_superframes(RsArgs A)
 {
     __shared__ uint8_t alpha_to[256], index_of[256];
+    __shared__ uint8_t ws[256 * RS_WS_BYTES];
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = A.n_sf * A.s;
     if (idx >= total) return;
     const int sf = idx / A.s, i = idx % A.s;
     RsIo io; io.base = A.data + (size_t)sf * A.sf_stride + i; io.pos_stride = (size_t)A.s;
-    const int c = rs_decode120(io, alpha_to, index_of);
+    const int c = rs_decode120(io, alpha_to, index_of, ws + threadIdx.x * RS_WS_BYTES);
     if (c < 0) atomicOr(A.uncorr + sf, 1);
     else if (c > 0) atomicAdd(A.corr + sf, c);
 }
@@ -179,6 +209,7 @@ struct RsMscIo {
 __global__ void __launch_bounds__(256) k_rs_msc(RsMscArgs A)
 {
     __shared__ uint8_t alpha_to[256], index_of[256];
+    __shared__ uint8_t ws[256 * RS_WS_BYTES];
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_ens = A.n_sf_per_ens * A.n_members * A.s;
@@ -192,7 +223,7 @@ __global__ void __launch_bounds__(256) k_rs_msc(RsMscArgs A)
     RsMscIo io;
     io.frame_bytes = A.frame_bytes; io.s = A.s; io.i = i; io.frame_stride = (size_t)A.frame_bytes;
     io.frames = A.out + (((size_t)b * A.n_members + m) * A.n_cif + r0) * A.frame_bytes;
-    const int c = rs_decode120(io, alpha_to, index_of);
+    const int c = rs_decode120(io, alpha_to, index_of, ws + threadIdx.x * RS_WS_BYTES);
     int* cnt = A.result + 2 * (((size_t)b * A.n_sf_per_ens + q) * A.n_members + m);
     if (c < 0) atomicOr(cnt + 1, 1);
     else if (c > 0) atomicAdd(cnt, c);
@@ -221,6 +252,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
     __shared__ __attribute__((aligned(16))) uint8_t s_dyn[2 * SF_MAX];
     __shared__ uint8_t alpha_to[256], index_of[256];
     __shared__ int s_corr, s_unc, s_sync, s_au_start[8], s_aubad;
+    __shared__ uint8_t s_ws[8 * RS_WS_BYTES];                   // error-path workspaces of the eight code words decoded at a time
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
     if (threadIdx.x == 0) s_aubad = 0;
     const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
@@ -288,7 +320,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
             }
             if (jg == 0 && c < A.s) {
                 RsIo io; io.base = s_sf + c; io.pos_stride = (size_t)A.s;
-                const int n = rs_correct120(io, syn, alpha_to, index_of);
+                const int n = rs_correct120(io, syn, alpha_to, index_of, s_ws + (t & 7) * RS_WS_BYTES);
                 if (n < 0) atomicOr(&s_unc, 1); else if (n > 0) atomicAdd(&s_corr, n);
             }
         }
