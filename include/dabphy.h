@@ -53,6 +53,11 @@ typedef struct {
                                        (VALU-bound) runs on a side stream while part p + 1 is gathered (HBM-bound).  0 or 1 = one gather and
                                        one decode launch per class, which is also what measures best on MI355X: parts that are not
                                        resident together leave the Viterbi kernel below its five waves per SIMD */
+    int32_t serial_sync;            /* 0 (default): with two or more frames per call the synchroniser first tries all frames of a batch at
+                                       once, each from the state a receiver in lock would be in (window index T_g, correctors unchanged),
+                                       accepts those whose assumption held and runs the frame-by-frame chain (2 dependent launches per
+                                       frame, OFDMProcessor::run's loop) for the rest: same results, a fraction of the latency while
+                                       tracking.  1: always the frame-by-frame chain */
 } dabphy_config;
 
 /* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)
@@ -218,6 +223,10 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensemble
  * (ofdm-processor.cpp:216) could not be certified because the samples pulled since the last acquisition were no longer all
  * available (more than 64 frames ago or out of the ring) and the two bracketing replays had not met (DESIGN.md sections 4.3, 7) */
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact);
+/* the wide synchroniser pass (dabphy_config.serial_sync) since dabphy_reset / dabphy_create (any pointer may be NULL): frames per
+ * ensemble that were accepted from it [n_ensembles]; passes queued; passes after which the frame-by-frame chain had to take over for
+ * at least one ensemble */
+int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
 /* Scan mode (RadioReceiver::restart(doScan = true) -> OFDMProcessor::set_scanMode, ofdm-processor.cpp:256-262,351-355), [n_ensembles]
  * each, since dabphy_reset: attempts = entries into the notSynced state (after the sLevel priming, after every hopeless null search,
  * after every failed window search) -- the reference reports onSignalPresence(false) when this exceeds 5 before a lock;

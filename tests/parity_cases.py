@@ -107,10 +107,10 @@ def dev_prot(d, s):
     return d.protection_uep(s.bitrate, s.level) if getattr(s, "uep", None) is not None else d.protection_eep(s.bitrate, s.profile_b, s.level)
 
 
-def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2, stage_log=None):
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2, stage_log=None, serial_sync=False):
     """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
     from welle_io_amd import capi  # noqa: F401
-    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync)
+    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync, serial_sync=serial_sync)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subs])
@@ -142,8 +142,10 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
                 break
             done += F
         stale, first = d.ratio_lag()
+        wf, passes, fallbacks = d.wide_sync_stats()
         for b in range(B):
             logs[b]["ratio_lag"] = (int(stale[b]), int(first[b]))
+            logs[b]["wide"] = (int(wf[b]), passes, fallbacks)
         return logs
     finally:
         d.close()
@@ -161,14 +163,14 @@ def fic_ratio_before(ok_flags):
 
 
 def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True, fft_placement=2, freqsync=2,
-                           ratio_lag_ok=False):
+                           ratio_lag_ok=False, serial_sync=False):
     """ratio_lag_ok: batch mode's documented deviation (include/dabphy.h, dabphy_process) is tolerated and PINNED: the frames must
     equal the oracle's up to the first frame before which the FIC ratio crossed the 50 % line within the last F (2F when pipelined)
     frames -- only there may a batch have consulted a stale ratio; what comes before is compared bit for bit, returns that frame"""
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
     o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse, fft_placement=fft_placement, freqsync=freqsync)
-    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con, fft_placement=fft_placement, freqsync=freqsync)
+    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con, fft_placement=fft_placement, freqsync=freqsync, serial_sync=serial_sync)
     for b in range(B):
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)
@@ -809,3 +811,29 @@ def check_rs_random(d, n_sf=300, seed=77, s_per_sf=8):
         assert (int(corr[k]), bool(unc[k])) == (int(c), bool(u)), (k, int(corr[k]), int(unc[k]), c, u)
         n_unc += bool(u)
     assert n_unc > n_sf // 4 and max(weights) == 12          # the beyond-capacity paths were really taken
+
+
+def check_wide_sync(d_factory, F=6, nf=34, pipeline_sync=False, cfo=37.0, snr_db=22, B=2):
+    """The wide synchroniser pass (all frames of a batch at once from the predicted in-lock state, k_sync_validate) against the
+    frame-by-frame chain and the oracle: same frames bit for bit; while the fine corrector still moves (the first ~20 frames at this
+    offset, ofdm-processor.cpp:450-451) every pass hands over to the serial chain, once it rests whole batches are accepted."""
+    logs_w, o, _ = check_stream_vs_oracle(d_factory, snr_db, cfo, 0, nf, False, B=B, F=F, pipeline_sync=pipeline_sync, seed=9)
+    logs_s, _, _ = check_stream_vs_oracle(d_factory, snr_db, cfo, 0, nf, False, B=B, F=F, pipeline_sync=pipeline_sync, seed=9, serial_sync=True)
+    for b in range(B):
+        w, s = logs_w[b], logs_s[b]
+        assert len(w["info"]) == len(s["info"])
+        assert all(np.array_equal(np.array(w[k]), np.array(s[k])) for k in ("fib", "ok", "soft"))
+        iw, isr = np.array(w["info"]), np.array(s["info"])
+        assert all(np.array_equal(iw[k], isr[k], equal_nan=(k == "snr")) for k in iw.dtype.names)
+        assert [bytes(m) for m in map(b"".join, w["msc"])] == [bytes(m) for m in map(b"".join, s["msc"])]
+        wf, passes, fallbacks = w["wide"]
+        assert s["wide"][0] == 0 and s["wide"][1] == 0                 # serial_sync: never queued
+        # a frame is accepted from the wide pass iff no frame before it IN ITS BATCH moved a corrector: a batch that lies inside a run
+        # of L frames with one fine-corrector value is accepted whole, and a run holds at least (L - 1 - (F - 1)) // F such batches
+        fine = [int(v) for v in np.array(w["info"])["fine"]]
+        runs = [len(list(g)) for _, g in __import__("itertools").groupby(fine)]
+        whole = max(0, (max(runs) - F) // F)
+        assert whole >= 1, fine                                        # (the stream is long enough to see an accepted batch)
+        assert wf >= F * whole, (wf, fine)
+        assert 1 <= fallbacks < passes, (passes, fallbacks)
+    return logs_w

@@ -136,3 +136,8 @@ def test_mixed_protection_classes_fused_decode(emu):
 
 def test_receiver_options_at_run_time(emu):
     P.check_runtime_options(factory)
+
+
+@pytest.mark.parametrize("pipeline", [False, 1, 2])
+def test_wide_synchroniser_pass(emu, pipeline):
+    P.check_wide_sync(factory, pipeline_sync=pipeline)

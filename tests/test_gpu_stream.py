@@ -141,3 +141,10 @@ def test_dropout_in_batch_mode(gpu):
 
 def test_receiver_options_at_run_time(gpu):
     P.check_runtime_options(factory)
+
+
+@pytest.mark.parametrize("pipeline", [False, 1, 2])
+def test_wide_synchroniser_pass(gpu, pipeline):
+    """all frames of a batch synchronised at once from the predicted in-lock state (k_sync_find_wide / k_sync_finish_wide /
+    k_sync_validate) = the frame-by-frame chain = the oracle, bit for bit; the counters show which path produced the frames"""
+    P.check_wide_sync(factory, pipeline_sync=pipeline, nf=44, F=8, B=3)

@@ -65,14 +65,23 @@ struct dabphy_handle {
     int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
     bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
+    // wide synchroniser pass (all frames of a batch at once, k_sync_find_wide/_finish_wide/_validate) and its serial fall-back
+    bool wide_sync = true;            // cfg.serial_sync == 0 (DABPHY_SYNC_WIDE overrides)
+    DevBuf s_redo[N_DESC];            // [B] first frame slot the wide pass did not settle
+    int32_t* d_any_redo = nullptr;    // [N_DESC] device flags; h_any_redo: their page-locked host copies
+    int32_t* h_any_redo = nullptr;
+    hipEvent_t ev_wide_done[N_DESC]{};
+    bool wide_pending[N_DESC]{};      // the wide pass of this descriptor buffer has been queued, its verdict not yet read
+    uint64_t chain_valid[N_DESC]{}; uint32_t chain_frames[N_DESC]{};   // n_valid and n_frames the chain of this buffer was queued with
+    uint64_t n_wide_passes = 0, n_wide_fallbacks = 0;
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
     int ahead = 0;                    // batches whose chain has been queued but which have not been decoded yet (pipelined modes: 1 or 2 between calls)
     uint32_t presynced = 0;           // frames already synchronised ahead into s_desc2[desc_sel] (pipelined mode)
     int soft_ring = 0;
     uint32_t last_frames = 0;         // n_frames of the last dabphy_process
     float* cur_cir = nullptr;
-    std::vector<FrameDesc> h_desc;    // host copy of the last batch's frame descriptors
-    std::vector<float> h_snr;
+    FrameDesc* h_desc = nullptr;      // host copy of the last batch's frame descriptors (page-locked, [B][max_frames])
+    float* h_snr = nullptr;
     // stage timing (HIP events on the handle's stream, recorded when profiling is on)
     enum { ST_SYNC = 0, ST_DEMOD, ST_SNR, ST_FIC, ST_MSC_GATHER, ST_MSC_VITERBI, ST_RS, ST_COUNT };
     bool profiling = false;
@@ -187,6 +196,24 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipStreamCreateWithFlags(&h->vit_stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_vit_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreateWithFlags(&h->ev_wide_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(int32_t) * dabphy_handle::N_DESC) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->owned.push_back(p); h->d_any_redo = reinterpret_cast<int32_t*>(p);
+        if (hipHostMalloc(&p, sizeof(int32_t) * dabphy_handle::N_DESC, hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_any_redo = reinterpret_cast<int32_t*>(p);
+        for (int i = 0; i < dabphy_handle::N_DESC; i++) h->h_any_redo[i] = 0;
+    }
+    {
+        void* p = nullptr; const size_t n = (size_t)cfg->n_ensembles * cfg->max_frames;
+        if (hipHostMalloc(&p, n * sizeof(FrameDesc), hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_desc = reinterpret_cast<FrameDesc*>(p);
+        if (hipHostMalloc(&p, n * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_snr = reinterpret_cast<float*>(p);
+    }
+    h->wide_sync = cfg->serial_sync == 0;
+    if (const char* e = getenv("DABPHY_SYNC_WIDE")) h->wide_sync = atoi(e) != 0;    // (experiments: overrides the configuration)
     h->msc_parts = cfg->msc_parts;
     if (const char* e = getenv("DABPHY_MSC_PARTS")) h->msc_parts = atoi(e);          // (experiments: overrides the configuration)
     if (h->msc_parts < 0) return fail(DABPHY_ERR_INVALID);
@@ -208,6 +235,10 @@ void dabphy_destroy(dabphy_handle* h)
     for (int i = 0; i < 2; i++) if (h->ev_ingest[i]) e = hipEventDestroy(h->ev_ingest[i]);
     if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);
     if (h->ev_chain_gate) e = hipEventDestroy(h->ev_chain_gate);
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_wide_done[i]) e = hipEventDestroy(h->ev_wide_done[i]); if (h->s_redo[i].p) e = hipFree(h->s_redo[i].p); }
+    if (h->h_any_redo) e = hipHostFree(h->h_any_redo);
+    if (h->h_desc) e = hipHostFree(h->h_desc);
+    if (h->h_snr) e = hipHostFree(h->h_snr);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
@@ -237,11 +268,14 @@ int dabphy_get_config(const dabphy_handle* h, dabphy_config* out)
 }
 
 static int reset_synchroniser(dabphy_handle* h, bool decoder_too);
+static int resolve_all_chains(dabphy_handle* h);
+constexpr int HIST_CAP = 64;     // window searches remembered per ensemble for the sLevel replay
 
 int dabphy_set_options(dabphy_handle* h, int32_t fft_placement, int32_t freqsync_method, int32_t disable_coarse, int32_t* restarted)
 {
     if (!h || fft_placement < 0 || fft_placement > 2 || freqsync_method < 0 || freqsync_method > 2) return DABPHY_ERR_INVALID;
     const bool need_reset = (h->cfg.disable_coarse != 0) != (disable_coarse != 0);      // ofdm-processor.cpp:521
+    if (h->s_desc2[0].p) { int r = resolve_all_chains(h); if (r) return r; }            // frames synchronised ahead keep the options they were queued with
     h->cfg.fft_placement = fft_placement; h->cfg.freqsync_method = freqsync_method; h->cfg.disable_coarse = disable_coarse != 0;
     if (restarted) *restarted = need_reset ? 1 : 0;
     // :523-528 -> OFDMProcessor::restart (:115-132): correctors, phase, sLevel and the sync state start over; the decoders (FIC
@@ -355,12 +389,82 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
 
 // =================================================================================== streaming receiver
 
+// ---- the synchroniser's launches.  It runs on its own stream; in pipelined mode (cfg.pipeline_sync) the frames of the NEXT batch are
+// synchronised while this batch is decoded on the main stream (they need only the samples and the synchroniser's own state).
+// Two forms:
+//   serial chain   per frame: k_sync_find (PRS window search; acquisition first for an ensemble that is not synchronised -- start of a
+//                  stream, or after a failed window search in whatever slot of a batch, as the reference falls back to notSynced,
+//                  ofdm-processor.cpp:347-350) then k_sync_finish (cyclic-prefix sums -> correctors -> state).  2 F dependent launches.
+//   wide pass      every frame of the batch at once, each from the state a receiver IN LOCK would be in (k_sync.hip: sync_predict), then
+//                  k_sync_validate accepts the frames whose assumption held and says where the serial chain has to take over.  The
+//                  verdict is read by the host the next time the batch is needed (resolve_chain): in pipelined mode that is a whole
+//                  decode later, so nothing waits for it.
+static SyncArgs sync_args(dabphy_handle* h, int sel, uint32_t F, uint64_t n_valid)
+{
+    SyncArgs sa{};
+    sa.tab = h->tab; sa.iq = h->s_iq; sa.iq_stride = h->s_stride; sa.ring = (int64_t)h->s_ring; sa.n_valid = (int64_t)n_valid;
+    sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)h->cfg.n_ensembles; sa.n_frames = (int)F;
+    sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse; sa.freqsync = h->cfg.freqsync_method;
+    sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
+    sa.hist = h->s_hist.as<FrameDesc>(); sa.hist_cap = HIST_CAP;
+    return sa;
+}
+static void launch_serial_chain(dabphy_handle* h, SyncArgs sa)
+{
+    for (int f = 0; f < sa.n_frames; f++) {
+        sa.frame = f;
+        launch_sync_find(sa, h->sync_stream);
+        launch_sync_finish(sa, h->sync_stream);
+        if (h->track_slevel) launch_slevel_catchup(sa, h->sync_stream);
+    }
+}
+static int queue_chain(dabphy_handle* h, int sel, uint32_t F)
+{
+    SyncArgs sa = sync_args(h, sel, F, h->s_valid);
+    h->chain_valid[sel] = h->s_valid; h->chain_frames[sel] = F;
+    { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
+    // one frame per call (the real-time facade) gains nothing from the wide pass; two batches ahead its verdict would come too late
+    if (h->wide_sync && F >= 2 && h->cfg.pipeline_sync != 3 && !h->track_slevel) {
+        HIPCHK(h, hipMemsetAsync(h->d_any_redo + sel, 0, sizeof(int32_t), h->sync_stream));
+        sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel;
+        launch_sync_wide(sa, h->sync_stream);
+        HIPCHK(h, hipMemcpyAsync(h->h_any_redo + sel, h->d_any_redo + sel, sizeof(int32_t), hipMemcpyDeviceToHost, h->sync_stream));
+        HIPCHK(h, hipEventRecord(h->ev_wide_done[sel], h->sync_stream));
+        h->wide_pending[sel] = true; h->n_wide_passes++;
+    } else {
+        launch_serial_chain(h, sa);
+    }
+    { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
+    return DABPHY_OK;
+}
+// reads the wide pass's verdict for descriptor buffer `sel` and queues the serial chain for what it did not settle
+static int resolve_chain(dabphy_handle* h, int sel)
+{
+    if (!h->wide_pending[sel]) return DABPHY_OK;
+    HIPCHK(h, hipEventSynchronize(h->ev_wide_done[sel]));
+    h->wide_pending[sel] = false;
+    if (h->h_any_redo[sel]) {
+        SyncArgs sa = sync_args(h, sel, h->chain_frames[sel], h->chain_valid[sel]);
+        sa.redo_from = h->s_redo[sel].as<int32_t>();
+        launch_serial_chain(h, sa);
+        { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
+        h->n_wide_fallbacks++;
+    }
+    return DABPHY_OK;
+}
+static int resolve_all_chains(dabphy_handle* h)
+{
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) { int r = resolve_chain(h, (h->desc_sel + i) % dabphy_handle::N_DESC); if (r) return r; }
+    return DABPHY_OK;
+}
+
 // OFDMProcessor::restart (ofdm-processor.cpp:115-132) + the start of run(): correctors, phase and sync state zero, sLevel primed over
 // the next T_F/2 samples (:252-255).  decoder_too (dabphy_reset: a freshly bound stream) also rewinds the stream to sample 0 and
 // clears the frame counter; without it (setReceiverOptions on a running receiver) the stream goes on where the DECODED frames end:
 // frames that pipelined mode had synchronised ahead are handed back, so the time de-interleavers see every CIF exactly once.
 static int reset_synchroniser(dabphy_handle* h, bool decoder_too)
 {
+    if (h->s_desc2[0].p) { int r = resolve_all_chains(h); if (r) return r; }
     if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const uint32_t B = h->cfg.n_ensembles;
@@ -389,7 +493,7 @@ int dabphy_reset(dabphy_handle* h)
 {
     if (!h) return DABPHY_ERR_INVALID;
     int r = reset_synchroniser(h, true); if (r) return r;
-    h->desc_sel = 0;
+    h->desc_sel = 0; h->n_wide_passes = h->n_wide_fallbacks = 0;
     HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
     for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
@@ -624,7 +728,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
 }
 
 namespace {
-int launch_superframe_stats(dabphy_handle* h); constexpr int HIST_CAP = 64;
+int launch_superframe_stats(dabphy_handle* h);
 int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st = nullptr, int ens0 = 0, int ens_count = 0);
 // device buffers of the superframe filter for one class and F frames per batch (the window state is zeroed when it is (re)allocated)
 int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F)
@@ -656,6 +760,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     int r;
     for (int k = 0; k < dabphy_handle::N_DESC; k++) {
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
+        if ((r = ensure(h, h->s_redo[k], (size_t)B * sizeof(int32_t)))) return r;
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
     {   // + a tail of zeros (one sub-channel's worth: 864 CU x 64 bits) that the fused MSC decode loads for CIFs that do not exist yet
@@ -702,27 +807,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         hipError_t e = hipEventRecord(end ? h->ev_end[stage] : h->ev_beg[stage], st ? st : h->stream); (void)e;
         h->ev_used[stage] = true;
     };
-    // The synchroniser runs on its own stream.  Pipelined mode (cfg.pipeline_sync): while this batch is decoded on the
-    // main stream, the frame chain of the NEXT batch already runs on the sync stream (it needs only the samples and its
-    // own state), so its serial latency disappears behind the decode kernels.
-    auto launch_sync_chain = [&](int sel) {
-        SyncArgs sa{};
-        sa.tab = h->tab; sa.iq = h->s_iq; sa.iq_stride = h->s_stride; sa.ring = (int64_t)h->s_ring; sa.n_valid = (int64_t)h->s_valid;
-        sa.loop = h->s_loop; sa.state = h->d_state; sa.dec = h->d_dec; sa.desc = h->s_desc2[sel].as<FrameDesc>(); sa.n_ens = (int)B; sa.n_frames = (int)F;
-        sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse; sa.freqsync = h->cfg.freqsync_method;
-        sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
-        sa.hist = h->s_hist.as<FrameDesc>(); sa.hist_cap = HIST_CAP;
-        { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
-        for (uint32_t f = 0; f < F; f++) {
-            // (acquisition runs at the head of k_sync_find for an ensemble that is not synchronised -- start of a stream, or after a
-            // failed window search in whatever slot of a batch, as the reference falls back to notSynced, ofdm-processor.cpp:347-350)
-            sa.frame = (int)f;
-            launch_sync_find(sa, h->sync_stream);       // PRS window search of frame f
-            launch_sync_finish(sa, h->sync_stream);     // cyclic-prefix products + their ordered sums -> correctors -> state
-            if (h->track_slevel) launch_slevel_catchup(sa, h->sync_stream);
-        }
-        { hipError_t e = hipEventRecord(h->ev_chain_end[sel], h->sync_stream); (void)e; }
-    };
     if (h->presynced != 0 && h->presynced != F) { h->err = "pipelined mode needs a constant n_frames"; return DABPHY_ERR_STATE; }
     if (h->commit_slot >= 0) {
         // asynchronous ingest: everything committed must have landed before this call's kernels read the ring (the copy stream is
@@ -737,9 +821,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     if (h->ahead == 0) {
         // the previous batch's decoder results (FIC ratio) must be final before the chain consults them
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        launch_sync_chain(cur);
+        if ((r = queue_chain(h, cur, F))) return r;
         h->ahead = 1;
     }
+    if ((r = resolve_chain(h, cur))) return r;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_chain_end[cur], 0));      // this batch's chain only: later ones may still be running
     // Pipelined modes: the chains of the NEXT batch(es) (40 launches each) are handed to the driver after this batch's decode kernels, so
     // that the main stream never waits for the host, and start on the device
@@ -800,6 +885,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             launch_tii(ta, fs);
             h->tii_ran = true;
         }
+        // the host's copies of the descriptors and SNR reports leave here, beside the decoder, instead of behind the step's last kernel
+        HIPCHK(h, hipMemcpyAsync(h->h_desc, d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, fs));
+        HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
     // MSC: one gather + decode per protection class (stage events bracket the first class only: one class in the canonical ensemble).
@@ -881,13 +969,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     if (depth) {
         if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
-        for (; h->ahead < 1 + depth; h->ahead++) launch_sync_chain((cur + h->ahead) % ND);
+        for (; h->ahead < 1 + depth; h->ahead++) if ((r = queue_chain(h, (cur + h->ahead) % ND, F))) return r;
     }
     h->desc_sel = (cur + 1) % ND; h->ahead--;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
-    h->h_desc.resize((size_t)B * F); h->h_snr.resize((size_t)B * F);
-    HIPCHK(h, hipMemcpyAsync(h->h_desc.data(), d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_snr.data(), h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->last_frames = F;
     if ((r = sync(h))) return r;
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }
@@ -939,6 +1024,7 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
 {
     if (!h) return DABPHY_ERR_INVALID;
     std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
     if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
     int r = sync(h); if (r) return r;
@@ -946,10 +1032,27 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
     return DABPHY_OK;
 }
 
+int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
+    if (passes) *passes = h->n_wide_passes;
+    if (fallbacks) *fallbacks = h->n_wide_fallbacks;
+    if (wide_frames) {
+        std::vector<RxState> st(h->cfg.n_ensembles);
+        if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+        HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+        int r = sync(h); if (r) return r;
+        for (size_t i = 0; i < st.size(); i++) wide_frames[i] = st[i].n_wide_frames;
+    }
+    return DABPHY_OK;
+}
+
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact)
 {
     if (!h) return DABPHY_ERR_INVALID;
     std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
     if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
     int r = sync(h); if (r) return r;

@@ -22,6 +22,7 @@ struct RxState {
     int32_t n_relock_inexact; // re-acquisitions that started from a level the replay could not certify
     int32_t attempts;       // entries into the notSynced state since reset (ofdm-processor.cpp:256-262: what scan mode counts)
     int32_t first_lock_attempts; // `attempts` when the first window search succeeded (:351-355 onSignalPresence(true)); -1 = not yet
+    int32_t n_wide_frames;  // frames accepted from the wide (all frames of a batch at once) synchroniser pass
     // acquisition state machine (survives a call that ran out of samples mid-search)
     int32_t acq_phase;      // 0 priming sLevel, 1 first 50 samples, 2 looking for the dip, 3 looking for the end of the null
     int32_t acq_counter, acq_idx, acq_left;
@@ -56,6 +57,7 @@ struct FrameDesc {
     int32_t coarse_ran;     // 1: the coarse corrector was consulted for this frame (FIC ratio as the synchroniser knew it was < 50)
     int32_t fine_after, coarse_after;   // correctors after the frame (reported like onFrequencyCorrectorChange)
     int32_t null_L, null_f;             // oscillator state while the trailing null symbol was pulled (onNewNullSymbol)
+    int32_t exact_sums;                 // 1: the fine corrector of this frame needed the ordered float sums
 };
 
 // Argument block of the synchronisation kernels (k_sync.hip)
@@ -68,6 +70,8 @@ struct SyncArgs {
     int fft_placement, disable_coarse, freqsync;        // FFTPlacementMethod, disableCoarseCorrector, FreqsyncMethod (reference numbering)
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
     FrameDesc* hist; int hist_cap;                       // [B][hist_cap] ring of the window searches since the last acquisition (sLevel replay)
+    const int32_t* redo_from;                            // serial chain: [B] first frame slot the wide pass did not settle (nullptr: no wide pass ran)
+    int32_t* redo_out; int32_t* any_redo;                // k_sync_validate: [B] and a flag
 };
 
 struct DemodArgs {
@@ -228,6 +232,7 @@ void launch_lin_gather(const LinGatherArgs& a, hipStream_t s);
 void launch_fib_crc(const CrcArgs& a, hipStream_t s);
 void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
 void launch_sync_find(const SyncArgs& a, hipStream_t s);
+void launch_sync_wide(const SyncArgs& a, hipStream_t s);
 void launch_sync_finish(const SyncArgs& a, hipStream_t s);
 void launch_acquire(const SyncArgs& a, hipStream_t s);
 void launch_slevel_catchup(const SyncArgs& a, hipStream_t s);

@@ -61,8 +61,13 @@ __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const 
     e[2] = osc_mul(e[0], k.d512); e[3] = osc_mul(e[1], k.d512);
     e[4] = osc_mul(e[0], k.d1024); e[5] = osc_mul(e[1], k.d1024); e[6] = osc_mul(e[2], k.d1024); e[7] = osc_mul(e[3], k.d1024);
     uint32_t hard = 0;
+#ifdef DEMOD_EXP_NOCHECK
+#pragma unroll
+    for (int j = 0; j < 8; j++) { o[j].re = (float)e[j].re; o[j].im = (float)e[j].im; }
+#else
 #pragma unroll
     for (int j = 0; j < 8; j++) hard |= osc_round(e[j], o[j]) << j;
+#endif
     if (!wave_all(hard == 0)) {
         int32_t ph = c.ph; if (h) { ph -= st.s128; if (ph < 0) ph += INPUT_RATE; }
         uint32_t pb = (uint32_t)ph * 8u;

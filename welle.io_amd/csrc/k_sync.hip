@@ -124,25 +124,71 @@ __device__ __forceinline__ bool fine_decided(int32_t fine_old, const double (*bl
     return n_lo == n_hi;
 }
 
-__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, int32_t fine)
+// What a window search starts from: the members of RxState the tracking loop reads and writes.
+struct SyncIn { int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced; };
+__device__ __forceinline__ SyncIn sync_in_of(const RxState& g)
 {
-    RxState& st = A.state[b];              // updated field by field (the struct carries the 64-entry envelope history)
-    FrameDesc d = dfin;
-    int32_t coarse = d.coarse_after;                                  // after the coarse corrector of this frame
-    // null symbol (:462-463) is pulled with the new fine corrector
-    const int32_t J0 = d.start_index + T_U;
-    const int32_t L2 = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
-    const int32_t f_null = coarse + fine;
-    const int32_t L3 = mod_rate64((int64_t)L2 - (int64_t)T_NULL * f_null);
-    d.null_L = L2; d.null_f = f_null;
+    SyncIn s; s.pos = g.pos; s.frame_no = g.frame_no; s.local_phase = g.local_phase; s.coarse = g.coarse; s.fine = g.fine; s.synced = g.synced;
+    return s;
+}
+// The WIDE synchroniser (k_sync_find_wide / k_sync_finish_wide / k_sync_validate) works on all frames of a batch at once, each
+// from the state its predecessors leave behind IF they behave as a receiver in lock does: window index T_g (the search of frame n + 1
+// starts T_null behind the end of frame n, whatever index frame n found), correctors unchanged (the fine corrector moves by
+// (int16)(0.1 x the residual offset in Hz): zero once the residual is below 10 Hz, ofdm-processor.cpp:450-451).  Then every frame
+// pulls exactly T_F samples at coarse + fine Hz.  k_sync_validate walks the frames in order and accepts a frame only if the state
+// its predecessors REALLY left equals the one it was computed from; the rest of the batch goes through the serial chain.
+__device__ __forceinline__ SyncIn sync_predict(const SyncIn& base, int n)
+{
+    SyncIn s = base;
+    s.pos += (int64_t)n * T_F; s.frame_no += n;
+    s.local_phase = mod_rate64((int64_t)base.local_phase - (int64_t)n * T_F * (int64_t)(base.coarse + base.fine));
+    return s;
+}
+
+// descriptor of a frame slot before its window search (also what a slot without a frame keeps)
+__device__ __forceinline__ FrameDesc desc_begin(const SyncIn& st)
+{
+    FrameDesc d;
+    d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
+    d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0; d.coarse_ran = 0; d.exact_sums = 0;
+    return d;
+}
+// samples a window search needs in the ring: a whole frame with the largest possible window index
+constexpr int64_t SYNC_NEED = (int64_t)T_U + (T_U - 1) + 75 * (int64_t)T_S + T_NULL;
+
+// ofdm-processor.cpp:447-490 in two halves.  finish_desc: the new fine corrector completes the frame's descriptor (the null symbol,
+// :462-463, is pulled with it).  state_advance: what the frame leaves in the receiver state, from its finished descriptor alone.
+__device__ __forceinline__ void finish_desc(FrameDesc& d, int32_t fine)
+{
+    const int32_t coarse = d.coarse_after;                            // after the coarse corrector of this frame
+    d.null_L = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym);
+    d.null_f = coarse + fine;
     d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
+    d.valid = 1;
+}
+__device__ __forceinline__ void state_advance(const SyncArgs& A, const int b, RxState& st, const FrameDesc& d)
+{
+    int32_t coarse = d.coarse_after, fine = d.fine_after;
     if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
     else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
-    d.valid = 1;
-    dfin = d;
     hist_append(A, b, st, d);
-    st.pos += (int64_t)J0 + 75 * (int64_t)T_S + T_NULL;
-    st.local_phase = L3; st.coarse = coarse; st.fine = fine; st.frame_no += 1;
+    st.pos = d.pos + (int64_t)d.start_index + T_U + 75 * (int64_t)T_S + T_NULL;
+    st.local_phase = mod_rate64((int64_t)d.null_L - (int64_t)T_NULL * d.null_f);
+    st.coarse = coarse; st.fine = fine; st.frame_no = d.frame_no + 1;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, int32_t fine, int exact)
+{
+    FrameDesc d = dfin;
+    finish_desc(d, fine);
+    d.exact_sums = exact;
+    dfin = d;
+    if (!WIDE) {
+        RxState& st = A.state[b];          // updated field by field (the struct carries the 64-entry envelope history)
+        if (exact) st.n_exact_sums += 1;
+        state_advance(A, b, st, d);
+    }
 }
 
 // ---- finish with its own product stage: the same work-group forms the cyclic-prefix products (waves 2-3, two rows ahead,
@@ -227,6 +273,7 @@ __device__ __forceinline__ void cp_row_emit(const SyncArgs& A, const CpSteps& c,
 }
 
 constexpr int FINISH_THREADS = 256;
+template <bool WIDE>
 __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b, const int frame)
 {
     __shared__ __attribute__((aligned(16))) cf32 ring[3 * 512];          // product rows sy, sy+1, sy+2 (504 used of 512)
@@ -275,7 +322,7 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
         }
         __syncthreads();
         if (s_decided) {
-            if (t == 0) sync_finish_commit(A, b, dfin, s_fine);
+            if (t == 0) sync_finish_commit<WIDE>(A, b, dfin, s_fine, 0);
             return;
         }
     }
@@ -315,7 +362,8 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
     }
     if (t == 64) s_sum = acc;
     __syncthreads();
-    if (t == 0) { A.state[b].n_exact_sums += 1; sync_finish_commit(A, b, dfin, fine_from_arg(A.state[b].fine, fdlibm_atan2f(s_sum, acc))); }
+    // (A.state[b].fine is the fine corrector the frame was searched with in both modes: the wide pass predicts it unchanged)
+    if (t == 0) sync_finish_commit<WIDE>(A, b, dfin, fine_from_arg(A.state[b].fine, fdlibm_atan2f(s_sum, acc)), 1);
 }
 
 #ifndef SYNC_FINISH_OCC
@@ -324,7 +372,13 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
 __global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_OCC) k_sync_finish(SyncArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
-    sync_finish_body(A, blockIdx.x, A.frame);
+    if (A.redo_from && A.frame < A.redo_from[blockIdx.x]) return;     // accepted from the wide pass
+    sync_finish_body<false>(A, blockIdx.x, A.frame);
+}
+// the wide pass: work-group (frame, ensemble); throughput work, no priority
+__global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_OCC) k_sync_finish_wide(SyncArgs A)
+{
+    sync_finish_body<true>(A, blockIdx.y, blockIdx.x);
 }
 
 // ---- sLevel catches up with the samples that were pulled while tracking (ofdm-processor.cpp:216: once per sample, float result
@@ -473,6 +527,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
     acquire_body<256>(A, blockIdx.x, l1, s_st, s_done, threadIdx.x);
 }
 
+template <bool WIDE>
 __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, const int frame)
 {
     // 17 KiB of LDS, reused phase by phase (FFT tile -> |IFFT| + window maxima)
@@ -486,26 +541,19 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     const int t = threadIdx.x;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
     const cf32* __restrict__ nco = A.tab.nco;
-    if (!A.state[b].synced) {
+    if (!WIDE && !A.state[b].synced) {
         // notSynced: null-symbol search first (the FFT tile is free until the window search: it holds the sample tile and the state)
         static_assert(sizeof(tile) >= ACQ_TILE * sizeof(float) + sizeof(RxState) + 16, "acquisition scratch must fit the FFT tile");
         float* const l1 = reinterpret_cast<float*>(tile);
         RxState& s_st = *reinterpret_cast<RxState*>(l1 + ACQ_TILE);
         acquire_body<FFT_THREADS>(A, b, l1, s_st, redi[0], t);
     }
-    struct { int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced; } st;
-    {
-        const RxState& g = A.state[b];
-        st.pos = g.pos; st.frame_no = g.frame_no; st.local_phase = g.local_phase; st.coarse = g.coarse; st.fine = g.fine; st.synced = g.synced;
-    }
+    const SyncIn st = WIDE ? sync_predict(sync_in_of(A.state[b]), frame) : sync_in_of(A.state[b]);
     FrameDesc& dout = A.desc[(size_t)b * A.n_frames + frame];
-    FrameDesc d;
-    d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
-    d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0; d.coarse_ran = 0;
+    FrameDesc d = desc_begin(st);
 
     // a whole frame (with the largest possible window index) must be available
-    const int64_t need = (int64_t)T_U + (T_U - 1) + 75 * (int64_t)T_S + T_NULL;
-    if (!st.synced || (!A.loop && st.pos + need > A.n_valid)) {
+    if (!st.synced || (!A.loop && st.pos + SYNC_NEED > A.n_valid)) {
         if (t == 0) dout = d;
         return;
     }
@@ -637,6 +685,8 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
         if (t == 0) {
             d.start_index = startIndex; d.valid = 3;   // window search failed: SyncOnPhase -> notSynced
             dout = d;
+        }
+        if (!WIDE && t == 0) {                         // (a wide slot that fails is left to the serial chain: k_sync_validate)
             RxState& g = A.state[b];
             g.pos = st.pos + T_U;
             g.local_phase = mod_rate64((int64_t)d.L0 - (int64_t)T_U * d.f_prs);
@@ -646,7 +696,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
         return;
     }
     d.start_index = startIndex;
-    if (t == 0 && A.state[b].first_lock_attempts < 0) A.state[b].first_lock_attempts = A.state[b].attempts;    // ofdm-processor.cpp:351-355
+    if (!WIDE && t == 0 && A.state[b].first_lock_attempts < 0) A.state[b].first_lock_attempts = A.state[b].attempts;    // ofdm-processor.cpp:351-355
     const int32_t J0 = startIndex + T_U;
     d.L1 = mod_rate64((int64_t)d.L0 - (int64_t)J0 * d.f_prs);
 
@@ -752,7 +802,46 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
 __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find(SyncArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
-    sync_find_body(A, blockIdx.x, A.frame);
+    if (A.redo_from && A.frame < A.redo_from[blockIdx.x]) return;     // accepted from the wide pass
+    sync_find_body<false>(A, blockIdx.x, A.frame);
+}
+__global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find_wide(SyncArgs A)
+{
+    sync_find_body<true>(A, blockIdx.y, blockIdx.x);
+}
+
+// The wide pass's judge: one thread per ensemble walks the batch in order.  A frame is accepted iff the state its predecessors left
+// is the one it was computed from and it is an ordinary tracked frame; accepting it advances the state exactly as the serial chain
+// does (state_advance).  redo_from[b] = first slot the serial chain has to do (n_frames: none); *any_redo |= some ensemble has one.
+__global__ void __launch_bounds__(64) k_sync_validate(SyncArgs A)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.n_ens) return;
+    RxState& g = A.state[b];
+    FrameDesc* const desc = A.desc + (size_t)b * A.n_frames;
+    const SyncIn base = sync_in_of(g);
+    int n = 0;
+    if (base.synced) {
+        for (; n < A.n_frames; n++) {
+            const SyncIn p = sync_predict(base, n);
+            if (g.pos != p.pos || g.frame_no != p.frame_no || g.local_phase != p.local_phase || g.coarse != p.coarse || g.fine != p.fine) break;
+            if (!A.loop && g.pos + SYNC_NEED > A.n_valid) {
+                // out of samples: this slot and the ones behind it stay empty, as the serial chain leaves them
+                const FrameDesc e = desc_begin(sync_in_of(g));
+                for (int m = n; m < A.n_frames; m++) desc[m] = e;
+                n = A.n_frames;
+                break;
+            }
+            const FrameDesc d = desc[n];
+            if (d.valid != 1) break;                                   // failed window search: the serial chain takes it from here
+            if (d.exact_sums) g.n_exact_sums += 1;
+            if (g.first_lock_attempts < 0) g.first_lock_attempts = g.attempts;                  // ofdm-processor.cpp:351-355
+            state_advance(A, b, g, d);
+            g.n_wide_frames += 1;
+        }
+    }
+    A.redo_out[b] = n;
+    if (n < A.n_frames) *A.any_redo = 1;
 }
 
 // Continuous mode (dabphy_set_track_slevel): the level follows the tracked frames one by one (3 ms per frame on one lane: meant for
@@ -777,6 +866,12 @@ void launch_slevel_catchup(const SyncArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_slevel_catchup, dim3(a.n_ens), dim3(256), 0, s, a);
 }
 
+void launch_sync_wide(const SyncArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sync_find_wide, dim3(a.n_frames, a.n_ens), dim3(FFT_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_sync_validate, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+}
 void launch_sync_find(const SyncArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sync_find, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
