@@ -227,6 +227,10 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
  * ensemble that were accepted from it [n_ensembles]; passes queued; passes after which the frame-by-frame chain had to take over for
  * at least one ensemble */
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
+/* OFDM symbols (since dabphy_create) whose samples dabphy_process mixed with oscillator values converted without / with the
+ * per-sample rounding test (csrc/osc_exact.h: the synchroniser marks the symbols that read one of the 36 table entries next to a
+ * float rounding boundary; only those take the test and, where it cannot decide, the table) */
+int dabphy_get_osc_stats(dabphy_handle* h, uint64_t* unchecked_symbols, uint64_t* checked_symbols);
 /* Scan mode (RadioReceiver::restart(doScan = true) -> OFDMProcessor::set_scanMode, ofdm-processor.cpp:256-262,351-355), [n_ensembles]
  * each, since dabphy_reset: attempts = entries into the notSynced state (after the sLevel priming, after every hopeless null search,
  * after every failed window search) -- the reference reports onSignalPresence(false) when this exceeds 5 before a lock;

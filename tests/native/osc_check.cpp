@@ -3,6 +3,9 @@
 //   2. oscillator chains as k_demod / k_sync run them (base from osc_exp, up to CHAIN multiplications by osc_step factors):
 //      every sample osc_round does not flag must equal the reference's table entry (float)cos/sin(2 pi i / RATE) bit for bit;
 //      the flag rate is reported.
+//   3. k_demod's unchecked conversion (a symbol's base = osc_exp x osc_exp step, tree of depth 4 inside a symbol): every sample
+//      whose table index is not in osc_unsafe_list must convert to the table entry WITHOUT the test; the largest error seen must
+//      stay below the bound the header derives (2.4e-15), itself well below OSC_UNSAFE_DIST.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -57,7 +60,51 @@ int main(int argc, char** argv)
             ph = (int32_t)np;
         }
     }
-    printf("{\"exp_max_err\": %.3Le, \"chain_max_err\": %.3Le, \"samples\": %ld, \"hard\": %ld, \"mismatch\": %ld, \"margin\": %.3e}\n",
+    // ---- 3. the unchecked path
+    int32_t U[OSC_MAX_UNSAFE]; const int nu = osc_unsafe_list(U);
+    std::vector<char> unsafe(INPUT_RATE, 0); for (int i = 0; i < nu; i++) unsafe[U[i]] = 1;
+    long un_total = 0, un_bad = 0, un_skipped = 0; long double un_maxerr = 0;
+    for (long c = 0; c < n_chains; c++) {
+        int32_t ph = (int32_t)(rnd() % INPUT_RATE);
+        const int32_t f = (c % 4 == 0) ? (int32_t)(rnd() % 201) - 100 : (int32_t)(rnd() % 70001) - 35000;
+        const dc64 d128 = osc_step(128, f), d256 = osc_step(256, f), d512 = osc_step(512, f), d1024 = osc_step(1024, f);
+        const dc64 base0 = osc_exp(ph); const int32_t ph_first = ph;
+        dc64 base = base0;
+        for (int s = 0; s < 75; s++) {
+            for (int h = 0; h < 2; h++) {
+                dc64 e[8];
+                e[0] = h ? osc_mul(base, d128) : base;
+                e[1] = osc_mul(e[0], d256);
+                e[2] = osc_mul(e[0], d512); e[3] = osc_mul(e[1], d512);
+                e[4] = osc_mul(e[0], d1024); e[5] = osc_mul(e[1], d1024); e[6] = osc_mul(e[2], d1024); e[7] = osc_mul(e[3], d1024);
+                for (int j = 0; j < 8; j++) {
+                    int64_t pi = ((int64_t)ph - (int64_t)(128 * h + 256 * j) * f) % INPUT_RATE; if (pi < 0) pi += INPUT_RATE;
+                    const long double th = 2.0L * 3.14159265358979323846264338327950288L * pi / INPUT_RATE;
+                    const long double er = fabsl((long double)e[j].re - cosl(th)), ei = fabsl((long double)e[j].im - sinl(th));
+                    if (er > un_maxerr) un_maxerr = er;
+                    if (ei > un_maxerr) un_maxerr = ei;
+                    if (unsafe[pi]) { un_skipped++; continue; }
+                    un_total++;
+                    const cf32 o = {(float)e[j].re, (float)e[j].im};
+                    if (memcmp(&o, &table[pi], 8) != 0) un_bad++;
+                }
+            }
+            int64_t np = ((int64_t)ph - (int64_t)2552 * f) % INPUT_RATE; if (np < 0) np += INPUT_RATE;
+            ph = (int32_t)np;
+            base = osc_mul(base0, osc_step((int64_t)(s + 1) * 2552, f)); (void)ph_first;
+        }
+    }
+    // ... and every table entry once through a product of two factors (all 2 048 000 indices as i = a + b)
+    for (int i = 0; i < INPUT_RATE; i++) {
+        const int32_t a = (int32_t)(rnd() % INPUT_RATE); int32_t b = i - a; if (b < 0) b += INPUT_RATE;
+        const dc64 e = osc_mul(osc_exp(a), osc_exp(b));
+        if (unsafe[i]) continue;
+        const cf32 o = {(float)e.re, (float)e.im};
+        un_total++;
+        if (memcmp(&o, &table[i], 8) != 0) un_bad++;
+    }
+    printf("{\"unsafe_entries\": %d, \"unchecked_samples\": %ld, \"unchecked_mismatch\": %ld, \"unchecked_max_err\": %.3Le, \"unsafe_dist\": %.3e, \"unchecked_skipped\": %ld, ", nu, un_total, un_bad, un_maxerr, OSC_UNSAFE_DIST, un_skipped);
+    printf("\"exp_max_err\": %.3Le, \"chain_max_err\": %.3Le, \"samples\": %ld, \"hard\": %ld, \"mismatch\": %ld, \"margin\": %.3e}\n",
            maxerr, maxchain, total, hard, bad, OSC_MARGIN);
-    return bad != 0;
+    return bad != 0 || un_bad != 0;
 }

@@ -143,6 +143,7 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
             done += F
         stale, first = d.ratio_lag()
         wf, passes, fallbacks = d.wide_sync_stats()
+        logs[0]["osc"] = d.osc_stats()
         for b in range(B):
             logs[b]["ratio_lag"] = (int(stale[b]), int(first[b]))
             logs[b]["wide"] = (int(wf[b]), passes, fallbacks)
@@ -819,6 +820,10 @@ def check_wide_sync(d_factory, F=6, nf=34, pipeline_sync=False, cfo=37.0, snr_db
     offset, ofdm-processor.cpp:450-451) every pass hands over to the serial chain, once it rests whole batches are accepted."""
     logs_w, o, _ = check_stream_vs_oracle(d_factory, snr_db, cfo, 0, nf, False, B=B, F=F, pipeline_sync=pipeline_sync, seed=9)
     logs_s, _, _ = check_stream_vs_oracle(d_factory, snr_db, cfo, 0, nf, False, B=B, F=F, pipeline_sync=pipeline_sync, seed=9, serial_sync=True)
+    # k_demod's two oscillator conversions (csrc/osc_exact.h) were both taken -- the soft bits above are the oracle's either way -- and
+    # the checked one is the exception (a symbol in 25 or so reads a table entry next to a float rounding boundary)
+    fast, checked = logs_w[0]["osc"]
+    assert fast > 0 and checked > 0 and checked < 0.2 * fast, (fast, checked)
     for b in range(B):
         w, s = logs_w[b], logs_s[b]
         assert len(w["info"]) == len(s["info"])

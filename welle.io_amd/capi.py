@@ -155,6 +155,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_wide_sync_stats(self.h, _p(wf), C.byref(a), C.byref(b)))
         return wf, a.value, b.value
 
+    def osc_stats(self):
+        """(symbols mixed with the unchecked oscillator conversion, symbols that took the checked one) since create"""
+        a = C.c_uint64(0); b = C.c_uint64(0)
+        self._chk(self.lib.dabphy_get_osc_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_track_slevel(self, on=True):
         self._chk(self.lib.dabphy_set_track_slevel(self.h, int(on)))
 

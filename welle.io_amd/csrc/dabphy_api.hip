@@ -2,6 +2,7 @@
 // buffer management and kernel sequencing.  No arithmetic of the hot path happens on the host.
 #include "dabphy_kernels.h"
 #include "dabphy_host.h"
+#include "osc_exact.h"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -29,6 +30,7 @@ struct dabphy_handle {
     // constant tables in HBM
     cf32 *d_tw = nullptr, *d_ref = nullptr, *d_nco = nullptr;
     int16_t* d_bin2soft = nullptr; uint32_t* d_prbs_words = nullptr; int16_t* d_fic_map = nullptr;
+    int32_t* d_osc_unsafe = nullptr; unsigned long long* d_osc_stats = nullptr;   // osc_exact.h: unsafe table entries; symbols mixed unchecked / checked
     Tables tab{};
     // grow-only scratch
     DevBuf iq, soft, con, prs_mag, snr, desc, in8, map, vsym, vdec, vout, ok;
@@ -173,7 +175,15 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if ((r = upload_const(h, &h->d_prbs_words, T.prbs_words))) return fail(r);
     dabphy_protection pf; protection_fic(&pf);
     if ((r = upload_const(h, &h->d_fic_map, depuncture_map(&pf)))) return fail(r);
+    if ((r = upload_const(h, &h->d_osc_unsafe, T.osc_unsafe))) return fail(r);
     h->tab.tw = h->d_tw; h->tab.ref = h->d_ref; h->tab.nco = h->d_nco; h->tab.bin2soft = h->d_bin2soft; h->tab.prbs_bytes = nullptr;
+    h->tab.osc_unsafe = h->d_osc_unsafe; h->tab.n_osc_unsafe = T.n_osc_unsafe;
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, 2 * sizeof(unsigned long long)) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->owned.push_back(p); h->d_osc_stats = reinterpret_cast<unsigned long long*>(p);
+        if (hipMemset(p, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    }
     void* st = nullptr;
     if (hipMalloc(&st, sizeof(RxState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
     h->owned.push_back(st); h->d_state = reinterpret_cast<RxState*>(st);
@@ -844,6 +854,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     da.desc = d_desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
     da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames;
     da.con = h->cfg.want_constellation ? h->s_con.as<cf32>() : nullptr; da.prs_mag = h->s_mag.as<float>();
+    da.osc_stats = h->d_osc_stats;
     mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
     mark(dabphy_handle::ST_DEMOD, true);
@@ -1029,6 +1040,17 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
     int r = sync(h); if (r) return r;
     for (size_t i = 0; i < st.size(); i++) { if (attempts) attempts[i] = st[i].attempts; if (attempts_at_first_lock) attempts_at_first_lock[i] = st[i].first_lock_attempts; }
+    return DABPHY_OK;
+}
+
+int dabphy_get_osc_stats(dabphy_handle* h, uint64_t* unchecked_symbols, uint64_t* checked_symbols)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(v, h->d_osc_stats, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    if (unchecked_symbols) *unchecked_symbols = v[0];
+    if (checked_symbols) *checked_symbols = v[1];
     return DABPHY_OK;
 }
 
@@ -1382,6 +1404,8 @@ int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uin
             FrameDesc& x = d[(size_t)b * n_frames + f];
             memset(&x, 0, sizeof x);
             x.pos = (int64_t)(per * f); x.frame_no = f; x.valid = 1; x.f_prs = x.f_sym = f_hz; x.L0 = 12345; x.L1 = 54321;
+            const HostTables& T = host_tables();
+            for (int i = 0; i < T.n_osc_unsafe; i++) osc_hazard_entry(x.osc_hazard, T.osc_unsafe[i], x.start_index, x.L0, x.f_prs, x.L1, x.f_sym);
         }
     HIPCHK(h, hipMemcpyAsync(h->desc.p, d.data(), total * sizeof(FrameDesc), hipMemcpyHostToDevice, h->stream));
     DemodArgs a{};

@@ -127,6 +127,8 @@ struct Tables {
     const cf32* nco;         // 2 048 000 oscillator phasors (ofdm-processor.cpp:92-94)
     const int16_t* bin2soft; // 2048: FFT bin -> soft-bit index i (perm[i] == bin), -1 for unused bins
     const uint8_t* prbs_bytes; // 1152 bytes: PRBS packed MSB-first (fic-handler.cpp:62-71)
+    const int32_t* osc_unsafe; // OSC_MAX_UNSAFE oscillator table indices (padded with -1) the unchecked conversion must not meet (osc_exact.h)
+    int n_osc_unsafe;
 };
 
 } // namespace dabphy

@@ -10,7 +10,10 @@
 //   EEP / UEP profiles     backend/eep-protection.cpp:32-113, uep-protection.cpp:27-118, dab-constants.cpp:45-109
 //   PRBS                   backend/fic-handler.cpp:62-71, energy_dispersal.h:39-49
 #include "dabphy_host.h"
+#include "osc_exact.h"
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <complex>
@@ -47,6 +50,9 @@ static void build(HostTables& T)
         T.nco[i].re = (float)cos(2.0 * M_PI * i / INPUT_RATE);
         T.nco[i].im = (float)sin(2.0 * M_PI * i / INPUT_RATE);
     }
+    T.osc_unsafe.assign(OSC_MAX_UNSAFE, -1);
+    T.n_osc_unsafe = osc_unsafe_list(T.osc_unsafe.data());
+    if (T.n_osc_unsafe < 0) { fprintf(stderr, "dabphy: this libm's oscillator table has more than %d entries next to a float rounding boundary\n", OSC_MAX_UNSAFE); abort(); }
     T.ref.assign(T_U, cf32{0.f, 0.f});
     for (int i = 1; i <= K_CARR / 2; i++) {
         float phi = prs_phase(i);

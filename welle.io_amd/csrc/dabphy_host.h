@@ -11,6 +11,8 @@ constexpr int PRBS_MAX_BITS = 9216;      // 24 * 384 kbit/s
 struct HostTables {
     std::vector<cf32> tw, ref, nco;
     std::vector<int16_t> perm, bin2soft;
+    std::vector<int32_t> osc_unsafe;     // OSC_MAX_UNSAFE entries, -1 padded; n_osc_unsafe used (osc_exact.h)
+    int n_osc_unsafe = 0;
     std::vector<uint8_t> prbs_bits;
     std::vector<uint32_t> prbs_words;    // 32 PRBS bits per word in the byte order of the decoded output
     int8_t pcodes[24][32];

@@ -58,7 +58,11 @@ struct FrameDesc {
     int32_t fine_after, coarse_after;   // correctors after the frame (reported like onFrequencyCorrectorChange)
     int32_t null_L, null_f;             // oscillator state while the trailing null symbol was pulled (onNewNullSymbol)
     int32_t exact_sums;                 // 1: the fine corrector of this frame needed the ordered float sums
+    uint32_t osc_hazard[3];             // bit s: the useful part of symbol s (0 = PRS) reads an oscillator table entry for which k_demod
+                                        // must take the checked conversion (osc_exact.h: osc_hazard_entry); written with the descriptor
+    uint32_t pad_;
 };
+static_assert(sizeof(FrameDesc) == 80, "FrameDesc layout");
 
 // Argument block of the synchronisation kernels (k_sync.hip)
 struct SyncArgs {
@@ -83,6 +87,7 @@ struct DemodArgs {
     int8_t* soft; int soft_ring;                          // [B][soft_ring][75][3072]
     cf32* con;                                            // optional [B][n_frames][1200]
     float* prs_mag;                                       // optional [B][n_frames][2048]
+    unsigned long long* osc_stats;                        // optional [2]: symbols mixed with the unchecked / the checked oscillator conversion
 };
 
 struct SnrArgs {

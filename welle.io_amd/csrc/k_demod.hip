@@ -33,25 +33,26 @@ struct MixSteps { int32_t s128, sTS; uint32_t s256_bytes; };   // (128 f, T_s f)
 constexpr uint32_t NCO_BYTES = (uint32_t)INPUT_RATE * 8u;      // the oscillator table, one cf32 per phase step
 
 // The oscillator of one thread: exp(j 2 pi phase / RATE) of its sample t of the current symbol, and the factors that
-// advance it by 128 / 256 / T_s samples (osc_exact.h).
-struct OscChain { dc64 base, d128, d256, d512, d1024, dts; };
+// advance it by 128 / 256 / 512 / 1024 samples (osc_exact.h).
+struct OscChain { dc64 base, d128, d256, d512, d1024; };
 
 __device__ __forceinline__ void osc_chain_steps(OscChain& k, int32_t f_hz)
 {
     // the same in every lane (f_hz is per frame): kept in scalar registers, 24 VGPRs less
-    const dc64 a = osc_step(128, f_hz), b = osc_step(256, f_hz), c = osc_step(T_S, f_hz), b2 = osc_step(512, f_hz), b4 = osc_step(1024, f_hz);
+    const dc64 a = osc_step(128, f_hz), b = osc_step(256, f_hz), b2 = osc_step(512, f_hz), b4 = osc_step(1024, f_hz);
     k.d128.re = uniform_f64(a.re); k.d128.im = uniform_f64(a.im);
     k.d256.re = uniform_f64(b.re); k.d256.im = uniform_f64(b.im);
     k.d512.re = uniform_f64(b2.re); k.d512.im = uniform_f64(b2.im);
     k.d1024.re = uniform_f64(b4.re); k.d1024.im = uniform_f64(b4.im);
-    k.dts.re = uniform_f64(c.re); k.dts.im = uniform_f64(c.im);
 }
 
 // Oscillator values of one half of a symbol in round-A order: o[j] = oscillatorTable[phase(t + 128h + 256j)]
 // (ofdm-processor.cpp:211-214), computed, not gathered.  A sample whose double sits too close to a float rounding boundary
 // (about 4 in 10^5) is read from the table; the walk over the integer phases only happens in a wave that has one.
+// `checked` = the symbol reads a table entry next to a float rounding boundary (FrameDesc::osc_hazard, about one symbol in 25):
+// only then does the conversion need osc_round's test; every other symbol converts its doubles directly (osc_exact.h).
 __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const cf32* __restrict__ nco, const SymCursor& c,
-                                         const MixSteps& st, int h)
+                                         const MixSteps& st, int h, bool checked)
 {
     // e[j] = base * exp(-j 2 pi (128 h + 256 j) f / RATE) as a tree of depth 3 (steps of 256, 512, 1024 samples) instead of a chain of
     // seven dependent double-precision complex multiplications: same operation count, no latency chain (and a shorter error chain)
@@ -60,14 +61,14 @@ __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const 
     e[1] = osc_mul(e[0], k.d256);
     e[2] = osc_mul(e[0], k.d512); e[3] = osc_mul(e[1], k.d512);
     e[4] = osc_mul(e[0], k.d1024); e[5] = osc_mul(e[1], k.d1024); e[6] = osc_mul(e[2], k.d1024); e[7] = osc_mul(e[3], k.d1024);
-    uint32_t hard = 0;
-#ifdef DEMOD_EXP_NOCHECK
+    if (!checked) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) { o[j].re = (float)e[j].re; o[j].im = (float)e[j].im; }
-#else
+        for (int j = 0; j < 8; j++) { o[j].re = (float)e[j].re; o[j].im = (float)e[j].im; }
+        return;
+    }
+    uint32_t hard = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) hard |= osc_round(e[j], o[j]) << j;
-#endif
     if (!wave_all(hard == 0)) {
         int32_t ph = c.ph; if (h) { ph -= st.s128; if (ph < 0) ph += INPUT_RATE; }
         uint32_t pb = (uint32_t)ph * 8u;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const 
 
 // One half of a symbol straight from the sample ring in HBM: x[j] = sample (t + 128h + 256j), times its oscillator value
 __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__ iq, uint32_t ring, const SymCursor& c,
-                                          const OscChain& k, const cf32* __restrict__ nco, const MixSteps& st, int h, int mix)
+                                          const OscChain& k, const cf32* __restrict__ nco, const MixSteps& st, int h, int mix, bool checked)
 {
     uint32_t a = c.a + 128u * h; if (a >= ring) a -= ring;
 #pragma unroll
@@ -90,7 +91,7 @@ __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__
         a += 256u; if (a >= ring) a -= ring;
     }
     if (mix) {
-        cf32 o[8]; osc_half(o, k, nco, c, st, h);
+        cf32 o[8]; osc_half(o, k, nco, c, st, h, checked);
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[j]);
     }
@@ -98,12 +99,12 @@ __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__
 
 // ... or from the LDS stage an earlier LDS-DMA filled with the symbol's 2048 samples in natural order
 __device__ __forceinline__ void stage_half(cf32 (&x)[8], const cf32* stage, const SymCursor& c, const OscChain& k,
-                                           const cf32* __restrict__ nco, const MixSteps& st, int h, int mix, int t)
+                                           const cf32* __restrict__ nco, const MixSteps& st, int h, int mix, int t, bool checked)
 {
 #pragma unroll
     for (int j = 0; j < 8; j++) x[j] = stage[t + 128 * h + 256 * j];
     if (mix) {
-        cf32 o[8]; osc_half(o, k, nco, c, st, h);
+        cf32 o[8]; osc_half(o, k, nco, c, st, h, checked);
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[j]);
     }
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     cf32* const stage = nullptr;
 #endif
     __shared__ __attribute__((aligned(16))) int8_t softbuf[SOFT_PER_SYM];
+    __shared__ __attribute__((aligned(16))) dc64 s_symstep[L_SYM];   // exp(-j 2 pi k T_s f / RATE): symbol k of the chunk against its first
     const int t = threadIdx.x;
     const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
     const FrameDesc d = A.desc[(size_t)b * A.n_frames + f];
@@ -174,6 +176,13 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     };
     auto steps_for = [&](int32_t fhz) { MixSteps m; m.s128 = mod_rate(128LL * fhz); m.s256_bytes = 8u * (uint32_t)mod_rate(256LL * fhz); m.sTS = mod_rate((int64_t)T_S * fhz); return m; };
 
+    // (selected, not indexed: a dynamically indexed member would move the whole descriptor to scratch memory)
+    const uint32_t hz0 = d.osc_hazard[0], hz1 = d.osc_hazard[1], hz2 = d.osc_hazard[2];
+#ifdef DEMOD_FORCE_CHECKED                      // (timing experiments only: one conversion compiled in)
+    auto hazard_bit = [&](int) { return DEMOD_FORCE_CHECKED != 0; };
+#else
+    auto hazard_bit = [&](int sym) { return (((sym < 32 ? hz0 : sym < 64 ? hz1 : hz2) >> (sym & 31)) & 1u) != 0; };
+#endif
     cf32 prev[N_SLOTS], v[16];
     OscChain osc{};
     {   // reference symbol of the chunk (the PRS for chunk 0)
@@ -183,8 +192,9 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         const MixSteps ms = steps_for(sref == 0 ? d.f_prs : d.f_sym);
         if (A.mix) { osc_chain_steps(osc, sref == 0 ? d.f_prs : d.f_sym); osc.base = osc_exp(c.ph); }
         __syncthreads();
+        const bool checked = hazard_bit(sref);
 #pragma unroll
-        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, nco, ms, h, A.mix); fft_round_a<false>(x, h, tile, w, t); }
+        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, nco, ms, h, A.mix, checked); fft_round_a<false>(x, h, tile, w, t); }
         fft_rounds_bc<false>(v, tile, w, t);
         if (sref == 0 && A.prs_mag) {
             // |bin| of the PRS for the SNR estimate (ofdm-decoder.cpp:240-266): stored in bin order, summed by k_snr_frames
@@ -214,7 +224,13 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         lds_dma16<0>(g + 512, l + 512); lds_dma16<1024>(g + 512, l + 512); lds_dma16<2048>(g + 512, l + 512); lds_dma16<3072>(g + 512, l + 512);
     };
     bool staged = dma_ok(sym0);
-    if (A.mix) { osc_chain_steps(osc, d.f_sym); osc.base = osc_exp(cur.ph); }
+    // Every symbol's base is ONE product of two osc_exp values (the thread's base at the chunk's first symbol and the wave-uniform step
+    // to symbol k, from LDS), not a chain of k products: the unchecked conversion's error budget (osc_exact.h) counts on it.
+    dc64 base0{};
+    if (A.mix) {
+        osc_chain_steps(osc, d.f_sym); base0 = osc_exp(cur.ph); osc.base = base0;
+        if (t < s_end - s_begin) s_symstep[t] = osc_step((int64_t)t * T_S, d.f_sym);      // (published by the barrier that opens the loop)
+    }
     if (staged) dma_issue(sym0);       // overlaps nothing yet (the reference symbol is done), but primes the pipeline
     // The 3 KiB of soft bits of symbol s leave at the START of iteration s+1: the barrier that opens an iteration is then also
     // the one that completes the soft-bit staging (4 barriers per symbol, not 5), and the wait for the LDS-DMA -- the wave's
@@ -225,14 +241,17 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
 #pragma unroll
         for (int i = 0; i < 3; i++) dst[t + 128 * i] = src[t + 128 * i];
     };
+    uint32_t n_checked = 0;
     for (int s = s_begin; s < s_end; s++) {
+        const bool checked = hazard_bit(s);
+        n_checked += checked ? 1u : 0u;
         if (staged) lds_dma_wait();
         __syncthreads();                                         // tile free again, stage complete, soft bits of s-1 complete
         if (s > s_begin) store_soft(s - 1);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             cf32 x[8];
-            if (staged) stage_half(x, stage, cur, osc, nco, ms, h, A.mix, t); else load_half(x, iq, ring, cur, osc, nco, ms, h, A.mix);
+            if (staged) stage_half(x, stage, cur, osc, nco, ms, h, A.mix, t, checked); else load_half(x, iq, ring, cur, osc, nco, ms, h, A.mix, checked);
             fft_round_a<false>(x, h, tile, w, t);
         }
         uint32_t next0 = sym0 + T_S; if (next0 >= ring) next0 -= ring;
@@ -241,7 +260,8 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         sym0 = next0; staged = next_staged;
         cur.a += T_S; if (cur.a >= ring) cur.a -= ring;
         cur.ph -= ms.sTS; if (cur.ph < 0) cur.ph += INPUT_RATE;
-        if (A.mix) osc.base = osc_mul(osc.base, osc.dts);
+        // the base is re-anchored every OSC_REANCHOR symbols: the unchecked conversion's error budget (osc_exact.h) counts on it
+        if (A.mix && s + 1 < s_end) osc.base = osc_mul(base0, s_symstep[s + 1 - s_begin]);
         cf32 r1[N_SLOTS]; float l1[N_SLOTS];
         {
             cf32 cs[N_SLOTS]; carrier_slots(cs, v, t);
@@ -285,6 +305,10 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     }
     __syncthreads();
     store_soft(s_end - 1);
+    if (A.osc_stats && A.mix && t == 0) {
+        atomicAdd(&A.osc_stats[0], (unsigned long long)((uint32_t)(s_end - s_begin) - n_checked));
+        atomicAdd(&A.osc_stats[1], (unsigned long long)n_checked);
+    }
 }
 
 // SNR estimate of OfdmDecoder::get_snr(method 1) (ofdm-decoder.cpp:240-266): one thread per (ensemble, frame) runs the

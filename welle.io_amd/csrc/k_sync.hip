@@ -151,6 +151,7 @@ __device__ __forceinline__ FrameDesc desc_begin(const SyncIn& st)
     FrameDesc d;
     d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
     d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0; d.coarse_ran = 0; d.exact_sums = 0;
+    d.osc_hazard[0] = d.osc_hazard[1] = d.osc_hazard[2] = 0; d.pad_ = 0;
     return d;
 }
 // samples a window search needs in the ring: a whole frame with the largest possible window index
@@ -178,11 +179,12 @@ __device__ __forceinline__ void state_advance(const SyncArgs& A, const int b, Rx
 }
 
 template <bool WIDE>
-__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, int32_t fine, int exact)
+__device__ __forceinline__ void sync_finish_commit(const SyncArgs& A, const int b, FrameDesc& dfin, int32_t fine, int exact, const uint32_t (*hz)[3])
 {
     FrameDesc d = dfin;
     finish_desc(d, fine);
     d.exact_sums = exact;
+    for (int i = 0; i < A.tab.n_osc_unsafe; i++) { d.osc_hazard[0] |= hz[i][0]; d.osc_hazard[1] |= hz[i][1]; d.osc_hazard[2] |= hz[i][2]; }
     dfin = d;
     if (!WIDE) {
         RxState& st = A.state[b];          // updated field by field (the struct carries the 64-entry envelope history)
@@ -285,6 +287,14 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
     if (pending != 2) return;
     const FrameDesc d = dfin;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
+    // which symbols of this frame read an oscillator table entry next to a float rounding boundary (osc_exact.h): one lane per entry
+    // solves its congruence; the masks are OR-ed into the descriptor at the commit (there are barriers in between)
+    __shared__ uint32_t s_hz[OSC_MAX_UNSAFE][3];
+    if (t < A.tab.n_osc_unsafe) {
+        uint32_t m[3] = {0u, 0u, 0u};
+        osc_hazard_entry(m, A.tab.osc_unsafe[t], d.start_index, d.L0, d.f_prs, d.L1, d.f_sym);
+        s_hz[t][0] = m[0]; s_hz[t][1] = m[1]; s_hz[t][2] = m[2];
+    }
     {
         // ---- fast path: all four waves form the products, sums in double precision, the int16 decided by interval (fine_decided)
         __shared__ int s_decided, s_fine;
@@ -322,7 +332,7 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
         }
         __syncthreads();
         if (s_decided) {
-            if (t == 0) sync_finish_commit<WIDE>(A, b, dfin, s_fine, 0);
+            if (t == 0) sync_finish_commit<WIDE>(A, b, dfin, s_fine, 0, s_hz);
             return;
         }
     }
@@ -363,7 +373,7 @@ __device__ __forceinline__ void sync_finish_body(const SyncArgs& A, const int b,
     if (t == 64) s_sum = acc;
     __syncthreads();
     // (A.state[b].fine is the fine corrector the frame was searched with in both modes: the wide pass predicts it unchanged)
-    if (t == 0) sync_finish_commit<WIDE>(A, b, dfin, fine_from_arg(A.state[b].fine, fdlibm_atan2f(s_sum, acc)), 1);
+    if (t == 0) sync_finish_commit<WIDE>(A, b, dfin, fine_from_arg(A.state[b].fine, fdlibm_atan2f(s_sum, acc)), 1, s_hz);
 }
 
 #ifndef SYNC_FINISH_OCC
