@@ -17,8 +17,10 @@ from welle_io_amd import capi, synth  # noqa: E402
 x = synth.make_stream(5, snr_db=20, seed=1)
 frames = P.cut_frames(x, 4)
 libs = sys.argv[1:] or [os.path.join(ROOT, "welle.io_amd", "libdabphy_hip.so")]
+chunks = [int(c) for c in os.environ.get("CHUNKS", "25").split(",")]
 for lib in libs:
-    d = capi.DabPhy(lib_path=lib, demod_chunk=25)
-    for f in (137, 137, 0):
-        print(os.path.basename(lib), "f_hz", f, "ms", d.time_demod(frames, 256, 20, mix=1, f_hz=f, iters=5), flush=True)
-    d.close()
+    for ch in chunks:
+        d = capi.DabPhy(lib_path=lib, demod_chunk=ch)
+        for f in (137, 137, 0):
+            print(os.path.basename(lib), "chunk", ch, "f_hz", f, "ms", d.time_demod(frames, 256, 20, mix=1, f_hz=f, iters=5), flush=True)
+        d.close()
