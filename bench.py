@@ -196,7 +196,7 @@ def main():
             got = gather_fibs(dist, d_fib, d_ok, rank, world)
             fib, ok = got[0] if rank == 0 else (None, None)     # rank 0 now holds every rank's FIBs on its host
         else:
-            fib, ok = dev.fibs()                           # decoded FIBs + CRC flags to the host
+            fib, ok = dev.fibs_host()                      # decoded FIBs + CRC flags on the host (page-locked copies that came back with the batch)
         return fib, ok, sf
 
     # warm-up: acquisition, time-de-interleaver fill, superframe synchronisation.  Rank 0 logs what two ensembles of the batch (first

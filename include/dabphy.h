@@ -216,6 +216,9 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok);
 /* the same buffers where they lie in HBM (DEVICE pointers, valid until the next dabphy_process / dabphy_destroy; complete when
  * dabphy_process has returned): for consumers on the device, e.g. the multi-GPU gather of the FIC over RCCL */
 int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_t** d_crc_ok);
+/* ... and the page-locked HOST copies dabphy_process brings back with every batch (same layout, valid until the next
+ * dabphy_process / dabphy_destroy): what dabphy_get_fibs copies from; a consumer that only reads can skip that copy */
+int dabphy_get_fibs_host(dabphy_handle* h, const uint8_t** fib, const uint8_t** crc_ok);
 int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent /* [n_ensembles] */);
 /* synchroniser counters since dabphy_reset (any pointer may be NULL), [n_ensembles] each: failed window searches
  * (PhaseReference::findIndex < 0, ofdm-processor.cpp:347); frames whose fine corrector had to be settled by the ordered float sums

@@ -283,6 +283,15 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_fibs(self.h, _p(fib), _p(ok)))
         return fib, ok
 
+    def fibs_host(self):
+        """the same, as read-only views of the library's page-locked host copies (valid until the next process())"""
+        B, F = self.cfg.n_ensembles, self._last
+        pf = C.POINTER(C.c_uint8)(); po = C.POINTER(C.c_uint8)()
+        self._chk(self.lib.dabphy_get_fibs_host(self.h, C.byref(pf), C.byref(po)))
+        fib = np.ctypeslib.as_array(pf, shape=(B * F * 384,)).reshape(B, F, 12, 32)
+        ok = np.ctypeslib.as_array(po, shape=(B * F * 12,)).reshape(B, F, 12)
+        return fib, ok
+
     def fic_ratio(self):
         r = np.zeros(self.cfg.n_ensembles, np.int32)
         self._chk(self.lib.dabphy_get_fic_ratio(self.h, _p(r)))

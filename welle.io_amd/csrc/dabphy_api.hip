@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <algorithm>
+#include <chrono>
 
 using namespace dabphy;
 
@@ -65,6 +66,7 @@ struct dabphy_handle {
     static constexpr int MAX_PARTS = 8;
     hipEvent_t ev_part[MAX_PARTS]{}, ev_vit_done[2]{};
     int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
+    int vit_split = 1;                                   // launches the fused MSC decode of a big class is cut into (DABPHY_VIT_SPLIT)
     bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     // wide synchroniser pass (all frames of a batch at once, k_sync_find_wide/_finish_wide/_validate) and its serial fall-back
@@ -84,6 +86,8 @@ struct dabphy_handle {
     float* cur_cir = nullptr;
     FrameDesc* h_desc = nullptr;      // host copy of the last batch's frame descriptors (page-locked, [B][max_frames])
     float* h_snr = nullptr;
+    uint8_t *h_fib = nullptr, *h_ok = nullptr;   // ... of its FIBs [B][F][12][32] and CRC flags [B][F][12]: they cross PCIe inside the step, beside the decoder
+    int32_t* h_sf_stats = nullptr; bool h_sf_stats_valid = false;   // ... of the superframe totals when the filter rode in dabphy_process
     // stage timing (HIP events on the handle's stream, recorded when profiling is on)
     enum { ST_SYNC = 0, ST_DEMOD, ST_SNR, ST_FIC, ST_MSC_GATHER, ST_MSC_VITERBI, ST_RS, ST_COUNT };
     bool profiling = false;
@@ -223,6 +227,12 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
         h->h_desc = reinterpret_cast<FrameDesc*>(p);
         if (hipHostMalloc(&p, n * sizeof(float), hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
         h->h_snr = reinterpret_cast<float*>(p);
+        if (hipHostMalloc(&p, n * 384, hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_fib = reinterpret_cast<uint8_t*>(p);
+        if (hipHostMalloc(&p, n * 12, hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_ok = reinterpret_cast<uint8_t*>(p);
+        if (hipHostMalloc(&p, (size_t)cfg->n_ensembles * 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_sf_stats = reinterpret_cast<int32_t*>(p);
     }
     h->wide_sync = cfg->serial_sync == 0;
     if (const char* e = getenv("DABPHY_SYNC_WIDE")) h->wide_sync = atoi(e) != 0;    // (experiments: overrides the configuration)
@@ -230,6 +240,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (const char* e = getenv("DABPHY_MSC_PARTS")) h->msc_parts = atoi(e);          // (experiments: overrides the configuration)
     if (h->msc_parts < 0) return fail(DABPHY_ERR_INVALID);
     if (const char* e = getenv("DABPHY_FUSED_MSC")) h->fused_msc = atoi(e) != 0;
+    if (const char* e = getenv("DABPHY_VIT_SPLIT")) h->vit_split = atoi(e);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
@@ -251,6 +262,9 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->h_any_redo) e = hipHostFree(h->h_any_redo);
     if (h->h_desc) e = hipHostFree(h->h_desc);
     if (h->h_snr) e = hipHostFree(h->h_snr);
+    if (h->h_fib) e = hipHostFree(h->h_fib);
+    if (h->h_ok) e = hipHostFree(h->h_ok);
+    if (h->h_sf_stats) e = hipHostFree(h->h_sf_stats);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
@@ -763,9 +777,17 @@ int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t
 }
 
 // One batch: acquisition where needed, n_frames frame steps of the synchroniser, then the fully parallel stages.
+// DABPHY_DEBUG_TIMING=1: host-side time line of dabphy_process (microseconds since entry, averaged, printed by dabphy_destroy)
+struct HostTimeline { double acc[6] = {0, 0, 0, 0, 0, 0}; long n = 0; };
+static HostTimeline g_tl; static int g_tl_on = -1;
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int dabphy_process(dabphy_handle* h, uint32_t n_frames)
 {
     if (!h || n_frames == 0 || n_frames > h->cfg.max_frames) return DABPHY_ERR_INVALID;
+    if (g_tl_on < 0) g_tl_on = getenv("DABPHY_DEBUG_TIMING") ? 1 : 0;
+    const double tl0 = g_tl_on ? now_us() : 0.0; double tl[6] = {0, 0, 0, 0, 0, 0};
+    auto tick = [&](int i) { if (g_tl_on) tl[i] = now_us() - tl0; };
     if (!h->s_iq) { h->err = "no sample stream bound"; return DABPHY_ERR_STATE; }
     const uint32_t B = h->cfg.n_ensembles, F = n_frames;
     const int ring_frames = (int)h->cfg.max_frames + 5;
@@ -836,7 +858,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if ((r = queue_chain(h, cur, F))) return r;
         h->ahead = 1;
     }
+    tick(0);
     if ((r = resolve_chain(h, cur))) return r;
+    tick(1);
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_chain_end[cur], 0));      // this batch's chain only: later ones may still be running
     // Pipelined modes: the chains of the NEXT batch(es) (40 launches each) are handed to the driver after this batch's decode kernels, so
     // that the main stream never waits for the host, and start on the device
@@ -859,6 +883,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     da.osc_stats = h->d_osc_stats;
     mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
+    tick(2);
     mark(dabphy_handle::ST_DEMOD, true);
     if (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
@@ -901,6 +926,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // the host's copies of the descriptors and SNR reports leave here, beside the decoder, instead of behind the step's last kernel
         HIPCHK(h, hipMemcpyAsync(h->h_desc, d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
+        HIPCHK(h, hipMemcpyAsync(h->h_fib, h->s_fib.p, (size_t)B * F * 384, hipMemcpyDeviceToHost, fs));
+        HIPCHK(h, hipMemcpyAsync(h->h_ok, h->s_ok.p, (size_t)B * F * 12, hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
     // MSC: one gather + decode per protection class (stage events bracket the first class only: one class in the canonical ensemble).
@@ -908,7 +935,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     // Viterbi kernel -- VALU-bound -- runs on a side stream while part p + 1 is gathered -- HBM / LDS-DMA-bound --, and with auto
     // superframes the filter of part p follows its Viterbi on the same side stream.  The stage times then overlap (they are spans).
     h->last_frames = F;
-    h->sf_stats_ready = false;
+    h->sf_stats_ready = false; h->h_sf_stats_valid = false;
     bool sf_done_in_parts = false;
     // parts of a class: whole ensembles, whole 64-codeword groups, and (automatic choice) enough groups per part to fill the device
     auto parts_of = [&](const dabphy_handle::MscClass& cls) {
@@ -938,7 +965,16 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             fa.steps = cls.steps.as<MscStep>(); fa.n_windows = cls.n_windows; fa.start_bit = cls.start_bits.as<int32_t>(); fa.n_members = M; fa.desc = d_desc; fa.zero_off16 = (uint32_t)(((size_t)B * ring_frames * SOFT_PER_FRAME) >> 4);
             fa.c = c; fa.prbs_words = h->d_prbs_words;
             if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, false);
-            launch_viterbi_msc(fa, h->stream);
+            // Two launches of half the groups each, back to back.  A launch's last round of work-groups leaves execution slots idle;
+            // the benchmark batch's 5760 groups on 1024 SIMDs pay for 6 rounds either way (5.6 -> 6 or 2.8 + 2.8 -> 3 + 3), and the idle
+            // slots behind the FIRST half are where the next batch's synchroniser pass and the FIC decode find room in the middle
+            // of the step instead of behind it.
+            const int halves = (h->vit_split > 1 && c.n_groups >= 4096) ? h->vit_split : 1;
+            for (int p = 0; p < halves; p++) {
+                FusedMscArgs fp = fa;
+                fp.c.g_begin = (int)((int64_t)c.n_groups * p / halves); fp.c.g_end = (int)((int64_t)c.n_groups * (p + 1) / halves);
+                launch_viterbi_msc(fp, h->stream);
+            }
             if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
             continue;
         }
@@ -979,6 +1015,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
                 if (parts_of(cls) == 1 && is_dabplus_rate(cls) && (r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>()))) return r;
         }
         h->sf_stats_ready = true;
+        HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
+        h->h_sf_stats_valid = true;
     }
     if (depth) {
         if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
@@ -987,7 +1025,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     h->desc_sel = (cur + 1) % ND; h->ahead--;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
     h->last_frames = F;
+    tick(3);
     if ((r = sync(h))) return r;
+    tick(4);
+    if (g_tl_on) { for (int i = 0; i < 5; i++) g_tl.acc[i] += tl[i]; g_tl.n++; if (g_tl.n % 8 == 0) fprintf(stderr, "dabphy timing [us]: before resolve %.1f, resolved %.1f, demod launched %.1f, all launched %.1f, synced %.1f (n=%ld)\n", g_tl.acc[0] / g_tl.n, g_tl.acc[1] / g_tl.n, g_tl.acc[2] / g_tl.n, g_tl.acc[3] / g_tl.n, g_tl.acc[4] / g_tl.n, g_tl.n); }
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }
     return DABPHY_OK;
 }
@@ -1008,9 +1049,15 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
 {
     if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
     const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
-    HIPCHK(h, hipMemcpyAsync(fib, h->s_fib.p, n * 384, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(crc_ok, h->s_ok.p, n * 12, hipMemcpyDeviceToHost, h->stream));
-    return sync(h);
+    memcpy(fib, h->h_fib, n * 384); memcpy(crc_ok, h->h_ok, n * 12);      // (they crossed PCIe inside dabphy_process)
+    return DABPHY_OK;
+}
+
+int dabphy_get_fibs_host(dabphy_handle* h, const uint8_t** fib, const uint8_t** crc_ok)
+{
+    if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
+    *fib = h->h_fib; *crc_ok = h->h_ok;
+    return DABPHY_OK;
 }
 
 int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_t** d_crc_ok)
@@ -1326,6 +1373,11 @@ int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
 {
     if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
     int r;
+    if (h->sf_stats_ready && h->h_sf_stats_valid) {      // the filter rode in dabphy_process and its totals came back with the batch
+        h->sf_stats_ready = false; h->h_sf_stats_valid = false;
+        memcpy(stats, h->h_sf_stats, sizeof(int32_t) * 4 * h->cfg.n_ensembles);
+        return DABPHY_OK;
+    }
     if (!h->sf_stats_ready) { if ((r = launch_superframe_stats(h))) return r; }
     h->sf_stats_ready = false;                   // one filter pass per batch: a second call would feed the same frames again
     HIPCHK(h, hipMemcpyAsync(stats, h->sf_stats.p, sizeof(int32_t) * 4 * h->cfg.n_ensembles, hipMemcpyDeviceToHost, h->stream));

@@ -245,6 +245,14 @@ __device__ __forceinline__ uint16_t crc16_msb(const uint8_t* data, int len, bool
     return final_invert ? (uint16_t)~crc : crc;
 }
 
+// the same CRC a byte at a time through a 256-entry table of the polynomial (LDS): crc' = (crc << 8) ^ tab[(crc >> 8) ^ byte]
+__device__ __forceinline__ uint16_t crc16_msb_tab(const uint8_t* data, int len, bool initial_invert, bool final_invert, const uint16_t* tab)
+{
+    uint32_t crc = initial_invert ? 0xFFFFu : 0x0000u;
+    for (int o = 0; o < len; o++) crc = ((crc << 8) & 0xFFFFu) ^ tab[(crc >> 8) ^ data[o]];
+    return (uint16_t)(final_invert ? ~crc : crc);
+}
+
 template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
 __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArgs A)
 {
@@ -253,7 +261,13 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
     __shared__ uint8_t alpha_to[256], index_of[256];
     __shared__ int s_corr, s_unc, s_sync, s_au_start[8], s_aubad;
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];                   // error-path workspaces of the eight code words decoded at a time
+    __shared__ uint16_t s_crctab[256];                          // CRC-16-CCITT (0x1021), one byte per step: the AU checks
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
+    for (int v = threadIdx.x; v < 256; v += 64) {
+        uint16_t c = (uint16_t)(v << 8);
+        for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1);
+        s_crctab[v] = c;
+    }
     if (threadIdx.x == 0) s_aubad = 0;
     const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb;
@@ -273,15 +287,30 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
     int nv = 0;
     for (int f = 0; f < A.n_frames; f++) nv += A.desc[(size_t)b * A.n_frames + f].valid == 1 ? 1 : 0;
     const long long c0 = 4 * A.desc[(size_t)b * A.n_frames].frame_no;
-    for (int r = 0; r < 4 * nv; r++) {
-        // frames the reference's DabAudio would have emitted: after the 16-CIF fill of the time de-interleaver (dab-audio.cpp:146-149)
-        if (c0 + r < 16) continue;
-        const uint8_t* src = A.out + (bm * A.n_cif + r) * fb;
+    // A logical frame is fb = 24 * (bitrate / 8) bytes: it travels as 8-byte words, one per lane (three rounds at most), and row r + 1
+    // is requested before row r is worked on -- 80 dependent round trips to HBM were a third of this kernel's time.
+    const int fw = fb >> 3;                                                    // 8-byte words per row
+    constexpr int ROW_ROUNDS = (SF_MAX / 5 / 8 + 63) / 64;
+    uint2 nxt[ROW_ROUNDS];
+    auto row_fetch = [&](int r) {
+        const uint2* src = reinterpret_cast<const uint2*>(A.out + (bm * A.n_cif + r) * fb);
+#pragma unroll
+        for (int i = 0; i < ROW_ROUNDS; i++) if (t + 64 * i < fw) nxt[i] = src[t + 64 * i];
+    };
+    int r_first = 0;
+    while (r_first < 4 * nv && c0 + r_first < 16) r_first++;                   // frames before the 16-CIF fill of the time de-interleaver (dab-audio.cpp:146-149) are never emitted
+    if (r_first < 4 * nv) row_fetch(r_first);
+    for (int r = r_first; r < 4 * nv; r++) {
         __syncthreads();
         int dst_slot;
         if (frame_count == 5) { dst_slot = head; head = head == 4 ? 0 : head + 1; }   // :78-81 "shift the previous frames": drop the oldest
         else { dst_slot = head + frame_count; if (dst_slot >= 5) dst_slot -= 5; frame_count++; }
-        for (int i = t; i < fb; i += 64) s_raw[dst_slot * fb + i] = src[i];
+        {
+            uint2* dst = reinterpret_cast<uint2*>(s_raw + dst_slot * fb);
+#pragma unroll
+            for (int i = 0; i < ROW_ROUNDS; i++) if (t + 64 * i < fw) dst[t + 64 * i] = nxt[i];
+        }
+        if (r + 1 < 4 * nv) row_fetch(r + 1);
         __syncthreads();
         if (frame_count < 5) continue;
         for (int k = 0; k < 5; k++) {                                          // :97 decode on a copy, frames in age order
@@ -368,7 +397,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
         if (e_i < ne && ev[e_i].sync && au_i < ev[e_i].num_aus) {
             const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
             const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
-            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb(au, au_len - 2, true, true, 0x1021)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
+            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, s_crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
             else atomicAdd(&s_aubad, 1);
         }
     }
