@@ -12,7 +12,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/prof; rm -rf $O; mkdir -p $O
 BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt-schedule $BENCH_EXTRA"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $BENCH > $O/stats.log 2>&1
-KR='k_demod|k_viterbi|k_msc_gather|k_sync_find|k_sync_finish|k_fic_gather|k_rs_msc|k_superframe|k_acquire'
+KR='k_demod|k_viterbi|k_msc_gather|k_sync_|k_fic_gather|k_rs_msc|k_superframe|k_acquire'
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O -o pmc_write -- $BENCH > $O/pmc_write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-include-regex 'k_viterbi|k_msc_gather' --output-format csv -d $O -o pmc_vit -- $BENCH > $O/pmc_vit.log 2>&1

@@ -386,7 +386,10 @@ __global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_OCC) k_sync_finish
     sync_finish_body<false>(A, blockIdx.x, A.frame);
 }
 // the wide pass: work-group (frame, ensemble); throughput work, no priority
-__global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_OCC) k_sync_finish_wide(SyncArgs A)
+#ifndef SYNC_FINISH_WIDE_OCC
+#define SYNC_FINISH_WIDE_OCC SYNC_FINISH_OCC
+#endif
+__global__ void __launch_bounds__(FINISH_THREADS, SYNC_FINISH_WIDE_OCC) k_sync_finish_wide(SyncArgs A)
 {
     sync_finish_body<true>(A, blockIdx.y, blockIdx.x);
 }
