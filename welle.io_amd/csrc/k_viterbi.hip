@@ -418,7 +418,10 @@ __device__ __forceinline__ void bm_from_soft(u16x2 (&BM)[4], int v0, int v1, int
     BM[2] = asv(m2 | ((1020u - m2) << 16)); BM[3] = asv(m3 | ((1020u - m3) << 16));
 }
 
-__global__ void __launch_bounds__(64, 5) k_viterbi_msc(FusedMscArgs A)
+#ifndef VITM_OCC
+#define VITM_OCC 5
+#endif
+__global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lds[FM_LDS];
   const int lane = threadIdx.x;
