@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ensembles", type=int, default=256, help="ensembles per GPU")
-    ap.add_argument("--frames", type=int, default=20, help="transmission frames per ensemble and step")
+    ap.add_argument("--frames", type=int, default=32, help="transmission frames per ensemble and step (round 2 timed 16 ... 64: the kernels' per-frame cost falls with the batch depth up to about 32-48 frames; round 1 and most of round 2 ran 20)")
     ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and with it the parity check of this run)")
     ap.add_argument("--no-alt-schedule", action="store_true", help="skip the extra (untimed) pass with the other pipelined schedule")

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-B, F = int(os.environ.get("PROF_B", "256")), int(os.environ.get("PROF_F", "20"))
+B, F = int(os.environ.get("PROF_B", "256")), int(os.environ.get("PROF_F", "32"))
 
 shutil.copy(os.path.join(SRC, "stats_kernel_stats.csv"), os.path.join(DST, TAG + "_bench_kernel_stats.csv"))
 

@@ -7,7 +7,7 @@ from conftest import GPU_LIB  # noqa: E402
 import parity_cases as P  # noqa: E402
 from welle_io_amd import capi, synth  # noqa: E402
 
-B = int(os.environ.get("PROBE_B", "256")); F = int(os.environ.get("PROBE_F", "20"))
+B = int(os.environ.get("PROBE_B", "256")); F = int(os.environ.get("PROBE_F", "32"))
 x = synth.make_stream(5, snr_db=20, seed=1)
 frames = P.cut_frames(x, 4)
 d = capi.DabPhy(lib_path=GPU_LIB, demod_chunk=int(os.environ.get("PROBE_CHUNK", "15")))
