@@ -294,7 +294,7 @@ def main():
               "algorithmic_bytes": B * F * 72 * (4 * 1542 + 1536 // 8), "hbm_bytes": vj.get("hbm_bytes_per_launch") if vj else None,
               "valu_insts_per_launch": vj.get("valu_insts_per_launch") if vj else None,
               "counter_source": "static: profiles/viterbi_counters.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh; not measured by this run)" if vj else None}
-        if vj and vit_ms > 0:
+        if vj and vj.get("valu_insts_per_launch") and vit_ms > 0:
             ips = vj["valu_insts_per_launch"] / (vit_ms * 1e-3)
             rv.update(unit="wave-instructions/s", achieved=ips, peak=n_simd * CLOCK_HZ / 2.0, frac=ips / (n_simd * CLOCK_HZ / 2.0),
                       peak_note="MI355X_MICROARCH.md: one plain wave64 VALU instruction per SIMD every 2 cycles at 2.4 GHz")

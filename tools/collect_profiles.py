@@ -64,7 +64,7 @@ json.dump({
     "fetch_size_kb_raw": fk, "write_size_kb_raw": wk,
     "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 counts 128-B requests of wide coalesced streams at 64 B, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported",
     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
-    "command": "tools/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-include-regex ... -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline",
+    "command": "tools/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-include-regex ... -- python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-alt-schedule",
     "source": "profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv (median launch)" % (TAG, TAG),
     "traffic_over_algorithmic": hbm / alg,
 }, open(os.path.join(DST, "demod_hbm_traffic.json"), "w"), indent=1)
@@ -75,16 +75,25 @@ for k in sorted(fetch):
 
 # ---- Viterbi stage: instruction counts and HBM traffic of the MSC launch (grid = B*F*72/64 one-wave work-groups), for bench.py's
 # roofline_viterbi block; the ubench's issue costs
-vit_grid = B * F * 72            # work-items of the MSC launch (64 per group)
+vit_grid = B * F * 72            # work-items of the MSC launch (64 per group) on the two-kernel path
+
+
+def is_msc_launch(r):
+    """the fused MSC decode (any grid: a work-group walks several 64-codeword groups when there are more groups than wave slots), or
+    the MSC launch of the two-kernel path (the FIC class uses the same k_viterbi with a smaller grid)"""
+    name = r["Kernel_Name"]
+    return "k_viterbi_msc" in name or ("k_viterbi(" in name and int(r["Grid_Size"]) == vit_grid)
+
+
 if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
     shutil.copy(os.path.join(SRC, "pmc_vit_counter_collection.csv"), os.path.join(DST, TAG + "_pmc_sq_viterbi_gather.csv"))
     acc = {}
     for r in rows("pmc_vit_counter_collection.csv"):
-        if "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid:        # k_viterbi_msc (fused) or k_viterbi (two-kernel path)
+        if is_msc_launch(r):
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     med = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
-    fv = [float(r["Counter_Value"]) for r in rows("pmc_fetch_counter_collection.csv") if r["Counter_Name"] == "FETCH_SIZE" and "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid]
-    wv = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and "k_viterbi" in r["Kernel_Name"] and int(r["Grid_Size"]) == vit_grid]
+    fv = [float(r["Counter_Value"]) for r in rows("pmc_fetch_counter_collection.csv") if r["Counter_Name"] == "FETCH_SIZE" and is_msc_launch(r)]
+    wv = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and is_msc_launch(r)]
     fg = [float(r["Counter_Value"]) for r in rows("pmc_fetch_counter_collection.csv") if r["Counter_Name"] == "FETCH_SIZE" and "k_msc_gather" in r["Kernel_Name"]]
     wg = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and "k_msc_gather" in r["Kernel_Name"]]
     mid = lambda v: sorted(v)[len(v) // 2] if v else 0.0
