@@ -587,11 +587,16 @@ void launch_viterbi_msc(const FusedMscArgs& a, hipStream_t s)
     }
     const int n = a.c.g_end - a.c.g_begin;
     if (n <= 0) return;
-    const int per = (n + 8 * n_simd - 1) / (8 * n_simd);
+    // One work-group (= one wave) per resident wave slot: VITM_OCC per SIMD.  With more groups than slots work-group i walks groups
+    // i, i + grid, ... (the kernel's loop), so every SIMD gets the same number of groups to within one -- 9216 groups on 5120 slots:
+    // four waves with two groups and one with one on every SIMD, instead of SIMDs with five and SIMDs with four two-group waves.
+    static int occ = 0;
+    if (!occ) { const char* e = getenv("DABPHY_VITM_SLOTS"); occ = e ? atoi(e) : VITM_OCC; if (occ < 1) occ = VITM_OCC; }
+    const int grid = n < occ * n_simd ? n : occ * n_simd;
     // (experiments: extra dynamic LDS per wave caps the kernel's occupancy and leaves registers to the synchroniser's kernels)
     static int pad = -1;
     if (pad < 0) { const char* e = getenv("DABPHY_VIT_LDS_PAD"); pad = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k_viterbi_msc, dim3((n + per - 1) / per), dim3(64), (size_t)pad, s, a);
+    hipLaunchKernelGGL(k_viterbi_msc, dim3(grid), dim3(64), (size_t)pad, s, a);
 }
 
 // ------------------------------------------------------------------------------------------ linear gather
