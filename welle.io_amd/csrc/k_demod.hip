@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     // to symbol k, from LDS), not a chain of k products: the unchecked conversion's error budget (osc_exact.h) counts on it.
     dc64 base0{};
     if (A.mix) {
-        osc_chain_steps(osc, d.f_sym); base0 = osc_exp(cur.ph); osc.base = base0;
+        if (s_begin == 1 && d.f_prs != d.f_sym) osc_chain_steps(osc, d.f_sym);   // (the reference symbol's factors serve unless it was the PRS pulled at another frequency)
+        base0 = osc_exp(cur.ph); osc.base = base0;
         if (t < s_end - s_begin) s_symstep[t] = osc_step((int64_t)t * T_S, d.f_sym);      // (published by the barrier that opens the loop)
     }
     if (staged) dma_issue(sym0);       // overlaps nothing yet (the reference symbol is done), but primes the pipeline
