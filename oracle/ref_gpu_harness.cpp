@@ -10,6 +10,7 @@
 #include <vector>
 #include "gpu_radio_receiver.h"
 #include "gpu_batch_receiver.h"
+#include "gpu_node_receiver.h"
 #include "../include/dabphy.h"
 
 namespace {
@@ -151,6 +152,36 @@ int gpu_scan_run(const float* iq, int64_t n_samples, int32_t* calls, int cap)
 // ---- batch mode: n_ens ensembles (streams of equal length, [n_ens][n_samples] cf32), each with its own FIBProcessor;
 // out per ensemble: ensemble id, number of services listed, number of FIBs that passed the CRC, onServiceDetected calls
 int gpu_batch_run2(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int signal_clock, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii);
+// GpuNodeReceiver: n_ens ensembles (iq = [n_ens][n_samples]) sharded over `n_devices` shards on the devices listed (a device may repeat);
+// outputs per GLOBAL ensemble as gpu_batch_run
+int gpu_node_run(const float* iq, int64_t n_samples, int n_ens, const int32_t* devices, int n_devices, int frames_per_step, int n_steps,
+                 int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_shards)
+{
+    std::vector<std::unique_ptr<Rec>> recs;
+    std::vector<RadioControllerInterface*> ctl;
+    std::vector<int> fib_ok(n_ens, 0);
+    struct CountRec : Rec { int* ok; void onFIBDecodeSuccess(bool good, const uint8_t* bits) override { if (good) (*ok)++; Rec::onFIBDecodeSuccess(good, bits); } };
+    for (int e = 0; e < n_ens; e++) { auto r = std::unique_ptr<CountRec>(new CountRec); r->ok = &fib_ok[e]; ctl.push_back(r.get()); recs.push_back(std::move(r)); }
+    try {
+        RadioReceiverOptions rro;
+        GpuNodeReceiver rx(ctl, (uint32_t)frames_per_step, rro, std::vector<int>(devices, devices + n_devices));
+        *n_shards = (int32_t)rx.shards();
+        for (size_t s = 0; s < rx.shards(); s++) {
+            const size_t lo = rx.first_ensemble(s), n = rx.at(s).ensembles();
+            if (dabphy_stream_upload(rx.at(s).phy(), iq + 2 * lo * (size_t)n_samples, (uint64_t)n_samples, 0) != DABPHY_OK) return -2;
+            (void)n;
+        }
+        for (int k = 0; k < n_steps; k++) rx.process((uint32_t)frames_per_step);
+        for (int e = 0; e < n_ens; e++) {
+            eid[e] = rx.getEnsembleId(e); n_listed[e] = (int32_t)rx.getServiceList(e).size(); n_fib_ok[e] = fib_ok[e];
+            n_detected[e] = recs[e]->n_services;
+        }
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "gpu_node_run: %s\n", ex.what());
+        return -1;
+    }
+    return 0;
+}
 int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii)
 {
     return gpu_batch_run2(iq, n_samples, n_ens, frames_per_step, n_steps, 1, eid, n_listed, n_fib_ok, n_detected, n_tii);

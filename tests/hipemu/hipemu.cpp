@@ -1,6 +1,7 @@
 // tests/hipemu/hipemu.cpp -- TEST INFRASTRUCTURE: fiber scheduler behind tests/hipemu/hip/hip_runtime.h.
 #include "hip/hip_runtime.h"
 #include <stdexcept>
+#include <mutex>
 
 hipemu_idx threadIdx, blockIdx, blockDim, gridDim;
 
@@ -84,7 +85,11 @@ unsigned long long hipemu_ballot_impl(bool p) {
     return m;
 }
 
+// One kernel at a time: the model keeps its block state (and the statics that stand in for LDS) in globals.  Host code with several
+// threads (welle.io_amd/host/gpu_node_receiver.cpp: one per shard) then simply takes turns, kernel by kernel.
+static std::mutex g_launch_mutex;
 void hipemu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    std::lock_guard<std::mutex> one_at_a_time(g_launch_mutex);
     const int nt = (int)(block.x * block.y * block.z);
     if (nt > 1024) throw std::runtime_error("hipemu: block too large");
     if ((int)B.f.size() < nt) {

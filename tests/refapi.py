@@ -524,6 +524,19 @@ def gpu_batch_services(iq, frames_per_step, n_steps, signal_clock=True, lib=GPU_
     return nl, nd
 
 
+def gpu_node_run(iq, devices, frames_per_step, n_steps, lib=GPU_EMU_SO):
+    """GpuNodeReceiver: [n_ens][n_samples] cf32 sharded by ensemble over one GpuBatchReceiver per entry of `devices`, the shards decoded
+    concurrently -> per GLOBAL ensemble (eid, services listed, FIBs ok, onServiceDetected calls), number of shards"""
+    L = C.CDLL(lib)
+    iq = np.ascontiguousarray(iq, np.complex64); B, n = iq.shape
+    dev = np.asarray(devices, np.int32)
+    eid = np.zeros(B, np.int32); nl = np.zeros(B, np.int32); ok = np.zeros(B, np.int32); nd = np.zeros(B, np.int32); ns = np.zeros(1, np.int32)
+    L.gpu_node_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = L.gpu_node_run(_p(iq), n, B, _p(dev), len(dev), frames_per_step, n_steps, _p(eid), _p(nl), _p(ok), _p(nd), _p(ns))
+    assert r == 0, "gpu_node_run failed (%d)" % r
+    return eid, nl, ok, nd, int(ns[0])
+
+
 def gpu_batch_run(iq, frames_per_step, n_steps, lib=GPU_EMU_SO):
     """GpuBatchReceiver (one reference FIBProcessor per ensemble) over [n_ens][n_samples] cf32 -> per-ensemble (eid, services listed, FIBs ok, onServiceDetected calls)"""
     L = C.CDLL(lib)

@@ -33,6 +33,19 @@ def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(gpu):
     assert list(eid) == eids and (listed == 18).all() and (ok >= 48).all() and (ok % 12 == 0).all()
 
 
+def test_node_receiver_shards_ensembles_over_devices(gpu):
+    """GpuNodeReceiver on the device: five ensembles over two shards (both on this box's one GPU: two handles, two host threads
+    decoding concurrently) = one GpuBatchReceiver over all five"""
+    import numpy as np
+    streams = [synth.make_stream(9, eid=0x1000 + 0x111 * e, snr_db=20, cfo_hz=[0, 120, -80, 33, -7][e], seed=60 + e) for e in range(5)]
+    x = np.stack(streams)
+    one = R.gpu_batch_run(x, 4, 2, lib=R.GPU_HIP_SO)
+    eid, listed, ok, detected, shards = R.gpu_node_run(x, [0, 0], 4, 2, lib=R.GPU_HIP_SO)
+    assert shards == 2 and list(eid) == [0x1000 + 0x111 * e for e in range(5)]
+    assert list(listed) == list(one[1]) and list(ok) == list(one[2]) and list(detected) == list(one[3])
+    assert (listed == 18).all() and (ok >= 48).all()
+
+
 def test_facade_accepts_all_sync_options(gpu):
     import numpy as np
     x, tx = synth.make_stream(10, snr_db=18, cfo_hz=2300, delay=300, return_tx=True, seed=6)

@@ -95,6 +95,23 @@ def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(emu):
         assert ok[e] >= 12 * 4 and ok[e] % 12 == 0      # every FIB of every demodulated frame passed its CRC
 
 
+def test_node_receiver_shards_ensembles_over_devices(emu):
+    """GpuNodeReceiver (SURVEY 8e in-process: shard by ensemble, one GpuBatchReceiver = one handle = one device per shard, the shards
+    decoded concurrently by one host thread each, no collective): five different ensembles over two shards (3 + 2) give what one
+    GpuBatchReceiver gives for all five; more devices than ensembles leave no empty shard"""
+    nf = 9
+    streams = [synth.make_stream(nf, eid=0x1000 + 0x111 * e, snr_db=20, cfo_hz=[0, 120, -80, 33, -7][e], seed=60 + e) for e in range(5)]
+    x = np.stack(streams)
+    one = R.gpu_batch_run(x, 4, 2, lib=R.GPU_EMU_SO)
+    eid, listed, ok, detected, shards = R.gpu_node_run(x, [0, 0], 4, 2, lib=R.GPU_EMU_SO)
+    assert shards == 2
+    assert list(eid) == list(one[0]) == [0x1000 + 0x111 * e for e in range(5)]
+    assert list(listed) == list(one[1]) and list(ok) == list(one[2]) and list(detected) == list(one[3])
+    assert all(v == 18 for v in listed) and all(v >= 48 for v in ok)
+    *_, shards = R.gpu_node_run(x[:2], [0, 0, 0, 0], 4, 1, lib=R.GPU_EMU_SO)
+    assert shards == 2
+
+
 def test_facade_reports_tii_measurements(emu):
     """RadioReceiverOptions::decodeTII through the façade: onTIIMeasurement carries what the TIIDecoder restatement computes from the
     same frames (the reference's own decoder thread drops frames at will, so the oracle -- pinned to the real class fed pair by

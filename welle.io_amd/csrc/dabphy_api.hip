@@ -105,6 +105,19 @@ struct dabphy_handle {
 
 namespace {
 
+// A handle lives on one device; HIP's current device is a property of the calling THREAD.  Every entry point makes the handle's device
+// current for its duration, so that one process can own several handles on several devices (welle.io_amd/host/gpu_node_receiver.h:
+// one host thread per device) and a caller's own device selection survives the call.
+struct DeviceBind {
+    int prev = -1; bool switched = false;
+    explicit DeviceBind(const dabphy_handle* h)
+    {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->cfg.device) switched = hipSetDevice(h->cfg.device) == hipSuccess;
+    }
+    ~DeviceBind() { if (switched) { hipError_t e = hipSetDevice(prev); (void)e; } }
+    DeviceBind(const DeviceBind&) = delete; DeviceBind& operator=(const DeviceBind&) = delete;
+};
+
 #define HIPCHK(h, call)                                                                                   \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return DABPHY_ERR_HIP; } } while (0)
 
@@ -249,6 +262,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
 
 void dabphy_destroy(dabphy_handle* h)
 {
+    DeviceBind dev_(h);
     if (!h) return;
     hipError_t e;
     if (h->sync_stream) { e = hipStreamSynchronize(h->sync_stream); e = hipStreamDestroy(h->sync_stream); }
@@ -288,6 +302,7 @@ const char* dabphy_device_name(const dabphy_handle* h) { return h ? h->devname :
 
 int dabphy_get_config(const dabphy_handle* h, dabphy_config* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out) return DABPHY_ERR_INVALID;
     *out = h->cfg;
     return DABPHY_OK;
@@ -299,6 +314,7 @@ constexpr int HIST_CAP = 64;     // window searches remembered per ensemble for 
 
 int dabphy_set_options(dabphy_handle* h, int32_t fft_placement, int32_t freqsync_method, int32_t disable_coarse, int32_t* restarted)
 {
+    DeviceBind dev_(h);
     if (!h || fft_placement < 0 || fft_placement > 2 || freqsync_method < 0 || freqsync_method > 2) return DABPHY_ERR_INVALID;
     const bool need_reset = (h->cfg.disable_coarse != 0) != (disable_coarse != 0);      // ofdm-processor.cpp:521
     if (h->s_desc2[0].p) { int r = resolve_all_chains(h); if (r) return r; }            // frames synchronised ahead keep the options they were queued with
@@ -320,6 +336,7 @@ int dabphy_protection_input_bits(const dabphy_protection* p) { return p ? protec
 
 int dabphy_demod_frames(dabphy_handle* h, const float* frames, uint32_t n_frames, int8_t* soft, float* constellation, float* snr)
 {
+    DeviceBind dev_(h);
     if (!h || !frames || !soft || n_frames == 0) return DABPHY_ERR_INVALID;
     const size_t per = (size_t)T_U + 75 * (size_t)T_S;
     int r;
@@ -368,12 +385,14 @@ static int run_lin_decode(dabphy_handle* h, const int8_t* in, size_t in_stride, 
 
 int dabphy_viterbi_batch(dabphy_handle* h, const int8_t* in, uint32_t nbits, uint32_t n_codewords, uint8_t* out)
 {
+    DeviceBind dev_(h);
     if (!h || !in || !out || n_codewords == 0 || nbits == 0 || nbits % 32 || nbits > PRBS_MAX_BITS) return DABPHY_ERR_INVALID;
     return run_lin_decode(h, in, (size_t)4 * (nbits + 6), nullptr, (int)nbits, n_codewords, 0, out);
 }
 
 int dabphy_msc_deconvolve(dabphy_handle* h, const dabphy_protection* prot, const int8_t* in, uint32_t n_codewords, uint8_t* out)
 {
+    DeviceBind dev_(h);
     if (!h || !prot || !in || !out || n_codewords == 0 || !protection_valid(prot) || prot->nbits > PRBS_MAX_BITS) return DABPHY_ERR_INVALID;
     const std::vector<int16_t> m = depuncture_map(prot);
     int r;
@@ -385,6 +404,7 @@ int dabphy_msc_deconvolve(dabphy_handle* h, const dabphy_protection* prot, const
 
 int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, uint8_t* fib, uint8_t* crc_ok, int32_t* ratio_percent)
 {
+    DeviceBind dev_(h);
     if (!h || !soft || !fib || !crc_ok || n_frames == 0) return DABPHY_ERR_INVALID;
     int r;
     if ((r = ensure(h, h->in8, (size_t)n_frames * 9216))) return r;
@@ -517,6 +537,7 @@ static int reset_synchroniser(dabphy_handle* h, bool decoder_too)
 
 int dabphy_reset(dabphy_handle* h)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     int r = reset_synchroniser(h, true); if (r) return r;
     h->desc_sel = 0; h->n_wide_passes = h->n_wide_fallbacks = 0;
@@ -531,6 +552,7 @@ int dabphy_reset(dabphy_handle* h)
 int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_samples, uint64_t stride_samples,
                               uint64_t n_valid, int32_t loop)
 {
+    DeviceBind dev_(h);
     if (!h || !d_iq || ring_samples < (uint64_t)T_F || stride_samples < ring_samples) return DABPHY_ERR_INVALID;
     h->s_iq = reinterpret_cast<const cf32*>(d_iq); h->s_ring = ring_samples; h->s_stride = stride_samples;
     h->s_valid = n_valid; h->s_enqueued = 0; h->commit_slot = -1; h->s_loop = loop;
@@ -539,6 +561,7 @@ int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_
 
 int dabphy_stream_upload(dabphy_handle* h, const float* iq, uint64_t n_samples, int32_t loop)
 {
+    DeviceBind dev_(h);
     if (!h || !iq || n_samples < (uint64_t)T_F) return DABPHY_ERR_INVALID;
     const size_t bytes = (size_t)h->cfg.n_ensembles * n_samples * sizeof(cf32);
     int r;
@@ -550,6 +573,7 @@ int dabphy_stream_upload(dabphy_handle* h, const float* iq, uint64_t n_samples, 
 
 int dabphy_stream_open(dabphy_handle* h, uint64_t ring_samples)
 {
+    DeviceBind dev_(h);
     if (!h || ring_samples < 4 * (uint64_t)T_F) return DABPHY_ERR_INVALID;
     const size_t bytes = (size_t)h->cfg.n_ensembles * ring_samples * sizeof(cf32);
     int r;
@@ -560,6 +584,7 @@ int dabphy_stream_open(dabphy_handle* h, uint64_t ring_samples)
 
 int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples)
 {
+    DeviceBind dev_(h);
     if (!h || !iq || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring) return DABPHY_ERR_INVALID;
     // the chain that may be running ahead must not race with the copy
     HIPCHK(h, hipStreamSynchronize(h->sync_stream));
@@ -577,6 +602,7 @@ int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples)
 
 int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format)
 {
+    DeviceBind dev_(h);
     if (format == DABPHY_FMT_CF32) return dabphy_stream_write(h, reinterpret_cast<const float*>(data), n_samples);
     if (!h || !data || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring ||
         format < DABPHY_FMT_U8 || format > DABPHY_FMT_S16BE) return DABPHY_ERR_INVALID;
@@ -596,6 +622,7 @@ int dabphy_stream_write_raw(dabphy_handle* h, const void* data, uint64_t n_sampl
 
 int dabphy_stream_read(dabphy_handle* h, uint32_t ensemble, uint64_t pos, uint64_t n_samples, float* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out || !h->s_iq || ensemble >= h->cfg.n_ensembles || n_samples == 0 || n_samples > h->s_ring) return DABPHY_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     const cf32* src = h->s_iq + (size_t)ensemble * h->s_stride;
@@ -607,6 +634,7 @@ int dabphy_stream_read(dabphy_handle* h, uint32_t ensemble, uint64_t pos, uint64
 
 int dabphy_stream_write_raw_async(dabphy_handle* h, const void* data, uint64_t n_samples, int32_t format)
 {
+    DeviceBind dev_(h);
     if (!h || !data || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring ||
         format < DABPHY_FMT_U8 || format > DABPHY_FMT_S16BE) return DABPHY_ERR_INVALID;
     const size_t bps = (format == DABPHY_FMT_U8 || format == DABPHY_FMT_S8) ? 2 : 4;
@@ -629,6 +657,7 @@ int dabphy_stream_write_raw_async(dabphy_handle* h, const void* data, uint64_t n
 
 int dabphy_stream_commit(dabphy_handle* h)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     if (h->s_enqueued > h->s_valid) { h->s_valid = h->s_enqueued; h->commit_slot = h->raw_sel ^ 1; }
     return DABPHY_OK;
@@ -644,6 +673,7 @@ void dabphy_host_free(void* p) { if (p) { hipError_t e = hipHostFree(p); (void)e
 
 uint64_t dabphy_stream_consumed(dabphy_handle* h)
 {
+    DeviceBind dev_(h);
     if (!h) return 0;
     std::vector<RxState> st(h->cfg.n_ensembles);
     if (hipStreamSynchronize(h->sync_stream) != hipSuccess) return 0;
@@ -655,6 +685,7 @@ uint64_t dabphy_stream_consumed(dabphy_handle* h)
 
 int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n)
 {
+    DeviceBind dev_(h);
     if (!h || (n && !list)) return DABPHY_ERR_INVALID;
     for (uint32_t i = 0; i < n; i++) {
         const dabphy_subchannel& s = list[i];
@@ -784,6 +815,7 @@ static inline double now_us() { return std::chrono::duration<double, std::micro>
 
 int dabphy_process(dabphy_handle* h, uint32_t n_frames)
 {
+    DeviceBind dev_(h);
     if (!h || n_frames == 0 || n_frames > h->cfg.max_frames) return DABPHY_ERR_INVALID;
     if (g_tl_on < 0) g_tl_on = getenv("DABPHY_DEBUG_TIMING") ? 1 : 0;
     const double tl0 = g_tl_on ? now_us() : 0.0; double tl[6] = {0, 0, 0, 0, 0, 0};
@@ -1035,6 +1067,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
 
 int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out || !h->last_frames) return DABPHY_ERR_INVALID;
     const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
     for (size_t i = 0; i < n; i++) {
@@ -1047,6 +1080,7 @@ int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out)
 
 int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
 {
+    DeviceBind dev_(h);
     if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
     const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
     memcpy(fib, h->h_fib, n * 384); memcpy(crc_ok, h->h_ok, n * 12);      // (they crossed PCIe inside dabphy_process)
@@ -1055,6 +1089,7 @@ int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
 
 int dabphy_get_fibs_host(dabphy_handle* h, const uint8_t** fib, const uint8_t** crc_ok)
 {
+    DeviceBind dev_(h);
     if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
     *fib = h->h_fib; *crc_ok = h->h_ok;
     return DABPHY_OK;
@@ -1062,6 +1097,7 @@ int dabphy_get_fibs_host(dabphy_handle* h, const uint8_t** fib, const uint8_t** 
 
 int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_t** d_crc_ok)
 {
+    DeviceBind dev_(h);
     if (!h || !d_fib || !d_crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
     *d_fib = h->s_fib.as<uint8_t>(); *d_crc_ok = h->s_ok.as<uint8_t>();
     return DABPHY_OK;
@@ -1069,6 +1105,7 @@ int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_
 
 int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first_stale_frame)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     std::vector<DecState> st(h->cfg.n_ensembles);
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
@@ -1082,6 +1119,7 @@ int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first
 
 int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts_at_first_lock)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     std::vector<RxState> st(h->cfg.n_ensembles);
     if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
@@ -1094,6 +1132,7 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
 
 int dabphy_get_osc_stats(dabphy_handle* h, uint64_t* unchecked_symbols, uint64_t* checked_symbols)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     unsigned long long v[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(v, h->d_osc_stats, sizeof v, hipMemcpyDeviceToHost, h->stream));
@@ -1105,6 +1144,7 @@ int dabphy_get_osc_stats(dabphy_handle* h, uint64_t* unchecked_symbols, uint64_t
 
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
     if (passes) *passes = h->n_wide_passes;
@@ -1121,6 +1161,7 @@ int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t*
 
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     std::vector<RxState> st(h->cfg.n_ensembles);
     if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
@@ -1133,6 +1174,7 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
 
 int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
 {
+    DeviceBind dev_(h);
     if (!h || !ratio_percent) return DABPHY_ERR_INVALID;
     std::vector<DecState> st(h->cfg.n_ensembles);
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
@@ -1143,6 +1185,7 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
 
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows)
 {
+    DeviceBind dev_(h);
     if (!h || !out || subch_index >= h->subch.size() || !h->last_frames) return DABPHY_ERR_INVALID;
     if (out_capacity < (size_t)h->cfg.n_ensembles * 4 * h->last_frames * (h->subch[subch_index].prot.nbits / 8)) { h->err = "dabphy_get_msc: output buffer too small"; return DABPHY_ERR_INVALID; }
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
@@ -1175,6 +1218,7 @@ int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t 
 
 int dabphy_get_impulse_response(dabphy_handle* h, float* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out || !h->last_frames || !h->cfg.want_impulse_response) return DABPHY_ERR_INVALID;
     HIPCHK(h, hipMemcpyAsync(out, h->cur_cir, (size_t)h->cfg.n_ensembles * h->last_frames * T_U * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     return sync(h);
@@ -1182,6 +1226,7 @@ int dabphy_get_impulse_response(dabphy_handle* h, float* out)
 
 int dabphy_get_null_symbols(dabphy_handle* h, float* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out || !h->last_frames || !h->last_desc || !h->s_iq) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
     int r;
@@ -1196,6 +1241,7 @@ int dabphy_get_null_symbols(dabphy_handle* h, float* out)
 
 int dabphy_get_constellation(dabphy_handle* h, float* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out || !h->last_frames || !h->cfg.want_constellation) return DABPHY_ERR_INVALID;
     HIPCHK(h, hipMemcpyAsync(out, h->s_con.p, (size_t)h->cfg.n_ensembles * h->last_frames * 1200 * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
     return sync(h);
@@ -1203,6 +1249,7 @@ int dabphy_get_constellation(dabphy_handle* h, float* out)
 
 int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, int8_t* out)
 {
+    DeviceBind dev_(h);
     if (!h || !out || ensemble >= h->cfg.n_ensembles || frame >= h->last_frames) return DABPHY_ERR_INVALID;
     const FrameDesc& d = h->h_desc[(size_t)ensemble * h->last_frames + frame];
     const size_t slot = (size_t)(d.frame_no % h->soft_ring);
@@ -1212,6 +1259,7 @@ int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, in
 
 int dabphy_set_profiling(dabphy_handle* h, int32_t on)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     h->profiling = on != 0;
     return DABPHY_OK;
@@ -1219,6 +1267,7 @@ int dabphy_set_profiling(dabphy_handle* h, int32_t on)
 
 int dabphy_get_stage_times(dabphy_handle* h, float* ms)
 {
+    DeviceBind dev_(h);
     if (!h || !ms) return DABPHY_ERR_INVALID;
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) {
         ms[i] = 0.0f;
@@ -1230,6 +1279,7 @@ int dabphy_get_stage_times(dabphy_handle* h, float* ms)
 
 int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint32_t n_sf, int32_t* corrected, int32_t* uncorrectable)
 {
+    DeviceBind dev_(h);
     if (!h || !sf || !corrected || !uncorrectable || s_per_sf == 0 || n_sf == 0) return DABPHY_ERR_INVALID;
     const size_t bytes = (size_t)120 * s_per_sf * n_sf;
     int r;
@@ -1248,6 +1298,7 @@ int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint
 
 int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* first_cif, int32_t* corrected, int32_t* uncorrectable)
 {
+    DeviceBind dev_(h);
     if (!h || !first_cif || !h->last_frames || subch_index >= (int32_t)h->subch.size()) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
     const int n_cif = (int)(4 * F), n_sf = n_cif / 5 + 1;
@@ -1312,6 +1363,7 @@ int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, 
 
 int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
 {
+    DeviceBind dev_(h);
     static_assert(sizeof(dabphy_sf_event) == sizeof(SfEvent), "event layouts must match");
     if (!h || !events || !n_events || subch_index >= h->subch.size() || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
@@ -1357,6 +1409,7 @@ int launch_superframe_stats(dabphy_handle* h)
 
 int dabphy_set_track_slevel(dabphy_handle* h, int32_t on)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     h->track_slevel = on != 0;
     return DABPHY_OK;
@@ -1364,6 +1417,7 @@ int dabphy_set_track_slevel(dabphy_handle* h, int32_t on)
 
 int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     h->sf_auto = on != 0;
     return DABPHY_OK;
@@ -1371,6 +1425,7 @@ int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on)
 
 int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
 {
+    DeviceBind dev_(h);
     if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
     int r;
     if (h->sf_stats_ready && h->h_sf_stats_valid) {      // the filter rode in dabphy_process and its totals came back with the batch
@@ -1387,6 +1442,7 @@ int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
 // RadioReceiverOptions::decodeTII (radio-receiver-options.h:75, consulted once per frame at ofdm-processor.cpp:376-386,464)
 int dabphy_set_tii(dabphy_handle* h, int32_t on)
 {
+    DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     if (on && !h->tii_rot.p) {
         const TiiTables& T = tii_tables();
@@ -1410,6 +1466,7 @@ int dabphy_set_tii(dabphy_handle* h, int32_t on)
 
 int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, uint32_t max_per_ensemble)
 {
+    DeviceBind dev_(h);
     if (!h || !n || (!out && max_per_ensemble) || !h->last_frames) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles;
     if (!h->tii_ran) { for (uint32_t b = 0; b < B; b++) n[b] = 0; return DABPHY_OK; }
@@ -1427,6 +1484,7 @@ int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, ui
 
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)
 {
+    DeviceBind dev_(h);
     if (!h || !counts) return DABPHY_ERR_INVALID;
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, 3 * sizeof *d));
@@ -1443,6 +1501,7 @@ int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)
 int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
                       int32_t mix, int32_t f_hz, uint32_t iters, float* ms)
 {
+    DeviceBind dev_(h);
     if (!h || !frames || !ms || n_src == 0 || n_ens == 0 || n_frames == 0 || iters == 0) return DABPHY_ERR_INVALID;
     const size_t per = (size_t)T_U + 75 * (size_t)T_S;
     const size_t total = (size_t)n_ens * n_frames;
@@ -1481,6 +1540,7 @@ int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uin
 
 int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather, float* ms_decode)
 {
+    DeviceBind dev_(h);
     if (!h || !ms_gather || !ms_decode || nbits == 0 || nbits % 32 || nbits > PRBS_MAX_BITS || n_codewords == 0 || iters == 0) return DABPHY_ERR_INVALID;
     const size_t stride = (size_t)4 * (nbits + 6);
     int r;

@@ -1,0 +1,49 @@
+// welle.io_amd/host/gpu_node_receiver.h -- the ensembles of one node sharded over its GPUs.
+//
+// One DAB ensemble is a single stream, so the path shards by ensemble and nothing crosses devices on the data path: ensemble e of N
+// lives on shard e / ceil(N / shards), every shard is a GpuBatchReceiver (one libdabphy_hip.so handle = one device, its own
+// reference FIBProcessor per ensemble) driven by its own host thread, and process() is the only synchronisation point -- it returns
+// when every shard has decoded its batch and handed its FIBs to its controllers.  This is the in-process counterpart of
+// `bench.py --gpus N` (one process per GPU over torch.distributed, where the FIC of all ranks is gathered to rank 0 over RCCL): a C++
+// host that owns the whole node needs no collective at all, the controllers are already in its address space.
+//
+// Threading contract: the controllers of different shards are called concurrently (one thread per shard), those of one shard in
+// ensemble order from that shard's thread; a controller object must therefore not be shared between ensembles of different shards.
+// The library makes a handle's device current for the duration of every call (csrc/dabphy_api.hip: DeviceBind), so the caller's own
+// thread may talk to any shard's phy() -- sample input, sub-channel selection -- between process() calls.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "gpu_batch_receiver.h"
+
+class GpuNodeReceiver {
+    public:
+        // controllers.size() = number of ensembles on the node; devices = HIP ordinals, one shard each (a device may be listed twice:
+        // two shards then share it, which is how the single-GPU test runs)
+        GpuNodeReceiver(const std::vector<RadioControllerInterface*>& controllers, uint32_t max_frames, RadioReceiverOptions rro, const std::vector<int>& devices);
+        GpuNodeReceiver(const GpuNodeReceiver&) = delete;
+        GpuNodeReceiver& operator=(const GpuNodeReceiver&) = delete;
+
+        size_t ensembles() const { return n_ens; }
+        size_t shards() const { return shard.size(); }
+        size_t first_ensemble(size_t s) const { return first[s]; }           // global index of shard s's ensemble 0
+        size_t shard_of(size_t e) const { return e / per; }
+        GpuBatchReceiver& at(size_t s) { return *shard[s]; }                 // its phy(): dabphy_stream_* / dabphy_set_subchannels for ITS ensembles
+
+        // decode the next n_frames of every ensemble on every device, concurrently; returns the number of (ensemble, frame) pairs demodulated
+        size_t process(uint32_t n_frames);
+
+        // the reference's getters by global ensemble index (RadioReceiver::getEnsembleId() ... radio-receiver.h:88-104)
+        uint16_t getEnsembleId(size_t e) const { return shard[e / per]->getEnsembleId(e % per); }
+        DabLabel getEnsembleLabel(size_t e) const { return shard[e / per]->getEnsembleLabel(e % per); }
+        std::vector<Service> getServiceList(size_t e) const { return shard[e / per]->getServiceList(e % per); }
+        std::list<ServiceComponent> getComponents(size_t e, const Service& s) const { return shard[e / per]->getComponents(e % per, s); }
+        Subchannel getSubchannel(size_t e, const ServiceComponent& sc) const { return shard[e / per]->getSubchannel(e % per, sc); }
+        void setSignalClock(bool on) { for (auto& s : shard) s->setSignalClock(on); }
+
+    private:
+        size_t n_ens = 0, per = 1;
+        std::vector<std::unique_ptr<GpuBatchReceiver>> shard;
+        std::vector<size_t> first;
+};
