@@ -28,7 +28,7 @@ __device__ __forceinline__ int32_t mod_rate(int64_t x)
 
 // Position of a symbol's useful part as seen by thread t: ring index of its sample t and that sample's oscillator phase.
 struct SymCursor { uint32_t a; int32_t ph; };
-struct MixSteps { int32_t s128, sTS; uint32_t s256_bytes; };   // (128 f, T_s f) mod RATE; 8 * ((256 f) mod RATE)
+struct MixSteps { int32_t s128, sTS; uint32_t s256_bytes; int32_t f1; };   // (128 f, T_s f) mod RATE; 8 * ((256 f) mod RATE); f mod RATE
 
 constexpr uint32_t NCO_BYTES = (uint32_t)INPUT_RATE * 8u;      // the oscillator table, one cf32 per phase step
 
@@ -54,6 +54,14 @@ __device__ __forceinline__ void osc_chain_steps(OscChain& k, int32_t f_hz)
 __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const cf32* __restrict__ nco, const SymCursor& c,
                                          const MixSteps& st, int h, bool checked)
 {
+    if (st.f1 == 0) {
+        // f = 0 (a carrier offset below the fine corrector's dead zone of 10 Hz leaves it there): the phase never moves, every sample
+        // of the frame reads the same table entry -- read it (one uniform load) instead of computing 16 values that are all equal
+        const cf32 v = nco[c.ph];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = v;
+        return;
+    }
     // e[j] = base * exp(-j 2 pi (128 h + 256 j) f / RATE) as a tree of depth 3 (steps of 256, 512, 1024 samples) instead of a chain of
     // seven dependent double-precision complex multiplications: same operation count, no latency chain (and a shorter error chain)
     dc64 e[8];
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         else c.ph = mod_rate((int64_t)d.L1 - (int64_t)(off - J0 + t + 1) * d.f_sym);
         return c;
     };
-    auto steps_for = [&](int32_t fhz) { MixSteps m; m.s128 = mod_rate(128LL * fhz); m.s256_bytes = 8u * (uint32_t)mod_rate(256LL * fhz); m.sTS = mod_rate((int64_t)T_S * fhz); return m; };
+    auto steps_for = [&](int32_t fhz) { MixSteps m; m.s128 = mod_rate(128LL * fhz); m.s256_bytes = 8u * (uint32_t)mod_rate(256LL * fhz); m.sTS = mod_rate((int64_t)T_S * fhz); m.f1 = mod_rate((int64_t)fhz); return m; };
 
     // (selected, not indexed: a dynamically indexed member would move the whole descriptor to scratch memory)
     const uint32_t hz0 = d.osc_hazard[0], hz1 = d.osc_hazard[1], hz2 = d.osc_hazard[2];
