@@ -302,6 +302,12 @@ def main():
                 cyc = ub["cycles_per_instruction_kernel_mix"]
                 rv.update(peak_measured_mix=n_simd * CLOCK_HZ / cyc, frac_of_measured_mix=ips / (n_simd * CLOCK_HZ / cyc),
                           measured_mix_note="profiles/valu_rate.json: issue cost of this kernel's instruction mix from tools/ubench/valu_rate.hip (packed 16-bit ops %.2f cycles, plain %.2f)" % (ub["cycles_packed"], ub["cycles_plain"]))
+        if vj and vj.get("lds_idx_active_cycles"):
+            # north star: "LDS-bank efficiency for Viterbi ACS".  The ACS itself touches no LDS (path metrics are register-resident); the
+            # kernel's LDS traffic is the byte gather from its de-interleaver window ring
+            rv.update(lds_bank_efficiency=1.0 - vj["lds_bank_conflict_cycles"] / vj["lds_idx_active_cycles"],
+                      lds_insts_per_trellis_step=vj["lds_insts_per_launch"] / (B * F * 72 * 1542 / 64.0) if vj.get("lds_insts_per_launch") else None,
+                      lds_note="SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the launch (static, profiles/viterbi_counters.json): the 16-byte row pitch the LDS-DMA dictates makes the byte reads of 64 consecutive rows 4-way conflicted; LDS is active about 4 % of the wave cycles (DESIGN.md 4.2), the add-compare-select runs in VGPRs")
         line["roofline_viterbi"] = rv
         # what a plain device-to-device copy moves on this box (read + write), for scale next to the 8 TB/s specification the fraction is
         # taken against ("measure the denominator"); never used as `peak`
