@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--ensembles", type=int, default=256, help="ensembles per GPU")
-    ap.add_argument("--frames", type=int, default=32, help="transmission frames per ensemble and step (round 2 timed 16 ... 64: the kernels' per-frame cost falls with the batch depth up to about 32-48 frames; round 1 and most of round 2 ran 20)")
+    ap.add_argument("--frames", type=int, default=32, help="transmission frames per ensemble and step (round 1 and most of round 2 ran 20; DESIGN.md section 6 has the sweep)")
     ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and with it the parity check of this run)")
     ap.add_argument("--no-alt-schedule", action="store_true", help="skip the extra (untimed) pass with the other pipelined schedule")
@@ -177,7 +177,8 @@ def main():
     from welle_io_amd.distributed import gather_fibs
 
     B, F = args.ensembles, args.frames
-    iq, cfo_hz, base, txs = workload.make_batch(B, rank=rank, cfo_max_hz=args.cfo_max_hz, device="cuda")
+    rec_frames = workload.rec_frames_for(F)                # the looping recording is at least one batch long: a step reads every sample once
+    iq, cfo_hz, base, txs = workload.make_batch(B, rank=rank, cfo_max_hz=args.cfo_max_hz, device="cuda", rec_frames=rec_frames)
     N = iq.shape[1]
     torch.cuda.synchronize()
     subchs = txs[0].subchs
@@ -269,7 +270,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 (FFT/demap) + u16 (Viterbi metrics) + u8 (GF(256))", "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of %d synthetic Mode-I ensembles x %d frames (2.048 Msps cf32, HBM-resident, 18 x 64 kbit/s DAB+ EEP-3A sub-channels each), full chain incl. Viterbi + Reed-Solomon" % (B, F),
-                       "ensembles_per_gpu": B, "frames_per_step": F, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B,
+                       "ensembles_per_gpu": B, "frames_per_step": F, "recording_frames": rec_frames, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B,
                        "demod_chunk": dev.demod_chunk(), "parity_test": "tests/test_gpu_bench_config.py decodes this configuration against the oracle"},
             "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
             "roofline": {"kernel": "k_demod (NCO + 2048-pt FFT + DQPSK demap + freq de-interleave)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
@@ -349,7 +350,7 @@ def main():
             line["alt_schedule"] = line["alt_schedules"][0]
         if world == 1 and not args.no_cpu_baseline:
             rows = {e: iq[e].cpu().numpy() for e in check}
-            line["cpu_baseline"], line["parity_check"] = cpu_baseline(rows, n_loops=12, gpu_logs=logs)
+            line["cpu_baseline"], line["parity_check"] = cpu_baseline(rows, n_loops=max(1, 240 // rec_frames), gpu_logs=logs)
         print(json.dumps(line), flush=True)
     if dev is not None:
         dev.close()

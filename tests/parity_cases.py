@@ -623,7 +623,7 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
                 L["sf"] += sf[b]
     finally:
         d.close()
-    loops = (n_steps * F + 3) // workload.REC_FRAMES + 2
+    loops = (n_steps * F + 3) // (iq.shape[1] // 196608) + 2
     for b in check_ens:
         L = logs[b]
         row = iq[b].cpu().numpy()

@@ -14,19 +14,20 @@ from welle_io_amd import capi, workload
 
 pytestmark = pytest.mark.gpu
 
-_base = None
+_base = {}
 
 
-def base_streams():
-    global _base
-    if _base is None:
-        _base = workload.make_base_streams(4, workload.REC_FRAMES, seed0=0)
-    return _base
+def base_streams(frames_per_step=20):
+    """the looping recordings bench.py builds for this batch depth (at least one batch long: workload.rec_frames_for)"""
+    n = workload.rec_frames_for(frames_per_step)
+    if n not in _base:
+        _base[n] = workload.make_base_streams(4, n, seed0=0)
+    return _base[n]
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_benchmarked_configuration(gpu, mode):
-    P.check_bench_config(capi, GPU_LIB, 256, 32, mode, check_ens=[0, 1, 2, 77, 128, 129, 191, 254, 255], n_steps=3, base=base_streams(), expect_chunk=25)
+    P.check_bench_config(capi, GPU_LIB, 256, 32, mode, check_ens=[0, 1, 2, 77, 128, 129, 191, 254, 255], n_steps=3, base=base_streams(32), expect_chunk=25)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -37,7 +38,7 @@ def test_benchmarked_configuration_20_frames(gpu, mode):
 
 def test_benchmarked_configuration_one_work_group_per_frame(gpu):
     """demod_chunk = 75 (one work-group walks all symbols of a frame) forced onto the big batch"""
-    P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 129, 255], n_steps=2, base=base_streams(), expect_chunk=75, demod_chunk=75)
+    P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 129, 255], n_steps=2, base=base_streams(32), expect_chunk=75, demod_chunk=75)
 
 
 def test_demod_chunk_sizes(gpu):
