@@ -198,6 +198,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames);
  * that frame the ensemble's output is the reference's bit for bit; from it on it is unless the corrector's step differed.  Always 0
  * with one frame per call, with disable_coarse, and while the ratio stays on one side of 50 %.  [n_ensembles] each, may be NULL. */
 int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first_stale_frame);
+/* ... and those of them that can have changed anything, [n_ensembles] each: the coarse corrector was consulted although the reference
+ * would not have AND it moved coarseCorrector (a consultation that returns no correction has no other effect,
+ * ofdm-processor.cpp:397-409), or it was not consulted although the reference would have.  While this count is zero the ensemble's
+ * output is the reference's frame for frame; first_effective_frame is where it may part from it (-1: nowhere) */
+int dabphy_get_ratio_lag_effect(dabphy_handle* h, int32_t* effective_frames, int64_t* first_effective_frame);
 
 typedef struct {
     int64_t sample_pos;             /* absolute index of the sync buffer start (ofdm-processor.cpp:337) */

@@ -142,10 +142,12 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
                 break
             done += F
         stale, first = d.ratio_lag()
+        eff, first_eff = d.ratio_lag_effect()
         wf, passes, fallbacks = d.wide_sync_stats()
         logs[0]["osc"] = d.osc_stats()
         for b in range(B):
             logs[b]["ratio_lag"] = (int(stale[b]), int(first[b]))
+            logs[b]["ratio_lag_effect"] = (int(eff[b]), int(first_eff[b]))
             logs[b]["wide"] = (int(wf[b]), passes, fallbacks)
         return logs
     finally:
@@ -186,6 +188,10 @@ def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, see
             else:
                 # the library knows exactly where its synchroniser consulted a stale ratio: nothing may differ before that frame
                 assert stale > 0 and 0 <= first_stale <= same.index(False), "frame %d differs from the oracle, the first stale coarse decision is reported at frame %d" % (same.index(False), first_stale)
+                # ... and more precisely where a stale decision can have MATTERED (it moved the corrector, or the corrector was not asked):
+                # as long as the library reports none of those, batch mode IS the reference
+                eff, first_eff = L["ratio_lag_effect"]
+                assert eff > 0 and 0 <= first_eff <= same.index(False), "frame %d differs from the oracle, the first stale decision with an effect is reported at frame %d (%d in all)" % (same.index(False), first_eff, eff)
             if not all(same):
                 k = same.index(False)
                 rb = fic_ratio_before(o["fib"].reshape(-1, 12, 33)[:, :, 0])

@@ -25,7 +25,7 @@ def factory(**kw):
     return capi.DabPhy(lib_path=lib, **kw)
 
 
-frames = wide = fast = checked = lagged = 0
+frames = wide = fast = checked = lagged = effective = 0
 for it in range(n):
     snr = float(rng.choice([10, 13, 16, 20, 25, 30]))
     cfo = float(rng.uniform(-60, 60)) if rng.rand() < 0.5 else float(rng.uniform(-450, 450))
@@ -33,8 +33,8 @@ for it in range(n):
     nf = int(rng.choice([18, 26, 34]))
     logs, o, _ = P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, False, B=2, F=F, pipeline_sync=pipe, seed=seed, ratio_lag_ok=True)
     L = logs[0]
-    k = len(L["info"]); frames += k; wide += L["wide"][0]; fast += L["osc"][0]; checked += L["osc"][1]; lagged += int(L["ratio_lag"][0] > 0)
-    print("stream %3d  snr %4.0f dB  cfo %7.1f Hz  delay %4d  F %d  schedule %d  frames %2d  from the wide pass %2d  oscillator symbols unchecked/checked %d/%d  ratio lag %s"
-          % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"]), flush=True)
-print("streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d  mismatches 0"
-      % (n, frames, wide, fast, checked, lagged))
+    k = len(L["info"]); frames += k; wide += L["wide"][0]; fast += L["osc"][0]; checked += L["osc"][1]; lagged += int(L["ratio_lag"][0] > 0); effective += int(L["ratio_lag_effect"][0] > 0)
+    print("stream %3d  snr %4.0f dB  cfo %7.1f Hz  delay %4d  F %d  schedule %d  frames %2d  from the wide pass %2d  oscillator symbols unchecked/checked %d/%d  ratio lag %s with an effect %s"
+          % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"], L["ratio_lag_effect"]), flush=True)
+print("streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  mismatches 0"
+      % (n, frames, wide, fast, checked, lagged, effective))

@@ -322,6 +322,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_ratio_lag(self.h, _p(n), _p(f)))
         return n, f
 
+    def ratio_lag_effect(self):
+        """(stale coarse-corrector decisions that can have changed anything, frame number of the first one or -1) per ensemble"""
+        n = np.zeros(self.cfg.n_ensembles, np.int32); f = np.zeros(self.cfg.n_ensembles, np.int64)
+        self._chk(self.lib.dabphy_get_ratio_lag_effect(self.h, _p(n), _p(f)))
+        return n, f
+
     def scan_stats(self):
         a = np.zeros(self.cfg.n_ensembles, np.int32); f = np.zeros(self.cfg.n_ensembles, np.int32)
         self._chk(self.lib.dabphy_get_scan_stats(self.h, _p(a), _p(f)))

@@ -1117,6 +1117,20 @@ int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first
     return DABPHY_OK;
 }
 
+int dabphy_get_ratio_lag_effect(dabphy_handle* h, int32_t* effective_frames, int64_t* first_effective_frame)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<DecState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) {
+        if (effective_frames) effective_frames[i] = st[i].effective_stale_frames;
+        if (first_effective_frame) first_effective_frame[i] = st[i].effective_stale_frames ? st[i].first_effective_frame : -1;
+    }
+    return DABPHY_OK;
+}
+
 int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts_at_first_lock)
 {
     DeviceBind dev_(h);

@@ -41,6 +41,11 @@ struct DecState {
                                   // the ratio of an earlier batch -- differs from the one the reference makes with the ratio after the
                                   // previous frame (ofdm-processor.cpp:397): from the first such frame on this ensemble may deviate
     int64_t first_stale_frame;    // its frame number, -1: none
+    // ... of which those that can have changed anything: the corrector was consulted although the reference would not have AND it moved
+    // coarseCorrector (consulting it has no other effect, ofdm-processor.cpp:397-409), or it was NOT consulted although the reference
+    // would have (what it would have returned is not known).  Zero = this ensemble's output is the reference's, frame for frame.
+    int32_t effective_stale_frames; int32_t pad_;
+    int64_t first_effective_frame;
 };
 
 // Where one transmission frame sits in the sample stream and which oscillator settings were in force while
@@ -60,7 +65,7 @@ struct FrameDesc {
     int32_t exact_sums;                 // 1: the fine corrector of this frame needed the ordered float sums
     uint32_t osc_hazard[3];             // bit s: the useful part of symbol s (0 = PRS) reads an oscillator table entry for which k_demod
                                         // must take the checked conversion (osc_exact.h: osc_hazard_entry); written with the descriptor
-    uint32_t pad_;
+    int32_t coarse_step;                // what the coarse corrector added to coarseCorrector in this frame [Hz] (0: not consulted, or no correction)
 };
 static_assert(sizeof(FrameDesc) == 80, "FrameDesc layout");
 

@@ -151,7 +151,7 @@ __device__ __forceinline__ FrameDesc desc_begin(const SyncIn& st)
     FrameDesc d;
     d.pos = st.pos; d.frame_no = st.frame_no; d.start_index = -1; d.L0 = st.local_phase; d.f_prs = st.coarse + st.fine;
     d.L1 = 0; d.f_sym = 0; d.valid = 0; d.fine_after = st.fine; d.coarse_after = st.coarse; d.null_L = 0; d.null_f = 0; d.coarse_ran = 0; d.exact_sums = 0;
-    d.osc_hazard[0] = d.osc_hazard[1] = d.osc_hazard[2] = 0; d.pad_ = 0;
+    d.osc_hazard[0] = d.osc_hazard[1] = d.osc_hazard[2] = 0; d.coarse_step = 0;
     return d;
 }
 // samples a window search needs in the ring: a whole frame with the largest possible window index
@@ -805,6 +805,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     }
     d.f_sym = coarse + st.fine;
     d.coarse_after = coarse;
+    d.coarse_step = coarse - st.coarse;
     d.valid = 2;                                   // pending: k_sync_finish completes it
     if (t == 0) dout = d;
 }

@@ -662,6 +662,10 @@ __global__ void k_fic_ratio(CrcArgs A)
         if ((int)(!A.disable_coarse && r * 10 < 50) != d.coarse_ran) {
             if (A.state[b].stale_ratio_frames == 0) A.state[b].first_stale_frame = d.frame_no;
             A.state[b].stale_ratio_frames += 1;
+            if (!d.coarse_ran || d.coarse_step != 0) {          // a needless consultation that moved nothing changes nothing
+                if (A.state[b].effective_stale_frames == 0) A.state[b].first_effective_frame = d.frame_no;
+                A.state[b].effective_stale_frames += 1;
+            }
         }
         for (int k = 0; k < 12; k++) {
             if (A.ok[((size_t)b * A.n_frames + f) * 12 + k]) { if (r < 10) r++; }
