@@ -190,7 +190,10 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
  * Note on the coarse corrector: the reference consults the FIB CRC success ratio of the PREVIOUS frame
  * (ofdm-processor.cpp:397); that feedback is exact when n_frames == 1.  With n_frames > 1 the ratio of the
  * last finished batch is used for the whole batch -- identical once the ratio is >= 50 (normal tracking) or
- * with disable_coarse. */
+ * with disable_coarse; dabphy_get_ratio_lag / dabphy_get_ratio_lag_effect report exactly where that was not so
+ * and whether it can have mattered.
+ * The FIBs, CRC flags, frame information and (with dabphy_set_auto_superframes) the superframe totals of the batch
+ * are back in page-locked host memory when the call returns; everything else is copied on request. */
 int dabphy_process(dabphy_handle* h, uint32_t n_frames);
 /* ... and the library tells exactly when that matters: stale_frames[b] = frames of ensemble b (since dabphy_reset) for which the
  * synchroniser, running ahead of the decoder, consulted the coarse corrector although the reference -- which knows the ratio after the
