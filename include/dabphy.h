@@ -58,6 +58,13 @@ typedef struct {
                                        accepts those whose assumption held and runs the frame-by-frame chain (2 dependent launches per
                                        frame, OFDMProcessor::run's loop) for the rest: same results, a fraction of the latency while
                                        tracking.  1: always the frame-by-frame chain */
+    int32_t no_batch_replay;        /* 0 (default): batch mode (n_frames > 1) follows the reference's state machine EXACTLY also where the FIC
+                                       decodes badly: when a coarse-corrector decision of a batch was taken with a stale FIC ratio and can
+                                       have mattered (dabphy_get_ratio_lag_effect), dabphy_process puts back everything the batch changed
+                                       and decodes it a second time frame by frame, with the FIC of frame n feeding the decision of frame
+                                       n + 1 as in OFDMProcessor::run (ofdm-processor.cpp:397).  Costs a copy of the carried state per batch
+                                       (a few MB, device to device) and, in such a batch, about three times its normal time.
+                                       1: report only (round 1's behaviour) */
 } dabphy_config;
 
 /* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)
@@ -190,8 +197,9 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
  * Note on the coarse corrector: the reference consults the FIB CRC success ratio of the PREVIOUS frame
  * (ofdm-processor.cpp:397); that feedback is exact when n_frames == 1.  With n_frames > 1 the ratio of the
  * last finished batch is used for the whole batch -- identical once the ratio is >= 50 (normal tracking) or
- * with disable_coarse; dabphy_get_ratio_lag / dabphy_get_ratio_lag_effect report exactly where that was not so
- * and whether it can have mattered.
+ * with disable_coarse; where that was not so AND can have mattered the batch is decoded a second time frame by
+ * frame (dabphy_config.no_batch_replay), so the results are the reference's in every case;
+ * dabphy_get_ratio_lag / dabphy_get_ratio_lag_effect report such decisions when the replay is turned off.
  * The FIBs, CRC flags, frame information and (with dabphy_set_auto_superframes) the superframe totals of the batch
  * are back in page-locked host memory when the call returns; everything else is copied on request. */
 int dabphy_process(dabphy_handle* h, uint32_t n_frames);
@@ -238,6 +246,8 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
  * ensemble that were accepted from it [n_ensembles]; passes queued; passes after which the frame-by-frame chain had to take over for
  * at least one ensemble */
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
+/* batches decoded a second time (see dabphy_config.no_batch_replay) since dabphy_reset / dabphy_create */
+int dabphy_get_replayed_batches(dabphy_handle* h, uint64_t* batches);
 /* OFDM symbols (since dabphy_create) whose samples dabphy_process mixed with oscillator values converted without / with the
  * per-sample rounding test (csrc/osc_exact.h: the synchroniser marks the symbols that read one of the 36 table entries next to a
  * float rounding boundary; only those take the test and, where it cannot decide, the table) */

@@ -107,10 +107,10 @@ def dev_prot(d, s):
     return d.protection_uep(s.bitrate, s.level) if getattr(s, "uep", None) is not None else d.protection_eep(s.bitrate, s.profile_b, s.level)
 
 
-def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2, stage_log=None, serial_sync=False):
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2, stage_log=None, serial_sync=False, exact_batch=True):
     """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
     from welle_io_amd import capi  # noqa: F401
-    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync, serial_sync=serial_sync)
+    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync, serial_sync=serial_sync, exact_batch=exact_batch)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subs])
@@ -145,6 +145,7 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
         eff, first_eff = d.ratio_lag_effect()
         wf, passes, fallbacks = d.wide_sync_stats()
         logs[0]["osc"] = d.osc_stats()
+        logs[0]["replayed"] = d.replayed_batches()
         for b in range(B):
             logs[b]["ratio_lag"] = (int(stale[b]), int(first[b]))
             logs[b]["ratio_lag_effect"] = (int(eff[b]), int(first_eff[b]))
@@ -166,14 +167,17 @@ def fic_ratio_before(ok_flags):
 
 
 def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True, fft_placement=2, freqsync=2,
-                           ratio_lag_ok=False, serial_sync=False):
+                           ratio_lag_ok=False, serial_sync=False, exact_batch=None):
     """ratio_lag_ok: batch mode's documented deviation (include/dabphy.h, dabphy_process) is tolerated and PINNED: the frames must
     equal the oracle's up to the first frame before which the FIC ratio crossed the 50 % line within the last F (2F when pipelined)
-    frames -- only there may a batch have consulted a stale ratio; what comes before is compared bit for bit, returns that frame"""
+    frames -- only there may a batch have consulted a stale ratio; what comes before is compared bit for bit, returns that frame.
+    exact_batch: None = the library's default (replay on) unless ratio_lag_ok asks for the report-only mode it pins"""
+    if exact_batch is None:
+        exact_batch = not ratio_lag_ok
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
     o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse, fft_placement=fft_placement, freqsync=freqsync)
-    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con, fft_placement=fft_placement, freqsync=freqsync, serial_sync=serial_sync)
+    logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con, fft_placement=fft_placement, freqsync=freqsync, serial_sync=serial_sync, exact_batch=exact_batch)
     for b in range(B):
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)
@@ -848,3 +852,16 @@ def check_wide_sync(d_factory, F=6, nf=34, pipeline_sync=False, cfo=37.0, snr_db
         assert wf >= F * whole, (wf, fine)
         assert 1 <= fallbacks < passes, (passes, fallbacks)
     return logs_w
+
+
+def check_exact_batch(d_factory, snr_db, cfo, F, seed, pipeline_sync=False, nf=25, B=1, expect_replay=None):
+    """Exact batch mode (the default, dabphy_config.no_batch_replay = 0): batch mode with the reference's own FIC-ratio feedback.  The same low-SNR streams on which plain batch
+    mode may part from the reference behind a stale coarse-corrector decision (check_stream_vs_oracle(ratio_lag_ok=True)) must now
+    equal the oracle frame for frame, with NO tolerance: every FIB, corrector, soft bit, null symbol, MSC byte -- and the lag reports
+    must come back empty, because a batch with an effective stale decision was put back and decoded again frame by frame."""
+    logs, o, _ = check_stream_vs_oracle(d_factory, snr_db, cfo, 150, nf, False, B=B, F=F, seed=seed, pipeline_sync=pipeline_sync, exact_batch=True)
+    for b in range(B):
+        assert logs[b]["ratio_lag_effect"] == (0, -1), logs[b]["ratio_lag_effect"]
+    if expect_replay is not None:
+        assert (logs[0]["replayed"] > 0) == expect_replay, logs[0]["replayed"]
+    return logs

@@ -141,3 +141,12 @@ def test_receiver_options_at_run_time(emu):
 @pytest.mark.parametrize("pipeline", [False, 1, 2])
 def test_wide_synchroniser_pass(emu, pipeline):
     P.check_wide_sync(factory, pipeline_sync=pipeline)
+
+
+@pytest.mark.parametrize("snr,cfo,F,seed,pipeline,replay", [(3, -1000, 4, 5, False, True), (3, -1000, 4, 5, 1, True), (3, -1000, 4, 5, 2, None), (3, -1000, 4, 5, 3, None),
+                                                            (4, 300, 4, 3, 1, None), (2, 40, 4, 9, 2, None), (3, -1000, 8, 11, False, None), (4, 17400, 5, 13, 1, None), (5, 2300, 6, 7, False, None)])
+def test_exact_batch_mode(emu, snr, cfo, F, seed, pipeline, replay):
+    """Exact batch mode (the default): the low-SNR batch streams again, now required to equal the oracle frame for frame without any
+    tolerance (a batch whose stale coarse-corrector decision can have mattered is put back and decoded a second time with the
+    reference's per-frame FIC-ratio feedback); the first two are known to need that second pass"""
+    P.check_exact_batch(factory, snr, cfo, F, seed, pipeline_sync=pipeline, expect_replay=replay)

@@ -148,3 +148,12 @@ def test_wide_synchroniser_pass(gpu, pipeline):
     """all frames of a batch synchronised at once from the predicted in-lock state (k_sync_find_wide / k_sync_finish_wide /
     k_sync_validate) = the frame-by-frame chain = the oracle, bit for bit; the counters show which path produced the frames"""
     P.check_wide_sync(factory, pipeline_sync=pipeline, nf=44, F=8, B=3)
+
+
+@pytest.mark.parametrize("snr,cfo,F,seed,pipeline,replay", [(3, -1000, 4, 5, False, True), (3, -1000, 4, 5, 1, True), (3, -1000, 4, 5, 2, None), (3, -1000, 4, 5, 3, None),
+                                                            (4, 300, 4, 3, 1, None), (2, 40, 4, 9, 2, None), (3, -1000, 8, 11, False, None), (4, 17400, 5, 13, 1, None), (5, 2300, 6, 7, False, None)])
+def test_exact_batch_mode(gpu, snr, cfo, F, seed, pipeline, replay):
+    """Exact batch mode (the default): the low-SNR batch streams again, now required to equal the oracle frame for frame without any
+    tolerance (a batch whose stale coarse-corrector decision can have mattered is put back and decoded a second time with the
+    reference's per-frame FIC-ratio feedback); the first two are known to need that second pass"""
+    P.check_exact_batch(factory, snr, cfo, F, seed, pipeline_sync=pipeline, expect_replay=replay)

@@ -47,6 +47,7 @@ struct dabphy_handle {
         DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
         DevBuf steps; int n_windows = 0;     // fused decode (k_viterbi_msc): per-step window-ring descriptors, 16-byte windows of the punctured stream
         DevBuf sf_state;                     // SuperframeFilter window of every (ensemble, member)
+        DevBuf sf_snap;                      // ... as it was in front of the current batch (exact batch mode)
     };
     const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
     DevBuf s_iq_own;
@@ -78,6 +79,12 @@ struct dabphy_handle {
     bool wide_pending[N_DESC]{};      // the wide pass of this descriptor buffer has been queued, its verdict not yet read
     uint64_t chain_valid[N_DESC]{}; uint32_t chain_frames[N_DESC]{};   // n_valid and n_frames the chain of this buffer was queued with
     uint64_t n_wide_passes = 0, n_wide_fallbacks = 0;
+    // exact batch mode (cfg.no_batch_replay == 0): state as it was in front of a batch, to replay the batch frame by frame when one of its
+    // coarse-corrector decisions was taken with a stale FIC ratio and can have mattered (k_fic_ratio's verdict)
+    bool exact_batch = false;
+    DevBuf snap_state[N_DESC], snap_dec, snap_tii;
+    int32_t* d_any_eff = nullptr; int32_t* h_any_eff = nullptr;
+    uint64_t n_replayed_batches = 0;
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
     int ahead = 0;                    // batches whose chain has been queued but which have not been decoded yet (pipelined modes: 1 or 2 between calls)
     uint32_t presynced = 0;           // frames already synchronised ahead into s_desc2[desc_sel] (pipelined mode)
@@ -247,6 +254,16 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
         if (hipHostMalloc(&p, (size_t)cfg->n_ensembles * 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
         h->h_sf_stats = reinterpret_cast<int32_t*>(p);
     }
+    h->exact_batch = cfg->no_batch_replay == 0;
+    if (const char* e = getenv("DABPHY_EXACT_BATCH")) h->exact_batch = atoi(e) != 0;   // (experiments: overrides the configuration)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(int32_t)) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->owned.push_back(p); h->d_any_eff = reinterpret_cast<int32_t*>(p);
+        if (hipMemset(p, 0, sizeof(int32_t)) != hipSuccess) return fail(DABPHY_ERR_HIP);
+        if (hipHostMalloc(&p, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        h->h_any_eff = reinterpret_cast<int32_t*>(p); *h->h_any_eff = 0;
+    }
     h->wide_sync = cfg->serial_sync == 0;
     if (const char* e = getenv("DABPHY_SYNC_WIDE")) h->wide_sync = atoi(e) != 0;    // (experiments: overrides the configuration)
     h->msc_parts = cfg->msc_parts;
@@ -279,6 +296,11 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->h_fib) e = hipHostFree(h->h_fib);
     if (h->h_ok) e = hipHostFree(h->h_ok);
     if (h->h_sf_stats) e = hipHostFree(h->h_sf_stats);
+    if (h->h_any_eff) e = hipHostFree(h->h_any_eff);
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) if (h->snap_state[i].p) e = hipFree(h->snap_state[i].p);
+    if (h->snap_dec.p) e = hipFree(h->snap_dec.p);
+    if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
+    for (auto& c : h->classes) if (c.sf_snap.p) e = hipFree(c.sf_snap.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
@@ -468,6 +490,8 @@ static int queue_chain(dabphy_handle* h, int sel, uint32_t F)
 {
     SyncArgs sa = sync_args(h, sel, F, h->s_valid);
     h->chain_valid[sel] = h->s_valid; h->chain_frames[sel] = F;
+    if (h->exact_batch && h->snap_state[sel].p)
+        HIPCHK(h, hipMemcpyAsync(h->snap_state[sel].p, h->d_state, sizeof(RxState) * h->cfg.n_ensembles, hipMemcpyDeviceToDevice, h->sync_stream));
     { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
     // one frame per call (the real-time facade) gains nothing from the wide pass; two batches ahead its verdict would come too late
     if (h->wide_sync && F >= 2 && h->cfg.pipeline_sync != 3 && !h->track_slevel) {
@@ -540,7 +564,7 @@ int dabphy_reset(dabphy_handle* h)
     DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
     int r = reset_synchroniser(h, true); if (r) return r;
-    h->desc_sel = 0; h->n_wide_passes = h->n_wide_fallbacks = 0;
+    h->desc_sel = 0; h->n_wide_passes = h->n_wide_fallbacks = 0; h->n_replayed_batches = 0;
     HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
     for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
@@ -827,6 +851,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     for (int k = 0; k < dabphy_handle::N_DESC; k++) {
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
         if ((r = ensure(h, h->s_redo[k], (size_t)B * sizeof(int32_t)))) return r;
+        if (h->exact_batch && (r = ensure(h, h->snap_state[k], (size_t)B * sizeof(RxState)))) return r;
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
     {   // + a tail of zeros (one sub-channel's worth: 864 CU x 64 bits) that the fused MSC decode loads for CIFs that do not exist yet
@@ -864,6 +889,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if (h->sf_auto && (r = prepare_superframes(h, cls, F))) return r;
         }
         if (h->sf_auto && (r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
+        if (h->exact_batch) {
+            if ((r = ensure(h, h->snap_dec, (size_t)B * sizeof(DecState)))) return r;
+            if (h->tii_state.p && (r = ensure(h, h->snap_tii, h->tii_state.cap))) return r;
+            for (auto& cls : h->classes) if (cls.sf_state.p && (r = ensure(h, cls.sf_snap, cls.sf_state.cap))) return r;
+        }
     }
     h->soft_ring = ring_frames;
 
@@ -907,17 +937,44 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     h->last_desc = d_desc;
     h->cur_cir = h->cfg.want_impulse_response ? h->s_cir2[cur].as<float>() : nullptr;
 
+    // The decode of the batch whose descriptors are in d_desc.  `replay` = the second pass of exact batch mode (see below).
+    auto decode = [&](const bool replay) -> int {
     DemodArgs da{};
     da.tab = h->tab; da.iq = h->s_iq; da.iq_stride = h->s_stride; da.ring = (int64_t)h->s_ring;
     da.desc = d_desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
     da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames;
     da.con = h->cfg.want_constellation ? h->s_con.as<cf32>() : nullptr; da.prs_mag = h->s_mag.as<float>();
     da.osc_stats = h->d_osc_stats;
+    if (replay) {
+        // Exact batch mode, second pass: the batch again, frame by frame, with the reference's own feedback -- the window search of
+        // frame f consults the FIC ratio as it stands after frame f - 1 (ofdm-processor.cpp:397), which takes that frame's FIC: chain
+        // step, the first chunk of the frame's symbols (PRS + FIC symbols), FIC decode of the class, ratio of frame f.  Everything else
+        // of the batch follows below as in the first pass (the demod kernel writes the same soft bits again where nothing changed).
+        SyncArgs sa = sync_args(h, cur, F, h->chain_valid[cur]);
+        VitClass c = fic_c;
+        c.sym = h->fsym.as<uint32_t>(); c.dec = h->fdec.as<uint2>(); c.out = h->s_fib.as<uint8_t>();
+        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
+        g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
+        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
+        for (uint32_t f = 0; f < F; f++) {
+            sa.frame = (int)f;
+            launch_sync_find(sa, h->stream);
+            launch_sync_finish(sa, h->stream);
+            DemodArgs d1 = da; d1.frame_first = (int)f; d1.frame_count = 1; d1.chunk_count = 1; d1.con = nullptr; d1.osc_stats = nullptr;
+            launch_demod(d1, (int)B, h->stream);
+            launch_fic_gather(g, h->stream);
+            launch_viterbi(v, h->stream);
+            launch_fib_crc(k, h->stream);
+            CrcArgs kf = k; kf.frame_first = (int)f; kf.frame_count = 1;
+            launch_fic_ratio(kf, h->stream);
+        }
+    }
     mark(dabphy_handle::ST_DEMOD, false);
     launch_demod(da, (int)B, h->stream);
     tick(2);
     mark(dabphy_handle::ST_DEMOD, true);
-    if (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
+    if (!replay && (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3)) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
     mark(dabphy_handle::ST_SNR, false);
     launch_snr(sn, h->stream);
@@ -939,7 +996,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         launch_viterbi(v, fs);
         CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
         launch_fib_crc(k, fs);
-        launch_fic_ratio(k, fs);
+        k.any_effective = h->d_any_eff;
+        if (!replay) launch_fic_ratio(k, fs);                    // (the second pass of exact batch mode has advanced the ratio frame by frame)
+        HIPCHK(h, hipMemcpyAsync(h->h_any_eff, h->d_any_eff, sizeof(int32_t), hipMemcpyDeviceToHost, fs));
         mark(dabphy_handle::ST_FIC, true, fs);
         h->tii_ran = false;
         if (h->tii_on) {
@@ -1050,6 +1109,17 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
         h->h_sf_stats_valid = true;
     }
+    return DABPHY_OK;
+    };
+    if (h->exact_batch) {
+        // what the decoders carry from batch to batch, as it is in front of this one (the synchroniser's share was saved when this
+        // batch's chain was queued: queue_chain)
+        HIPCHK(h, hipMemcpyAsync(h->snap_dec.p, h->d_dec, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
+        if (h->tii_state.p && h->snap_tii.p) HIPCHK(h, hipMemcpyAsync(h->snap_tii.p, h->tii_state.p, h->tii_state.cap, hipMemcpyDeviceToDevice, h->stream));
+        for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_snap.p, cls.sf_state.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_any_eff, 0, sizeof(int32_t), h->stream));
+    }
+    if ((r = decode(false))) return r;
     if (depth) {
         if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
         for (; h->ahead < 1 + depth; h->ahead++) if ((r = queue_chain(h, (cur + h->ahead) % ND, F))) return r;
@@ -1060,6 +1130,27 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     tick(3);
     if ((r = sync(h))) return r;
     tick(4);
+    if (h->exact_batch && F > 1 && *h->h_any_eff) {
+        // Exact batch mode: a coarse-corrector decision of this batch was taken with a stale FIC ratio and can have mattered.  Everything
+        // the batch changed is put back -- synchroniser state (as saved when its chain was queued), decoder state, superframe windows,
+        // TII sums; the soft-bit ring and the outputs are simply written again -- and the batch is decoded a second time with the
+        // feedback the reference has; the chains that ran ahead on the wrong state are queued again behind it.
+        HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+        HIPCHK(h, hipStreamSynchronize(h->aux_stream));
+        for (int i = 0; i < ND; i++) h->wide_pending[i] = false;
+        HIPCHK(h, hipMemcpyAsync(h->d_state, h->snap_state[cur].p, sizeof(RxState) * B, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_dec, h->snap_dec.p, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
+        if (h->tii_state.p && h->snap_tii.p) HIPCHK(h, hipMemcpyAsync(h->tii_state.p, h->snap_tii.p, h->tii_state.cap, hipMemcpyDeviceToDevice, h->stream));
+        for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_state.p, cls.sf_snap.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_any_eff, 0, sizeof(int32_t), h->stream));
+        if ((r = decode(true))) return r;
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
+        if ((r = sync(h))) return r;
+        // the batches synchronised ahead started from the state the first pass left: again, from the right one.  (The chain reads the
+        // FIC ratio: the main stream has just been drained.)
+        for (int i = 1; i <= depth; i++) if ((r = queue_chain(h, (cur + i) % ND, F))) return r;
+        h->n_replayed_batches++;
+    }
     if (g_tl_on) { for (int i = 0; i < 5; i++) g_tl.acc[i] += tl[i]; g_tl.n++; if (g_tl.n % 8 == 0) fprintf(stderr, "dabphy timing [us]: before resolve %.1f, resolved %.1f, demod launched %.1f, all launched %.1f, synced %.1f (n=%ld)\n", g_tl.acc[0] / g_tl.n, g_tl.acc[1] / g_tl.n, g_tl.acc[2] / g_tl.n, g_tl.acc[3] / g_tl.n, g_tl.acc[4] / g_tl.n, g_tl.n); }
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }
     return DABPHY_OK;
@@ -1141,6 +1232,13 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
     HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
     int r = sync(h); if (r) return r;
     for (size_t i = 0; i < st.size(); i++) { if (attempts) attempts[i] = st[i].attempts; if (attempts_at_first_lock) attempts_at_first_lock[i] = st[i].first_lock_attempts; }
+    return DABPHY_OK;
+}
+
+int dabphy_get_replayed_batches(dabphy_handle* h, uint64_t* batches)
+{
+    if (!h || !batches) return DABPHY_ERR_INVALID;
+    *batches = h->n_replayed_batches;
     return DABPHY_OK;
 }
 

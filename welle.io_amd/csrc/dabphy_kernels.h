@@ -93,6 +93,7 @@ struct DemodArgs {
     cf32* con;                                            // optional [B][n_frames][1200]
     float* prs_mag;                                       // optional [B][n_frames][2048]
     unsigned long long* osc_stats;                        // optional [2]: symbols mixed with the unchecked / the checked oscillator conversion
+    int frame_first, frame_count, chunk_count;            // launch only frames [frame_first, frame_first + frame_count) and the first chunk_count chunks of a frame; 0 = all
 };
 
 struct SnrArgs {
@@ -160,6 +161,8 @@ struct CrcArgs {
     uint8_t* ok;            // [B][F][12]
     DecState* state; const FrameDesc* desc; int n_ens, n_frames;
     int disable_coarse;     // RadioReceiverOptions::disableCoarseCorrector as the synchroniser used it (k_fic_ratio checks the ratio it saw)
+    int frame_first, frame_count;   // k_fic_ratio: walk only these frame slots (0 = all)
+    int32_t* any_effective; // k_fic_ratio: set to 1 when a stale decision with a possible effect is found (optional)
 };
 
 // Gather from a plain [n_cw][in_stride] array of soft bits (the Viterbi::deconvolve / Protection::deconvolve seams)

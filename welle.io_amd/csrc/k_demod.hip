@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     __shared__ __attribute__((aligned(16))) int8_t softbuf[SOFT_PER_SYM];
     __shared__ __attribute__((aligned(16))) dc64 s_symstep[L_SYM];   // exp(-j 2 pi k T_s f / RATE): symbol k of the chunk against its first
     const int t = threadIdx.x;
-    const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
+    const int chunk = blockIdx.x, f = A.frame_first + (int)blockIdx.y, b = blockIdx.z;
     const FrameDesc d = A.desc[(size_t)b * A.n_frames + f];
     if (d.valid != 1) return;
     const cf32* __restrict__ iq = A.iq + (size_t)b * A.iq_stride;
@@ -381,9 +381,11 @@ void launch_selftest_div127(unsigned long long* out, hipStream_t s)
 
 void launch_demod(const DemodArgs& a, int n_ens, hipStream_t s)
 {
-    const int chunks = (75 + a.chunk_len - 1) / a.chunk_len;
-    if (a.con) hipLaunchKernelGGL(k_demod<true>, dim3(chunks, a.n_frames, n_ens), dim3(FFT_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_demod<false>, dim3(chunks, a.n_frames, n_ens), dim3(FFT_THREADS), 0, s, a);
+    int chunks = (75 + a.chunk_len - 1) / a.chunk_len;
+    if (a.chunk_count > 0 && a.chunk_count < chunks) chunks = a.chunk_count;
+    const int frames = a.frame_count > 0 ? a.frame_count : a.n_frames - a.frame_first;
+    if (a.con) hipLaunchKernelGGL(k_demod<true>, dim3(chunks, frames, n_ens), dim3(FFT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_demod<false>, dim3(chunks, frames, n_ens), dim3(FFT_THREADS), 0, s, a);
 }
 
 void launch_snr(const SnrArgs& a, hipStream_t s)

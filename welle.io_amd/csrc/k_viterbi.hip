@@ -655,7 +655,8 @@ __global__ void k_fic_ratio(CrcArgs A)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= A.n_ens) return;
     int r = A.state[b].fic_ratio;
-    for (int f = 0; f < A.n_frames; f++) {
+    const int f_end = A.frame_count > 0 ? A.frame_first + A.frame_count : A.n_frames;
+    for (int f = A.frame_first; f < f_end; f++) {
         const FrameDesc& d = A.desc[(size_t)b * A.n_frames + f];
         if (d.valid != 1) continue;
         // what the reference's synchroniser sees before this frame (ofdm-processor.cpp:397) against what ours saw when it ran ahead
@@ -665,6 +666,7 @@ __global__ void k_fic_ratio(CrcArgs A)
             if (!d.coarse_ran || d.coarse_step != 0) {          // a needless consultation that moved nothing changes nothing
                 if (A.state[b].effective_stale_frames == 0) A.state[b].first_effective_frame = d.frame_no;
                 A.state[b].effective_stale_frames += 1;
+                if (A.any_effective) *A.any_effective = 1;
             }
         }
         for (int k = 0; k < 12; k++) {
