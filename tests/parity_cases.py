@@ -296,7 +296,7 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, a
 
 
 # ---- DAB+ superframe filter on the device vs the oracle's (itself pinned to the real SuperframeFilter)
-def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True, auto_modes=(False, True)):
+def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True, auto_modes=(False, True), cfo=20, stats=None, min_synced=1):
     """superframes straddle the batches (12 logical frames per batch, 5 per superframe); the noise level makes the Viterbi
     output carry byte errors for Reed-Solomon to correct (no loss of lock: batch mode and the reference drop different
     frames then), and the transmitter damages some superframes beyond repair: a broken access unit, more byte errors than
@@ -314,7 +314,7 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
             if q == 8 and k == 0:
                 for j in range(4, 10): data[j * (sc.bitrate // 8)] ^= 0x81           # header column uncorrectable -> Fire code fails -> window slides
         return bytes(data)
-    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=20, delay=50, return_tx=True, seed=seed, payload_fn=payload)
+    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=50, return_tx=True, seed=seed, payload_fn=payload)
     subs = [tx.subchs[1], tx.subchs[6]]
     o = R.orc_receiver_run(x, subchs=subs)
     d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
@@ -347,7 +347,10 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
                 assert n >= len(want) - 4 and n > 0, (n, len(want))
                 assert got[b][i] == [(w[0], w[1], w[2], w[3], w[4], w[5], w[6]) for w in want[:n]], "superframe events of sub-channel %d differ" % i
                 ns = len(got_sf[b][i])
-                assert ns >= 1 and all(np.array_equal(got_sf[b][i][k], so[k]) for k in range(ns)), "corrected superframes differ"
+                assert all(np.array_equal(got_sf[b][i][k], so[k]) for k in range(ns)), "corrected superframes differ"
+                assert ns >= 1 or min_synced == 0, "no superframe synchronised"
+        if stats is not None:
+            stats["replayed"] = d.replayed_batches()
     finally:
         d.close()
     # the all-sub-channels variant: only totals leave the device -- launched by superframes_stats(), or by process() itself
@@ -363,6 +366,8 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
                 if not (d.frame_info()["valid"] == 1).any():
                     break
                 tot += d.superframes_stats()
+            if stats is not None:
+                stats["replayed_auto_%d" % int(auto)] = d.replayed_batches()
             for b in range(B):
                 ev = [e for i in range(len(subs)) for e in got[b][i]]
                 want = (sum(e[2] for e in ev), sum(e[0] for e in ev), sum(e[1] for e in ev), sum(e[4] - bin(e[6]).count("1") for e in ev if e[2]))

@@ -150,3 +150,12 @@ def test_exact_batch_mode(emu, snr, cfo, F, seed, pipeline, replay):
     tolerance (a batch whose stale coarse-corrector decision can have mattered is put back and decoded a second time with the
     reference's per-frame FIC-ratio feedback); the first two are known to need that second pass"""
     P.check_exact_batch(factory, snr, cfo, F, seed, pipeline_sync=pipeline, expect_replay=replay)
+
+
+def test_superframes_through_a_replayed_batch(emu):
+    """exact batch mode with the superframe filter: a 3.5 dB stream in which one batch has to be decoded a second time -- the filter's
+    windows are put back with the rest of the state -- gives the oracle's superframe events, corrected superframes and totals whether
+    the filter is called per sub-channel, for all of them after the batch, or rides inside dabphy_process"""
+    st = {}
+    P.check_superframes_vs_oracle(factory, F=3, nf=22, snr_db=3.5, seed=7, B=1, damage=True, cfo=40, stats=st)
+    assert st["replayed"] >= 1 and st["replayed_auto_0"] >= 1 and st["replayed_auto_1"] >= 1, st
