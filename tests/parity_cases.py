@@ -428,7 +428,7 @@ TII_NETWORKS = [
 ]
 
 
-def check_tii_vs_oracle(d_factory, F=4, nf=17, snr_db=20, cfo=70, pipeline_sync=False):
+def check_tii_vs_oracle(d_factory, F=4, nf=17, snr_db=20, cfo=70, pipeline_sync=False, stats=None, counts=True):
     """TII side path over a batch of different single-frequency networks vs the restated TIIDecoder fed by the oracle receiver
     (itself pinned to the real class, test_oracle_vs_ref.py).  Measurements must agree exactly: comb, pattern, the frame that
     completed them, delay_samples and the float error."""
@@ -437,7 +437,7 @@ def check_tii_vs_oracle(d_factory, F=4, nf=17, snr_db=20, cfo=70, pipeline_sync=
     n = max(len(x) for x in xs)
     xs = [np.concatenate([x, np.zeros(n - len(x), np.complex64)]) for x in xs]
     want = [R.orc_receiver_run(x, tii=True) for x in xs]
-    assert len(want[0]["tii"]) >= 4 and len(want[1]["tii"]) >= 2 and len(want[2]["tii"]) == 0 and len(want[3]["tii"]) >= 4, [len(w["tii"]) for w in want]
+    assert not counts or (len(want[0]["tii"]) >= 4 and len(want[1]["tii"]) >= 2 and len(want[2]["tii"]) == 0 and len(want[3]["tii"]) >= 4), [len(w["tii"]) for w in want]
     d = d_factory(n_ensembles=B, max_frames=F, pipeline_sync=pipeline_sync, want_constellation=False)
     try:
         d.stream_upload(np.stack(xs))
@@ -460,6 +460,8 @@ def check_tii_vs_oracle(d_factory, F=4, nf=17, snr_db=20, cfo=70, pipeline_sync=
             w = [e for e in want[b]["tii"] if e[0] < nfr]
             assert sorted(got[b]) == w, "TII measurements of ensemble %d differ:\n got  %s\n want %s" % (b, sorted(got[b]), w)
             assert nfr >= want[b]["n_frames"] - F * (2 if pipeline_sync else 1)
+        if stats is not None:
+            stats["replayed"] = d.replayed_batches()
     finally:
         d.close()
 

@@ -159,3 +159,12 @@ def test_superframes_through_a_replayed_batch(emu):
     st = {}
     P.check_superframes_vs_oracle(factory, F=3, nf=22, snr_db=3.5, seed=7, B=1, damage=True, cfo=40, stats=st)
     assert st["replayed"] >= 1 and st["replayed_auto_0"] >= 1 and st["replayed_auto_1"] >= 1, st
+
+
+@pytest.mark.parametrize("snr,cfo,F,pipeline", [(4, -1000, 4, False), (3.5, -1000, 3, 2)])
+def test_tii_through_replayed_batches(emu, snr, cfo, F, pipeline):
+    """exact batch mode with the TII side path: at 3.5-4 dB batches have to be decoded a second time (the TII sums are put back with the
+    rest of the state); the measurements still equal the TIIDecoder restatement fed by the oracle receiver"""
+    st = {}
+    P.check_tii_vs_oracle(factory, F=F, nf=21, snr_db=snr, cfo=cfo, pipeline_sync=pipeline, stats=st, counts=False)
+    assert st["replayed"] >= 1, st
