@@ -143,8 +143,8 @@ def test_wide_synchroniser_pass(emu, pipeline):
     P.check_wide_sync(factory, pipeline_sync=pipeline)
 
 
-@pytest.mark.parametrize("snr,cfo,F,seed,pipeline,replay", [(3, -1000, 4, 5, False, True), (3, -1000, 4, 5, 1, True), (3, -1000, 4, 5, 2, None), (3, -1000, 4, 5, 3, None),
-                                                            (4, 300, 4, 3, 1, None), (2, 40, 4, 9, 2, None), (3, -1000, 8, 11, False, None), (4, 17400, 5, 13, 1, None), (5, 2300, 6, 7, False, None)])
+@pytest.mark.parametrize("snr,cfo,F,seed,pipeline,replay", [(3, -1000, 4, 5, False, True), (3, -1000, 4, 5, 1, True), (3, -1000, 4, 5, 3, None),
+                                                            (2, 40, 4, 9, 2, None), (4, 17400, 5, 13, 1, None)])      # (the device suite runs four more)
 def test_exact_batch_mode(emu, snr, cfo, F, seed, pipeline, replay):
     """Exact batch mode (the default): the low-SNR batch streams again, now required to equal the oracle frame for frame without any
     tolerance (a batch whose stale coarse-corrector decision can have mattered is put back and decoded a second time with the
@@ -161,7 +161,7 @@ def test_superframes_through_a_replayed_batch(emu):
     assert st["replayed"] >= 1 and st["replayed_auto_0"] >= 1 and st["replayed_auto_1"] >= 1, st
 
 
-@pytest.mark.parametrize("snr,cfo,F,pipeline", [(4, -1000, 4, False), (3.5, -1000, 3, 2)])
+@pytest.mark.parametrize("snr,cfo,F,pipeline", [(3.5, -1000, 3, 2)])                                            # (the device suite also runs the unpipelined case)
 def test_tii_through_replayed_batches(emu, snr, cfo, F, pipeline):
     """exact batch mode with the TII side path: at 3.5-4 dB batches have to be decoded a second time (the TII sums are put back with the
     rest of the state); the measurements still equal the TIIDecoder restatement fed by the oracle receiver"""
