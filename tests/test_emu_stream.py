@@ -168,3 +168,12 @@ def test_tii_through_replayed_batches(emu, snr, cfo, F, pipeline):
     st = {}
     P.check_tii_vs_oracle(factory, F=F, nf=21, snr_db=snr, cfo=cfo, pipeline_sync=pipeline, stats=st, counts=False)
     assert st["replayed"] >= 1, st
+
+
+@pytest.mark.parametrize("snr,cfo,seed,F", [(3, 300, 17, 3), (20, 37, 9, 4)])
+def test_live_ring_in_batches(emu, snr, cfo, seed, F):
+    """a live ring (s16 samples written as they arrive) decoded F frames per call: slots without samples inside the batches, the wide
+    synchroniser pass and its serial fall-back, at 3 dB a loss of lock with re-acquisition -- FIBs and MSC bytes = the oracle's"""
+    st = {}
+    P.check_live_batch_vs_oracle(factory, F=F, snr_db=snr, cfo=cfo, seed=seed, stats=st)
+    assert st["wide"][0][0] >= 1, st
