@@ -874,7 +874,7 @@ def check_exact_batch(d_factory, snr_db, cfo, F, seed, pipeline_sync=False, nf=2
     return logs
 
 
-def check_live_batch_vs_oracle(d_factory, F=3, nf=21, snr_db=3.5, cfo=-1000.0, seed=5, fmt="s16le", stats=None):
+def check_live_batch_vs_oracle(d_factory, F=3, nf=21, snr_db=3.5, cfo=-1000.0, seed=5, fmt="s16le", stats=None, ring_frames=None):
     """live ring (dabphy_stream_open / _write_raw, not a looping recording) decoded F frames per call: the synchroniser meets the end of
     the written samples inside a batch (slots without a frame), the wide pass has to leave those to nobody, and at this SNR exact batch
     mode decodes batches twice from the samples the first pass used.  FIBs and MSC bytes = the oracle's."""
@@ -885,7 +885,10 @@ def check_live_batch_vs_oracle(d_factory, F=3, nf=21, snr_db=3.5, cfo=-1000.0, s
     o = R.orc_receiver_run(xf, subchs=subs)
     d = d_factory(n_ensembles=1, max_frames=F, want_constellation=False)
     try:
-        ring = (nf + 4) * T_F          # nothing leaves the ring: a re-acquisition can replay sLevel exactly; the feed still starves slots
+        # default: nothing leaves the ring, a re-acquisition can replay sLevel exactly; the feed still starves slots.
+        # ring_frames: a ring shorter than the lock lasted -- the replay then brackets the level from [0, 2.125], the bound that holds for
+        # samples converted from u8 / s8 / s16, and ~10 frames of history are enough for the two ends to meet
+        ring = (ring_frames if ring_frames else nf + 4) * T_F
         d.stream_open(ring)
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
         fibs, oks, msc = [], [], [[] for _ in subs]
@@ -909,7 +912,7 @@ def check_live_batch_vs_oracle(d_factory, F=3, nf=21, snr_db=3.5, cfo=-1000.0, s
                 m, fv = d.msc(i); msc[i].append(m[0, fv[0]:4 * len(valid)].tobytes())
             idle = 0 if (valid or wr < len(raw)) else idle + 1          # (out of lock the receiver may need several batches to find the next null symbol)
             room = ring - (wr - d.stream_consumed())
-            feed(min(room, (F - 1) * T_F + 777))           # an uneven amount: batches with one, two or no starved slots
+            feed(min(room - (T_F if ring_frames else 0), (F - 1) * T_F + 777))           # an uneven amount: batches with one, two or no starved slots
         n = len(fibs)
         assert n >= o["n_frames"] - 1, (n, o["n_frames"])
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
@@ -919,5 +922,6 @@ def check_live_batch_vs_oracle(d_factory, F=3, nf=21, snr_db=3.5, cfo=-1000.0, s
             assert len(got) > 0 and got == want[:len(got)], "MSC bytes of sub-channel %d differ" % i
         if stats is not None:
             stats["replayed"] = d.replayed_batches(); stats["wide"] = d.wide_sync_stats()
+            lost, _ = d.sync_stats(); stats["lost"] = int(lost[0]); stats["relock_inexact"] = int(d.relock_inexact[0])
     finally:
         d.close()

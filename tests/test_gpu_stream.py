@@ -184,3 +184,12 @@ def test_live_ring_in_batches(gpu, snr, cfo, seed, F):
     st = {}
     P.check_live_batch_vs_oracle(factory, F=F, snr_db=snr, cfo=cfo, seed=seed, stats=st)
     assert st["wide"][0][0] >= 1, st
+
+
+def test_live_ring_shorter_than_the_lock(gpu):
+    """3 dB, lock lost after 12 frames in a live ring of 13: the samples sLevel would have to be replayed from are gone, the two
+    bracketing replays start from 0 and from the bound of converted s16 samples (2.125, not 3e38) and meet within the history that
+    is left: the re-acquisition is certified and lands where the reference's does"""
+    st = {}
+    P.check_live_batch_vs_oracle(factory, F=3, snr_db=3, cfo=300, seed=17, stats=st, ring_frames=13)
+    assert st["lost"] >= 1 and st["relock_inexact"] == 0, st

@@ -52,6 +52,7 @@ struct dabphy_handle {
     const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
     DevBuf s_iq_own;
     uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
+    bool s_bounded = false;           // every sample the stream ever held came through k_ingest from u8 / s8 / s16: |re|, |im| <= 1
     std::vector<dabphy_subchannel> subch;
     std::vector<MscClass> classes;
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
@@ -475,6 +476,8 @@ static SyncArgs sync_args(dabphy_handle* h, int sel, uint32_t F, uint64_t n_vali
     sa.fft_placement = h->cfg.fft_placement; sa.disable_coarse = h->cfg.disable_coarse; sa.freqsync = h->cfg.freqsync_method;
     sa.cir = h->cfg.want_impulse_response ? h->s_cir2[sel].as<float>() : nullptr;
     sa.hist = h->s_hist.as<FrameDesc>(); sa.hist_cap = HIST_CAP;
+    // |re| + |im| of a sample with |re|, |im| <= 1 after the oscillator (|o| = 1 to 1e-7) is at most sqrt(2) * sqrt(2) = 2; a little room for rounding
+    sa.level_max = h->s_bounded ? 2.125f : 3.0e38f;
     return sa;
 }
 static void launch_serial_chain(dabphy_handle* h, SyncArgs sa)
@@ -580,6 +583,7 @@ int dabphy_stream_bind_device(dabphy_handle* h, const void* d_iq, uint64_t ring_
     if (!h || !d_iq || ring_samples < (uint64_t)T_F || stride_samples < ring_samples) return DABPHY_ERR_INVALID;
     h->s_iq = reinterpret_cast<const cf32*>(d_iq); h->s_ring = ring_samples; h->s_stride = stride_samples;
     h->s_valid = n_valid; h->s_enqueued = 0; h->commit_slot = -1; h->s_loop = loop;
+    h->s_bounded = false;                                         // the caller's cf32 samples: no bound known
     return dabphy_reset(h);
 }
 
@@ -603,13 +607,16 @@ int dabphy_stream_open(dabphy_handle* h, uint64_t ring_samples)
     int r;
     if ((r = ensure(h, h->s_iq_own, bytes))) return r;
     HIPCHK(h, hipMemsetAsync(h->s_iq_own.p, 0, bytes, h->stream));
-    return dabphy_stream_bind_device(h, h->s_iq_own.p, ring_samples, ring_samples, 0, 0);
+    r = dabphy_stream_bind_device(h, h->s_iq_own.p, ring_samples, ring_samples, 0, 0);
+    h->s_bounded = true;                                          // an empty ring of zeros; a cf32 write (dabphy_stream_write) lifts the bound
+    return r;
 }
 
 int dabphy_stream_write(dabphy_handle* h, const float* iq, uint64_t n_samples)
 {
     DeviceBind dev_(h);
     if (!h || !iq || !h->s_iq_own.p || h->s_iq != h->s_iq_own.as<cf32>() || n_samples == 0 || n_samples > h->s_ring) return DABPHY_ERR_INVALID;
+    h->s_bounded = false;                                         // cf32 from the caller: any magnitude
     // the chain that may be running ahead must not race with the copy
     HIPCHK(h, hipStreamSynchronize(h->sync_stream));
     const uint64_t w = h->s_valid % h->s_ring;

@@ -79,6 +79,7 @@ struct SyncArgs {
     int fft_placement, disable_coarse, freqsync;        // FFTPlacementMethod, disableCoarseCorrector, FreqsyncMethod (reference numbering)
     float* cir;                                          // optional [B][n_frames][2048] impulse responses
     FrameDesc* hist; int hist_cap;                       // [B][hist_cap] ring of the window searches since the last acquisition (sLevel replay)
+    float level_max;                                     // upper bound of OFDMProcessor::sLevel for this stream (3e38: unknown): where the bracketing replay starts from above
     const int32_t* redo_from;                            // serial chain: [B] first frame slot the wide pass did not settle (nullptr: no wide pass ran)
     int32_t* redo_out; int32_t* any_redo;                // k_sync_validate: [B] and a flag
 };

@@ -409,7 +409,10 @@ __device__ __forceinline__ void slevel_replay(const SyncArgs& A, const int b, Rx
         if (!A.loop)                                                         // samples that have left the ring cannot be replayed
             for (int i = s_st.hist_count - 1; i >= 0; i--) if (hist[(s_st.hist_head + i) % A.hist_cap].pos < A.n_valid - A.ring) { first = i + 1; dropped = true; break; }
         s_first = first;
-        s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? 3.0e38f : s_st.s_level;
+        // (the upper end of the bracket: sLevel is a running convex combination of |re| + |im| of oscillator-corrected samples, so a bound
+        // on those bounds it: 2 for streams that only ever held converted u8 / s8 / s16 samples -- then ~10 frames of history certify the
+        // level, against ~50 from the 3e38 an unbounded cf32 stream has to assume)
+        s_lo = dropped ? 0.0f : s_st.s_level; s_hi = dropped ? A.level_max : s_st.s_level;
     }
     __syncthreads();
     for (int e = s_first; e < s_st.hist_count; e++) {
