@@ -161,7 +161,7 @@ def test_superframes_through_a_replayed_batch(emu):
     assert st["replayed"] >= 1 and st["replayed_auto_0"] >= 1 and st["replayed_auto_1"] >= 1, st
 
 
-@pytest.mark.parametrize("snr,cfo,F,pipeline", [(3.5, -1000, 3, 2)])                                            # (the device suite also runs the unpipelined case)
+@pytest.mark.parametrize("snr,cfo,F,pipeline", [(4, -1000, 4, False)])                                           # (the device suite also runs a pipelined case with three replays)
 def test_tii_through_replayed_batches(emu, snr, cfo, F, pipeline):
     """exact batch mode with the TII side path: at 3.5-4 dB batches have to be decoded a second time (the TII sums are put back with the
     rest of the state); the measurements still equal the TIIDecoder restatement fed by the oracle receiver"""
