@@ -493,7 +493,7 @@ static int queue_chain(dabphy_handle* h, int sel, uint32_t F)
 {
     SyncArgs sa = sync_args(h, sel, F, h->s_valid);
     h->chain_valid[sel] = h->s_valid; h->chain_frames[sel] = F;
-    if (h->exact_batch && h->snap_state[sel].p)
+    if (h->exact_batch && F > 1 && h->snap_state[sel].p)              // (one frame per call is exact by construction: nothing to put back)
         HIPCHK(h, hipMemcpyAsync(h->snap_state[sel].p, h->d_state, sizeof(RxState) * h->cfg.n_ensembles, hipMemcpyDeviceToDevice, h->sync_stream));
     { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
     // one frame per call (the real-time facade) gains nothing from the wide pass; two batches ahead its verdict would come too late
@@ -1118,7 +1118,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     return DABPHY_OK;
     };
-    if (h->exact_batch) {
+    if (h->exact_batch && F > 1) {
         // what the decoders carry from batch to batch, as it is in front of this one (the synchroniser's share was saved when this
         // batch's chain was queued: queue_chain)
         HIPCHK(h, hipMemcpyAsync(h->snap_dec.p, h->d_dec, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
