@@ -925,3 +925,48 @@ def check_live_batch_vs_oracle(d_factory, F=3, nf=21, snr_db=3.5, cfo=-1000.0, s
             lost, _ = d.sync_stats(); stats["lost"] = int(lost[0]); stats["relock_inexact"] = int(d.relock_inexact[0])
     finally:
         d.close()
+
+
+def check_exact_batch_mixed(d_factory, F=4, pipeline_sync=False, nf=25):
+    """exact batch mode with DIFFERENT ensembles in one handle: ensemble 0 is the 3 dB stream whose second batch has to be decoded twice,
+    ensemble 1 a clean 20 dB stream, ensemble 2 a 4 dB one -- the replay puts the state of ALL of them back and decodes the batch again;
+    every ensemble must still equal ITS oracle run frame for frame (FIBs, CRC flags, correctors, MSC bytes)"""
+    params = [(3, -1000.0, 5), (20, 37.0, 9), (4, 300.0, 3)]
+    xs, orcs, subs = [], [], None
+    for snr, cfo, seed in params:
+        x, tx = synth.make_stream(nf, snr_db=snr, cfo_hz=cfo, delay=150, return_tx=True, seed=seed)
+        subs = [tx.subchs[0], tx.subchs[9]]
+        xs.append(x); orcs.append(R.orc_receiver_run(x, subchs=subs))
+    n = max(len(x) for x in xs)
+    xs = [np.concatenate([x, np.zeros(n - len(x), np.complex64)]) for x in xs]
+    B = len(xs)
+    d = d_factory(n_ensembles=B, max_frames=F, pipeline_sync=pipeline_sync, want_constellation=False)
+    try:
+        d.stream_upload(np.stack(xs))
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subs])
+        fib = [[] for _ in range(B)]; ok = [[] for _ in range(B)]; corr = [[] for _ in range(B)]; msc = [[[] for _ in subs] for _ in range(B)]
+        for _ in range((nf + F - 1) // F + 3):
+            d.process(F)
+            info = d.frame_info(); fb, okk = d.fibs(); mscs = [d.msc(i) for i in range(len(subs))]
+            for b in range(B):
+                valid = [f for f in range(F) if info[b, f]["valid"] == 1]
+                for f in valid:
+                    fib[b].append(fb[b, f]); ok[b].append(okk[b, f]); corr[b].append((int(info[b, f]["fine"]), int(info[b, f]["coarse"])))
+                for i in range(len(subs)):
+                    m, fv = mscs[i]; msc[b][i].append(m[b, fv[b]:4 * len(valid)].tobytes())
+        assert d.replayed_batches() >= 1
+        eff, _ = d.ratio_lag_effect()
+        assert (eff == 0).all(), eff
+        for b in range(B):
+            o = orcs[b]
+            k = min(len(fib[b]), o["n_frames"] - 1)               # (the zero padding differs from the oracle's end of stream only after the last whole frame)
+            assert k >= o["n_frames"] - 1 - F * (1 + {0: 0, 1: 1, 2: 1, 3: 2}[int(pipeline_sync)]), (b, k, o["n_frames"])
+            ofib = o["fib"][:12 * k].reshape(k, 12, 33)
+            assert np.array_equal(np.array(ok[b][:k]), ofib[:, :, 0]) and np.array_equal(np.array(fib[b][:k]), ofib[:, :, 1:]), "ensemble %d: FIBs differ" % b
+            assert corr[b][:k] == [tuple(int(v) for v in c) for c in o["corr"][:k]], "ensemble %d: correctors differ" % b
+            for i in range(len(subs)):
+                got = b"".join(msc[b][i]); want = bytes(o["msc"][i])
+                m = min(len(got), max(0, 4 * k - 16) * subs[i].frame_bytes)
+                assert m > 0 and got[:m] == want[:m], "ensemble %d: MSC bytes of sub-channel %d differ" % (b, i)
+    finally:
+        d.close()

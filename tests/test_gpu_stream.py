@@ -193,3 +193,9 @@ def test_live_ring_shorter_than_the_lock(gpu):
     st = {}
     P.check_live_batch_vs_oracle(factory, F=3, snr_db=3, cfo=300, seed=17, stats=st, ring_frames=13)
     assert st["lost"] >= 1 and st["relock_inexact"] == 0, st
+
+
+@pytest.mark.parametrize("pipeline", [False, 1, 2, 3])
+def test_exact_batch_mode_with_different_ensembles(gpu, pipeline):
+    """one ensemble of three makes a batch be decoded twice: all three must still equal their own oracle runs"""
+    P.check_exact_batch_mixed(factory, pipeline_sync=pipeline)
