@@ -3,7 +3,9 @@ schedule, every stream through tests/parity_cases.check_stream_vs_oracle -- FIBs
 symbols, SNR reports and the MSC bytes of three sub-channels against the oracle, frame by frame; batch mode's documented deviation
 (a coarse-corrector decision taken with a stale FIC ratio) is tolerated only from the frame the library itself reports -- and reports
 how many frames came from the wide synchroniser pass and how many OFDM symbols took the unchecked / checked oscillator conversion.
-python tools/sweep_batch.py [n_streams] [seed]"""
+python tools/sweep_batch.py [n_streams] [seed] [exact]
+With `exact` the library's default is swept instead -- exact batch mode, replay armed -- at 2-8 dB, and NO tolerance is given: every frame
+must equal the oracle's; the replayed batches are counted."""
 import os
 import sys
 
@@ -19,22 +21,26 @@ from welle_io_amd import capi  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = os.environ.get("DABPHY_LIB", GPU_LIB)
+exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
 
 
 def factory(**kw):
     return capi.DabPhy(lib_path=lib, **kw)
 
 
-frames = wide = fast = checked = lagged = effective = 0
+frames = wide = fast = checked = lagged = effective = replayed = 0
 for it in range(n):
-    snr = float(rng.choice([10, 13, 16, 20, 25, 30]))
+    snr = float(rng.choice([2, 3, 4, 5, 6, 8])) if exact else float(rng.choice([10, 13, 16, 20, 25, 30]))
     cfo = float(rng.uniform(-60, 60)) if rng.rand() < 0.5 else float(rng.uniform(-450, 450))
     delay = int(rng.randint(0, 2000)); F = int(rng.choice([2, 3, 5, 8])); pipe = int(rng.choice([0, 1, 2])); seed = int(rng.randint(1 << 30))
     nf = int(rng.choice([18, 26, 34]))
-    logs, o, _ = P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, False, B=2, F=F, pipeline_sync=pipe, seed=seed, ratio_lag_ok=True)
+    if exact and rng.rand() < 0.5:
+        cfo = float(rng.choice([-2400, -1000, 300, 1500, 2300, 17400]))
+    logs, o, _ = P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, False, B=2, F=F, pipeline_sync=pipe, seed=seed, ratio_lag_ok=not exact)
+    replayed += logs[0]["replayed"]
     L = logs[0]
     k = len(L["info"]); frames += k; wide += L["wide"][0]; fast += L["osc"][0]; checked += L["osc"][1]; lagged += int(L["ratio_lag"][0] > 0); effective += int(L["ratio_lag_effect"][0] > 0)
     print("stream %3d  snr %4.0f dB  cfo %7.1f Hz  delay %4d  F %d  schedule %d  frames %2d  from the wide pass %2d  oscillator symbols unchecked/checked %d/%d  ratio lag %s with an effect %s"
           % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"], L["ratio_lag_effect"]), flush=True)
-print("streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  mismatches 0"
-      % (n, frames, wide, fast, checked, lagged, effective))
+print("streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  batches decoded twice %d  mismatches 0"
+      % (n, frames, wide, fast, checked, lagged, effective, replayed))
