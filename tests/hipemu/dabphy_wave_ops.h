@@ -47,6 +47,9 @@ static inline uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
     return ((a[0] & 0x8000) ? 0xffu : 0u) | ((b[0] & 0x8000) ? 0xff00u : 0u) | ((a[1] & 0x8000) ? 0xff0000u : 0u) | ((b[1] & 0x8000) ? 0xff000000u : 0u);
 }
 
+static inline int mul_i24(int x, int m) { return (int)((uint32_t)x * (uint32_t)m); }
+static inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
+
 template <int VARIANT> static inline float div127_fast(float x) { return 127.0f / x; }
 constexpr float DIV127_LO = 0x1p-100f, DIV127_HI = 0x1p100f;
 // the model decides per lane: both sides of a wave_all() branch must compute the same result wherever the fast side is legal

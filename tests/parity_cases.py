@@ -167,14 +167,14 @@ def fic_ratio_before(ok_flags):
 
 
 def check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=1, seed=3, F=4, pipeline_sync=False, disable_coarse=False, con=True, fft_placement=2, freqsync=2,
-                           ratio_lag_ok=False, serial_sync=False, exact_batch=None):
+                           ratio_lag_ok=False, serial_sync=False, exact_batch=None, channel=None):
     """ratio_lag_ok: batch mode's documented deviation (include/dabphy.h, dabphy_process) is tolerated and PINNED: the frames must
     equal the oracle's up to the first frame before which the FIC ratio crossed the 50 % line within the last F (2F when pipelined)
     frames -- only there may a batch have consulted a stale ratio; what comes before is compared bit for bit, returns that frame.
     exact_batch: None = the library's default (replay on) unless ratio_lag_ok asks for the report-only mode it pins"""
     if exact_batch is None:
         exact_batch = not ratio_lag_ok
-    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed)
+    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=delay, return_tx=True, seed=seed, channel=channel)
     subs = [tx.subchs[0], tx.subchs[5], tx.subchs[9]]
     o = R.orc_receiver_run(x, subchs=subs, want_soft=True, disable_coarse=disable_coarse, fft_placement=fft_placement, freqsync=freqsync)
     logs = run_stream(d_factory, x, subs, 1 if lockstep else F, o["n_frames"], B=B, pipeline_sync=pipeline_sync, disable_coarse=disable_coarse, con=con, fft_placement=fft_placement, freqsync=freqsync, serial_sync=serial_sync, exact_batch=exact_batch)
@@ -970,3 +970,29 @@ def check_exact_batch_mixed(d_factory, F=4, pipeline_sync=False, nf=25):
                 assert m > 0 and got[:m] == want[:m], "ensemble %d: MSC bytes of sub-channel %d differ" % (b, i)
     finally:
         d.close()
+
+
+# ---------------------------------------------------------------------------------------------- channel impairments
+# What the reference's own soak harness exercises (welle-cli/tests.cpp:305-370: multipath and the comparison of the FFT placement
+# methods, phasereference.cpp:73-256) and what stresses the synchroniser's batch machinery here: the wide pass predicts "same window
+# index, same correctors" for every frame of a batch, and a drifting sampling clock, a second path that outweighs the first, or a
+# fading envelope break that prediction in most batches -- the frame-by-frame chain then takes over (redo_from), and the result must
+# still be the oracle's, frame for frame, with NO tolerance.
+CHANNELS = {
+    "ppm+60":      dict(ppm=60.0),
+    "ppm-100":     dict(ppm=-100.0),
+    "echo300":     dict(echoes=[(300, 0.7)]),
+    "pre-echo":    dict(echoes=[(-200, 0.6), (400, 0.4j)]),
+    "sfn3":        dict(echoes=[(95, 0.9 * np.exp(0.7j)), (260, 0.55 * np.exp(-2.1j))]),
+    "echo600":     dict(echoes=[(600, 0.8)]),                     # beyond the guard interval (504 samples)
+    "fade7":       dict(fade=(0.3, 7.0)),
+    "ppm+fade":    dict(ppm=40.0, fade=(0.3, 7.0), echoes=[(150, 0.5j)]),
+}
+
+
+def check_impaired_stream(d_factory, channel, F, schedule, placement, snr_db=18, cfo=55, delay=137, nf=None, seed=11, B=1, lockstep=False):
+    """one stream through `channel`, decoded F frames per call in pipeline schedule `schedule` with FFT placement method `placement`,
+    against the oracle: FIBs, CRC flags, correctors, constellation, null symbols, all soft bits, MSC bytes, SNR"""
+    nf = nf or (3 * F + 4 if schedule == 0 else 4 * F + 5)
+    check_stream_vs_oracle(d_factory, snr_db, cfo, delay, nf, lockstep, B=B, seed=seed, F=F, pipeline_sync=schedule, fft_placement=placement,
+                           channel=CHANNELS[channel] if isinstance(channel, str) else channel)

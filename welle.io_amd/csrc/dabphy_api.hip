@@ -278,6 +278,17 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     return DABPHY_OK;
 }
 
+namespace {
+// every device buffer of one protection class (dabphy_set_subchannels replaces the classes, dabphy_destroy ends them)
+void free_class(dabphy_handle::MscClass& c)
+{
+    hipError_t e = hipSuccess;
+    DevBuf* bufs[] = {&c.map, &c.start_bits, &c.tiles, &c.out, &c.steps, &c.sf_state, &c.sf_snap};
+    for (DevBuf* b : bufs) if (b->p) { e = hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    (void)e;
+}
+}
+
 void dabphy_destroy(dabphy_handle* h)
 {
     DeviceBind dev_(h);
@@ -301,7 +312,6 @@ void dabphy_destroy(dabphy_handle* h)
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (h->snap_state[i].p) e = hipFree(h->snap_state[i].p);
     if (h->snap_dec.p) e = hipFree(h->snap_dec.p);
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
-    for (auto& c : h->classes) if (c.sf_snap.p) e = hipFree(c.sf_snap.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
@@ -313,7 +323,7 @@ void dabphy_destroy(dabphy_handle* h)
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
     { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     { DevBuf* tb[] = {&h->s_hist, &h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
-    for (auto& c : h->classes) { if (c.map.p) e = hipFree(c.map.p); if (c.start_bits.p) e = hipFree(c.start_bits.p); if (c.tiles.p) e = hipFree(c.tiles.p); if (c.out.p) e = hipFree(c.out.p); if (c.sf_state.p) e = hipFree(c.sf_state.p); if (c.steps.p) e = hipFree(c.steps.p); }
+    for (auto& c : h->classes) free_class(c);
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
     for (DevBuf* b : bufs) if (b->p) e = hipFree(b->p);
     (void)e;
@@ -723,16 +733,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         if (!protection_valid(&s.prot) || s.prot.nbits > PRBS_MAX_BITS || s.start_cu < 0 || s.size_cu <= 0 || s.start_cu + s.size_cu > 864 ||
             protection_input_bits(&s.prot) > s.size_cu * 64) { h->err = "invalid sub-channel " + std::to_string(i); return DABPHY_ERR_INVALID; }
     }
-    for (auto& c : h->classes) {
-        hipError_t e;
-        if (c.map.p) e = hipFree(c.map.p);
-        if (c.start_bits.p) e = hipFree(c.start_bits.p);
-        if (c.tiles.p) e = hipFree(c.tiles.p);
-        if (c.sf_state.p) e = hipFree(c.sf_state.p);
-        if (c.out.p) e = hipFree(c.out.p);
-        if (c.steps.p) e = hipFree(c.steps.p);
-        (void)e;
-    }
+    for (auto& c : h->classes) free_class(c);
     h->classes.clear();
     h->last_frames = 0; h->last_desc = nullptr; h->sf_stats_ready = false;     // the class outputs of the last batch are gone with the classes
     h->subch.assign(list, list + n);
@@ -769,7 +770,8 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         {
             static const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
             constexpr int ROWS = 96, SLOT = ROWS * 16, ZERO = 2 * SLOT;
-            std::vector<MscStep> st((size_t)nsteps + 2);      // (+2: the kernel requests descriptors one pair of steps ahead)
+            constexpr int PADDING = 6;                        // the kernel requests descriptors one block of six steps ahead
+            std::vector<MscStep> st((size_t)nsteps + PADDING);
             std::vector<int> wlo((size_t)nsteps, -1), whi((size_t)nsteps, -1);
             for (int q = 0; q < nsteps; q++) {
                 uint32_t off[4];
@@ -783,7 +785,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
                 }
                 st[q].off01 = off[0] | (off[1] << 16); st[q].off23 = off[2] | (off[3] << 16);
             }
-            st[(size_t)nsteps].off01 = st[(size_t)nsteps + 1].off01 = ZERO | (ZERO << 16); st[(size_t)nsteps].off23 = st[(size_t)nsteps + 1].off23 = ZERO | (ZERO << 16);
+            for (int q = nsteps; q < nsteps + PADDING; q++) st[(size_t)q].off01 = st[(size_t)q].off23 = ZERO | (ZERO << 16);
             const int n_in = protection_input_bits(&c.prot);
             c.n_windows = (n_in + 15) / 16;
             // lowest window any LATER step reads: when it moves up, the window below it has died and its slot takes the window after the next
@@ -791,7 +793,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
             for (int q = nsteps - 2, low = c.n_windows; q >= 0; q--) { if (wlo[q + 1] >= 0) low = wlo[q + 1]; low_after[q] = low; }
             int seen = 1, prev_low = 0;
             std::vector<int> load_step((size_t)c.n_windows + 2, -10);
-            bool ok = true; int why = 0;
+            bool ok = nsteps % 6 == 0; int why = ok ? 0 : 8;    // (the kernel walks the trellis in blocks of six steps: true for every 24 * bitrate + 6)
             for (int q = 0; q < nsteps; q++) {
                 if (whi[q] > seen) {
                     st[q].off01 |= MSC_FIRST_USE; seen = whi[q];
@@ -955,7 +957,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     if (replay) {
         // Exact batch mode, second pass: the batch again, frame by frame, with the reference's own feedback -- the window search of
         // frame f consults the FIC ratio as it stands after frame f - 1 (ofdm-processor.cpp:397), which takes that frame's FIC: chain
-        // step, the first chunk of the frame's symbols (PRS + FIC symbols), FIC decode of the class, ratio of frame f.  Everything else
+        // step, the first chunk(s) of the frame's symbols (PRS + the three FIC symbols), FIC decode of the class, ratio of frame f.  Everything else
         // of the batch follows below as in the first pass (the demod kernel writes the same soft bits again where nothing changed).
         SyncArgs sa = sync_args(h, cur, F, h->chain_valid[cur]);
         VitClass c = fic_c;
@@ -968,7 +970,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             sa.frame = (int)f;
             launch_sync_find(sa, h->stream);
             launch_sync_finish(sa, h->stream);
-            DemodArgs d1 = da; d1.frame_first = (int)f; d1.frame_count = 1; d1.chunk_count = 1; d1.con = nullptr; d1.osc_stats = nullptr;
+            DemodArgs d1 = da; d1.frame_first = (int)f; d1.frame_count = 1; d1.con = nullptr; d1.osc_stats = nullptr;
+            d1.chunk_count = (3 + da.chunk_len - 1) / da.chunk_len;          // the chunks that hold the FIC symbols 1..3 (demod_chunk may be 1 or 2)
             launch_demod(d1, (int)B, h->stream);
             launch_fic_gather(g, h->stream);
             launch_viterbi(v, h->stream);

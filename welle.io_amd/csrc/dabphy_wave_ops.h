@@ -111,6 +111,12 @@ __device__ __forceinline__ uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
     return __builtin_amdgcn_perm(bu, au, 0x0b090a08u);       // pool {S0 = b, S1 = a}: 8 = a[15], 10 = b[15], 9 = a[31], 11 = b[31]
 }
 
+// x * m for |x|, |m| < 2^23, m wave-uniform: one v_mul_i32_i24 (written as asm: left to itself the compiler re-associates sums of such
+// products, loses the operand ranges on the way and ends up with the quarter-rate 32-bit v_mul_lo_u32)
+__device__ __forceinline__ int mul_i24(int x, int m) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "s"(m), "v"(x)); return r; }
+// ({hi, lo} >> sh) & 0xffffffff, 0 <= sh <= 31 (v_alignbit_b32)
+__device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
 // 127 / x for x in [2^-100, 2^100]: v_rcp_f32 (1 ulp) + one residual correction, 4 instructions instead of the 11 of the
 // IEEE division sequence.  DIV127_VARIANT 1 adds a second correction.  dabphy_selftest_div127 compares every variant
 // with the correctly rounded quotient for ALL floats of that range on the device it runs on; k_demod only uses the

@@ -11,133 +11,65 @@
 //
 // MI355X mapping.  The reference decodes one codeword at a time with 64 scalar states.  Here ONE LANE
 // decodes ONE CODEWORD: a wavefront carries 64 independent codewords, the 64 path metrics of each live in
-// 32 VGPRs as packed uint16 pairs (state 2j | state 2j+1 << 16) and a trellis step is 32 packed butterflies of
-// 2 x v_pk_add_u16 + v_pk_min_u16 + v_pk_sub_i16 with no cross-lane traffic and no LDS.  Decisions (64 bit per
-// step and codeword) stream to HBM as one coalesced 8-byte store per lane and are read back by the same
-// lane during traceback.  Exact-integer equivalence with the reference: metrics are uint16 without
-// wrap-around (minimum subtracted every 32 steps; spread <= 6*1020, growth <= 32*1020), decisions are
-// "m0 > m1" evaluated on the true integers, ties keep the m0/m2 branch -- the reference's own
-// renormalisation schedule (viterbi.cpp:104-120) changes no decision, so none of it is mimicked.
+// 32 VGPRs as pairs of uint16 and a trellis step is 32 x (2 plain 32-bit additions, v_pk_min_u16, v_pk_sub_i16) in a
+// pairing of states that rotates through six layouts (viterbi_acs.h), with no cross-lane traffic and no LDS.
+// Decisions (64 bit per step and codeword) stream to HBM as one coalesced 8-byte store per lane and are read
+// back by the same lane during traceback.  Exact-integer equivalence with the reference: metrics are uint16
+// without wrap-around, decisions are "m0 > m1" evaluated on the true integers, ties keep the m0/m2 branch --
+// the reference's own renormalisation schedule (viterbi.cpp:104-120) changes no decision, so none of it is mimicked.
 #include "dabphy_kernels.h"
 #include <cstdlib>
 #include <dabphy_wave_ops.h>
+#include "viterbi_acs.h"
 
 namespace dabphy {
 
-__device__ __forceinline__ uint32_t asu(u16x2 a) { uint32_t r; __builtin_memcpy(&r, &a, 4); return r; }
-__device__ __forceinline__ u16x2 asv(uint32_t a) { u16x2 r; __builtin_memcpy(&r, &a, 4); return r; }
-__device__ __forceinline__ u16x2 pkmin(u16x2 a, u16x2 b) { return (a < b) ? a : b; }
-__device__ __forceinline__ u16x2 splat(uint32_t x) { return asv(x | (x << 16)); }
-
-// Branch pattern of butterfly i (0..15): bit j = parity((2i) & poly_j) for polys {0155, 0117, 0123}
-// (viterbi.cpp:36,170-177; the 4th output repeats poly 0155).  Butterfly i+16 has bit 0 flipped.
-__host__ __device__ constexpr int parity6(int x) { x ^= x >> 4; x ^= x >> 2; x ^= x >> 1; return x & 1; }
-__host__ __device__ constexpr int bf_pattern(int i)
-{
-    return parity6((2 * i) & 0155) | (parity6((2 * i) & 0117) << 1) | (parity6((2 * i) & 0123) << 2);
-}
-
 // Symbol word of one trellis step as the gathers store it.  s0..s3 = the four soft symbols 0..255 of the step (output j of
-// the mother code, viterbi.cpp:233-238 mapping applied); outputs 0 and 3 share a generator, so three branch-metric terms
-// describe the step (viterbi.cpp:259-261):  m0 = bm(pattern 0) = s0+s3 + s1 + s2,  m1 = bm(pattern 1) = 510-(s0+s3) + s1 + s2,
-// c = 255 - 2 s1 (bm(p | 2) = bm(p) + c).  Packed m0 | m1 << 10 | (c + 256) << 20, so the decoder spends its
-// instructions on the trellis, not on unpacking bytes.
+// the mother code, viterbi.cpp:233-238 mapping applied; 255 cannot occur: an int8 + 127 is at most 254).  Outputs 0 and 3 share a
+// generator, so the engine takes x0 = (s0 - 127) + (s3 - 127), v1 = s1 - 127, v2 = s2 - 127 (viterbi_acs.h): packed
+// int16 | int8 << 16 | int8 << 24, so the decoder spends three instructions on unpacking.
 __device__ __forceinline__ uint32_t pack_step(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3)
 {
-    const uint32_t t0 = s0 + s3, u = s1 + s2;
-    return (t0 + u) | ((510u - t0 + u) << 10) | ((511u - 2u * s1) << 20);
+    return ((s0 + s3 - 254u) & 0xffffu) | (((s1 - 127u) & 0xffu) << 16) | ((s2 - 127u) << 24);
 }
 __device__ __forceinline__ uint32_t pack_step_word(uint32_t w) { return pack_step(w & 0xff, (w >> 8) & 0xff, (w >> 16) & 0xff, w >> 24); }
-
-// Register layout: R[j] = (metric of state 2j | metric of state 2j+1 << 16).  Butterfly k (0..31) reads old[k] and
-// old[k+32] -- half (k & 1) of R[k >> 1] and of R[16 + (k >> 1)], broadcast to both halves by the op_sel bits of the
-// packed add -- and produces new[2k], new[2k+1] = N[k]: the layout is stationary, no register is ever re-paired.
-//   P = (old[k],    old[k])    + (bm(p), bm(p^7))   = (m0, m2)          (viterbi.cpp:263-268 BFLY)
-//   Q = (old[k+32], old[k+32]) + (bm(p^7), bm(p))   = (m1, m3)
-//   N[k] = min(P, Q);  decisions d = m0 > m1 | m2 > m3 = sign bits of Q - P (ties keep the m0 / m2 branch)
-// Decision words: pk_sign_bytes(D[i], D[i+16]) = bytes [d(2i), d(2i+32), d(2i+1), d(2i+33)] as 0x00 / 0xff, masked onto
-// bit (i & 7) of word (i >> 3).  Decision of state s at a step: word (s >> 4) & 1, byte 2 * (s & 1) + (s >> 5), bit (s >> 1) & 7.
-constexpr int VIT_PF = 4;        // trellis steps per software-pipeline stage (even, divides 32)
-
-#ifndef VIT_INTERLEAVE
-#define VIT_INTERLEAVE 1
-#endif
-template <int K>
-__device__ __forceinline__ void bfly(const u16x2 (&R)[32], u16x2 (&N)[32], u16x2 (&D)[32], const u16x2 (&BM)[4])
+template <int F>
+__device__ __forceinline__ uint2 step_from_word(uint32_t (&M)[32], uint32_t w, uint32_t ones)
 {
-    constexpr int p = bf_pattern(K & 15) ^ (K >> 4);
-    const u16x2 a = (K & 1) ? pk_dup_hi(R[K >> 1]) : pk_dup_lo(R[K >> 1]);
-    const u16x2 b = (K & 1) ? pk_dup_hi(R[16 + (K >> 1)]) : pk_dup_lo(R[16 + (K >> 1)]);
-    const u16x2 bm = (p < 4) ? BM[p] : pk_swap(BM[p ^ 7]);                                     // (bm(p), bm(p^7))
-    const u16x2 P = a + bm, Q = b + pk_swap(bm);
-    N[K] = pkmin(P, Q);
-    D[K] = Q - P;
+    return acs::step<F>(M, (int)(int16_t)(w & 0xffffu), (int)(int8_t)((w >> 16) & 0xffu), (int)w >> 24, ones);
 }
 
-template <int I>
-__device__ __forceinline__ void decide(const u16x2 (&D)[32], uint32_t& accA, uint32_t& accB, uint32_t ones)
+// Traceback of one codeword from state 0, skipping the 6 tail steps (chainback_viterbi, viterbi.cpp:313-339); bits are packed MSB
+// first (decoder_adapter.cpp:61-67) into little-endian 32-bit words and XORed with the energy-dispersal sequence when asked to
+// (fic-handler.cpp:206-208, energy_dispersal.h:51-53).  The decision words do not depend on the path, so 8 steps are fetched at a
+// time and resolved from registers (acs::back: four instructions per step).  dec_lane = this lane's column of the group's decisions.
+__device__ __forceinline__ void traceback(const uint2* __restrict__ dec_g, uint32_t lane, int nbits, uint32_t* __restrict__ out, bool live,
+                                          int dedisperse, const uint32_t* __restrict__ prbs_words)
 {
-    // `ones` = 0x01010101 kept in an SGPR (opaque to the compiler) so that mask-and-merge is one v_and_or_b32 (a VOP3
-    // instruction cannot carry a 32-bit literal)
-    const uint32_t x = pk_sign_bytes(D[I], D[I + 16]);
-    if (I < 8) accA = and_or(x, ones << (I & 7), accA);
-    else       accB = and_or(x, ones << (I & 7), accB);
-}
-
-// butterflies I and I + 16 followed at once by their decision bytes: the two difference registers die immediately
-template <int I>
-__device__ __forceinline__ void bfly_pairs(const u16x2 (&R)[32], u16x2 (&N)[32], const u16x2 (&BM)[4], uint32_t& accA, uint32_t& accB, uint32_t ones)
-{
-    u16x2 D[32];
-#if VIT_INTERLEAVE == 2
-    bfly<I>(R, N, D, BM); bfly<I + 16>(R, N, D, BM); bfly<I + 1>(R, N, D, BM); bfly<I + 17>(R, N, D, BM);
-    bfly<I + 2>(R, N, D, BM); bfly<I + 18>(R, N, D, BM); bfly<I + 3>(R, N, D, BM); bfly<I + 19>(R, N, D, BM);
-    decide<I>(D, accA, accB, ones); decide<I + 1>(D, accA, accB, ones); decide<I + 2>(D, accA, accB, ones); decide<I + 3>(D, accA, accB, ones);
-    if constexpr (I + 4 < 16) bfly_pairs<I + 4>(R, N, BM, accA, accB, ones);
-#elif VIT_INTERLEAVE
-    bfly<I>(R, N, D, BM);
-    bfly<I + 16>(R, N, D, BM);
-    bfly<I + 1>(R, N, D, BM);
-    bfly<I + 17>(R, N, D, BM);
-    decide<I>(D, accA, accB, ones);
-    decide<I + 1>(D, accA, accB, ones);
-    if constexpr (I + 2 < 16) bfly_pairs<I + 2>(R, N, BM, accA, accB, ones);
-#else
-    bfly<I>(R, N, D, BM);
-    bfly<I + 16>(R, N, D, BM);
-    decide<I>(D, accA, accB, ones);
-    if constexpr (I + 1 < 16) bfly_pairs<I + 1>(R, N, BM, accA, accB, ones);
-#endif
-}
-
-__device__ __forceinline__ void trellis_step(const u16x2 (&R)[32], u16x2 (&N)[32], uint32_t sy, uint2* dec_out, uint32_t ones)
-{
-    // sy = pack_step(): bm(0), bm(1) and c with bm(p | 2) = bm(p) + c; bm(p ^ 7) = 1020 - bm(p)
-    const uint32_t m0 = sy & 0x3ffu, m1 = (sy >> 10) & 0x3ffu;
-    const uint32_t m2 = m0 + (sy >> 20) - 256u, m3 = m1 + (sy >> 20) - 256u;
-    u16x2 BM[4];    // BM[p] = (bm(p), bm(p ^ 7))
-    BM[0] = asv(m0 | ((1020u - m0) << 16)); BM[1] = asv(m1 | ((1020u - m1) << 16));
-    BM[2] = asv(m2 | ((1020u - m2) << 16)); BM[3] = asv(m3 | ((1020u - m3) << 16));
-    uint32_t accA = 0, accB = 0;
-    bfly_pairs<0>(R, N, BM, accA, accB, ones);
-    *dec_out = make_uint2(accA, accB);
-}
-
-__device__ __forceinline__ void renorm(u16x2 (&R)[32])
-{
-    u16x2 t[16];                                                       // tree, not a chain: no back-to-back dependent packed ops
+    uint32_t J = 0, outw = 0;
+    uint32_t rho = (uint32_t)acs::dec_rot((nbits - 1) % 6);       // step t = n + 6 ran in layout t % 6 = n % 6
+    uint2 dq[8], dn[8];                                           // this iteration's decision words and the next one's (already in flight)
 #pragma unroll
-    for (int j = 0; j < 16; j++) t[j] = pkmin(R[j], R[j + 16]);
+    for (int k = 0; k < 8; k++) dq[k] = dec_g[(uint32_t)((nbits - 1 - k + 6) * 64) + lane];
+    for (int n = nbits - 1; n >= 0; n -= 8) {
+        {
+            const int m = n >= 8 ? n - 8 : n;                     // the last iteration re-reads its own words
 #pragma unroll
-    for (int w = 8; w > 0; w >>= 1)
+            for (int k = 0; k < 8; k++) dn[k] = dec_g[(uint32_t)((m - k + 6) * 64) + lane];
+        }
 #pragma unroll
-        for (int j = 0; j < w; j++) t[j] = pkmin(t[j], t[j + w]);
-    const uint32_t mu = asu(t[0]);
-    uint32_t lo = mu & 0xffffu, hi = mu >> 16;
-    const uint32_t mn = lo < hi ? lo : hi;
-    const u16x2 sub = splat(mn);
+        for (int k = 0; k < 8; k++) {
+            acs::back(dq[k], J, outw, rho);
+            rho = rho == 5 ? 0 : rho + 1;
+        }
+        if (((n - 7) & 31) == 0) {
+            const int wi = (n - 7) >> 5;
+            const uint32_t word = acs::back_word(outw);
+            if (live) out[wi] = dedisperse ? word ^ prbs_words[wi] : word;
+        }
 #pragma unroll
-    for (int j = 0; j < 32; j++) R[j] = R[j] - sub;
+        for (int k = 0; k < 8; k++) dq[k] = dn[k];
+    }
 }
 
 // One wavefront per work-group; a work-group walks groups g, g + gridDim.x, ... of 64 codewords (launch_viterbi sizes the
@@ -155,79 +87,45 @@ __global__ void __launch_bounds__(64, VIT_OCC) k_viterbi(VitArgs A)
     uint2* __restrict__ dec = A.c.dec + (size_t)g * nsteps * 64 + lane;
 
     const uint32_t ones = opaque_sgpr(0x01010101u);
-    u16x2 R[32], N[32];
-    // init_viterbi (viterbi.cpp:342-354): all 63, start state 0 biased to 0
-#pragma unroll
-    for (int j = 0; j < 32; j++) R[j] = splat(63);
-    R[0] = asv(63u << 16);
+    uint32_t M[32];
+    acs::init(M);
 
-    // VIT_PF trellis steps per iteration (R -> N -> R ...); the symbols of the NEXT iteration are requested before the
+    // Six trellis steps per iteration (one turn through the layouts); the symbols of the NEXT iteration are requested before the
     // current ones are consumed, so a wave waits neither on its own loads nor on the completion of its decision stores
     // (one vmcnt counter covers both on gfx9: a wait for a load also waits for every older store).
-    int s = 0;
-    uint32_t y[VIT_PF];
+    const int nblk = nsteps / 6;
+    uint32_t y[6];
 #pragma unroll
-    for (int k = 0; k < VIT_PF; k++) y[k] = sym[(size_t)(k < nsteps ? k : nsteps - 1) * 64];
-    for (; s + VIT_PF <= nsteps; s += VIT_PF) {
-        uint32_t n[VIT_PF];
+    for (int k = 0; k < 6; k++) y[k] = sym[(size_t)(k < nsteps ? k : nsteps - 1) * 64];
+    int s = 0, since_renorm = 0;
+    for (int blk = 0; blk < nblk; blk++, s += 6) {
+        uint32_t n[6];
         {
-            const int i0 = (s + 2 * VIT_PF <= nsteps) ? s + VIT_PF : nsteps - VIT_PF;     // clamp: the last iterations re-read valid memory
+            const int i0 = (s + 12 <= nsteps) ? s + 6 : s;        // the last iteration re-reads valid memory
             const uint32_t* __restrict__ q = sym + (size_t)i0 * 64;
 #pragma unroll
-            for (int k = 0; k < VIT_PF; k++) n[k] = q[k * 64];
+            for (int k = 0; k < 6; k++) n[k] = q[k * 64];
         }
+        dec[(size_t)(s + 0) * 64] = step_from_word<0>(M, y[0], ones);
+        dec[(size_t)(s + 1) * 64] = step_from_word<1>(M, y[1], ones);
+        dec[(size_t)(s + 2) * 64] = step_from_word<2>(M, y[2], ones);
+        dec[(size_t)(s + 3) * 64] = step_from_word<3>(M, y[3], ones);
+        dec[(size_t)(s + 4) * 64] = step_from_word<4>(M, y[4], ones);
+        dec[(size_t)(s + 5) * 64] = step_from_word<5>(M, y[5], ones);
+        if (++since_renorm == acs::RENORM_BLOCKS) { acs::renorm(M); since_renorm = 0; }
 #pragma unroll
-        for (int k = 0; k < VIT_PF; k += 2) {
-            trellis_step(R, N, y[k], dec + (size_t)(s + k) * 64, ones);
-            trellis_step(N, R, y[k + 1], dec + (size_t)(s + k + 1) * 64, ones);
-        }
-        if ((s & 24) == 24 && ((s + VIT_PF) & 31) == 0) renorm(R);   // every 32 steps: 6120 + 32 * 1020 < 65536
-#pragma unroll
-        for (int k = 0; k < VIT_PF; k++) y[k] = n[k];
+        for (int k = 0; k < 6; k++) y[k] = n[k];
     }
-    for (; s + 1 < nsteps; s += 2) {
-        trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64, ones);
-        trellis_step(N, R, sym[(size_t)(s + 1) * 64], dec + (size_t)(s + 1) * 64, ones);
-    }
-    if (s < nsteps) {
-        trellis_step(R, N, sym[(size_t)s * 64], dec + (size_t)s * 64, ones);
-    }
+    // fewer than six steps left (a length that is not a multiple of six: only through the dabphy_viterbi_batch seam)
+    if (s < nsteps) { dec[(size_t)s * 64] = step_from_word<0>(M, sym[(size_t)s * 64], ones); s++; }
+    if (s < nsteps) { dec[(size_t)s * 64] = step_from_word<1>(M, sym[(size_t)s * 64], ones); s++; }
+    if (s < nsteps) { dec[(size_t)s * 64] = step_from_word<2>(M, sym[(size_t)s * 64], ones); s++; }
+    if (s < nsteps) { dec[(size_t)s * 64] = step_from_word<3>(M, sym[(size_t)s * 64], ones); s++; }
+    if (s < nsteps) { dec[(size_t)s * 64] = step_from_word<4>(M, sym[(size_t)s * 64], ones); s++; }
 
-    // chainback_viterbi (viterbi.cpp:313-339) from state 0, skipping the 6 tail steps; bits are packed MSB
-    // first (decoder_adapter.cpp:61-67) into little-endian 32-bit words and XORed with the energy-dispersal
-    // sequence when asked to (fic-handler.cpp:206-208, energy_dispersal.h:51-53).  The decision words do not
-    // depend on the path, so 8 steps are fetched at a time and resolved from registers.
     const int cw = g * 64 + lane;
-    uint32_t* out = reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32);
-    uint32_t T = 0, acc = 0;
-    uint2 dq[8], dn[8];                                           // this iteration's decision words and the next one's (already in flight)
-#pragma unroll
-    for (int k = 0; k < 8; k++) dq[k] = dec[(size_t)(nbits - 1 - k + 6) * 64];
-    for (int n = nbits - 1; n >= 0; n -= 8) {
-        {
-            const int m = n >= 8 ? n - 8 : n;                     // the last iteration re-reads its own words
-#pragma unroll
-            for (int k = 0; k < 8; k++) dn[k] = dec[(size_t)(m - k + 6) * 64];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int nn = n - k;                                 // n is 7 mod 8: nn & 7 = 7 - k
-            const uint32_t dx = dq[k].x, dy = dq[k].y;
-            const uint32_t wsel = dx ^ ((dx ^ dy) & (0u - ((T >> 4) & 1u)));   // (T & 16) ? dy : dx as a bitwise blend: a select of two array
-                                                                                 // elements would turn dq[] into an indexed LDS array
-            const uint32_t bit = ((T >> 1) & 7) + 8 * (2 * (T & 1) + (T >> 5));
-            const uint32_t kk = (wsel >> bit) & 1;
-            T = (T >> 1) | (kk << 5);
-            acc |= kk << (8 * ((nn >> 3) & 3) + k);                // 7 - (nn & 7) = k
-        }
-        if (((n - 7) & 31) == 0) {
-            const int wi = (n - 7) >> 5;
-            if (cw < A.c.n_cw) out[wi] = A.c.dedisperse ? acc ^ A.prbs_words[wi] : acc;
-            acc = 0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) dq[k] = dn[k];
-    }
+    traceback(A.c.dec + (size_t)g * nsteps * 64, (uint32_t)lane, nbits, reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32),
+              cw < A.c.n_cw, A.c.dedisperse, A.prbs_words);
   }
 }
 
@@ -404,20 +302,6 @@ constexpr int FM_ZERO = 2 * FM_SLOT;              // third slot: zeros (erasures
 constexpr int FM_ROWPTR = 3 * FM_SLOT;            // then the rows' sources: byte offset / 16 into the soft-bit ring (rows without a source CIF point at the zeros behind the ring)
 constexpr int FM_LDS = FM_ROWPTR + FM_ROWS * 4;
 
-// branch metrics straight from the four soft values v_j (signed; symbol s_j = v_j + 127, viterbi.cpp:233-236 -- the clamp at 0 only
-// matters for v = -128, which the demapper never produces: |v| <= 127 by construction, ofdm-decoder.cpp:208-212, asserted by the tests)
-__device__ __forceinline__ void bm_from_soft(u16x2 (&BM)[4], int v0, int v1, int v2, int v3)
-{
-    // viterbi.cpp:259-261 with outputs 0 and 3 sharing a generator: bm(0) = s0+s3+s1+s2, bm(1) = 510-(s0+s3)+s1+s2, bm(p|2) = bm(p) + 255 - 2 s1
-    const int a = v0 + v3, b = v1 + v2;
-    const uint32_t m0 = (uint32_t)(a + b + 508), m1 = (uint32_t)((b - a) + 510);
-    const uint32_t c = (uint32_t)(1 - 2 * v1);      // 255 - 2 (v1 + 127); added modulo 2^32
-    const uint32_t m2 = m0 + c, m3 = m1 + c;
-    // BM[p] = (bm(p), bm(p ^ 7))
-    BM[0] = asv(m0 | ((1020u - m0) << 16)); BM[1] = asv(m1 | ((1020u - m1) << 16));
-    BM[2] = asv(m2 | ((1020u - m2) << 16)); BM[3] = asv(m3 | ((1020u - m3) << 16));
-}
-
 #ifndef VITM_OCC
 #define VITM_OCC 5
 #endif
@@ -434,8 +318,7 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     const int cw = g * 64 + lane;
     const bool live = cw < A.c.n_cw;
     const int pair = live ? cw / R : -1, r = live ? cw % R : 0;
-    const int b = live ? pair / A.n_members : 0, m = live ? pair % A.n_members : 0;
-    const long long c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;         // CIF whose arrival emits this logical frame
+    const int b = live ? pair / A.n_members : 0;
     const int pair0 = __shfl(pair, 0);
     const unsigned long long in0 = __ballot(pair == pair0);                              // segment 0 = the leading lanes of pair0
     const int n0 = __popcll(in0);
@@ -445,7 +328,6 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     const int pair1 = __shfl(pair, first1);
     const long long c_a0 = 4 * A.desc[(size_t)__shfl(b, 0) * A.n_frames].frame_no + __shfl(r, 0);            // first CIF of segment 0 ...
     const long long c_a1 = 4 * A.desc[(size_t)__shfl(b, first1) * A.n_frames].frame_no + __shfl(r, first1);  // ... and of segment 1
-    (void)c_glob;
     const int nrows = (n0 < 64 && pair1 >= 0) ? 64 + 30 : n0 + 15;
     __syncthreads();                                                                     // (one wave per work-group: orders the LDS reuse between groups)
     // zero the window slots and the erasure slot; row pointers
@@ -483,10 +365,8 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
     uint2* __restrict__ const dec_g = A.c.dec + (size_t)g * nsteps * 64;
     const uint32_t ones = opaque_sgpr(0x01010101u);
-    u16x2 Rm[32], Nm[32];
-#pragma unroll
-    for (int j = 0; j < 32; j++) Rm[j] = splat(63);
-    Rm[0] = asv(63u << 16);
+    uint32_t M[32];
+    acs::init(M);
 #ifdef FM_EXP_BROADCAST          // (timing experiment only: every lane reads the same bytes -- no bank conflicts, wrong results)
     const uint32_t lane_base = 0u; (void)rb;
 #else
@@ -500,81 +380,54 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     lds_dma_wait();                                                  // windows 0 and 1 have landed
     int cur[4];
     int next_window = 2;
-    // Per step: branch metrics from this step's bytes; then the bytes of step s + 1 are requested into the same registers (after
-    // waiting for its window, if it is the first step to read a new one) and travel while the 32 butterflies run; then -- this
-    // step's own reads have been consumed -- the window after the next is requested into the slot this step was the last to read.
-    // The wait is s_waitcnt vmcnt(2): memory operations complete in order, the load is older than the last two decision stores
-    // (the host checks that when it builds the table), so the newest stores stay in flight.
-    // The descriptors of steps s + 2, s + 3 are requested (scalar loads) while steps s, s + 1 run.
-    // (two halves: between them the loop requests the descriptors of the next pair of steps -- scalar loads share the LDS counter
-    // and return out of order, so any wait for LDS bytes also waits for them: they are issued right AFTER such a wait and have a
-    // whole step to arrive)
-    u16x2 BM[4];
-    auto step_a = [&]() { bm_from_soft(BM, cur[0], cur[1], cur[2], cur[3]); };
-    auto step_b_nofetch = [&](int s, const MscStep& d_cur, const u16x2 (&Rin)[32], u16x2 (&Nout)[32]) {
-        if (d_cur.off01 & MSC_LOAD_NEXT) { wave_converge(); load_window(next_window); next_window++; }     // every lane has consumed its reads of the dying window
-        uint32_t accA = 0, accB = 0;
-        bfly_pairs<0>(Rin, Nout, BM, accA, accB, ones);
-        dec_g[(uint32_t)(s * 64 + lane)] = make_uint2(accA, accB);
-    };
-    auto fetch_for = [&](const MscStep& d_next) {                     // the bytes of the step that follows (after the butterflies: four registers less while they run)
+    // Per step: the soft values of this step (signed; symbol = value + 127, viterbi.cpp:233-236 -- the clamp at 0 only matters for
+    // -128, which the demapper never produces: |v| <= 127 by construction, ofdm-decoder.cpp:208-212, asserted by the tests) are
+    // taken from the registers the previous step requested them into; if this step was the last to read a window, the window after
+    // the next is requested into its slot; then the 32 butterflies and the decision store; then the bytes of step s + 1 are
+    // requested into the same registers (after waiting for its window, if it is the first step to read a new one).
+    // The wait for a window is s_waitcnt vmcnt(2): memory operations complete in order, the load is older than the last two decision
+    // stores (the host checks that when it builds the table), so the newest stores stay in flight.
+    // Descriptors come through the constant address space (scalar loads), one block of six steps ahead (six entries of padding end the
+    // table).  Scalar loads share the LDS counter and return out of order, so any wait for LDS bytes also waits for them: they are
+    // issued right AFTER the first such wait of a block and have a whole step to arrive.
+    const DABPHY_CONST_AS MscStep* steps = as_constant(A.steps);
+    auto desc_at = [&](int i) { MscStep d; d.off01 = steps[i].off01; d.off23 = steps[i].off23; return d; };
+    auto one_step = [&](auto fc, int s, const MscStep& d_cur, const MscStep& d_next, auto&& after_wait) {
+        constexpr int F = decltype(fc)::value;
+        int x0 = cur[0] + cur[3], v1 = cur[1], v2 = cur[2];
+        asm volatile("" : "+v"(x0), "+v"(v1), "+v"(v2));                  // this step's LDS reads have been consumed here ...
+        after_wait();
+        if (d_cur.off01 & MSC_LOAD_NEXT) { wave_converge(); load_window(next_window); next_window++; }     // ... by every lane, before the dying window's slot is refilled
+        const uint2 dd = acs::step<F>(M, x0, v1, v2, ones);
+        dec_g[(uint32_t)(s * 64 + lane)] = dd;
 #ifndef FM_EXP_NOWAIT            // (timing experiment only)
         if (d_next.off01 & MSC_FIRST_USE) lds_dma_wait_but<2>();
 #endif
         fetch(d_next, cur);
     };
-    // descriptors through the constant address space (scalar loads), one pair of steps ahead (two entries of padding end the table)
-    const DABPHY_CONST_AS MscStep* steps = as_constant(A.steps);
-    auto desc_at = [&](int i) { MscStep d; d.off01 = steps[i].off01; d.off23 = steps[i].off23; return d; };
-    MscStep d0 = desc_at(0), d1 = desc_at(1);
+    auto nothing = []() {};
+    MscStep d0 = desc_at(0), d1 = desc_at(1), d2 = desc_at(2), d3 = desc_at(3), d4 = desc_at(4), d5 = desc_at(5);
     fetch(d0, cur);
-    int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-        step_a();                                                    // (waits for the LDS bytes of step s: nothing scalar is in flight here)
-        const MscStep e0 = desc_at(s + 2), e1 = desc_at(s + 3);
-        step_b_nofetch(s, d0, Rm, Nm);
-        fetch_for(d1);
-        step_a();
-        step_b_nofetch(s + 1, d1, Nm, Rm);
-        fetch_for(e0);
-        if ((s & 30) == 30) renorm(Rm);                              // every 32 steps: 6120 + 32 * 1020 < 65536
-        d0 = e0; d1 = e1;
+    int since_renorm = 0;
+    for (int s = 0; s < nsteps; s += 6) {                            // (nsteps is a multiple of six for every sub-channel size: 24 * bitrate + 6)
+        MscStep e0, e1, e2, e3, e4, e5;
+        one_step(std::integral_constant<int, 0>{}, s, d0, d1, [&]() {
+            e0 = desc_at(s + 6); e1 = desc_at(s + 7); e2 = desc_at(s + 8); e3 = desc_at(s + 9); e4 = desc_at(s + 10); e5 = desc_at(s + 11);
+        });
+        one_step(std::integral_constant<int, 1>{}, s + 1, d1, d2, nothing);
+        one_step(std::integral_constant<int, 2>{}, s + 2, d2, d3, nothing);
+        one_step(std::integral_constant<int, 3>{}, s + 3, d3, d4, nothing);
+        one_step(std::integral_constant<int, 4>{}, s + 4, d4, d5, nothing);
+        one_step(std::integral_constant<int, 5>{}, s + 5, d5, e0, nothing);
+        if (++since_renorm == acs::RENORM_BLOCKS) { acs::renorm(M); since_renorm = 0; }
+        d0 = e0; d1 = e1; d2 = e2; d3 = e3; d4 = e4; d5 = e5;
     }
-    if (s < nsteps) { step_a(); step_b_nofetch(s, d0, Rm, Nm); }
     lds_dma_wait();                                                  // (no load may still be in flight when the next group reuses the slots)
 
     // traceback: as in k_viterbi
     const int cw_out = g * 64 + lane;                                // (recomputed: nothing but the trellis lives across the step loop)
-    const bool live_out = cw_out < A.c.n_cw;
-    uint32_t* out = reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw_out * (nbits / 32);
-    uint32_t T = 0, acc = 0;
-    uint2 dq[8], dn[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) dq[k] = dec_g[(uint32_t)((nbits - 1 - k + 6) * 64 + lane)];
-    for (int n = nbits - 1; n >= 0; n -= 8) {
-        {
-            const int mm = n >= 8 ? n - 8 : n;
-#pragma unroll
-            for (int k = 0; k < 8; k++) dn[k] = dec_g[(uint32_t)((mm - k + 6) * 64 + lane)];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int nn = n - k;
-            const uint32_t dx = dq[k].x, dy = dq[k].y;
-            const uint32_t wsel = dx ^ ((dx ^ dy) & (0u - ((T >> 4) & 1u)));
-            const uint32_t bit = ((T >> 1) & 7) + 8 * (2 * (T & 1) + (T >> 5));
-            const uint32_t kk = (wsel >> bit) & 1;
-            T = (T >> 1) | (kk << 5);
-            acc |= kk << (8 * ((nn >> 3) & 3) + k);
-        }
-        if (((n - 7) & 31) == 0) {
-            const int wi = (n - 7) >> 5;
-            if (live_out) out[wi] = A.c.dedisperse ? acc ^ A.prbs_words[wi] : acc;
-            acc = 0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) dq[k] = dn[k];
-    }
+    traceback(dec_g, (uint32_t)lane, nbits, reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw_out * (nbits / 32), cw_out < A.c.n_cw,
+              A.c.dedisperse, A.prbs_words);
   }
 }
 

@@ -337,11 +337,59 @@ class EnsembleTx:
         return frame * (self.amplitude / rms)
 
 
+def resample_ppm(x, ppm, taps=16):
+    """x as a receiver whose sampling clock is `ppm` parts per million FAST sees it: y[n] = x(n * (1 + ppm * 1e-6)), band-limited
+    interpolation (Hann-windowed sinc, `taps` taps).  The PRS of frame k then arrives k * 196608 * ppm * 1e-6 samples early."""
+    if not ppm:
+        return x
+    n_out = int((len(x) - taps) / (1.0 + ppm * 1e-6))
+    t = np.arange(n_out, dtype=np.float64) * (1.0 + ppm * 1e-6) + taps // 2
+    k0 = np.floor(t).astype(np.int64)
+    frac = t - k0
+    y = np.zeros(n_out, np.complex128)
+    for j in range(-taps // 2 + 1, taps // 2 + 1):
+        u = frac - j                                               # distance from tap j to the interpolation point
+        w = np.sinc(u) * (0.5 + 0.5 * np.cos(np.pi * u / (taps // 2)))
+        y += x[k0 + j] * w
+    return y
+
+
+def apply_channel(x, channel):
+    """The impairments the reference's own soak harness is built for (welle-cli/tests.cpp:305-370: multipath, FFT-window placement):
+    channel = dict with any of
+      echoes  [(delay_samples, complex gain), ...]  added to the direct path; a NEGATIVE delay is a pre-echo (the strongest path is
+              not the first: what separates the three FFT placement methods, phasereference.cpp:73-256)
+      fade    (depth, hz)  amplitude 1 + depth * cos(2 pi hz t): flat fading
+      ppm     sampling-clock offset of the receiver (the window index then drifts from frame to frame)."""
+    if not channel:
+        return x
+    y = x
+    ech = channel.get("echoes")
+    if ech:
+        lead = max(0, -min(d for d, _ in ech))                    # pre-echoes: the whole signal moves back by the largest lead
+        n = len(x) + lead
+        y = np.zeros(n, np.complex128)
+        y[lead:] += x
+        for d, g in ech:
+            o = lead + d
+            m = min(len(x), n - o)
+            y[o:o + m] += g * x[:m]
+        y = y[:len(x)]
+    fd = channel.get("fade")
+    if fd:
+        depth, hz = fd
+        y = y * (1.0 + depth * np.cos(2 * np.pi * hz * np.arange(len(y)) / 2048000.0))
+    if channel.get("ppm"):
+        y = resample_ppm(y, channel["ppm"])
+    return y
+
+
 def make_stream(n_frames, eid=0x1000, subchs=None, seed=0, snr_db=None, cfo_hz=0.0, delay=0,
-                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False, tii=None, extra_figs_fn=None):
+                noise_seed=1234, amplitude=0.25, payload_fn=None, return_tx=False, tii=None, extra_figs_fn=None, channel=None):
     """cf32 interleaved stream of n_frames frames (+ `delay` leading noise/zero samples).
     tii: None, or a list of transmitters (comb, pattern, delay_samples, gain) of a single-frequency network: identical
-    frames, each with its own TII in the null symbol, summed with their relative delays."""
+    frames, each with its own TII in the null symbol, summed with their relative delays.
+    channel: multipath / fading / sampling-clock offset between transmitter and receiver (apply_channel)."""
     tx = EnsembleTx(eid, subchs, seed, payload_fn, amplitude, tii=tii[0][:2] if tii else None, extra_figs_fn=extra_figs_fn)
     x = np.concatenate([tx.next_frame() for _ in range(n_frames)])
     if tii:
@@ -350,6 +398,7 @@ def make_stream(n_frames, eid=0x1000, subchs=None, seed=0, snr_db=None, cfo_hz=0
             t2 = EnsembleTx(eid, subchs, seed, payload_fn, amplitude, tii=(comb, pattern))
             y = np.concatenate([t2.next_frame() for _ in range(n_frames)])
             x = x + g * np.concatenate([np.zeros(d, np.complex128), y])[:len(x)]
+    x = apply_channel(x, channel)
     if delay:
         x = np.concatenate([np.zeros(delay, np.complex128), x])
     if cfo_hz:
