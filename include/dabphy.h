@@ -343,11 +343,14 @@ int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);
 /* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
  * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
  *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.
- * dabphy_time_viterbi: decodes n_codewords random-content codewords of nbits `iters` times; *ms_gather / *ms_decode. */
+ * dabphy_time_viterbi: decodes n_codewords random-content codewords of nbits `iters` times; *ms_gather / *ms_decode.
+ * dabphy_time_fused_msc: re-runs the fused MSC decode of the last dabphy_process batch (first protection class) `iters` times
+ *   with nothing else on the device; *ms = mean kernel time.  DABPHY_ERR_STATE before the first such batch. */
 int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
                       int32_t mix, int32_t f_hz, uint32_t iters, float* ms);
 int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
                         float* ms_decode);
+int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
 
 /* Device self-test of the reciprocal-based 127/x the demapper uses in place of the IEEE division sequence
  * (ofdm-decoder.cpp:208 computes 127.0f / l1_norm): every float x in [2^-100, 2^100] is divided both ways on the device.

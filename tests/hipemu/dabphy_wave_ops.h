@@ -50,6 +50,13 @@ static inline uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
 static inline int mul_i24(int x, int m) { return (int)((uint32_t)x * (uint32_t)m); }
 static inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
 
+// buffer addressing model: the resource is the base pointer
+typedef char* BufRsrc;
+static inline BufRsrc buf_rsrc(const void* base) { return (char*)base; }
+static inline uint2 buf_load_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes) { uint2 v; memcpy(&v, r + lane_bytes + uniform_bytes, 8); return v; }
+static inline void buf_store_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint2 v) { memcpy(r + lane_bytes + uniform_bytes, &v, 8); }
+static inline void buf_store_b32(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint32_t v) { memcpy(r + lane_bytes + uniform_bytes, &v, 4); }
+
 template <int VARIANT> static inline float div127_fast(float x) { return 127.0f / x; }
 constexpr float DIV127_LO = 0x1p-100f, DIV127_HI = 0x1p100f;
 // the model decides per lane: both sides of a wave_all() branch must compute the same result wherever the fast side is legal

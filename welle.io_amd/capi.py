@@ -200,6 +200,11 @@ class DabPhy:
         self._chk(self.lib.dabphy_time_viterbi(self.h, nbits, n_codewords, iters, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def time_fused_msc(self, iters=3):
+        a = C.c_float(0)
+        self._chk(self.lib.dabphy_time_fused_msc(self.h, iters, C.byref(a)))
+        return a.value
+
     # ---- streaming receiver
     def reset(self):
         self._chk(self.lib.dabphy_reset(self.h))

@@ -69,6 +69,7 @@ struct dabphy_handle {
     hipEvent_t ev_part[MAX_PARTS]{}, ev_vit_done[2]{};
     int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
     int vit_split = 1;                                   // launches the fused MSC decode of a big class is cut into (DABPHY_VIT_SPLIT)
+    FusedMscArgs last_fused{}; bool have_last_fused = false;   // the fused decode launch of the last batch (dabphy_time_fused_msc re-runs it alone)
     bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     // wide synchroniser pass (all frames of a batch at once, k_sync_find_wide/_finish_wide/_validate) and its serial fall-back
@@ -1065,6 +1066,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             FusedMscArgs fa{}; fa.soft = da.soft; fa.soft_ring = ring_frames; fa.n_ens = (int)B; fa.n_frames = (int)F;
             fa.steps = cls.steps.as<MscStep>(); fa.n_windows = cls.n_windows; fa.start_bit = cls.start_bits.as<int32_t>(); fa.n_members = M; fa.desc = d_desc; fa.zero_off16 = (uint32_t)(((size_t)B * ring_frames * SOFT_PER_FRAME) >> 4);
             fa.c = c; fa.prbs_words = h->d_prbs_words;
+            if (first_cls) { h->last_fused = fa; h->have_last_fused = true; }
             if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, false);
             // Two launches of half the groups each, back to back.  A launch's last round of work-groups leaves execution slots idle;
             // the benchmark batch's 5760 groups on 1024 SIMDs pay for 6 rounds either way (5.6 -> 6 or 2.8 + 2.8 -> 3 + 3), and the idle
@@ -1694,6 +1696,24 @@ int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, 
     }
     *ms_gather = tg / iters; *ms_decode = tv / iters;
     HIPCHK(h, hipEventDestroy(e0)); HIPCHK(h, hipEventDestroy(e1)); HIPCHK(h, hipEventDestroy(e2));
+    return sync(h);
+}
+
+int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
+{
+    DeviceBind dev_(h);
+    if (!h || !ms || iters == 0) return DABPHY_ERR_INVALID;
+    if (!h->have_last_fused) { h->err = "no batch has been decoded by the fused MSC kernel yet"; return DABPHY_ERR_STATE; }
+    HIPCHK(h, hipDeviceSynchronize());                       // alone on the device: nothing of the pipeline beside it
+    hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    launch_viterbi_msc(h->last_fused, h->stream);            // (same inputs, same outputs: the launch is idempotent)
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (uint32_t i = 0; i < iters; i++) launch_viterbi_msc(h->last_fused, h->stream);
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float t = 0; HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    HIPCHK(h, hipEventDestroy(e0)); HIPCHK(h, hipEventDestroy(e1));
     return sync(h);
 }
 

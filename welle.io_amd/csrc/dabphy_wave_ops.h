@@ -117,6 +117,25 @@ __device__ __forceinline__ int mul_i24(int x, int m) { int r; asm("v_mul_i32_i24
 // ({hi, lo} >> sh) & 0xffffffff, 0 <= sh <= 31 (v_alignbit_b32)
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
+// ---- buffer addressing: (wave-uniform base in a 128-bit scalar resource) + (per-lane byte offset, one VGPR) + (wave-uniform byte offset,
+// one SGPR).  Global loads and stores of the form uniform_pointer[lane] otherwise cost a 64-bit VGPR address pair per array and a 64-bit
+// add per access in a loop that is short of registers.  Raw buffer (stride 0), range = 2 GiB from the base.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int buf_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ uint2 buf_load_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes)
+{
+    const buf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0); return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void buf_store_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint2 v)
+{
+    buf_u32x2 w; w.x = v.x; w.y = v.y; __builtin_amdgcn_raw_buffer_store_b64(w, r, lane_bytes, uniform_bytes, 0);
+}
+__device__ __forceinline__ void buf_store_b32(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_bytes, uniform_bytes, 0);
+}
+
 // 127 / x for x in [2^-100, 2^100]: v_rcp_f32 (1 ulp) + one residual correction, 4 instructions instead of the 11 of the
 // IEEE division sequence.  DIV127_VARIANT 1 adds a second correction.  dabphy_selftest_div127 compares every variant
 // with the correctly rounded quotient for ALL floats of that range on the device it runs on; k_demod only uses the

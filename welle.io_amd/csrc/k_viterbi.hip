@@ -310,8 +310,9 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
   __shared__ __attribute__((aligned(16))) uint8_t lds[FM_LDS];
   const int lane = threadIdx.x;
   const int nsteps = A.c.nsteps, nbits = A.c.nbits, R = 4 * A.n_frames;
-  const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-  (void)map16;
+  uint32_t* const out_words = reinterpret_cast<uint32_t*>(A.c.out);
+  const int words_per_cw = nbits / 32;
+  const uint32_t lane8 = (uint32_t)lane * 8u;                       // byte offset of this lane in a decision row
 #pragma unroll 1
   for (int g = A.c.g_begin + blockIdx.x; g < A.c.g_end; g += gridDim.x) {
     // ---- which rows this wave needs: segments = runs of lanes with the same (b, m) (their CIFs are consecutive by construction)
@@ -364,6 +365,7 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
 
     // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
     uint2* __restrict__ const dec_g = A.c.dec + (size_t)g * nsteps * 64;
+    const BufRsrc dec_rs = buf_rsrc(dec_g);
     const uint32_t ones = opaque_sgpr(0x01010101u);
     uint32_t M[32];
     acs::init(M);
@@ -374,6 +376,9 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
 #endif
     const int8_t* lds_c = reinterpret_cast<const int8_t*>(lds);        // (sign-extending byte reads)
     auto fetch = [&](const MscStep& d, int (&y)[4]) {
+#ifdef FM_EXP_NOLDS              // (timing experiment only)
+        y[0] = (int)(d.off01 & 127) - 60; y[1] = (int)(d.off23 & 127) - 61; y[2] = lane - 30; y[3] = 5; return;
+#endif
         y[0] = lds_c[lane_base + (d.off01 & MSC_OFF_MASK)]; y[1] = lds_c[lane_base + ((d.off01 >> 16) & MSC_OFF_MASK)];
         y[2] = lds_c[lane_base + (d.off23 & 0xffffu)]; y[3] = lds_c[lane_base + (d.off23 >> 16)];
     };
@@ -387,8 +392,7 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     // requested into the same registers (after waiting for its window, if it is the first step to read a new one).
     // The wait for a window is s_waitcnt vmcnt(2): memory operations complete in order, the load is older than the last two decision
     // stores (the host checks that when it builds the table), so the newest stores stay in flight.
-    // Descriptors come through the constant address space (scalar loads), one block of six steps ahead (six entries of padding end the
-    // table).  Scalar loads share the LDS counter and return out of order, so any wait for LDS bytes also waits for them: they are
+    // Descriptors come through the constant address space (scalar loads), six steps ahead (six entries of padding end the table).  Scalar loads share the LDS counter and return out of order, so any wait for LDS bytes also waits for them: they are
     // issued right AFTER the first such wait of a block and have a whole step to arrive.
     const DABPHY_CONST_AS MscStep* steps = as_constant(A.steps);
     auto desc_at = [&](int i) { MscStep d; d.off01 = steps[i].off01; d.off23 = steps[i].off23; return d; };
@@ -397,9 +401,15 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
         int x0 = cur[0] + cur[3], v1 = cur[1], v2 = cur[2];
         asm volatile("" : "+v"(x0), "+v"(v1), "+v"(v2));                  // this step's LDS reads have been consumed here ...
         after_wait();
+#ifndef FM_EXP_NODMA             // (timing experiment only)
         if (d_cur.off01 & MSC_LOAD_NEXT) { wave_converge(); load_window(next_window); next_window++; }     // ... by every lane, before the dying window's slot is refilled
+#endif
         const uint2 dd = acs::step<F>(M, x0, v1, v2, ones);
-        dec_g[(uint32_t)(s * 64 + lane)] = dd;
+#ifdef FM_EXP_NOSTORE            // (timing experiment only)
+        if (dd.x == 0x12345u && dd.y == 0x777u) buf_store_b64(dec_rs, lane8, (uint32_t)s * 512u, dd);
+#else
+        buf_store_b64(dec_rs, lane8, (uint32_t)s * 512u, dd);
+#endif
 #ifndef FM_EXP_NOWAIT            // (timing experiment only)
         if (d_next.off01 & MSC_FIRST_USE) lds_dma_wait_but<2>();
 #endif
@@ -410,24 +420,26 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     fetch(d0, cur);
     int since_renorm = 0;
     for (int s = 0; s < nsteps; s += 6) {                            // (nsteps is a multiple of six for every sub-channel size: 24 * bitrate + 6)
-        MscStep e0, e1, e2, e3, e4, e5;
-        one_step(std::integral_constant<int, 0>{}, s, d0, d1, [&]() {
-            e0 = desc_at(s + 6); e1 = desc_at(s + 7); e2 = desc_at(s + 8); e3 = desc_at(s + 9); e4 = desc_at(s + 10); e5 = desc_at(s + 11);
-        });
+        // the descriptors of the next block arrive pair by pair (four scalar registers in flight, not twelve: the loop is short of them)
+        MscStep ea, eb;
+        one_step(std::integral_constant<int, 0>{}, s, d0, d1, [&]() { ea = desc_at(s + 6); eb = desc_at(s + 7); });
         one_step(std::integral_constant<int, 1>{}, s + 1, d1, d2, nothing);
-        one_step(std::integral_constant<int, 2>{}, s + 2, d2, d3, nothing);
+        d0 = ea; d1 = eb;
+        one_step(std::integral_constant<int, 2>{}, s + 2, d2, d3, [&]() { ea = desc_at(s + 8); eb = desc_at(s + 9); });
         one_step(std::integral_constant<int, 3>{}, s + 3, d3, d4, nothing);
-        one_step(std::integral_constant<int, 4>{}, s + 4, d4, d5, nothing);
-        one_step(std::integral_constant<int, 5>{}, s + 5, d5, e0, nothing);
+        d2 = ea; d3 = eb;
+        one_step(std::integral_constant<int, 4>{}, s + 4, d4, d5, [&]() { ea = desc_at(s + 10); eb = desc_at(s + 11); });
+        one_step(std::integral_constant<int, 5>{}, s + 5, d5, d0, nothing);
+        d4 = ea; d5 = eb;
         if (++since_renorm == acs::RENORM_BLOCKS) { acs::renorm(M); since_renorm = 0; }
-        d0 = e0; d1 = e1; d2 = e2; d3 = e3; d4 = e4; d5 = e5;
     }
     lds_dma_wait();                                                  // (no load may still be in flight when the next group reuses the slots)
 
+#ifndef FM_EXP_NOTRACE            // (timing experiment only)
     // traceback: as in k_viterbi
     const int cw_out = g * 64 + lane;                                // (recomputed: nothing but the trellis lives across the step loop)
-    traceback(dec_g, (uint32_t)lane, nbits, reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw_out * (nbits / 32), cw_out < A.c.n_cw,
-              A.c.dedisperse, A.prbs_words);
+    traceback(dec_g, (uint32_t)lane, nbits, out_words + (size_t)cw_out * words_per_cw, cw_out < A.c.n_cw, A.c.dedisperse, A.prbs_words);
+#endif
   }
 }
 
@@ -443,13 +455,12 @@ void launch_viterbi_msc(const FusedMscArgs& a, hipStream_t s)
     // One work-group (= one wave) per resident wave slot: VITM_OCC per SIMD.  With more groups than slots work-group i walks groups
     // i, i + grid, ... (the kernel's loop), so every SIMD gets the same number of groups to within one -- 9216 groups on 5120 slots:
     // four waves with two groups and one with one on every SIMD, instead of SIMDs with five and SIMDs with four two-group waves.
-    static int occ = 0;
-    if (!occ) { const char* e = getenv("DABPHY_VITM_SLOTS"); occ = e ? atoi(e) : VITM_OCC; if (occ < 1) occ = VITM_OCC; }
+    int occ = VITM_OCC;
+#ifdef DABPHY_EXPERIMENTS
+    { const char* e = getenv("DABPHY_VITM_SLOTS"); if (e && atoi(e) > 0) occ = atoi(e); }
+#endif
     const int grid = n < occ * n_simd ? n : occ * n_simd;
-    // (experiments: extra dynamic LDS per wave caps the kernel's occupancy and leaves registers to the synchroniser's kernels)
-    static int pad = -1;
-    if (pad < 0) { const char* e = getenv("DABPHY_VIT_LDS_PAD"); pad = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k_viterbi_msc, dim3(grid), dim3(64), (size_t)pad, s, a);
+    hipLaunchKernelGGL(k_viterbi_msc, dim3(grid), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------ linear gather
