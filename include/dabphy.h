@@ -49,10 +49,6 @@ typedef struct {
                                        batch's demod kernel; 2: at once (it then competes with the demod kernel: more frames per
                                        second in total, a slower FFT stage); 3: queued like 1 but TWO batches ahead (the samples of
                                        the next two batches must be in the ring; the coarse-corrector feedback lags one batch more) */
-    int32_t msc_parts;              /* decode every MSC protection class in this many parts (whole ensembles each): part p's Viterbi kernel
-                                       (VALU-bound) runs on a side stream while part p + 1 is gathered (HBM-bound).  0 or 1 = one gather and
-                                       one decode launch per class, which is also what measures best on MI355X: parts that are not
-                                       resident together leave the Viterbi kernel below its five waves per SIMD */
     int32_t serial_sync;            /* 0 (default): with two or more frames per call the synchroniser first tries all frames of a batch at
                                        once, each from the state a receiver in lock would be in (window index T_g, correctors unchanged),
                                        accepts those whose assumption held and runs the frame-by-frame chain (2 dependent launches per

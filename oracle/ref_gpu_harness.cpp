@@ -149,6 +149,35 @@ int gpu_scan_run(const float* iq, int64_t n_samples, int32_t* calls, int cap)
     return rec.n;
 }
 
+// ---- worker-thread failure: an input whose getSamples throws after `fail_after` samples (a driver that dies under the receiver).  The
+// reference reports input trouble through onInputFailure() and ends its processing thread (ofdm-processor.cpp:492-499); an exception
+// that escaped the facade's std::thread would end the process instead.  Returns 1 when onInputFailure() arrived, the receiver could be
+// stopped and a selected service could still be removed afterwards; 0 when the callback did not arrive in time.
+int gpu_failing_input_run(const float* iq, int64_t n_samples, int64_t fail_after)
+{
+    struct Throwing : MemInput {
+        int64_t limit;
+        Throwing(const float* q, int64_t n_, int64_t lim) : MemInput(q, n_), limit(lim) {}
+        int32_t getSamples(DSPCOMPLEX* b, int32_t size) override
+        {
+            if (pos >= limit) throw std::runtime_error("device gone");
+            return MemInput::getSamples(b, size);
+        }
+    };
+    Rec rec;
+    Throwing in(iq, n_samples, fail_after);
+    RadioReceiverOptions rro; rro.decodeTII = false;
+    try {
+        GpuRadioReceiver rx(rec, in, rro);
+        rx.restart(false);
+        for (int i = 0; i < 5000 && !rec.failed; i++) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        const bool got = rec.failed;
+        rx.stop();                                   // (must not hang or throw after the worker has ended itself)
+        rx.restart_decoder();                        // clearSubchannels() with no worker running returns at once
+        return got ? 1 : 0;
+    } catch (const std::exception& e) { fprintf(stderr, "gpu_failing_input_run: %s\n", e.what()); return -1; }
+}
+
 // ---- batch mode: n_ens ensembles (streams of equal length, [n_ens][n_samples] cf32), each with its own FIBProcessor;
 // out per ensemble: ensemble id, number of services listed, number of FIBs that passed the CRC, onServiceDetected calls
 int gpu_batch_run2(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int signal_clock, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii);

@@ -612,11 +612,11 @@ def check_error_behaviour(d_factory):
 # ---- the configuration bench.py times (welle_io_amd/workload.py): B x F batch, looping ring, coarse corrector enabled, pipelined
 # synchroniser, all 18 sub-channels, superframe filter inside process() -- against the oracle on the very same samples
 def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_steps=3, demod_chunk=0, device="cuda", subs_idx=(0, 7, 17),
-                       base=None, expect_chunk=None, msc_parts=0):
+                       base=None, expect_chunk=None):
     from welle_io_amd import workload
     iq, cfo, base_np, txs = workload.make_batch(B, device=device, base=base)
     subchs = txs[0].subchs
-    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False, msc_parts=msc_parts)
+    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False)
     logs = {b: dict(fib=[], ok=[], corr=[], soft=[], msc=[[] for _ in subs_idx], sf=np.zeros(4, np.int64), n_logical=0) for b in check_ens}
     try:
         if expect_chunk is not None:

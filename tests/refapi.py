@@ -513,6 +513,14 @@ def gpu_scan_run(iq, lib=GPU_EMU_SO):
     return [int(v) for v in calls[:min(n, 8)]]
 
 
+def gpu_failing_input_run(iq, fail_after, lib=GPU_EMU_SO):
+    """GpuRadioReceiver over an input that throws after `fail_after` samples -> 1 if onInputFailure() was called and the receiver stopped cleanly"""
+    L = C.CDLL(lib)
+    iq = np.ascontiguousarray(iq, np.complex64)
+    L.gpu_failing_input_run.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    return L.gpu_failing_input_run(_p(iq), len(iq), int(fail_after))
+
+
 def gpu_batch_services(iq, frames_per_step, n_steps, signal_clock=True, lib=GPU_EMU_SO):
     """GpuBatchReceiver with / without its signal-time clock -> per-ensemble (services listed, onServiceDetected calls)"""
     L = C.CDLL(lib)

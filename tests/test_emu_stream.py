@@ -120,14 +120,6 @@ def test_dropout_in_batch_mode(emu):
     P.check_dropout_batch(factory)
 
 
-def test_msc_class_decoded_in_parts(emu):
-    """dabphy_config.msc_parts = 2: the class's gather / Viterbi / superframe-filter launches are split by ensemble range over side
-    streams (what dabphy_create picks automatically for benchmark-sized batches); same bytes and totals as the oracle"""
-    from welle_io_amd import workload
-    P.check_bench_config(capi, EMU_LIB, 4, 4, 1, check_ens=[0, 1, 2, 3], n_steps=4, demod_chunk=25, device="cpu", subs_idx=(0, 7, 17),
-                         base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=0), expect_chunk=25, msc_parts=2)
-
-
 def test_mixed_protection_classes_fused_decode(emu):
     """16 frames per call = 64 CIFs per sub-channel: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel -- the MSC
     gather inside the Viterbi kernel (k_viterbi_msc: LDS window ring fed by LDS-DMA, per-step descriptors from the depuncturing map)"""

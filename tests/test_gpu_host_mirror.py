@@ -87,3 +87,9 @@ def test_scan_mode_signal_presence(gpu):
     good, noise = scan_streams()
     assert R.gpu_scan_run(good, lib=R.GPU_HIP_SO) == [1]
     assert R.gpu_scan_run(noise, lib=R.GPU_HIP_SO) == [0]
+
+
+def test_worker_failure_becomes_input_failure(gpu):
+    """an exception on the facade's worker thread surfaces as onInputFailure() (ofdm-processor.cpp:492-499), on the device build too"""
+    x = synth.make_stream(6, snr_db=20, seed=2)
+    assert R.gpu_failing_input_run(x, 3 * 196608, lib=R.GPU_HIP_SO) == 1

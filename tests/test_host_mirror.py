@@ -156,3 +156,11 @@ def test_scan_mode_signal_presence(emu):
     good, noise = scan_streams()
     assert R.ref_scan_run(good) == [1] and R.gpu_scan_run(good, lib=R.GPU_EMU_SO) == [1]
     assert R.ref_scan_run(noise) == [0] and R.gpu_scan_run(noise, lib=R.GPU_EMU_SO) == [0]
+
+
+def test_worker_failure_becomes_input_failure(emu):
+    """an exception on the facade's worker thread (here: the input's getSamples throws mid-stream) is reported through
+    onInputFailure() like the reference's InputFailure (ofdm-processor.cpp:492-499) instead of ending the process; stop() and the
+    sub-channel bookkeeping still work afterwards"""
+    x = synth.make_stream(6, snr_db=20, seed=2)
+    assert R.gpu_failing_input_run(x, 3 * 196608, lib=R.GPU_EMU_SO) == 1

@@ -16,6 +16,17 @@ using namespace dabphy;
 
 namespace {
 
+// Environment variables are read only by builds made with -DDABPHY_EXPERIMENTS (timing / debugging builds and the GPU-less test
+// build): the product library is configured through dabphy_config alone.
+inline bool debug_env(const char* name)
+{
+#ifdef DABPHY_EXPERIMENTS
+    return getenv(name) != nullptr;
+#else
+    (void)name; return false;
+#endif
+}
+
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -64,11 +75,6 @@ struct dabphy_handle {
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
-    hipStream_t vit_stream[2] = {nullptr, nullptr};      // the MSC class is decoded in parts: part p's Viterbi (+ superframe filter) runs here while part p + 1 is gathered
-    static constexpr int MAX_PARTS = 8;
-    hipEvent_t ev_part[MAX_PARTS]{}, ev_vit_done[2]{};
-    int msc_parts = 0;                                   // 0 = automatic (DABPHY_MSC_PARTS overrides)
-    int vit_split = 1;                                   // launches the fused MSC decode of a big class is cut into (DABPHY_VIT_SPLIT)
     FusedMscArgs last_fused{}; bool have_last_fused = false;   // the fused decode launch of the last batch (dabphy_time_fused_msc re-runs it alone)
     bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
@@ -232,8 +238,6 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipEventCreateWithFlags(&h->ev_chain_gate, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
-    for (int i = 0; i < 2; i++) if (hipStreamCreateWithFlags(&h->vit_stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_vit_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
-    for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreateWithFlags(&h->ev_wide_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     {
         void* p = nullptr;
@@ -257,7 +261,9 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
         h->h_sf_stats = reinterpret_cast<int32_t*>(p);
     }
     h->exact_batch = cfg->no_batch_replay == 0;
+#ifdef DABPHY_EXPERIMENTS
     if (const char* e = getenv("DABPHY_EXACT_BATCH")) h->exact_batch = atoi(e) != 0;   // (experiments: overrides the configuration)
+#endif
     {
         void* p = nullptr;
         if (hipMalloc(&p, sizeof(int32_t)) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
@@ -267,12 +273,12 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
         h->h_any_eff = reinterpret_cast<int32_t*>(p); *h->h_any_eff = 0;
     }
     h->wide_sync = cfg->serial_sync == 0;
+#ifdef DABPHY_EXPERIMENTS
     if (const char* e = getenv("DABPHY_SYNC_WIDE")) h->wide_sync = atoi(e) != 0;    // (experiments: overrides the configuration)
-    h->msc_parts = cfg->msc_parts;
-    if (const char* e = getenv("DABPHY_MSC_PARTS")) h->msc_parts = atoi(e);          // (experiments: overrides the configuration)
-    if (h->msc_parts < 0) return fail(DABPHY_ERR_INVALID);
+#endif
+#ifdef DABPHY_EXPERIMENTS
     if (const char* e = getenv("DABPHY_FUSED_MSC")) h->fused_msc = atoi(e) != 0;
-    if (const char* e = getenv("DABPHY_VIT_SPLIT")) h->vit_split = atoi(e);
+#endif
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     *out = h;
@@ -315,8 +321,6 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
-    for (int i = 0; i < 2; i++) { if (h->vit_stream[i]) { e = hipStreamSynchronize(h->vit_stream[i]); e = hipStreamDestroy(h->vit_stream[i]); } if (h->ev_vit_done[i]) e = hipEventDestroy(h->ev_vit_done[i]); }
-    for (int i = 0; i < dabphy_handle::MAX_PARTS; i++) if (h->ev_part[i]) e = hipEventDestroy(h->ev_part[i]);
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
@@ -565,8 +569,15 @@ static int reset_synchroniser(dabphy_handle* h, bool decoder_too)
         RxState& s = init[b];
         int64_t frame_no = decoder_too ? 0 : s.frame_no, pos = decoder_too ? 0 : s.pos;
         if (!ahead.empty()) { frame_no = ahead[(size_t)b * h->presynced].frame_no; pos = ahead[(size_t)b * h->presynced].pos; }
+        // counters that outlive OFDMProcessor::restart (`attempts` is a member that only the end of a scan clears, ofdm-processor.h:111,
+        // ofdm-processor.cpp:258-262,354) and this library's own statistics
+        const RxState keep = s;
         memset(&s, 0, sizeof s);
         s.acq_phase = 0; s.acq_left = T_F / 2; s.first_lock_attempts = -1; s.frame_no = frame_no; s.pos = pos;
+        if (!decoder_too) {
+            s.attempts = keep.attempts; s.first_lock_attempts = keep.first_lock_attempts; s.lost = keep.lost;
+            s.n_exact_sums = keep.n_exact_sums; s.n_relock_inexact = keep.n_relock_inexact; s.n_wide_frames = keep.n_wide_frames;
+        }
     }
     h->presynced = 0; h->ahead = 0;
     HIPCHK(h, hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(RxState), hipMemcpyHostToDevice, h->stream));
@@ -808,7 +819,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
                     if (prev_low + 1 < c.n_windows) { st[q].off01 |= MSC_LOAD_NEXT; load_step[prev_low + 1] = q; }
                 }
             }
-            if (!ok && getenv("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class nbits %d: no fused decode (window schedule, reason %d)\n", c.prot.nbits, why);
+            if (!ok && debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class nbits %d: no fused decode (window schedule, reason %d)\n", c.prot.nbits, why);
             if (!ok) c.n_windows = 0;             // (never for the profiles of EN 300 401; the two-kernel path decodes such a class)
             if ((r = ensure(h, c.steps, st.size() * sizeof(MscStep)))) return r;
             HIPCHK(h, hipMemcpy(c.steps.p, st.data(), st.size() * sizeof(MscStep), hipMemcpyHostToDevice));
@@ -851,7 +862,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
 {
     DeviceBind dev_(h);
     if (!h || n_frames == 0 || n_frames > h->cfg.max_frames) return DABPHY_ERR_INVALID;
-    if (g_tl_on < 0) g_tl_on = getenv("DABPHY_DEBUG_TIMING") ? 1 : 0;
+    if (g_tl_on < 0) g_tl_on = debug_env("DABPHY_DEBUG_TIMING") ? 1 : 0;
     const double tl0 = g_tl_on ? now_us() : 0.0; double tl[6] = {0, 0, 0, 0, 0, 0};
     auto tick = [&](int i) { if (g_tl_on) tl[i] = now_us() - tl0; };
     if (!h->s_iq) { h->err = "no sample stream bound"; return DABPHY_ERR_STATE; }
@@ -1032,23 +1043,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipMemcpyAsync(h->h_ok, h->s_ok.p, (size_t)B * F * 12, hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
-    // MSC: one gather + decode per protection class (stage events bracket the first class only: one class in the canonical ensemble).
-    // A big class is decoded in PARTS (whole ensembles each): the parts are gathered back to back on the main stream and part p's
-    // Viterbi kernel -- VALU-bound -- runs on a side stream while part p + 1 is gathered -- HBM / LDS-DMA-bound --, and with auto
-    // superframes the filter of part p follows its Viterbi on the same side stream.  The stage times then overlap (they are spans).
+    // MSC: one decode per protection class (stage events bracket the first class only: one class in the canonical ensemble).
     h->last_frames = F;
     h->sf_stats_ready = false; h->h_sf_stats_valid = false;
-    bool sf_done_in_parts = false;
-    // parts of a class: whole ensembles, whole 64-codeword groups, and (automatic choice) enough groups per part to fill the device
-    auto parts_of = [&](const dabphy_handle::MscClass& cls) {
-        const int M = (int)cls.members.size();
-        const int n_groups = (int)(((int64_t)B * 4 * F * M + 63) / 64);
-        const int want = h->msc_parts > 0 ? h->msc_parts : 1;
-        for (int q = std::min(want, (int)dabphy_handle::MAX_PARTS); q > 1; q--)
-            if (B % q == 0 && ((int64_t)(B / q) * 4 * F * M) % 64 == 0) return q;
-        return 1;
-    };
-    auto is_dabplus_rate = [](const dabphy_handle::MscClass& cls) { return (cls.prot.nbits / 24) % 8 == 0 && cls.prot.nbits / 8 >= 10; };
     for (auto& cls : h->classes) {
         VitClass c{};
         const int M = (int)cls.members.size();
@@ -1056,11 +1053,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if ((r = prepare_class(h, c, cls.prot.nbits, n_cw, 1))) return r;
         if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
         c.out = cls.out.as<uint8_t>();
-        MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
-        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
         const bool first_cls = (&cls == &h->classes.front());
-        const int parts = parts_of(cls);
-        if (parts == 1 && h->fused_msc && cls.n_windows > 0 && 4 * F >= 64) {
+        if (h->fused_msc && cls.n_windows > 0 && 4 * F >= 64) {
             // fused: the gather happens inside the Viterbi kernel (needs >= 64 CIFs per sub-channel and batch: a wave then spans at
             // most two (ensemble, sub-channel) pairs)
             FusedMscArgs fa{}; fa.soft = da.soft; fa.soft_ring = ring_frames; fa.n_ens = (int)B; fa.n_frames = (int)F;
@@ -1068,55 +1062,22 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             fa.c = c; fa.prbs_words = h->d_prbs_words;
             if (first_cls) { h->last_fused = fa; h->have_last_fused = true; }
             if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, false);
-            // Two launches of half the groups each, back to back.  A launch's last round of work-groups leaves execution slots idle;
-            // the benchmark batch's 5760 groups on 1024 SIMDs pay for 6 rounds either way (5.6 -> 6 or 2.8 + 2.8 -> 3 + 3), and the idle
-            // slots behind the FIRST half are where the next batch's synchroniser pass and the FIC decode find room in the middle
-            // of the step instead of behind it.
-            const int halves = (h->vit_split > 1 && c.n_groups >= 4096) ? h->vit_split : 1;
-            for (int p = 0; p < halves; p++) {
-                FusedMscArgs fp = fa;
-                fp.c.g_begin = (int)((int64_t)c.n_groups * p / halves); fp.c.g_end = (int)((int64_t)c.n_groups * (p + 1) / halves);
-                launch_viterbi_msc(fp, h->stream);
-            }
+            launch_viterbi_msc(fa, h->stream);
             if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
             continue;
         }
-        if (parts == 1) {
-            if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
-            launch_msc_gather(g, h->stream);
-            if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
-            VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
-            launch_viterbi(v, h->stream);
-            if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
-            continue;
-        }
-        const bool sf_here = h->sf_auto && is_dabplus_rate(cls);
-        if (h->sf_auto && !sf_done_in_parts) HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));   // before the first part's gather: ordered before every filter launch
-        sf_done_in_parts = sf_done_in_parts || h->sf_auto;
-        const int ens_per = (int)B / parts, grp_per = c.n_groups / parts;
+        // batches of fewer than 64 CIFs per sub-channel (and classes whose window schedule the fused kernel cannot follow): two kernels
+        MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
+        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
         if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
-        for (int p = 0; p < parts; p++) {
-            hipStream_t vs = h->vit_stream[p & 1];
-            MscGatherArgs gp = g; gp.c.g_begin = p * grp_per; gp.c.g_end = (p + 1) * grp_per;
-            launch_msc_gather(gp, h->stream);
-            HIPCHK(h, hipEventRecord(h->ev_part[p], h->stream));
-            HIPCHK(h, hipStreamWaitEvent(vs, h->ev_part[p], 0));
-            if (first_cls && p == 0) { mark(dabphy_handle::ST_MSC_VITERBI, false, vs); if (sf_here) mark(dabphy_handle::ST_RS, false, vs); }
-            VitArgs v{}; v.c = gp.c; v.prbs_words = h->d_prbs_words;
-            launch_viterbi(v, vs);
-            if (sf_here && (r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>(), vs, p * ens_per, ens_per))) return r;
-        }
-        if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, true);
-        for (int i = 0; i < 2; i++) { HIPCHK(h, hipEventRecord(h->ev_vit_done[i], h->vit_stream[i])); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_vit_done[i], 0)); }
-        if (first_cls) { mark(dabphy_handle::ST_MSC_VITERBI, true); if (sf_here) mark(dabphy_handle::ST_RS, true); }
+        launch_msc_gather(g, h->stream);
+        if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
+        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+        launch_viterbi(v, h->stream);
+        if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
     }
     if (h->sf_auto) {
-        if (!sf_done_in_parts) { if ((r = launch_superframe_stats(h))) return r; }
-        else {
-            // classes that were decoded in one piece while another was decoded in parts: filter them now, into the same totals
-            for (auto& cls : h->classes)
-                if (parts_of(cls) == 1 && is_dabplus_rate(cls) && (r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>()))) return r;
-        }
+        if ((r = launch_superframe_stats(h))) return r;
         h->sf_stats_ready = true;
         HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
         h->h_sf_stats_valid = true;

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <iostream>
 #include <stdexcept>
 
 namespace {
@@ -21,6 +22,7 @@ namespace {
 constexpr uint64_t kRing = 80ull * 196608;
 constexpr uint64_t kAhead = 8ull * 196608;
 constexpr int kPull = 65536;                         // samples per InputInterface::getSamples call
+constexpr size_t kMaxQueued = 64;                    // logical frames a sub-channel's decoder thread may lag behind the channel decoder
 
 bool protection_of(const Subchannel& sub, dabphy_protection* p)
 {
@@ -79,7 +81,11 @@ GpuRadioReceiver::Stream::~Stream()
 void GpuRadioReceiver::Stream::push(const uint8_t* p)
 {
     {
-        std::lock_guard<std::mutex> lock(m);
+        // a full queue holds the channel decoder back (an unthrottled file input would otherwise run arbitrarily far ahead of the audio
+        // decoder): DabAudio::process waits the same way on its ring buffer (dab-audio.cpp:99-106)
+        std::unique_lock<std::mutex> lock(m);
+        cv_space.wait(lock, [&] { return closing || q.size() < kMaxQueued; });
+        if (closing) return;
         q.emplace_back(p, p + frame_bytes);
     }
     cv.notify_one();
@@ -96,6 +102,7 @@ void GpuRadioReceiver::Stream::run()
             if (q.empty()) return;
             f = std::move(q.front()); q.pop_front();
         }
+        cv_space.notify_one();
         for (int i = 0; i < 8 * frame_bytes; i++) bits[i] = (f[i >> 3] >> (7 - (i & 7))) & 1;     // DabAudio hands over one bit per byte
         adapter.addtoFrame(bits.data());                                                          // dab-audio.cpp:157
     }
@@ -146,7 +153,9 @@ void GpuRadioReceiver::restart_decoder()
 void GpuRadioReceiver::stop()
 {
     running = false;
-    if (worker.joinable()) worker.join();
+    sub_cv.notify_all();                                                // (nobody waits for a worker that is going away)
+    // onInputFailure() runs on the worker and controllers answer it with stop() (ofdm-processor.cpp:497): never join ourselves
+    if (worker.joinable() && worker.get_id() != std::this_thread::get_id()) worker.join();
 }
 
 void GpuRadioReceiver::setReceiverOptions(const RadioReceiverOptions rro)
@@ -192,12 +201,12 @@ bool GpuRadioReceiver::removeServiceToDecode(const Service& s)
         {
             std::lock_guard<std::mutex> lock(mutex);
             for (auto it = streams.begin(); it != streams.end(); ++it)
-                if ((*it)->sub.subChId == subch.subChId) { gone = *it; streams.erase(it); subchannels_dirty = true; break; }
+                if ((*it)->sub.subChId == subch.subChId) { gone = *it; streams.erase(it); mark_subchannels_dirty(); break; }
         }
         if (!gone) return false;
         // the caller may destroy its ProgrammeHandler as soon as this returns (MscHandler::removeSubchannel joins the DabAudio
         // thread): wait until the worker has let go of the stream, then end its decoder thread here
-        while (running && gone.use_count() > 1) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        wait_until_released();
         gone.reset();
         return true;
     }
@@ -230,7 +239,7 @@ bool GpuRadioReceiver::addSubchannel(ProgrammeHandlerInterface& handler, AudioSe
     auto st = std::make_shared<Stream>(handler, ascty, dumpFileName, sub);      // may throw like DecoderAdapter does (unknown component type)
     std::lock_guard<std::mutex> lock(mutex);
     streams.push_back(std::move(st));
-    subchannels_dirty = true;
+    mark_subchannels_dirty();
     return true;
 }
 
@@ -240,10 +249,19 @@ void GpuRadioReceiver::clearSubchannels()
     {
         std::lock_guard<std::mutex> lock(mutex);
         gone.swap(streams);
-        subchannels_dirty = true;
+        mark_subchannels_dirty();
     }
     // as in removeServiceToDecode: the handlers may go away once this returns
-    for (auto& g : gone) while (running && g.use_count() > 1) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    wait_until_released();
+}
+
+// Blocks until the worker has applied every sub-channel change requested so far (it then holds no reference to a removed stream), or
+// is not running: it applies them before every frame and while it starves, and signals sub_cv when it has.
+void GpuRadioReceiver::wait_until_released()
+{
+    std::unique_lock<std::mutex> lock(mutex);
+    const uint64_t want = sub_requested;
+    sub_cv.wait(lock, [&] { return !running || sub_applied >= want; });
 }
 
 // Pending changes from other threads (options, sub-channel selection) are applied here, on the worker: the handle is not thread-safe,
@@ -252,8 +270,10 @@ void GpuRadioReceiver::apply_pending()
 {
     std::lock_guard<std::mutex> lock(mutex);
     if (options_dirty) {
+        int32_t restarted = 0;
         if (dabphy_set_options(phy, placement_code(options.fftPlacementMethod), (int32_t)options.freqsyncMethod,
-                               options.disableCoarseCorrector, nullptr) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
+                               options.disableCoarseCorrector, &restarted) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(phy));
+        if (restarted) input.restart();             // OFDMProcessor::setReceiverOptions -> restart() also restarts the input (ofdm-processor.cpp:115-132)
         options_dirty = false;
     }
     if (subchannels_dirty) {
@@ -272,6 +292,8 @@ void GpuRadioReceiver::apply_pending()
         }
         active.swap(now);
         subchannels_dirty = false;
+        sub_applied = sub_requested;
+        sub_cv.notify_all();
     }
     tii_now = options.decodeTII;                                        // read once per frame, ofdm-processor.cpp:376-380
 }
@@ -352,7 +374,8 @@ void GpuRadioReceiver::run()
     std::vector<DSPCOMPLEX> buf(kPull);
     uint64_t written = 0;
     const uint64_t frame_need = 2048 + 2047 + 75ull * 2552 + 2656;       // what one SyncOnPhase pass may touch
-    bool input_done = false;
+    bool input_done = false, failed = false;
+    try {
     while (running) {
         apply_pending();                 // also while starving: a removed sub-channel's stream must be let go of
         // --- fill the ring like OFDMProcessor::getSamples pulls (count, then read; is_ok() while starving)
@@ -389,5 +412,23 @@ void GpuRadioReceiver::run()
         }
         if (!pulled && !progressed) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    active.clear();
+    }
+    catch (const std::exception& e) {
+        // a failed library call (device lost, out of memory) or a throwing input: this is a std::thread, nothing above would catch it.
+        // The reference ends its processing thread the same way for its InputFailure (ofdm-processor.cpp:492-499).
+        std::clog << "GpuRadioReceiver: " << e.what() << ", closing down" << std::endl;
+        failed = true;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        active.clear();
+        sub_applied = sub_requested;
+    }
+    if (failed) {
+        running = false;                 // before onInputFailure: the controller may call stop() from it (ofdm-processor.cpp:497)
+        sub_cv.notify_all();
+        rci.onInputFailure();
+        return;
+    }
+    sub_cv.notify_all();
 }

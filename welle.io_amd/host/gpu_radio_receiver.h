@@ -95,8 +95,9 @@ class GpuRadioReceiver {
           private:
             void run();
             DecoderAdapter adapter;
-            std::mutex m; std::condition_variable cv;
-            std::deque<std::vector<uint8_t>> q;
+            std::mutex m; std::condition_variable cv, cv_space;
+            std::deque<std::vector<uint8_t>> q;                         // at most kMaxQueued logical frames: push blocks beyond that, as
+                                                                        // DabAudio::process does on a full mscBuffer (dab-audio.cpp:99-106)
             bool closing = false;
             std::thread thread;
         };
@@ -116,6 +117,11 @@ class GpuRadioReceiver {
         bool options_dirty = false;
         std::list<std::shared_ptr<Stream>> streams;
         bool subchannels_dirty = false;
+        // the worker has let go of every stream that was removed up to request number sub_requested (both under `mutex`, sub_cv)
+        uint64_t sub_requested = 0, sub_applied = 0;
+        std::condition_variable sub_cv;
+        void mark_subchannels_dirty() { subchannels_dirty = true; ++sub_requested; }      // caller holds `mutex`
+        void wait_until_released();
         std::vector<std::shared_ptr<Stream>> active;   // worker thread only: the streams whose sub-channels the handle currently decodes, in its order
         std::atomic<bool> scan_mode{false};            // OFDMProcessor::scanMode (ofdm-processor.h:110)
         bool tii_now = false;
