@@ -612,11 +612,21 @@ def check_error_behaviour(d_factory):
 # ---- the configuration bench.py times (welle_io_amd/workload.py): B x F batch, looping ring, coarse corrector enabled, pipelined
 # synchroniser, all 18 sub-channels, superframe filter inside process() -- against the oracle on the very same samples
 def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_steps=3, demod_chunk=0, device="cuda", subs_idx=(0, 7, 17),
-                       base=None, expect_chunk=None):
+                       base=None, expect_chunk=None, channels=None, min_wide_fallbacks=None):
+    """channels: one channel (synth.apply_channel) per distinct recording -- the recordings then run through it ONCE over the whole test
+    (a drifting sampling clock has no seamless loop point) and the ring does not loop.  min_wide_fallbacks: the wide synchroniser pass
+    must have handed at least that many batches back to the frame-by-frame chain (what per-ensemble drift does in every batch)"""
     from welle_io_amd import workload
+    loop = channels is None
+    if channels is not None:
+        nd = len(channels)
+        base_np, txs = base if base is not None else workload.make_base_streams(nd, workload.REC_FRAMES, seed0=0)
+        need = (n_steps * F + 8) * 196608
+        rows = [synth.apply_channel(np.tile(base_np[e].astype(np.complex128), -(-(need + 4096) // base_np.shape[1])), channels[e])[:need] for e in range(nd)]
+        base = (np.stack(rows).astype(np.complex64), txs)
     iq, cfo, base_np, txs = workload.make_batch(B, device=device, base=base)
     subchs = txs[0].subchs
-    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False)
+    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False, loop=loop)
     logs = {b: dict(fib=[], ok=[], corr=[], soft=[], msc=[[] for _ in subs_idx], sf=np.zeros(4, np.int64), n_logical=0) for b in check_ens}
     try:
         if expect_chunk is not None:
@@ -638,15 +648,18 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
                     L["msc"][k].append(m[b, fv[b]:4 * len(valid)].tobytes())
                 L["n_logical"] += max(0, 4 * len(valid) - int(mscs[0][1][b]))
                 L["sf"] += sf[b]
+        wide = d.wide_sync_stats()
     finally:
         d.close()
-    loops = (n_steps * F + 3) // (iq.shape[1] // 196608) + 2
+    if min_wide_fallbacks is not None:
+        assert wide[2] >= min_wide_fallbacks, "wide synchroniser pass: %d passes, %d handed back to the serial chain" % (wide[1], wide[2])
+    loops = ((n_steps * F + 3) // (iq.shape[1] // 196608) + 2) if loop else 1
     for b in check_ens:
         L = logs[b]
         row = iq[b].cpu().numpy()
         o = R.orc_receiver_run(np.tile(row, loops), subchs=subchs, want_soft=True)
         n = len(L["fib"])
-        assert n >= n_steps * F - 2 and n <= o["n_frames"], (b, n, o["n_frames"])
+        assert n >= n_steps * F - (2 if loop else F + 2) and n <= o["n_frames"], (b, n, o["n_frames"])
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
         assert np.array_equal(np.array(L["ok"]), ofib[:, :, 0]), "ensemble %d: CRC flags differ" % b
         assert np.array_equal(np.array(L["fib"]), ofib[:, :, 1:]), "ensemble %d: FIB bytes differ" % b
