@@ -35,11 +35,11 @@ CLOCK_HZ = 2.4e9                                             # MI355X_MICROARCH.
 PARITY_SUBCH = (0, 7, 17)                                    # sub-channels whose MSC bytes the parity leg compares
 
 
-def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir):
+def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir, cwd=None):
     """n_proc concurrent receiver processes, receiver i over recording recs[i % len(recs)]; returns their result records"""
     args = [sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py")]
     procs = [subprocess.Popen(args + [recs[i % len(recs)], str(n_loops), mode, os.path.join(out_dir, "%s_%d.npz" % (mode, i)) if i < len(recs) else "-"],
-                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=open(os.path.join(out_dir, "%s_err.txt" % mode), "w") if i == 0 else subprocess.DEVNULL, text=True, env=env) for i in range(n_proc)]
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=open(os.path.join(out_dir, "%s_err.txt" % mode), "w") if i == 0 else subprocess.DEVNULL, text=True, env=env, cwd=cwd) for i in range(n_proc)]
     for p in procs:
         if p.stdout.readline().strip() != "READY":
             err = open(os.path.join(out_dir, "%s_err.txt" % mode)).read()[-400:]
@@ -52,6 +52,51 @@ def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir):
     for p in procs:
         p.wait()
     return res
+
+
+def _compare_with_receivers(td, mode, ens_list, gpu_logs):
+    """FIB bytes + CRC flags and the MSC bytes of PARITY_SUBCH of every ensemble in ens_list: GPU log vs the files receiver i of `mode`
+    left in td; raises AssertionError on the first difference; returns (frames compared, MSC bytes compared per sub-channel)"""
+    n = m = 0
+    for i, e in enumerate(ens_list):
+        z = np.load(os.path.join(td, "%s_%d.npz" % (mode, i)))
+        g = gpu_logs[e]
+        n = min(len(g["fib"]), len(z["fib"]) // 12)
+        assert n >= len(g["fib"]) - 1 and n > 0, (mode, e, n, len(g["fib"]))
+        zf = z["fib"][:12 * n].reshape(n, 12, 33)
+        ok = np.array_equal(np.array(g["ok"][:n]), zf[:, :, 0]) and np.array_equal(np.array(g["fib"][:n]), zf[:, :, 1:])
+        if not ok:
+            raise AssertionError("parity: FIBs of ensemble %d differ from the %s receiver's" % (e, mode))
+        for k, i_sub in enumerate(PARITY_SUBCH):
+            got = b"".join(g["msc"][k]); want = z["msc%d" % i_sub].tobytes()
+            m = min(len(got), len(want))
+            if m == 0 or got[:m] != want[:m]:
+                raise AssertionError("parity: MSC bytes of ensemble %d sub-channel %d differ from the %s receiver's" % (e, i_sub, mode))
+    return n, m
+
+
+def _host_has(*flags):
+    try:
+        have = set(open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split())
+    except Exception:
+        return False
+    return all(f in have for f in flags)
+
+
+def _stage_ms_from_profile(path, frames):
+    """profiling_points.csv of the reference's -DWITH_PROFILING build (thread, mark, CLOCK_THREAD_CPUTIME_ID stamp per PROFILE() call,
+    various/profiling.cpp:183-188): the CPU time between a mark and the next one on the same thread is booked on the FIRST of the two
+    (as the reference's own profiling.dot does, :150-160) -> CPU milliseconds per transmission frame and mark"""
+    import csv
+    last = {}; acc = {}
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            t = int(r["time_sec"]) + int(r["time_ns"]) * 1e-9
+            th = r["thread_id"]
+            if th in last:
+                acc[last[th][0]] = acc.get(last[th][0], 0.0) + (t - last[th][1])
+            last[th] = (r["mark"], t)
+    return {k: v * 1e3 / max(1, frames) for k, v in sorted(acc.items())}
 
 
 def cpu_baseline(rows, n_loops, gpu_logs):
@@ -73,37 +118,37 @@ def cpu_baseline(rows, n_loops, gpu_logs):
             path = os.path.join(td, "rec%d.npy" % e); np.save(path, rows[e]); recs.append(path)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         res = _run_receivers(recs, cores, n_loops, "port", env, td)
-        ref = None; ref_error = None
-        # the reference leg decodes only rows built from recording 0 (ensembles b with b % 4 == 0): on the random access units of the other
-        # recordings the reference's FAAD2 adapter throws ("NeAACDecDecode did not consume all bytes") and takes the process down --
-        # a crash in its audio layer above the PHY; the oracle leg covers every row
-        ref_ens = [e for e in ens if e % 4 == 0]
-        ref_recs = [recs[ens.index(e)] for e in ref_ens]
-        if ref_recs and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref.so")):
+        ref = None; ref_error = None; o3 = None; stage_ms = None
+        have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref.so"))
+        # the reference leg decodes the same rows as the oracle leg (the synthetic access units open with ID_END, so its FAAD2 adapter
+        # rejects them instead of half-decoding random bytes and throwing: synth.make_superframe)
+        if have_ref:
             try:
-                ref = _run_receivers(ref_recs, max(len(ref_recs), cores // 2), max(1, n_loops // 2), "reference", env, td)
+                ref = _run_receivers(recs, max(len(recs), cores // 2), max(1, n_loops // 2), "reference", env, td)
             except Exception as ex:                        # reported in the line (kind falls back to "port")
                 ref = None; ref_error = "%s: %s" % (type(ex).__name__, ex)
         # ---- parity of this run: GPU log vs CPU receivers on the same rows
         parity = {"ensembles": ens, "sub_channels": list(PARITY_SUBCH), "against": []}
         for mode in (["reference"] if ref else []) + ["port"]:
-            for i, e in enumerate(ref_ens if mode == "reference" else ens):
-                z = np.load(os.path.join(td, "%s_%d.npz" % (mode, i)))
-                g = gpu_logs[e]
-                n = min(len(g["fib"]), len(z["fib"]) // 12)
-                assert n >= len(g["fib"]) - 1 and n > 0, (mode, e, n, len(g["fib"]))
-                zf = z["fib"][:12 * n].reshape(n, 12, 33)
-                ok = np.array_equal(np.array(g["ok"][:n]), zf[:, :, 0]) and np.array_equal(np.array(g["fib"][:n]), zf[:, :, 1:])
-                if not ok:
-                    raise AssertionError("parity: FIBs of ensemble %d differ from the %s receiver's" % (e, mode))
-                for k, i_sub in enumerate(PARITY_SUBCH):
-                    got = b"".join(g["msc"][k]); want = z["msc%d" % i_sub].tobytes()
-                    m = min(len(got), len(want))
-                    if m == 0 or got[:m] != want[:m]:
-                        raise AssertionError("parity: MSC bytes of ensemble %d sub-channel %d differ from the %s receiver's" % (e, i_sub, mode))
-                parity["frames"] = n; parity["msc_bytes_per_sub_channel"] = m
-            parity["against"].append("reference backend (oracle/_ref), ensembles %s" % ref_ens if mode == "reference" else "oracle (C restatement), ensembles %s" % ens)
+            n, m = _compare_with_receivers(td, mode, ens, gpu_logs)
+            parity["frames"] = n; parity["msc_bytes_per_sub_channel"] = m
+            parity["against"].append(("reference backend (oracle/_ref), ensembles %s" if mode == "reference" else "oracle (C restatement), ensembles %s") % ens)
         parity["fib_equal"] = True; parity["msc_equal"] = True
+        # ---- SURVEY 8(d)'s extras: the -O3 courtesy build of the reference, and its own PROFILE() marks (one receiver, PHY stages)
+        if ref and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref_o3.so")) and _host_has("avx2", "fma", "bmi2"):
+            try:
+                r3 = _run_receivers(recs, max(len(recs), cores // 2), max(1, n_loops // 2), "reference_o3", env, td)
+                o3 = dict(value=sum(r["frames"] for r in r3) * FRAME_S / max(r["seconds"] for r in r3), per_receiver=r3[0]["frames"] * FRAME_S / r3[0]["seconds"],
+                          flags="-O3 -march=x86-64-v3 (built on the build machine: not -march=native of this host)", receivers=len(r3))
+            except Exception as ex:
+                o3 = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if ref and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwelle_ref_prof.so")):
+            try:
+                pd = os.path.join(td, "prof"); os.makedirs(pd)
+                rp = _run_receivers(recs[:1], 1, max(1, n_loops // 2), "reference_prof", env, td, cwd=pd)
+                stage_ms = _stage_ms_from_profile(os.path.join(pd, "profiling_points.csv"), rp[0]["frames"])
+            except Exception as ex:
+                stage_ms = {"error": "%s: %s" % (type(ex).__name__, ex)}
     port_value = sum(r["frames"] for r in res) * FRAME_S / max(r["seconds"] for r in res)
     port = dict(value=port_value, per_core=res[0]["frames"] * FRAME_S / res[0]["seconds"], receivers=cores,
                 fib_ok=sum(r["fib_ok"] for r in res), fibs=sum(r["fibs"] for r in res))
@@ -113,8 +158,9 @@ def cpu_baseline(rows, n_loops, gpu_logs):
                     kind="reference", per_receiver=ref[0]["frames"] * FRAME_S / ref[0]["seconds"],
                     sample="%d concurrent RadioReceivers of the reference backend (each 2-3 threads; PHY + FIG parsing + superframe filter + AAC; lock-step input so that no frame is dropped) x %d frames "
                            "(%.1f s of IQ each) of ensembles %s of this batch, 18 sub-channels, slowest receiver %.1f s"
-                           % (len(ref), ref[0]["frames"], ref[0]["frames"] * FRAME_S, ref_ens, slowest),
-                    fib_ok=sum(r["fib_ok"] for r in ref), fibs=sum(r["fibs"] for r in ref), oracle_port=port)
+                           % (len(ref), ref[0]["frames"], ref[0]["frames"] * FRAME_S, ens, slowest),
+                    fib_ok=sum(r["fib_ok"] for r in ref), fibs=sum(r["fibs"] for r in ref), oracle_port=port, o3=o3,
+                    stage_ms=stage_ms, stage_ms_note="CPU ms per transmission frame between the reference's own PROFILE() marks (various/profiling.h:39-62; -DWITH_PROFILING build of the same sources, ONE receiver alone on the host, thread CPU time): OFDMProcessor thread NotSynced..DecodeTII, OfdmDecoder thread ProcessPRS..SymbolProcessed, one DabAudio thread per sub-channel DAGetMSCData..DADone (18 of them: their marks are summed)")
     else:
         base = dict(value=port_value, unit="x real-time (ensembles decoded concurrently by all cores)", cores=cores, kind="port",
                     per_core=port["per_core"],
@@ -128,8 +174,21 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _static_profile(name, B, F):
-    """counter figures collected by tools/make_profiles.sh in their own rocprofv3 passes (NOT measured by this run; keyed by batch geometry)"""
+_BUILD_ID = {}
+
+
+def _build_id(lib_path):
+    """hashes of the sources and of the library file actually loaded (welle_io_amd/buildid.py), computed once"""
+    if not _BUILD_ID:
+        from welle_io_amd import buildid
+        _BUILD_ID.update(src_sha256=buildid.source_sha256(), lib_sha256=buildid.file_sha256(lib_path))
+    return _BUILD_ID
+
+
+def _static_profile(name, B, F, lib_path, stale):
+    """counter figures collected by tools/make_profiles.sh in their own rocprofv3 passes (NOT measured by this run; keyed by batch
+    geometry AND by the build: a profile whose src_sha256 is not that of the sources this library was built from is not reported --
+    its name is appended to `stale` instead)"""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
@@ -137,7 +196,22 @@ def _static_profile(name, B, F):
         pj = json.load(open(path))
     except Exception:
         return None
-    return pj if pj.get("ensembles") == B and pj.get("frames") == F else None
+    if "ensembles" in pj and not (pj.get("ensembles") == B and pj.get("frames") == F):
+        return None
+    if pj.get("src_sha256") != _build_id(lib_path)["src_sha256"]:
+        stale.append("profiles/%s (src_sha256 %s..., this build %s...)" % (name, str(pj.get("src_sha256"))[:12], _build_id(lib_path)["src_sha256"][:12]))
+        return None
+    return pj
+
+
+def _extra(cmd, env_extra, timeout):
+    """one of the side measurements (tools/): own process, own handle, after the timed region; returns its JSON line or an error record"""
+    try:
+        r = subprocess.run([sys.executable] + cmd, env=dict(os.environ, **env_extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
 def main():
@@ -150,6 +224,7 @@ def main():
     ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and with it the parity check of this run)")
     ap.add_argument("--no-alt-schedule", action="store_true", help="skip the extra (untimed) pass with the other pipelined schedule")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements behind the timed region (single-ensemble facade latency, host-u8 PCIe-inclusive rate)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -171,7 +246,20 @@ def main():
         backend = os.environ.get("DABPHY_DIST_BACKEND", "nccl")
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend)         # "nccl" = RCCL (no device_id: eager RCCL initialisation prints to stdout, and stdout is one JSON line)
+        # a rendezvous or an RCCL bring-up that hangs (a missing rank, an IPC handle the driver refuses) would otherwise sit silently
+        # until the driver's own limit: fail fast and say where
+        import datetime
+        import threading
+
+        def _hung():
+            sys.stderr.write("bench.py rank %d/%d: torch.distributed initialisation (backend %s, master %s:%s) did not finish within 240 s -- giving up\n"
+                             % (rank, world, backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")))
+            sys.stderr.flush(); os._exit(3)
+        dog = threading.Timer(240.0, _hung); dog.daemon = True; dog.start()
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))   # "nccl" = RCCL (no device_id: eager RCCL initialisation prints to stdout, and stdout is one JSON line)
+        if backend == "nccl":                    # the first collective is where RCCL really connects the ranks: do it under the watchdog
+            t_ = torch.zeros(1, device="cuda"); dist.all_reduce(t_); torch.cuda.synchronize()
+        dog.cancel()
     load_package()
     from welle_io_amd import capi, workload
     from welle_io_amd.distributed import gather_fibs
@@ -210,25 +298,32 @@ def main():
     del spin
     # warm-up: acquisition, time-de-interleaver fill, superframe synchronisation.  Rank 0 logs what two ensembles of the batch (first
     # and last) deliver from the very first frame on: the parity leg below compares it with CPU receivers decoding the same rows.
-    check = sorted({0, (B - 1) // 4 * 4, B - 1}) if rank == 0 else []        # first, last, and the last one built from recording 0
+    # Rank 0 of a single-GPU run: eight ensembles spread over the batch (all four recordings, both ends), compared below with the real
+    # reference backend AND the oracle.  Multi-rank runs: every rank checks the first and the last ensemble of ITS shard against the
+    # oracle (outside the timed region) and the verdicts are all-reduced into the line (parity_check.ranks_ok).
+    if world == 1:
+        check = sorted({0, 1, 2, 3, B // 2, B - 3, B - 2, B - 1} & set(range(B)))
+    else:
+        check = sorted({0, B - 1})
     logs = {e: dict(fib=[], ok=[], msc=[[] for _ in PARITY_SUBCH]) for e in check}
     for W in range(max(2, args.warmup)):
         fib, ok, sf = step()
-        if check and not args.no_cpu_baseline and W * F < 64:           # (the CPU receivers keep their first 64 frames for the comparison)
+        if check and (world > 1 or not args.no_cpu_baseline) and W * F < 64:           # (the CPU receivers keep their first 64 frames for the comparison)
             info = dev.frame_info()
             mscs = [dev.msc(i) for i in PARITY_SUBCH]
+            lfib, lok = (fib, ok) if dist is None else dev.fibs()        # (with ranks, `fib` is the gathered set and only rank 0 has it)
             for e in check:
                 valid = [f for f in range(F) if info[e, f]["valid"] == 1]
                 for f in valid:
-                    logs[e]["fib"].append(np.array(fib[e, f])); logs[e]["ok"].append(np.array(ok[e, f]))
+                    logs[e]["fib"].append(np.array(lfib[e, f])); logs[e]["ok"].append(np.array(lok[e, f]))
                 for k in range(len(PARITY_SUBCH)):
                     m, fv = mscs[k]
                     logs[e]["msc"][k].append(m[e, fv[e]:4 * len(valid)].tobytes())
     fib, ok, sf = step()
     # sanity outside the timed region: all FIBs pass CRC; every sub-channel of every ensemble delivers its 4F/5 superframes per
     # step, none uncorrectable, every access unit passes its CRC; the FIBs of ensemble 0 are the transmitted ones
-    if rank != 0:
-        fib, ok = dev.fibs()
+    if dist is not None:
+        fib, ok = dev.fibs()                               # every rank checks its own shard
     fib = np.asarray(fib); ok = np.asarray(ok)
     if os.environ.get("DABPHY_BENCH_NOCHECK") == "1":      # (kernel timing experiments with deliberately wrong results: tools only)
         sf[:, 0] = len(subchs) * (4 * F // 5); sf[:, 2:] = 0
@@ -237,6 +332,7 @@ def main():
     assert (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all(), "superframe filter: %s" % sf[:4]
     sent = set(b"".join(f) for f in txs[0].fib_log)
     assert all(fib[0, f].tobytes() in sent for f in range(F)), "decoded FIBs differ from the transmitted ones"
+    lib_sha_note = _build_id(lib_path)
 
     stage_acc = {}
     if dist is not None:
@@ -256,6 +352,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- multi-rank runs: every rank proves ITS shard (outside the timed region): the first and the last ensemble of the shard through
+    # the oracle on this host, FIBs + CRC flags + MSC bytes of three sub-channels from the very first frame on; the verdicts are summed
+    ranks_ok = None; rank_err = None
+    if world > 1:
+        import tempfile
+        flag = 0
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                recs = []
+                for e in check:
+                    path = os.path.join(td, "rec%d.npy" % e); np.save(path, iq[e].cpu().numpy()); recs.append(path)
+                env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+                _run_receivers(recs, len(recs), max(2, -(-80 // rec_frames)), "port", env, td)
+                _compare_with_receivers(td, "port", check, logs)
+            flag = 1
+        except Exception as ex:
+            rank_err = "rank %d: %s: %s" % (rank, type(ex).__name__, ex)
+            sys.stderr.write("bench.py parity leg, %s\n" % rank_err)
+        tf = torch.tensor([flag], device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+        ranks_ok = int(tf.item())
+
     if rank == 0:
         n_simd = 4 * torch.cuda.get_device_properties(local).multi_processor_count
         ms_step = dt / args.steps * 1e3
@@ -263,7 +381,8 @@ def main():
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         demod_ms = stages["demod"]
         ach = B * F * ALG_BYTES_DEMOD_PER_FRAME / (demod_ms * 1e-3) / 1e9
-        pj = _static_profile("demod_hbm_traffic.json", B, F)
+        stale = []
+        pj = _static_profile("demod_hbm_traffic.json", B, F, lib_path, stale)
         n_cw_steps = B * F * (4 * 774 + 72 * 1542)
         line = {
             "metric": "DAB Mode-I ensembles/s (x real-time)", "value": value, "unit": "x real-time (ensembles decoded concurrently)",
@@ -283,7 +402,7 @@ def main():
         }
         # ---- Viterbi stage: VALU issue roofline (the kernel holds its path metrics in VGPRs; no LDS traffic to be efficient with)
         vit_ms = stages.get("msc_viterbi", 0.0)
-        vj = _static_profile("viterbi_counters.json", B, F)
+        vj = _static_profile("viterbi_counters.json", B, F, lib_path, stale)
         ub = None
         try:
             ub = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
@@ -310,6 +429,9 @@ def main():
                       lds_insts_per_trellis_step=vj["lds_insts_per_launch"] / (B * F * 72 * 1542 / 64.0) if vj.get("lds_insts_per_launch") else None,
                       lds_note="SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the launch (static, profiles/viterbi_counters.json): the 16-byte row pitch the LDS-DMA dictates makes the byte reads of 64 consecutive rows 4-way conflicted; LDS is active about 4 % of the wave cycles (DESIGN.md 4.2), the add-compare-select runs in VGPRs")
         line["roofline_viterbi"] = rv
+        # which build this line was measured on, and which committed counter profiles were NOT reported because they belong to another one
+        line["profile_build"] = dict(lib_sha_note, stale_profile=stale or None,
+                                     note="static counter figures (roofline.traffic, roofline_viterbi.hbm_bytes / valu_insts / lds_*) are reported only when the profile's src_sha256 equals this build's (tools/make_profiles.sh + tools/collect_profiles.py regenerate them)")
         # what a plain device-to-device copy moves on this box (read + write), for scale next to the 8 TB/s specification the fraction is
         # taken against ("measure the denominator"); never used as `peak`
         try:
@@ -351,6 +473,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rows = {e: iq[e].cpu().numpy() for e in check}
             line["cpu_baseline"], line["parity_check"] = cpu_baseline(rows, n_loops=max(1, 240 // rec_frames), gpu_logs=logs)
+            line["parity_check"].update(ranks_ok=1, ranks=1)
+        if world > 1:
+            line["parity_check"] = {"ranks_ok": ranks_ok, "ranks": world, "per_rank": "ensembles %s of the rank's own shard: FIBs + CRC flags + MSC bytes of sub-channels %s from the first frame on vs the oracle (C restatement) on the same rows, outside the timed region" % (check, list(PARITY_SUBCH)),
+                                    "fib_equal": ranks_ok == world, "msc_equal": ranks_ok == world, "rank0_error": rank_err}
+        if world == 1 and not args.no_extras:
+            # BASELINE configs 2-3 and the PCIe-inclusive path, measured in this run (own processes, own handles, after the timed region;
+            # never `value`): the drop-in facade over one ensemble, one frame per call, every getter copied out, the reference's
+            # FIBProcessor on the host; and u8 IQ from page-locked host memory, double-buffered over PCIe, at the batch geometry
+            if dev is not None:
+                dev.close(); dev = None
+            del iq; torch.cuda.empty_cache()
+            line["facade"] = _extra([os.path.join(ROOT, "tools", "bench_facade.py"), "--json"], {}, 240)
+            line["host_u8"] = _extra([os.path.join(ROOT, "tools", "bench_host_u8.py")], {"HOSTU8_B": str(B), "HOSTU8_F": str(F), "HOSTU8_STEPS": "3"}, 300)
         print(json.dumps(line), flush=True)
     if dev is not None:
         dev.close()

@@ -1,8 +1,11 @@
 """Not a test: one CPU receiver over a looping recording, timed; bench.py starts one of these per host core for its `cpu_baseline`
 leg and compares what the first ones decoded with the GPU's output for the same rows (the run's parity check).
-argv: recording.npy n_loops mode(port|reference) out.npz|-
-  port       the oracle = single-threaded C restatement of the reference's PHY
-  reference  the real reference backend (oracle/_ref): RadioReceiver with its own threads, FIBProcessor, DecoderAdapter (incl. AAC)"""
+argv: recording.npy n_loops mode(port|reference|reference_o3|reference_prof) out.npz|-
+  port            the oracle = single-threaded C restatement of the reference's PHY
+  reference       the real reference backend (oracle/_ref): RadioReceiver with its own threads, FIBProcessor, DecoderAdapter (incl. AAC)
+  reference_o3    the same sources built -O3 -march=x86-64-v3 (oracle/Makefile ref-variants: SURVEY 8d's courtesy build)
+  reference_prof  ... built with -DWITH_PROFILING: the reference's own PROFILE() marks; that build writes profiling_points.csv into the
+                  working directory when the process ends (various/profiling.cpp:119-188)"""
 import json
 import os
 import sys
@@ -18,6 +21,9 @@ import refapi as R  # noqa: E402
 from welle_io_amd import synth  # noqa: E402
 
 rec = np.load(sys.argv[1]); n_loops = int(sys.argv[2]); mode = sys.argv[3]; out = sys.argv[4]
+if mode in ("reference_o3", "reference_prof"):
+    os.environ["WELLE_REF_LIB"] = os.path.join(ROOT, "oracle", "_ref", "libwelle_%s.so" % mode.replace("reference", "ref"))
+    mode = "reference"
 subchs = synth.EnsembleTx(eid=0x1000, seed=0).subchs          # the canonical 18 x 64 kbit/s EEP-3A layout
 x = np.tile(rec, n_loops)                                     # the looping ring as the device sees it, noise and carrier offset included
 if mode == "reference":

@@ -41,9 +41,10 @@ _ref_ofdm = None
 
 
 def ref():
+    """the reference library; WELLE_REF_LIB selects a variant build (oracle/Makefile ref-variants: -O3, -DWITH_PROFILING)"""
     global _ref
     if _ref is None:
-        _ref = C.CDLL(REF_SO)
+        _ref = C.CDLL(os.environ.get("WELLE_REF_LIB", REF_SO))
     return _ref
 
 

@@ -29,7 +29,15 @@ def test_single_gpu_line_and_parity_leg(gpu):
         assert k in j, k
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["parity_check"]["fib_equal"] and j["parity_check"]["msc_equal"] and j["parity_check"]["frames"] >= 15
+    assert j["parity_check"]["ranks_ok"] == 1 and len(j["parity_check"]["ensembles"]) >= 8          # eight ensembles, all four recordings
     assert j["cpu_baseline"]["kind"] in ("reference", "port") and j["cpu_baseline"]["value"] > 0
+    if j["cpu_baseline"]["kind"] == "reference":
+        # the real reference took EVERY checked ensemble (not only those built from recording 0), its -O3 build and its own PROFILE() marks ran
+        assert any("reference backend" in a and str(j["parity_check"]["ensembles"]) in a for a in j["parity_check"]["against"])
+        assert j["cpu_baseline"]["stage_ms"] and "ProcessSymbol" in j["cpu_baseline"]["stage_ms"] and "DADeconvolve" in j["cpu_baseline"]["stage_ms"]
+        assert j["cpu_baseline"]["o3"] is None or j["cpu_baseline"]["o3"].get("value", 1) > 0
+    assert "facade" in j and "host_u8" in j and j["host_u8"].get("x_real_time", 0) > 0
+    assert j["profile_build"]["src_sha256"] and j["profile_build"]["lib_sha256"]
 
 
 def test_rccl_gather_of_device_buffers_one_rank(gpu):
@@ -46,3 +54,5 @@ def test_gpus_2_starts_its_ranks(gpu):
     j = run_bench(["--gpus", "2", "--steps", "1", "--ensembles", "4", "--frames", "10", "--no-alt-schedule", "--no-cpu-baseline"], env)
     assert j["n_gpus"] == 2 and j["config"]["ensembles_per_gpu"] == 4
     assert j["rccl_ranks"] == (2 if torch.cuda.device_count() >= 2 else 0)
+    # every rank proved its own shard against the oracle outside the timed region
+    assert j["parity_check"]["ranks_ok"] == 2 and j["parity_check"]["fib_equal"] and j["parity_check"]["msc_equal"], j["parity_check"]

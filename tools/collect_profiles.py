@@ -7,6 +7,12 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package, PKG_DIR  # noqa: E402
+load_package()
+from welle_io_amd import buildid  # noqa: E402
+# the build these counters belong to (bench.py reports them only while the hashes match the library it runs)
+BUILD = {"src_sha256": buildid.source_sha256(), "lib_sha256": buildid.file_sha256(os.path.join(PKG_DIR, "libdabphy_hip.so"))}
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
@@ -66,7 +72,7 @@ json.dump({
     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
     "command": "tools/make_profiles.sh: rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-include-regex ... -- python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-alt-schedule",
     "source": "profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv (median launch)" % (TAG, TAG),
-    "traffic_over_algorithmic": hbm / alg,
+    "traffic_over_algorithmic": hbm / alg, **BUILD,
 }, open(os.path.join(DST, "demod_hbm_traffic.json"), "w"), indent=1)
 print(open(os.path.join(DST, "demod_hbm_traffic.json")).read())
 for k in sorted(fetch):
@@ -106,7 +112,7 @@ if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
         "gather_fetch_size_kb_raw": mid(fg), "gather_write_size_kb_raw": mid(wg), "gather_hbm_bytes_per_launch": int(mid(fg) * 1024 * 2 + mid(wg) * 1024),
         "algorithmic_bytes_per_launch": B * F * 72 * (4 * 1542 + 1536 // 8),
         "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported; median launch",
-        "source": "profiles/%s_pmc_sq_viterbi_gather.csv, profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv" % (TAG, TAG, TAG),
+        "source": "profiles/%s_pmc_sq_viterbi_gather.csv, profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv" % (TAG, TAG, TAG), **BUILD,
     }, open(os.path.join(DST, "viterbi_counters.json"), "w"), indent=1)
     print(open(os.path.join(DST, "viterbi_counters.json")).read())
 if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
@@ -118,8 +124,10 @@ if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
     if cyc:
         packed = [cyc[k] for k in ("v_pk_add_u16", "v_pk_min_u16", "v_pk_sub_i16", "v_perm_b32 (vgpr sel)", "v_and_or_b32", "v_pk_add_u16 op_sel") if k in cyc]
         cp = sum(packed) / len(packed); cl = cyc.get("v_add_u32", 2.4)
-        # instruction mix of one trellis step: 128 packed 16-bit operations, 32 decision-extraction operations (v_perm_b32 /
-        # v_and_or_b32), about 35 plain 32-bit ones (branch metrics, addresses, loop)
-        json.dump({"cycles_packed": cp, "cycles_plain": cl, "cycles_per_instruction_kernel_mix": (160 * cp + 35 * cl) / 195, "at_waves_per_simd": 5, "per_instruction": cyc,
-                   "source": "profiles/%s_ubench_valu_rate.txt (tools/ubench/valu_rate.hip on the GPU box, 2.4 GHz assumed)" % TAG},
+        # instruction mix of one trellis step (viterbi_acs.h; five of six layouts add with plain 32-bit additions): packed 16-bit min /
+        # sub and the decision extraction (v_perm_b32 / v_and_or_b32) 96 per step, plus 64 packed additions in the sixth layout -> 107
+        # on average; plain: 64 * 5 / 6 = 53 additions + about 35 for branch metrics, addresses and the loop
+        n_packed, n_plain = (5 * 96 + 160) / 6.0, 64 * 5 / 6.0 + 35
+        json.dump({"cycles_packed": cp, "cycles_plain": cl, "cycles_per_instruction_kernel_mix": (n_packed * cp + n_plain * cl) / (n_packed + n_plain), "at_waves_per_simd": 5, "per_instruction": cyc,
+                   "source": "profiles/%s_ubench_valu_rate.txt (tools/ubench/valu_rate.hip on the GPU box, 2.4 GHz assumed)" % TAG, **BUILD},
                   open(os.path.join(DST, "valu_rate.json"), "w"), indent=1)

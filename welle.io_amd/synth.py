@@ -490,6 +490,11 @@ def make_superframe(bitrate, rng, header=True):
         data[2] = 0x40 | 0x20 | 0x10                       # dac_rate = 48 kHz, SBR, stereo -> 3 AUs, au_start[0] = 6
         data[3] = a1 >> 4; data[4] = ((a1 & 0xF) << 4) | (a2 >> 8); data[5] = a2 & 0xFF
         for lo, hi in ((a0, a1), (a1, a2), (a2, n)):
+            # every access unit opens with ID_END (111): an AAC raw_data_block without a channel element, which a decoder rejects at
+            # once.  Random bytes with a valid CRC are otherwise sometimes HALF accepted by FAAD2, and the reference's adapter then
+            # throws on its decoder thread (dabplus_decoder.cpp:460) and takes the process down -- a crash above the PHY that would
+            # limit which ensembles the real reference can be run on
+            data[lo] |= 0xE0
             c = crc16(data[lo:hi - 2], True, True, 0x1021)
             data[hi - 2] = c >> 8; data[hi - 1] = c & 0xFF
         c = crc16(data[2:11], False, False, 0x782F)        # Fire code over bytes 2..10
