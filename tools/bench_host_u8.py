@@ -17,7 +17,7 @@ T_F = 196608
 load_package()
 from welle_io_amd import capi, synth  # noqa: E402
 
-tx = synth.EnsembleTx(eid=0x1000, seed=1, payload_fn=synth.dabplus_payload_fn(4 * F, 1))
+tx = synth.EnsembleTx(eid=0x1000, seed=1, payload_fn=synth.dabplus_payload_fn(80 * -(-4 * F // 80), 1))      # (payload period: whole superframes and interleaver periods; a block of F frames is then re-sent every step -- the time interleaver sees a splice per step, the rate does not care)
 for _ in range(F):
     tx.next_frame()
 x = np.concatenate([tx.next_frame() for _ in range(F)]).astype(np.complex64)

@@ -1,0 +1,292 @@
+// welle.io_amd/csrc/dabphy_getters.hip -- what a caller reads back after a batch (frame info, FIBs, MSC bytes, taps, statistics), stage profiling, the TII side path.
+// (split from dabphy_api.hip in round 3; dabphy_internal.h has the map of the translation units)
+#include "dabphy_internal.h"
+
+extern "C" {
+
+int dabphy_get_frame_info(dabphy_handle* h, dabphy_frame_info* out)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || !h->last_frames) return DABPHY_ERR_INVALID;
+    const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
+    for (size_t i = 0; i < n; i++) {
+        const FrameDesc& d = h->h_desc[i];
+        out[i].sample_pos = d.pos; out[i].frame_no = d.frame_no; out[i].start_index = d.start_index; out[i].valid = d.valid;
+        out[i].fine_corrector = d.fine_after; out[i].coarse_corrector = d.coarse_after; out[i].snr = h->h_snr[i];
+    }
+    return DABPHY_OK;
+}
+
+int dabphy_get_fibs(dabphy_handle* h, uint8_t* fib, uint8_t* crc_ok)
+{
+    DeviceBind dev_(h);
+    if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
+    const size_t n = (size_t)h->cfg.n_ensembles * h->last_frames;
+    memcpy(fib, h->h_fib, n * 384); memcpy(crc_ok, h->h_ok, n * 12);      // (they crossed PCIe inside dabphy_process)
+    return DABPHY_OK;
+}
+
+int dabphy_get_fibs_host(dabphy_handle* h, const uint8_t** fib, const uint8_t** crc_ok)
+{
+    DeviceBind dev_(h);
+    if (!h || !fib || !crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
+    *fib = h->h_fib; *crc_ok = h->h_ok;
+    return DABPHY_OK;
+}
+
+int dabphy_get_fibs_device(dabphy_handle* h, const uint8_t** d_fib, const uint8_t** d_crc_ok)
+{
+    DeviceBind dev_(h);
+    if (!h || !d_fib || !d_crc_ok || !h->last_frames) return DABPHY_ERR_INVALID;
+    *d_fib = h->s_fib.as<uint8_t>(); *d_crc_ok = h->s_ok.as<uint8_t>();
+    return DABPHY_OK;
+}
+
+int dabphy_get_ratio_lag(dabphy_handle* h, int32_t* stale_frames, int64_t* first_stale_frame)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<DecState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) {
+        if (stale_frames) stale_frames[i] = st[i].stale_ratio_frames;
+        if (first_stale_frame) first_stale_frame[i] = st[i].stale_ratio_frames ? st[i].first_stale_frame : -1;
+    }
+    return DABPHY_OK;
+}
+
+int dabphy_get_ratio_lag_effect(dabphy_handle* h, int32_t* effective_frames, int64_t* first_effective_frame)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<DecState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) {
+        if (effective_frames) effective_frames[i] = st[i].effective_stale_frames;
+        if (first_effective_frame) first_effective_frame[i] = st[i].effective_stale_frames ? st[i].first_effective_frame : -1;
+    }
+    return DABPHY_OK;
+}
+
+int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts_at_first_lock)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) { if (attempts) attempts[i] = st[i].attempts; if (attempts_at_first_lock) attempts_at_first_lock[i] = st[i].first_lock_attempts; }
+    return DABPHY_OK;
+}
+
+int dabphy_get_replayed_batches(dabphy_handle* h, uint64_t* batches)
+{
+    if (!h || !batches) return DABPHY_ERR_INVALID;
+    *batches = h->n_replayed_batches;
+    return DABPHY_OK;
+}
+
+int dabphy_get_osc_stats(dabphy_handle* h, uint64_t* unchecked_symbols, uint64_t* checked_symbols)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(v, h->d_osc_stats, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    if (unchecked_symbols) *unchecked_symbols = v[0];
+    if (checked_symbols) *checked_symbols = v[1];
+    return DABPHY_OK;
+}
+
+int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
+    if (passes) *passes = h->n_wide_passes;
+    if (fallbacks) *fallbacks = h->n_wide_fallbacks;
+    if (wide_frames) {
+        std::vector<RxState> st(h->cfg.n_ensembles);
+        if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+        HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+        int r = sync(h); if (r) return r;
+        for (size_t i = 0; i < st.size(); i++) wide_frames[i] = st[i].n_wide_frames;
+    }
+    return DABPHY_OK;
+}
+
+int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) { if (lost) lost[i] = st[i].lost; if (exact_sums) exact_sums[i] = st[i].n_exact_sums; if (relock_inexact) relock_inexact[i] = st[i].n_relock_inexact; }
+    return DABPHY_OK;
+}
+
+int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
+{
+    DeviceBind dev_(h);
+    if (!h || !ratio_percent) return DABPHY_ERR_INVALID;
+    std::vector<DecState> st(h->cfg.n_ensembles);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_dec, st.size() * sizeof(DecState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) ratio_percent[i] = st[i].fic_ratio * 10;
+    return DABPHY_OK;
+}
+
+int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || subch_index >= h->subch.size() || !h->last_frames) return DABPHY_ERR_INVALID;
+    if (out_capacity < (size_t)h->cfg.n_ensembles * 4 * h->last_frames * (h->subch[subch_index].prot.nbits / 8)) { h->err = "dabphy_get_msc: output buffer too small"; return DABPHY_ERR_INVALID; }
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    for (auto& cls : h->classes) {
+        for (size_t m = 0; m < cls.members.size(); m++) {
+            if (cls.members[m] != (int)subch_index) continue;
+            const size_t bytes = cls.prot.nbits / 8, nm = cls.members.size();
+            std::vector<uint8_t> all((size_t)B * 4 * F * nm * bytes);
+            HIPCHK(h, hipMemcpyAsync(all.data(), cls.out.p, all.size(), hipMemcpyDeviceToHost, h->stream));
+            int r = sync(h); if (r) return r;
+            const size_t Rn = (size_t)4 * F;
+            for (size_t b = 0; b < B; b++) memcpy(out + b * Rn * bytes, all.data() + ((b * nm + m) * Rn) * bytes, Rn * bytes);
+            if (first_valid)
+                for (uint32_t b = 0; b < B; b++) {
+                    // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149)
+                    const int64_t c0 = 4 * h->h_desc[(size_t)b * F].frame_no;
+                    first_valid[b] = c0 >= 16 ? 0 : (int32_t)(16 - c0);
+                }
+            if (n_rows)
+                for (uint32_t b = 0; b < B; b++) {
+                    int nv = 0;
+                    for (uint32_t f = 0; f < F; f++) nv += h->h_desc[(size_t)b * F + f].valid == 1 ? 1 : 0;
+                    n_rows[b] = 4 * nv;
+                }
+            return DABPHY_OK;
+        }
+    }
+    return DABPHY_ERR_INVALID;
+}
+
+int dabphy_get_impulse_response(dabphy_handle* h, float* out)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || !h->last_frames || !h->cfg.want_impulse_response) return DABPHY_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(out, h->cur_cir, (size_t)h->cfg.n_ensembles * h->last_frames * T_U * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_null_symbols(dabphy_handle* h, float* out)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || !h->last_frames || !h->last_desc || !h->s_iq) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    int r;
+    if ((r = ensure(h, h->s_null, (size_t)B * F * T_NULL * sizeof(cf32)))) return r;
+    NullArgs a{};
+    a.tab = h->tab; a.iq = h->s_iq; a.iq_stride = h->s_stride; a.ring = (int64_t)h->s_ring; a.desc = h->last_desc; a.n_frames = (int)F;
+    a.out = h->s_null.as<cf32>();
+    launch_null_symbols(a, (int)B, h->stream);
+    HIPCHK(h, hipMemcpyAsync(out, h->s_null.p, (size_t)B * F * T_NULL * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_constellation(dabphy_handle* h, float* out)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || !h->last_frames || !h->cfg.want_constellation) return DABPHY_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(out, h->s_con.p, (size_t)h->cfg.n_ensembles * h->last_frames * 1200 * sizeof(cf32), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, int8_t* out)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || ensemble >= h->cfg.n_ensembles || frame >= h->last_frames) return DABPHY_ERR_INVALID;
+    const FrameDesc& d = h->h_desc[(size_t)ensemble * h->last_frames + frame];
+    const size_t slot = (size_t)(d.frame_no % h->soft_ring);
+    HIPCHK(h, hipMemcpyAsync(out, h->s_soft.as<int8_t>() + ((size_t)ensemble * h->soft_ring + slot) * SOFT_PER_FRAME, SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_set_profiling(dabphy_handle* h, int32_t on)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    h->profiling = on != 0;
+    return DABPHY_OK;
+}
+
+int dabphy_get_stage_times(dabphy_handle* h, float* ms)
+{
+    DeviceBind dev_(h);
+    if (!h || !ms) return DABPHY_ERR_INVALID;
+    for (int i = 0; i < dabphy_handle::ST_COUNT; i++) {
+        ms[i] = 0.0f;
+        if (h->ev_used[i]) { float t = 0; if (hipEventElapsedTime(&t, h->ev_beg[i], h->ev_end[i]) == hipSuccess) ms[i] = t; }
+    }
+    ms[dabphy_handle::ST_SYNC] = h->chain_ms;    // measured on the sync stream (overlaps the previous batch's decode in pipelined mode)
+    return DABPHY_OK;
+}
+
+int dabphy_set_track_slevel(dabphy_handle* h, int32_t on)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    h->track_slevel = on != 0;
+    return DABPHY_OK;
+}
+
+
+// RadioReceiverOptions::decodeTII (radio-receiver-options.h:75, consulted once per frame at ofdm-processor.cpp:376-386,464)
+int dabphy_set_tii(dabphy_handle* h, int32_t on)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    if (on && !h->tii_rot.p) {
+        const TiiTables& T = tii_tables();
+        const uint32_t B = h->cfg.n_ensembles;
+        int r;
+        if ((r = ensure(h, h->tii_rot, T.rot.size() * sizeof(cf32)))) return r;
+        if ((r = ensure(h, h->tii_rank, sizeof T.rank))) return r;
+        if ((r = ensure(h, h->tii_pat, sizeof T.pattern))) return r;
+        if ((r = ensure(h, h->tii_state, (size_t)B * TII_SLOTS * sizeof(TiiSlot)))) return r;
+        if ((r = ensure(h, h->tii_ovf, (size_t)B * sizeof(int32_t)))) return r;
+        HIPCHK(h, hipMemcpyAsync(h->tii_rot.p, T.rot.data(), T.rot.size() * sizeof(cf32), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->tii_rank.p, T.rank, sizeof T.rank, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->tii_pat.p, T.pattern, sizeof T.pattern, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->tii_state.p, 0, h->tii_state.cap, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->tii_ovf.p, 0, h->tii_ovf.cap, h->stream));
+        if ((r = sync(h))) return r;
+    }
+    h->tii_on = on != 0;
+    return DABPHY_OK;
+}
+
+int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, uint32_t max_per_ensemble)
+{
+    DeviceBind dev_(h);
+    if (!h || !n || (!out && max_per_ensemble) || !h->last_frames) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles;
+    if (!h->tii_ran) { for (uint32_t b = 0; b < B; b++) n[b] = 0; return DABPHY_OK; }
+    static_assert(sizeof(dabphy_tii_measurement) == sizeof(TiiEvent), "dabphy_tii_measurement layout");
+    std::vector<TiiEvent> ev((size_t)B * h->tii_max_events);
+    HIPCHK(h, hipMemcpyAsync(n, h->tii_nev.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ev.data(), h->tii_events.p, ev.size() * sizeof(TiiEvent), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (uint32_t b = 0; b < B; b++) {
+        const uint32_t k = std::min<uint32_t>((uint32_t)n[b], std::min(max_per_ensemble, h->tii_max_events));
+        if (k) memcpy(out + (size_t)b * max_per_ensemble, ev.data() + (size_t)b * h->tii_max_events, k * sizeof(TiiEvent));
+    }
+    return DABPHY_OK;
+}
+
+} // extern "C"

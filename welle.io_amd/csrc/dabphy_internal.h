@@ -1,0 +1,202 @@
+// welle.io_amd/csrc/dabphy_internal.h -- what the translation units of the C ABI share: the handle (streams, events, device buffers of one
+// receiver batch), small host helpers, and the internal functions that cross files.  Not installed, not part of include/dabphy.h.
+//   dabphy_api.hip          create / destroy / options / sub-channel classes, the stateless seams (demod, Viterbi, FIC, RS) and the timing drivers
+//   dabphy_stream.hip       sample rings (bind / upload / write / raw formats), the synchroniser's chain and wide pass, reset
+//   dabphy_process.hip      dabphy_process: the pipelined schedules, exact batch mode (replay), the decode of one batch
+//   dabphy_superframes.hip  Reed-Solomon seams and the DAB+ superframe filter
+//   dabphy_getters.hip      everything a caller reads back after a batch, profiling, TII
+#pragma once
+#include "../../include/dabphy.h"
+#include "dabphy_kernels.h"
+#include "dabphy_host.h"
+#include "osc_exact.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <algorithm>
+#include <chrono>
+
+#define DABPHY_INTERNAL __attribute__((visibility("hidden")))
+
+namespace dabphy {
+
+// Environment variables are read only by builds made with -DDABPHY_EXPERIMENTS (timing / debugging builds and the GPU-less test
+// build): the product library is configured through dabphy_config alone.
+inline bool debug_env(const char* name)
+{
+#ifdef DABPHY_EXPERIMENTS
+    return getenv(name) != nullptr;
+#else
+    (void)name; return false;
+#endif
+}
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+
+constexpr int HIST_CAP = 64;     // window searches remembered per ensemble for the sLevel replay
+} // namespace dabphy
+using namespace dabphy;          // (internal header: the handle below names the kernels' argument blocks)
+
+struct dabphy_handle {
+    dabphy_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    char devname[256] = {0};
+    // constant tables in HBM
+    cf32 *d_tw = nullptr, *d_ref = nullptr, *d_nco = nullptr;
+    int16_t* d_bin2soft = nullptr; uint32_t* d_prbs_words = nullptr; int16_t* d_fic_map = nullptr;
+    int32_t* d_osc_unsafe = nullptr; unsigned long long* d_osc_stats = nullptr;   // osc_exact.h: unsafe table entries; symbols mixed unchecked / checked
+    Tables tab{};
+    // grow-only scratch
+    DevBuf iq, soft, con, prs_mag, snr, desc, in8, map, vsym, vdec, vout, ok;
+    DevBuf fsym, fdec;                      // Viterbi scratch of the FIC class (it decodes beside the MSC classes on aux_stream)
+    RxState* d_state = nullptr;       // [n_ensembles] synchroniser state
+    DecState* d_dec = nullptr;        // [n_ensembles] decoder state
+    std::vector<void*> owned;
+
+    // ---- streaming receiver (dabphy_stream_* / dabphy_process)
+    struct MscClass {
+        dabphy_protection prot{};
+        std::vector<int> members;     // indices into subch
+        DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
+        DevBuf steps; int n_windows = 0;     // fused decode (k_viterbi_msc): per-step window-ring descriptors, 16-byte windows of the punctured stream
+        DevBuf sf_state;                     // SuperframeFilter window of every (ensemble, member)
+        DevBuf sf_snap;                      // ... as it was in front of the current batch (exact batch mode)
+    };
+    const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
+    DevBuf s_iq_own;
+    uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
+    bool s_bounded = false;           // every sample the stream ever held came through k_ingest from u8 / s8 / s16: |re|, |im| <= 1
+    std::vector<dabphy_subchannel> subch;
+    std::vector<MscClass> classes;
+    DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
+    DevBuf s_raw2[2]; hipStream_t copy_stream = nullptr; hipEvent_t ev_ingest[2] = {nullptr, nullptr}; int raw_sel = 0;   // dabphy_stream_write_raw_async
+    uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
+    DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
+    DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
+    static constexpr int N_DESC = 3;    // descriptor buffers: the batch being decoded + up to two synchronised ahead
+    DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
+    hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
+    FusedMscArgs last_fused{}; bool have_last_fused = false;   // the fused decode launch of the last batch (dabphy_time_fused_msc re-runs it alone)
+    bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
+    hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
+    // wide synchroniser pass (all frames of a batch at once, k_sync_find_wide/_finish_wide/_validate) and its serial fall-back
+    bool wide_sync = true;            // cfg.serial_sync == 0 (DABPHY_SYNC_WIDE overrides)
+    DevBuf s_redo[N_DESC];            // [B] first frame slot the wide pass did not settle
+    int32_t* d_any_redo = nullptr;    // [N_DESC] device flags; h_any_redo: their page-locked host copies
+    int32_t* h_any_redo = nullptr;
+    hipEvent_t ev_wide_done[N_DESC]{};
+    bool wide_pending[N_DESC]{};      // the wide pass of this descriptor buffer has been queued, its verdict not yet read
+    uint64_t chain_valid[N_DESC]{}; uint32_t chain_frames[N_DESC]{};   // n_valid and n_frames the chain of this buffer was queued with
+    uint64_t n_wide_passes = 0, n_wide_fallbacks = 0;
+    // exact batch mode (cfg.no_batch_replay == 0): state as it was in front of a batch, to replay the batch frame by frame when one of its
+    // coarse-corrector decisions was taken with a stale FIC ratio and can have mattered (k_fic_ratio's verdict)
+    bool exact_batch = false;
+    DevBuf snap_state[N_DESC], snap_dec, snap_tii;
+    int32_t* d_any_eff = nullptr; int32_t* h_any_eff = nullptr;
+    uint64_t n_replayed_batches = 0;
+    int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next
+    int ahead = 0;                    // batches whose chain has been queued but which have not been decoded yet (pipelined modes: 1 or 2 between calls)
+    uint32_t presynced = 0;           // frames already synchronised ahead into s_desc2[desc_sel] (pipelined mode)
+    int soft_ring = 0;
+    uint32_t last_frames = 0;         // n_frames of the last dabphy_process
+    float* cur_cir = nullptr;
+    FrameDesc* h_desc = nullptr;      // host copy of the last batch's frame descriptors (page-locked, [B][max_frames])
+    float* h_snr = nullptr;
+    uint8_t *h_fib = nullptr, *h_ok = nullptr;   // ... of its FIBs [B][F][12][32] and CRC flags [B][F][12]: they cross PCIe inside the step, beside the decoder
+    int32_t* h_sf_stats = nullptr; bool h_sf_stats_valid = false;   // ... of the superframe totals when the filter rode in dabphy_process
+    // stage timing (HIP events on the handle's stream, recorded when profiling is on)
+    enum { ST_SYNC = 0, ST_DEMOD, ST_SNR, ST_FIC, ST_MSC_GATHER, ST_MSC_VITERBI, ST_RS, ST_COUNT };
+    bool profiling = false;
+    hipEvent_t ev_beg[ST_COUNT]{}, ev_end[ST_COUNT]{};
+    bool ev_used[ST_COUNT]{};
+    DevBuf rs_first, rs_result;
+    DevBuf s_hist;                          // [B][HIST_CAP] window searches since the last acquisition (sLevel replay in k_acquire)
+    // TII (RadioReceiverOptions::decodeTII): constants, per-batch scratch, per-ensemble sums that live across batches
+    bool tii_on = false; bool tii_ran = false;
+    bool track_slevel = false;        // dabphy_set_track_slevel: sLevel follows every tracked frame instead of catching up at a loss of lock
+    bool sf_auto = false, sf_stats_ready = false;   // dabphy_set_auto_superframes: the all-sub-channel filter rides in dabphy_process's submission
+    DevBuf tii_rot, tii_rank, tii_pat, tii_err, tii_likely, tii_state, tii_events, tii_nev, tii_ovf;
+    uint32_t tii_max_events = 0;
+};
+
+namespace dabphy {
+
+// A handle lives on one device; HIP's current device is a property of the calling THREAD.  Every entry point makes the handle's device
+// current for its duration, so that one process can own several handles on several devices (welle.io_amd/host/gpu_node_receiver.h:
+// one host thread per device) and a caller's own device selection survives the call.
+struct DeviceBind {
+    int prev = -1; bool switched = false;
+    explicit DeviceBind(const dabphy_handle* h)
+    {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->cfg.device) switched = hipSetDevice(h->cfg.device) == hipSuccess;
+    }
+    ~DeviceBind() { if (switched) { hipError_t e = hipSetDevice(prev); (void)e; } }
+    DeviceBind(const DeviceBind&) = delete; DeviceBind& operator=(const DeviceBind&) = delete;
+};
+
+#define HIPCHK(h, call)                                                                                   \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return DABPHY_ERR_HIP; } } while (0)
+
+inline int ensure(dabphy_handle* h, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (hipMalloc(&b.p, bytes) != hipSuccess) { h->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; b.p = nullptr; return DABPHY_ERR_NOMEM; }
+    b.cap = bytes;
+    return 0;
+}
+
+template <typename T> int upload_const(dabphy_handle* h, T** dst, const std::vector<T>& src)
+{
+    void* p = nullptr;
+    if (hipMalloc(&p, src.size() * sizeof(T)) != hipSuccess) { h->err = "hipMalloc(table) failed"; return DABPHY_ERR_NOMEM; }
+    h->owned.push_back(p);
+    HIPCHK(h, hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<T*>(p);
+    return 0;
+}
+
+inline int sync(dabphy_handle* h)
+{
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// Fill a VitClass for n_cw codewords of nbits and make sure its device buffers exist.
+inline int prepare_class(dabphy_handle* h, VitClass& c, int nbits, int n_cw, int dedisperse)
+{
+    c.nbits = nbits; c.nsteps = nbits + 6; c.n_cw = n_cw; c.n_groups = (n_cw + 63) / 64; c.dedisperse = dedisperse; c.g_begin = 0; c.g_end = c.n_groups;
+    const size_t cells = (size_t)c.n_groups * c.nsteps * 64;
+    int r;
+    if ((r = ensure(h, h->vsym, cells * sizeof(uint32_t)))) return r;
+    if ((r = ensure(h, h->vdec, cells * sizeof(uint2)))) return r;
+    if ((r = ensure(h, h->vout, (size_t)c.n_groups * 64 * (nbits / 8)))) return r;
+    c.sym = h->vsym.as<uint32_t>(); c.dec = h->vdec.as<uint2>(); c.out = h->vout.as<uint8_t>();
+    return 0;
+}
+
+} // namespace dabphy
+
+// ---- internal functions that cross translation units (C linkage like their callers, hidden from the library's export table)
+extern "C" {
+DABPHY_INTERNAL int reset_synchroniser(dabphy_handle* h, bool decoder_too);                       // dabphy_stream.hip
+DABPHY_INTERNAL int resolve_all_chains(dabphy_handle* h);
+DABPHY_INTERNAL SyncArgs sync_args(dabphy_handle* h, int sel, uint32_t F, uint64_t n_valid);
+DABPHY_INTERNAL void launch_serial_chain(dabphy_handle* h, SyncArgs sa);
+DABPHY_INTERNAL int queue_chain(dabphy_handle* h, int sel, uint32_t F);
+DABPHY_INTERNAL int resolve_chain(dabphy_handle* h, int sel);
+DABPHY_INTERNAL int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F);       // dabphy_superframes.hip
+DABPHY_INTERNAL int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st = nullptr, int ens0 = 0, int ens_count = 0);
+DABPHY_INTERNAL int launch_superframe_stats(dabphy_handle* h);
+}

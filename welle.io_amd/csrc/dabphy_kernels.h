@@ -146,6 +146,9 @@ struct MscGatherArgs {
 // (8 bytes per step: off0 | off1 << 16, off2 | off3 << 16 with two flags in the spare top bits -- bit 15 of off01: first step to read
 // a new window, wait for its load; bit 31 of off01: once this step has read, load the next window (they are loaded in order 2, 3, ...))
 struct MscStep { uint32_t off01, off23; };
+// geometry of the window ring (k_viterbi.hip: FM_*): 96 rows of 20 bytes per slot (16 window bytes + 4 bytes of padding: a pitch of five
+// dwords keeps the byte reads of consecutive rows on different LDS banks), slots 0 / 1 = windows, slot 2 = zeros (erasures)
+constexpr int MSC_ROW_PITCH = 20, MSC_SLOT_BYTES = 96 * MSC_ROW_PITCH, MSC_ZERO_OFF = 2 * MSC_SLOT_BYTES;
 constexpr uint32_t MSC_FIRST_USE = 1u << 15, MSC_LOAD_NEXT = 1u << 31, MSC_OFF_MASK = 0x7fffu;
 struct FusedMscArgs {
     const int8_t* soft; int soft_ring; int n_ens, n_frames;

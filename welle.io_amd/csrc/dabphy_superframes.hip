@@ -1,0 +1,177 @@
+// welle.io_amd/csrc/dabphy_superframes.hip -- Reed-Solomon seams (RSDecoder::DecodeSuperframe) and the DAB+ superframe filter (SuperframeFilter::Feed) of a batch.
+// (split from dabphy_api.hip in round 3; dabphy_internal.h has the map of the translation units)
+#include "dabphy_internal.h"
+
+extern "C" {
+
+// device buffers of the superframe filter for one class and F frames per batch (the window state is zeroed when it is (re)allocated)
+int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F)
+{
+    const uint32_t B = h->cfg.n_ensembles;
+    const int fb = cls.prot.nbits / 8, M = (int)cls.members.size();
+    if ((cls.prot.nbits / 24) % 8 || fb < 10) return 0;                  // not a DAB+ rate: the filter never runs on this class
+    const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+    const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
+    int r;
+    if (cls.sf_state.cap < stride * B * M) {
+        if ((r = ensure(h, cls.sf_state, stride * B * M))) return r;
+        HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
+    }
+    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * M * n_cif))) return r;
+    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B * M))) return r;
+    if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
+    return 0;
+}
+
+
+int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint32_t n_sf, int32_t* corrected, int32_t* uncorrectable)
+{
+    DeviceBind dev_(h);
+    if (!h || !sf || !corrected || !uncorrectable || s_per_sf == 0 || n_sf == 0) return DABPHY_ERR_INVALID;
+    const size_t bytes = (size_t)120 * s_per_sf * n_sf;
+    int r;
+    if ((r = ensure(h, h->in8, bytes))) return r;
+    if ((r = ensure(h, h->rs_result, 2 * sizeof(int) * n_sf))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->in8.p, sf, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->rs_result.p, 0, 2 * sizeof(int) * n_sf, h->stream));
+    RsArgs a{}; a.data = h->in8.as<uint8_t>(); a.sf_stride = (size_t)120 * s_per_sf; a.n_sf = (int)n_sf; a.s = (int)s_per_sf;
+    a.corr = h->rs_result.as<int>(); a.uncorr = h->rs_result.as<int>() + n_sf;
+    launch_rs_superframes(a, h->stream);
+    HIPCHK(h, hipMemcpyAsync(sf, h->in8.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(corrected, a.corr, sizeof(int) * n_sf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(uncorrectable, a.uncorr, sizeof(int) * n_sf, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* first_cif, int32_t* corrected, int32_t* uncorrectable)
+{
+    DeviceBind dev_(h);
+    if (!h || !first_cif || !h->last_frames || subch_index >= (int32_t)h->subch.size()) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    const int n_cif = (int)(4 * F), n_sf = n_cif / 5 + 1;
+    int r;
+    if ((r = ensure(h, h->rs_first, sizeof(int) * B))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->rs_first.p, first_cif, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    if (corrected) memset(corrected, 0, sizeof(int32_t) * B);
+    if (uncorrectable) memset(uncorrectable, 0, sizeof(int32_t) * B);
+    bool first_launch = true;
+    for (auto& cls : h->classes) {
+        int member = -1;
+        if (subch_index >= 0) {
+            for (size_t m = 0; m < cls.members.size(); m++) if (cls.members[m] == subch_index) member = (int)m;
+            if (member < 0) continue;
+        }
+        const int bitrate = cls.prot.nbits / 24;
+        if (bitrate % 8) continue;
+        const size_t nres = (size_t)B * n_sf * cls.members.size() * 2;
+        if ((r = ensure(h, h->rs_result, nres * sizeof(int)))) return r;
+        HIPCHK(h, hipMemsetAsync(h->rs_result.p, 0, nres * sizeof(int), h->stream));
+        RsMscArgs a{}; a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = (int)cls.members.size();
+        a.frame_bytes = cls.prot.nbits / 8; a.s = bitrate / 8; a.n_sf_per_ens = n_sf; a.member_only = member;
+        a.first_cif = h->rs_first.as<int>(); a.result = h->rs_result.as<int>();
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
+        launch_rs_msc(a, h->stream);
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
+        first_launch = false;
+        if (corrected || uncorrectable) {
+            std::vector<int> res(nres);
+            HIPCHK(h, hipMemcpyAsync(res.data(), h->rs_result.p, nres * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            if ((r = sync(h))) return r;
+            for (uint32_t b = 0; b < B; b++)
+                for (size_t k = 0; k < (size_t)n_sf * cls.members.size(); k++) {
+                    const size_t o = ((size_t)b * n_sf * cls.members.size() + k) * 2;   // [b][superframe][member]
+                    if (corrected) corrected[b] += res[o];
+                    if (uncorrectable) uncorrectable[b] += res[o + 1];
+                }
+        }
+    }
+    return sync(h);
+}
+
+// launches k_superframe for one class: member >= 0 -> that member only, -1 -> all members
+int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st, int ens0, int ens_count)
+{
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
+    const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+    const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
+    int r;
+    if ((r = prepare_superframes(h, cls, F))) return r;
+    SfArgs a{};
+    a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = M; a.frame_bytes = fb;
+    a.s = bitrate / 8; a.member = member; a.desc = h->last_desc; a.n_frames = (int)F;
+    a.state = cls.sf_state.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
+    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats; a.ens0 = ens0; a.ens_count = ens_count;
+    launch_superframe(a, st ? st : h->stream);
+    return 0;
+}
+
+int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
+{
+    DeviceBind dev_(h);
+    static_assert(sizeof(dabphy_sf_event) == sizeof(SfEvent), "event layouts must match");
+    if (!h || !events || !n_events || subch_index >= h->subch.size() || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    for (auto& cls : h->classes)
+        for (size_t m = 0; m < cls.members.size(); m++) {
+            if (cls.members[m] != (int)subch_index) continue;
+            const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
+            if (bitrate % 8 || fb < 10) { h->err = "sub-channel bit rate is not a DAB+ rate"; return DABPHY_ERR_INVALID; }
+            const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+            int r;
+            if ((r = run_superframes(h, cls, (int)m, nullptr))) return r;
+            for (uint32_t b = 0; b < B; b++) {          // rows of member m
+                const size_t bm = (size_t)b * M + m;
+                HIPCHK(h, hipMemcpyAsync(events + (size_t)b * n_cif, h->sf_events.as<SfEvent>() + bm * n_cif, sizeof(SfEvent) * n_cif, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(n_events + b, h->sf_count.as<int32_t>() + bm, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                if (sf) HIPCHK(h, hipMemcpyAsync(sf + (size_t)b * n_slots * 5 * fb, h->sf_bytes.as<uint8_t>() + bm * n_slots * 5 * fb, (size_t)n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
+            }
+            return sync(h);
+        }
+    return DABPHY_ERR_INVALID;
+}
+
+// SuperframeFilter over every DAB+ sub-channel of every ensemble: one launch per protection class on the main stream, totals into sf_stats
+int launch_superframe_stats(dabphy_handle* h)
+{
+    const uint32_t B = h->cfg.n_ensembles;
+    int r;
+    if ((r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
+    HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));
+    bool first_launch = true;
+    for (auto& cls : h->classes) {
+        const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
+        if (bitrate % 8 || fb < 10) continue;
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
+        if ((r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>()))) return r;
+        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
+        first_launch = false;
+    }
+    return 0;
+}
+
+int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    h->sf_auto = on != 0;
+    return DABPHY_OK;
+}
+
+int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
+{
+    DeviceBind dev_(h);
+    if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
+    int r;
+    if (h->sf_stats_ready && h->h_sf_stats_valid) {      // the filter rode in dabphy_process and its totals came back with the batch
+        h->sf_stats_ready = false; h->h_sf_stats_valid = false;
+        memcpy(stats, h->h_sf_stats, sizeof(int32_t) * 4 * h->cfg.n_ensembles);
+        return DABPHY_OK;
+    }
+    if (!h->sf_stats_ready) { if ((r = launch_superframe_stats(h))) return r; }
+    h->sf_stats_ready = false;                   // one filter pass per batch: a second call would feed the same frames again
+    HIPCHK(h, hipMemcpyAsync(stats, h->sf_stats.p, sizeof(int32_t) * 4 * h->cfg.n_ensembles, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+} // extern "C"

@@ -135,6 +135,14 @@ __device__ __forceinline__ void buf_store_b32(BufRsrc r, uint32_t lane_bytes, ui
 {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_bytes, uniform_bytes, 0);
 }
+// ... with a range of 4 GiB from the base (LDS-DMA sources: the soft-bit ring of a 256-ensemble batch is 2.2 GB)
+__device__ __forceinline__ BufRsrc buf_rsrc_4g(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000); }
+// LDS-DMA through a buffer resource: the dword at base + lane_bytes + uniform_bytes lands at lds_wave_base + 4 * lane (inactive lanes
+// transfer nothing); no 64-bit address arithmetic, no VGPR pair per request.  Completion is tracked by vmcnt like lds_dma4.
+__device__ __forceinline__ void buf_dma4(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, void* lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, lane_bytes, uniform_bytes, 0, 0);
+}
 
 // 127 / x for x in [2^-100, 2^100]: v_rcp_f32 (1 ulp) + one residual correction, 4 instructions instead of the 11 of the
 // IEEE division sequence.  DIV127_VARIANT 1 adds a second correction.  dabphy_selftest_div127 compares every variant

@@ -296,11 +296,16 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
 // when a window dies -- is the same for all lanes and comes from a per-class table (MscStep, built on the host from the depuncturing
 // map) through scalar loads.  Per step a lane adds its row base to four uniform offsets, reads four bytes from LDS (an erasure
 // reads a zero from a third, never written slot) and forms the branch metrics; the trellis and the traceback are k_viterbi's.
-constexpr int FM_ROWS = 96;                       // 16-row blocks of the LDS-DMA requests; 64 + 2 * 15 = 94 rows used at most
-constexpr int FM_SLOT = FM_ROWS * 16;             // bytes per window slot: [row][16]
+constexpr int FM_ROWS = 96;                       // 12-row blocks of the LDS-DMA requests; 64 + 2 * 15 = 94 rows used at most
+constexpr int FM_PITCH = MSC_ROW_PITCH;           // bytes per row of a window slot: 16 window bytes + 4 of padding.  FIVE dwords per row, so the
+                                                  // byte reads of 32 consecutive rows (lanes) at one column fall into 32 different banks; with
+                                                  // the 16-byte pitch of round 2 they were 4-way conflicted (SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.72)
+constexpr int FM_SLOT = FM_ROWS * FM_PITCH;       // bytes per window slot: [row][20]
 constexpr int FM_ZERO = 2 * FM_SLOT;              // third slot: zeros (erasures, viterbi.cpp:233-238 maps soft value 0 to symbol 127)
 constexpr int FM_ROWPTR = 3 * FM_SLOT;            // then the rows' sources: byte offset / 16 into the soft-bit ring (rows without a source CIF point at the zeros behind the ring)
 constexpr int FM_LDS = FM_ROWPTR + FM_ROWS * 4;
+constexpr int FM_REQ_ROWS = 12;                   // rows per LDS-DMA request: 12 x 5 = 60 lanes, lane l moves dword (l % 5) of row l / 5 (dword 4 = the padding: idle)
+static_assert(FM_ZERO == MSC_ZERO_OFF && FM_SLOT == MSC_SLOT_BYTES, "window ring layout: host table (dabphy_api.hip) and kernel");
 
 #ifndef VITM_OCC
 #define VITM_OCC 5
@@ -348,17 +353,21 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
         reinterpret_cast<uint32_t*>(lds + FM_ROWPTR)[row] = src;
     }
     __syncthreads();
-    // window w -> slot w & 1: 6 requests, lane l of request k moves dword (l & 3) of row 16 k + (l >> 2).  All six row addresses
-    // are read first, then the six requests go out back to back: no branch, no LDS round trip between them.
+    // window w -> slot w & 1: 8 requests of 12 rows x 5 dwords (60 lanes; the fifth dword of a row is padding and its lane stays idle).
+    // All eight row addresses are read first, then the requests go out back to back: no LDS round trip between them.  Sources are
+    // addressed through a buffer resource on the soft-bit ring: row offset (one VGPR) + the window's column (one SGPR).
+    const BufRsrc soft_rs = buf_rsrc_4g(A.soft);
     auto load_window = [&](int w) {
         uint8_t* slot = lds + (w & 1) * FM_SLOT;
         const uint32_t l = opaque_vgpr((uint32_t)lane);             // (nothing of this may be hoisted out of the step loop)
-        uint32_t src[FM_ROWS / 16];
+        const uint32_t r5 = (l * 205u) >> 10, q5 = l - 5u * r5;     // l / 5, l % 5 for l < 64
+        if (q5 < 4u && l < 5u * FM_REQ_ROWS) {
+            uint32_t src[FM_ROWS / FM_REQ_ROWS];
 #pragma unroll
-        for (int k = 0; k < FM_ROWS / 16; k++) src[k] = reinterpret_cast<const uint32_t*>(lds + FM_ROWPTR)[16 * k + (l >> 2)];
-        const int8_t* col = A.soft + (16 * w + 4 * (l & 3));
+            for (int k = 0; k < FM_ROWS / FM_REQ_ROWS; k++) src[k] = reinterpret_cast<const uint32_t*>(lds + FM_ROWPTR)[FM_REQ_ROWS * k + r5];
 #pragma unroll
-        for (int k = 0; k < FM_ROWS / 16; k++) lds_dma4(col + ((size_t)src[k] << 4), slot + 256 * k);
+            for (int k = 0; k < FM_ROWS / FM_REQ_ROWS; k++) buf_dma4(soft_rs, (src[k] << 4) + 4u * q5, 16u * (uint32_t)w, slot + FM_REQ_ROWS * FM_PITCH * k);
+        }
     };
     load_window(0);
     if (A.n_windows > 1) load_window(1);
@@ -372,7 +381,7 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
 #ifdef FM_EXP_BROADCAST          // (timing experiment only: every lane reads the same bytes -- no bank conflicts, wrong results)
     const uint32_t lane_base = 0u; (void)rb;
 #else
-    const uint32_t lane_base = (uint32_t)rb * 16u;
+    const uint32_t lane_base = (uint32_t)rb * (uint32_t)FM_PITCH;
 #endif
     const int8_t* lds_c = reinterpret_cast<const int8_t*>(lds);        // (sign-extending byte reads)
     auto fetch = [&](const MscStep& d, int (&y)[4]) {
