@@ -111,6 +111,12 @@ if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
         "hbm_bytes_per_launch": int(mid(fv) * 1024 * 2 + mid(wv) * 1024),
         "gather_fetch_size_kb_raw": mid(fg), "gather_write_size_kb_raw": mid(wg), "gather_hbm_bytes_per_launch": int(mid(fg) * 1024 * 2 + mid(wg) * 1024),
         "algorithmic_bytes_per_launch": B * F * 72 * (4 * 1542 + 1536 // 8),
+        # what is known without counters: the decision array, 8 bytes per trellis step and code word, written once and read back once
+        "decision_bytes_written_plus_read": 2 * (B * F * 72 // 64) * 1542 * 512,
+        # the guide calibrates the doubling for WIDE coalesced reads (128-byte requests tallied at 64): the decision reads are such reads,
+        # the soft-bit windows are 4-byte-per-lane LDS-DMA requests.  If those are tallied at their true 64 bytes: reads = decisions
+        # (known) + (raw FETCH - decisions / 2)
+        "hbm_bytes_if_narrow_requests_are_tallied_in_full": int((B * F * 72 // 64) * 1542 * 512 + (mid(fv) * 1024 - (B * F * 72 // 64) * 1542 * 512 / 2) + mid(wv) * 1024),
         "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported; median launch",
         "source": "profiles/%s_pmc_sq_viterbi_gather.csv, profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv" % (TAG, TAG, TAG), **BUILD,
     }, open(os.path.join(DST, "viterbi_counters.json"), "w"), indent=1)
