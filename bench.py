@@ -408,10 +408,13 @@ def main():
             ub = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
         except Exception:
             ub = None
-        rv = {"kernel": "k_viterbi_msc, MSC class (lane = codeword, 64 states in 32 VGPRs of packed u16; de-interleave + depuncture gather fused in through an LDS window ring)", "bound": "valu",
+        rv = {"kernel": "k_viterbi_msc, MSC class (lane = codeword, 64 states in 32 VGPRs of u16 pairs; SWAR additions in a six-layout rotating state pairing, viterbi_acs.h; de-interleave + depuncture gather fused in through an LDS window ring)", "bound": "valu",
               "kernel_ms": vit_ms, "kernel_ms_note": "HIP events around the launch inside the pipelined step: the FIC class and the next batch's synchroniser run beside it",
               "codeword_steps_per_s": B * F * 72 * 1542 / (vit_ms * 1e-3) if vit_ms > 0 else None,
               "algorithmic_bytes": B * F * 72 * (4 * 1542 + 1536 // 8), "hbm_bytes": vj.get("hbm_bytes_per_launch") if vj else None,
+              "hbm_bytes_if_narrow_requests_are_tallied_in_full": vj.get("hbm_bytes_if_narrow_requests_are_tallied_in_full") if vj else None,
+              "decision_bytes_written_plus_read": vj.get("decision_bytes_written_plus_read") if vj else None,
+              "hbm_note": "the decision array (8 bytes per trellis step and code word, written by the forward pass, read back by the traceback) is 3.9 x the algorithmic bytes on its own: what bounds this kernel now (DESIGN.md 4.2)",
               "valu_insts_per_launch": vj.get("valu_insts_per_launch") if vj else None,
               "counter_source": "static: profiles/viterbi_counters.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh; not measured by this run)" if vj else None}
         if vj and vj.get("valu_insts_per_launch") and vit_ms > 0:
@@ -427,7 +430,7 @@ def main():
             # kernel's LDS traffic is the byte gather from its de-interleaver window ring
             rv.update(lds_bank_efficiency=1.0 - vj["lds_bank_conflict_cycles"] / vj["lds_idx_active_cycles"],
                       lds_insts_per_trellis_step=vj["lds_insts_per_launch"] / (B * F * 72 * 1542 / 64.0) if vj.get("lds_insts_per_launch") else None,
-                      lds_note="SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the launch (static, profiles/viterbi_counters.json): the 16-byte row pitch the LDS-DMA dictates makes the byte reads of 64 consecutive rows 4-way conflicted; LDS is active about 4 % of the wave cycles (DESIGN.md 4.2), the add-compare-select runs in VGPRs")
+                      lds_note="1 - SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the launch (static, profiles/viterbi_counters.json): the window ring's rows are 20 bytes (five dwords) apart, so the byte reads of consecutive rows fall on different banks (round 2, 16-byte pitch: 0.28); the add-compare-select itself runs in VGPRs (DESIGN.md 4.2)")
         line["roofline_viterbi"] = rv
         # which build this line was measured on, and which committed counter profiles were NOT reported because they belong to another one
         line["profile_build"] = dict(lib_sha_note, stale_profile=stale or None,
