@@ -150,11 +150,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     mark(dabphy_handle::ST_DEMOD, true);
     if (!replay && (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3)) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
-    mark(dabphy_handle::ST_SNR, false);
-    launch_snr(sn, h->stream);
-    mark(dabphy_handle::ST_SNR, true);
 
-    // FIC: 4 codewords per frame.  Only B*F/16 wavefronts of 774 serial trellis steps: it runs on its own stream beside the
+    // SNR + FIC: 4 codewords per frame.  Only B*F/16 wavefronts of 774 serial trellis steps: it runs on its own stream beside the
     // MSC classes (own Viterbi scratch), filling execution slots instead of holding the whole device for a latency-bound tail.
     {
         VitClass c = fic_c;
@@ -164,6 +161,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         hipStream_t fs = h->aux_stream;
         HIPCHK(h, hipEventRecord(h->ev_demod_done, h->stream));
         HIPCHK(h, hipStreamWaitEvent(fs, h->ev_demod_done, 0));
+        // the SNR estimate (8192 threads of serial float sums over the PRS magnitudes) feeds nothing on the device: off the main stream,
+        // so that the MSC decode starts the moment the demod kernel ends
+        mark(dabphy_handle::ST_SNR, false, fs);
+        launch_snr(sn, fs);
+        mark(dabphy_handle::ST_SNR, true, fs);
         mark(dabphy_handle::ST_FIC, false, fs);
         launch_fic_gather(g, fs);
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;

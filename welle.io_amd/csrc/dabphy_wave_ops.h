@@ -85,6 +85,8 @@ __device__ __forceinline__ double uniform_f64(double x)
     u = ((unsigned long long)hi << 32) | lo; __builtin_memcpy(&x, &u, 8);
     return x;
 }
+// an int that is the same in every lane, moved to a scalar register
+__device__ __forceinline__ int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // a wave-uniform constant the compiler must keep in a scalar register instead of folding it into literals
 __device__ __forceinline__ uint32_t opaque_sgpr(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 // A read-only table as the CONSTANT address space sees it: hipcc turns a wave-uniform load from ordinary global memory that the
@@ -179,6 +181,8 @@ __device__ __forceinline__ void lds_dma4(const void* gptr, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
+// the wave's LDS reads have returned (so an LDS-DMA issued after this point cannot overtake them)
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ... until at most N of the wave's memory operations are still in flight (they complete in order: "everything but the
 // last N requests has landed")

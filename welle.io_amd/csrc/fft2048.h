@@ -148,6 +148,92 @@ __device__ __forceinline__ void fft_rounds_bc(cf32 (&v)[16], cf32* lds, const Ff
     // v[4b + a] = X[t + 128a + 512b] = X[t + 128 (a + 4b)]  -> already in j = a + 4b order
 }
 
+// ---- k_demod's variant of the two exchanges (DEMOD_STAGE 2): the raw samples of a symbol arrive IN the tile (LDS-DMA, 16-byte units
+// = sample pairs), round A overwrites each sample it read with one of its results (no barrier between reading and writing: a thread
+// only touches its own 16 elements), round B picks the positions up from there, and the second exchange is laid out so that each wave
+// reads only ITS half of the tile in round C -- the wave may then start the next symbol's transfer into that half without waiting for
+// the other one (4 barriers per symbol as before, 16 KiB of LDS less).  tools/layout/demod_inplace_layout.py checks the algebra:
+//   raw sample n, and result r of thread-half (t, h) written over sample t + 128h + 256r:  element (n & 255) + 260 (n >> 8) -- rows
+//       of 256 samples 32 bytes apart: every address below is one register + an immediate
+//   position 8q + r, q = 64 j1 + 16 j2 + 4 j3 + j4, is result r of thread-half j1 + 4 j2 + 16 j3 + 64 j4
+//   round B thread t = k + 8 j1 + 32 j2 works c = 4 j1 + j2: the 32 lanes of a read group differ in k and j1, elements j1 + 4k mod 32
+//   second exchange: E2(p) = 1040 (p >> 6 & 1) + (q ^ (q >> 8 & 1) << 3), q = (p & 63) | (p >> 7) << 6
+// every ds_read_b64 / ds_write_b64 is conflict-free by the rules of MI355X_MICROARCH.md (read groups of 32 lanes, write groups of 16).
+constexpr int FFT_RAW_PITCH = 260;                       // elements per row of 256 raw samples
+constexpr int FFT_INPLACE_TILE = 8 * FFT_RAW_PITCH;      // elements of the tile
+__device__ __forceinline__ int fft_raw_index(int t, int h, int j) { return t + 128 * h + FFT_RAW_PITCH * j; }
+
+// the 8 samples x[t + 128h + 256j] of one half out of the tile
+__device__ __forceinline__ void fft_raw_half(cf32 (&x)[8], const cf32* lds, int h, int t)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = lds[fft_raw_index(t, h, j)];
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_round_a_inplace(const cf32 (&x)[8], int h, cf32* lds, const FftTwiddles& w, int t)
+{
+    cf32 a[8];
+#pragma unroll
+    for (int j5 = 0; j5 < 4; j5++) { a[2 * j5] = x[j5]; a[2 * j5 + 1] = x[j5 + 4]; }
+#pragma unroll
+    for (int j5 = 0; j5 < 4; j5++) bfly2<INV>(a[2 * j5], a[2 * j5 + 1], w.t0);
+    bfly4<INV>(a[0], a[2], a[4], a[6], w.t0, w.t0, w.t0);
+    bfly4<INV>(a[1], a[3], a[5], a[7], w.a1, w.a2, w.a3);
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds[fft_raw_index(t, h, r)] = a[r];
+}
+
+// Rounds B and C over a tile round A wrote in place.  Out: v[j] = X[t + 128 j].  `after_c_reads` runs when this WAVE's reads of
+// round C have returned: from then on nobody reads the wave's half of the tile.
+template <bool INV, typename Hook = FftNoHook>
+__device__ __forceinline__ void fft_rounds_bc_split(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t, Hook after_c_reads = Hook())
+{
+    __syncthreads();
+    {
+        const int k = t & 7, j1 = (t >> 3) & 3, j2 = t >> 5, c = 4 * j1 + j2;
+        {
+            const cf32* rb = lds + (j1 + 4 * j2 + FFT_RAW_PITCH * k);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) v[4 * b + a] = rb[16 * b + 64 * a];
+        }
+        {
+            const cf32 w1 = w.twB[4 * k], w2 = w.twB[8 * k], w3 = w.twB[12 * k];   // tw[64k(i+1)]
+#pragma unroll
+            for (int b = 0; b < 4; b++) bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], w1, w2, w3);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int kp = k + 8 * a;                                                                              // tw[16 k'(i+1)]
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], w.twB[kp], w.twB[2 * kp], w.twB[3 * kp]);
+        }
+        __syncthreads();        // everyone has read exchange 1
+        cf32* wb0 = lds + (k + 64 * c + 8 * (j1 & 1)), * wb1 = lds + (k + 64 * c + 8 * ((j1 & 1) ^ 1));
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) ((a & 1) ? wb1 : wb0)[16 * (a >> 1) + 32 * (b & 1) + 4 * FFT_RAW_PITCH * (b >> 1)] = v[4 * b + a];
+    }
+    __syncthreads();
+    {
+        const cf32* r0 = lds + (4 * FFT_RAW_PITCH * (t >> 6) + (t & 63)), * r1 = lds + (4 * FFT_RAW_PITCH * (t >> 6) + ((t & 63) ^ 8));
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) v[4 * b + a] = ((b & 1) ? r1 : r0)[64 * a + 256 * b];
+        lds_reads_done();
+        after_c_reads();
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3], w.c128[0], w.c128[1], w.c128[2]);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            bfly4<INV>(v[a], v[4 + a], v[8 + a], v[12 + a], w.c512[a][0], w.c512[a][1], w.c512[a][2]);
+    }
+}
+
 // Whole transform.  In: v[8h + j] = x[t + 128h + 256j].  Out: v[j] = X[t + 128 j].  4 barriers.
 template <bool INV>
 __device__ __forceinline__ void fft2048_wg(cf32 (&v)[16], cf32* lds, const FftTwiddles& w, int t)

@@ -12,6 +12,7 @@
 // correction capacity (miscorrections included: tests/golden rs vectors, random error patterns of weight 0 .. 12 against
 // the oracle, which is pinned to decode_rs_char itself).  GF tables live in LDS.
 #include "dabphy_kernels.h"
+#include <dabphy_wave_ops.h>
 
 namespace dabphy {
 
@@ -253,8 +254,9 @@ __device__ __forceinline__ uint16_t crc16_msb_tab(const uint8_t* data, int len, 
     return (uint16_t)(final_invert ? ~crc : crc);
 }
 
+constexpr int SF_PREFETCH = 6;      // rows of the class output in flight per work-group
 template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
-__global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArgs A)
+__global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2) k_superframe(SfArgs A)
 {
     // LDS: the raw 5-frame window (a ring: `head` = oldest frame, nothing is ever shifted) and the working copy
     __shared__ __attribute__((aligned(16))) uint8_t s_dyn[2 * SF_MAX];
@@ -287,30 +289,37 @@ __global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 5 : 4) k_superframe(SfArg
     int nv = 0;
     for (int f = 0; f < A.n_frames; f++) nv += A.desc[(size_t)b * A.n_frames + f].valid == 1 ? 1 : 0;
     const long long c0 = 4 * A.desc[(size_t)b * A.n_frames].frame_no;
-    // A logical frame is fb = 24 * (bitrate / 8) bytes: it travels as 8-byte words, one per lane (three rounds at most), and row r + 1
-    // is requested before row r is worked on -- 80 dependent round trips to HBM were a third of this kernel's time.
-    const int fw = fb >> 3;                                                    // 8-byte words per row
-    constexpr int ROW_ROUNDS = (SF_MAX / 5 / 8 + 63) / 64;
-    uint2 nxt[ROW_ROUNDS];
-    auto row_fetch = [&](int r) {
-        const uint2* src = reinterpret_cast<const uint2*>(A.out + (bm * A.n_cif + r) * fb);
+    // A logical frame is fb = 24 * (bitrate / 8) bytes.  Rows travel HBM -> LDS by LDS-DMA, SF_PREFETCH rows ahead, into a ring of
+    // their own (no registers, nothing waits until the row is needed): a row per iteration used to be a round trip to HBM per iteration
+    // -- 128 dependent latencies per work-group and batch were most of this kernel's time.  Every row costs exactly ROW_DMA requests
+    // (lanes beyond the row re-fetch its last dword into the slot's padding), so "row r has landed" is a constant vmcnt.
+    constexpr int FB_MAX = SF_MAX / 5, ROW_DMA = (FB_MAX / 4 + 63) / 64, PRE_PITCH = ROW_DMA * 256;
+    __shared__ __attribute__((aligned(16))) uint8_t s_pre[SF_PREFETCH * PRE_PITCH];
+    const int fdw = fb >> 2;                                                   // dwords per row
+    const int n_rows = 4 * nv;
+    auto row_issue = [&](int r) {
+        const uint8_t* src = A.out + (bm * A.n_cif + r) * fb;
+        uint8_t* dst = s_pre + (r % SF_PREFETCH) * PRE_PITCH;
 #pragma unroll
-        for (int i = 0; i < ROW_ROUNDS; i++) if (t + 64 * i < fw) nxt[i] = src[t + 64 * i];
+        for (int i = 0; i < ROW_DMA; i++) { int w = t + 64 * i; w = w < fdw ? w : fdw - 1; lds_dma4(src + 4 * w, dst + 256 * i); }
     };
     int r_first = 0;
-    while (r_first < 4 * nv && c0 + r_first < 16) r_first++;                   // frames before the 16-CIF fill of the time de-interleaver (dab-audio.cpp:146-149) are never emitted
-    if (r_first < 4 * nv) row_fetch(r_first);
-    for (int r = r_first; r < 4 * nv; r++) {
+    while (r_first < n_rows && c0 + r_first < 16) r_first++;                   // frames before the 16-CIF fill of the time de-interleaver (dab-audio.cpp:146-149) are never emitted
+    for (int i = 0; i < SF_PREFETCH; i++) if (r_first + i < n_rows) row_issue(r_first + i);
+    for (int r = r_first; r < n_rows; r++) {
+        if (r + SF_PREFETCH - 1 < n_rows) lds_dma_wait_but<(SF_PREFETCH - 1) * ROW_DMA>(); else lds_dma_wait();
         __syncthreads();
         int dst_slot;
         if (frame_count == 5) { dst_slot = head; head = head == 4 ? 0 : head + 1; }   // :78-81 "shift the previous frames": drop the oldest
         else { dst_slot = head + frame_count; if (dst_slot >= 5) dst_slot -= 5; frame_count++; }
         {
-            uint2* dst = reinterpret_cast<uint2*>(s_raw + dst_slot * fb);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(s_pre + (r % SF_PREFETCH) * PRE_PITCH);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(s_raw + dst_slot * fb);
 #pragma unroll
-            for (int i = 0; i < ROW_ROUNDS; i++) if (t + 64 * i < fw) dst[t + 64 * i] = nxt[i];
+            for (int i = 0; i < ROW_DMA; i++) if (t + 64 * i < fdw) dst[t + 64 * i] = src[t + 64 * i];
         }
-        if (r + 1 < 4 * nv) row_fetch(r + 1);
+        lds_reads_done();
+        if (r + SF_PREFETCH < n_rows) row_issue(r + SF_PREFETCH);              // into the slot just emptied
         __syncthreads();
         if (frame_count < 5) continue;
         for (int k = 0; k < 5; k++) {                                          // :97 decode on a copy, frames in age order
