@@ -390,7 +390,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 (FFT/demap) + u16 (Viterbi metrics) + u8 (GF(256))", "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of %d synthetic Mode-I ensembles x %d frames (2.048 Msps cf32, HBM-resident, 18 x 64 kbit/s DAB+ EEP-3A sub-channels each), full chain incl. Viterbi + Reed-Solomon" % (B, F),
                        "ensembles_per_gpu": B, "frames_per_step": F, "recording_frames": rec_frames, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B,
-                       "demod_chunk": dev.demod_chunk(), "exact_batch_mode": "on (dabphy_config.no_batch_replay = 0): batches decoded a second time in this run: %d" % dev.replayed_batches(), "parity_test": "tests/test_gpu_bench_config.py decodes this configuration against the oracle"},
+                       "demod_chunk": dev.demod_chunk(), "exact_batch_mode": "on (dabphy_config.no_batch_replay = 0): batches decoded a second time in this run: %d" % dev.replayed_batches(), "superframe_wide_pass": "(ensemble, sub-channel) batches settled by the filter's wide pass / tried: %d / %d (the rest walked frame by frame)" % dev.wide_superframe_stats(), "parity_test": "tests/test_gpu_bench_config.py decodes this configuration against the oracle"},
             "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
             "roofline": {"kernel": "k_demod (NCO + 2048-pt FFT + DQPSK demap + freq de-interleave)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": pj.get("hbm_bytes_per_launch") if pj else None,

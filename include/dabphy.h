@@ -242,6 +242,10 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
  * ensemble that were accepted from it [n_ensembles]; passes queued; passes after which the frame-by-frame chain had to take over for
  * at least one ensemble */
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
+/* the wide pass of the DAB+ superframe filter since dabphy_create (either pointer may be NULL): (ensemble, sub-channel) batches whose
+ * superframe attempts were all made at once and accepted -- the rest were walked frame by frame as SuperframeFilter::Feed does
+ * (dabplus_decoder.cpp:50-158); results are identical either way -- and batches it was tried on */
+int dabphy_get_wide_superframe_stats(dabphy_handle* h, uint64_t* settled, uint64_t* tried);
 /* batches decoded a second time (see dabphy_config.no_batch_replay) since dabphy_reset / dabphy_create */
 int dabphy_get_replayed_batches(dabphy_handle* h, uint64_t* batches);
 /* OFDM symbols (since dabphy_create) whose samples dabphy_process mixed with oscillator values converted without / with the

@@ -351,6 +351,12 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
                 assert ns >= 1 or min_synced == 0, "no superframe synchronised"
         if stats is not None:
             stats["replayed"] = d.replayed_batches()
+        # both ways through the filter were taken: batches whose attempts all synchronised were settled by the wide pass, the damaged
+        # ones (and the first, which only fills the window) were walked frame by frame
+        settled, tried = d.wide_superframe_stats()
+        assert tried > 0 and (0 < settled < tried if damage and nf >= 16 else settled <= tried), (settled, tried)
+        if stats is not None:
+            stats["sf_wide"] = (settled, tried)
     finally:
         d.close()
     # the all-sub-channels variant: only totals leave the device -- launched by superframes_stats(), or by process() itself

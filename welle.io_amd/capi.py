@@ -160,6 +160,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_replayed_batches(self.h, C.byref(a)))
         return a.value
 
+    def wide_superframe_stats(self):
+        """(sub-channel batches the superframe filter's wide pass settled, batches it was tried on) since create"""
+        a = C.c_uint64(0); b = C.c_uint64(0)
+        self._chk(self.lib.dabphy_get_wide_superframe_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def osc_stats(self):
         """(symbols mixed with the unchecked oscillator conversion, symbols that took the checked one) since create"""
         a = C.c_uint64(0); b = C.c_uint64(0)

@@ -102,6 +102,20 @@ int dabphy_get_osc_stats(dabphy_handle* h, uint64_t* unchecked_symbols, uint64_t
     return DABPHY_OK;
 }
 
+int dabphy_get_wide_superframe_stats(dabphy_handle* h, uint64_t* settled, uint64_t* tried)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    unsigned long long v[2] = {0, 0};
+    if (h->sf_gf.p) {
+        HIPCHK(h, hipMemcpyAsync(v, h->sf_gf.as<uint8_t>() + 512, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        int r = sync(h); if (r) return r;
+    }
+    if (settled) *settled = v[0];
+    if (tried) *tried = v[1];
+    return DABPHY_OK;
+}
+
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks)
 {
     DeviceBind dev_(h);

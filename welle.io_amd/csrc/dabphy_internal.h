@@ -80,7 +80,7 @@ struct dabphy_handle {
     DevBuf s_raw2[2]; hipStream_t copy_stream = nullptr; hipEvent_t ev_ingest[2] = {nullptr, nullptr}; int raw_sel = 0;   // dabphy_stream_write_raw_async
     uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
     DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
-    DevBuf sf_events, sf_count, sf_bytes, sf_stats; const FrameDesc* last_desc = nullptr;
+    DevBuf sf_events, sf_count, sf_bytes, sf_stats, sf_gf, sf_accept; const FrameDesc* last_desc = nullptr;
     static constexpr int N_DESC = 3;    // descriptor buffers: the batch being decoded + up to two synchronised ahead
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;

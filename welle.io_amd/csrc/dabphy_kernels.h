@@ -233,6 +233,9 @@ struct SfArgs {
     uint8_t* sf; int n_slots;                     // [B][members][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
     int32_t* stats;                               // optional [B][4]: synchronised superframes, corrected symbols, uncorrectable attempts, AUs failing their CRC
     int ens0, ens_count;                          // this launch walks ensembles [ens0, ens0 + ens_count); ens_count = 0: all of them
+    const uint8_t* gf;                            // alpha_to[256], index_of[256] of GF(256) / 0x11D (init_rs.h:48-60)
+    int32_t* accepted;                            // [B][members]: set by the wide pass for what it settled (nullptr: serial walk only)
+    unsigned long long* wide_stats;               // [2]: (ensemble, member) batches the wide pass settled / was tried on
 };
 void launch_superframe(const SfArgs& a, hipStream_t s);
 void launch_rs_superframes(const RsArgs& a, hipStream_t s);

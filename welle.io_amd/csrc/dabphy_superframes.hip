@@ -20,6 +20,17 @@ int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t
     if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * M * n_cif))) return r;
     if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B * M))) return r;
     if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
+    if ((r = ensure(h, h->sf_accept, sizeof(int32_t) * B * M))) return r;
+    if (!h->sf_gf.p) {
+        // GF(256) of RS(120,110), generator polynomial 0x11D (init_rs.h:48-60): alpha_to[256], index_of[256]
+        static uint8_t gf[512];
+        int sr = 1;
+        gf[256 + 0] = 255; gf[255] = 0;
+        for (int i = 0; i < 255; i++) { gf[256 + sr] = (uint8_t)i; gf[i] = (uint8_t)sr; sr <<= 1; if (sr & 256) sr ^= 0x11D; sr &= 255; }
+        if ((r = ensure(h, h->sf_gf, sizeof gf + 2 * sizeof(unsigned long long)))) return r;      // + the wide pass' two counters
+        HIPCHK(h, hipMemsetAsync(h->sf_gf.p, 0, sizeof gf + 2 * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->sf_gf.p, gf, sizeof gf, hipMemcpyHostToDevice, h->stream));
+    }
     return 0;
 }
 
@@ -102,6 +113,8 @@ int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, 
     a.s = bitrate / 8; a.member = member; a.desc = h->last_desc; a.n_frames = (int)F;
     a.state = cls.sf_state.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
     a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats; a.ens0 = ens0; a.ens_count = ens_count;
+    a.gf = h->sf_gf.as<uint8_t>(); a.accepted = h->sf_accept.as<int32_t>();
+    a.wide_stats = reinterpret_cast<unsigned long long*>(h->sf_gf.as<uint8_t>() + 512);
     launch_superframe(a, st ? st : h->stream);
     return 0;
 }

@@ -254,57 +254,249 @@ __device__ __forceinline__ uint16_t crc16_msb_tab(const uint8_t* data, int len, 
     return (uint16_t)(final_invert ? ~crc : crc);
 }
 
-constexpr int SF_PREFETCH = 6;      // rows of the class output in flight per work-group
+constexpr int SF_PREFETCH = 6;      // rows of the class output in flight per work-group (serial walk)
+
+// GF(256) tables of the code (init_rs.h:48-60) from the copy the host uploaded, and the byte-wise table of CRC-16-CCITT (0x1021)
+__device__ __forceinline__ void sf_tables(const SfArgs& A, uint8_t* alpha_to, uint8_t* index_of, uint16_t* crctab, int t)
+{
+    reinterpret_cast<uint32_t*>(alpha_to)[t] = reinterpret_cast<const uint32_t*>(A.gf)[t];
+    reinterpret_cast<uint32_t*>(index_of)[t] = reinterpret_cast<const uint32_t*>(A.gf + 256)[t];
+    if (crctab)
+        for (int v = t; v < 256; v += 64) {
+            uint16_t c = (uint16_t)(v << 8);
+            for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1);
+            crctab[v] = c;
+        }
+}
+
+// What the batch holds for one (ensemble, member): fc frames carried in, of which the window machine still uses the last cu (a full
+// window that failed drops its oldest frame with the next one, dabplus_decoder.cpp:78-81); rows [r_first, n_rows) of the class output
+// are the frames it will be fed (rows are packed: k_msc_gather lays the logical frames of an ensemble out in CIF order from the first
+// frame number of the batch, whatever slots the demodulated frames occupied; frames before the 16-CIF fill of the time de-interleaver,
+// dab-audio.cpp:146-149, are never emitted).  If every attempt synchronises, attempts happen at frames 5q + 4 of that sequence: nq of them.
+struct SfPlan { int fc, cu, n_rows, r_first, avail, nq; };
+__device__ __forceinline__ SfPlan sf_plan(const SfArgs& A, int b, const uint8_t* st)
+{
+    SfPlan p;
+    p.fc = *reinterpret_cast<const int32_t*>(st);
+    p.cu = p.fc == 5 ? 4 : p.fc;
+    int nv = 0;
+    for (int f = 0; f < A.n_frames; f++) nv += A.desc[(size_t)b * A.n_frames + f].valid == 1 ? 1 : 0;
+    const long long c0 = 4 * A.desc[(size_t)b * A.n_frames].frame_no;
+    p.n_rows = 4 * nv;
+    p.r_first = 0;
+    while (p.r_first < p.n_rows && c0 + p.r_first < 16) p.r_first++;
+    p.avail = p.n_rows - p.r_first;
+    p.nq = p.avail > 0 ? (p.cu + p.avail) / 5 : 0;
+    return p;
+}
+
+// One attempt on the 5-frame copy in s_sf: Reed-Solomon over its s code words, then CheckSync (dabplus_decoder.cpp:97-213).
+// Thread 0 gets the attempt's event (cif and sf_slot are the caller's); sh.sync / corr / unc are valid for all threads on return.
+struct SfShared { int corr, unc, sync, au_start[8]; };
+__device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const uint8_t* alpha_to, const uint8_t* index_of, uint8_t* s_ws,
+                                           SfShared& sh, SfEvent& e, int t)
+{
+    const int sf_len = 5 * fb;
+    if (t == 0) { sh.corr = 0; sh.unc = 0; }
+    __syncthreads();
+    // Syndromes, eight codewords at a time with the whole wave: S_i = XOR_j d_j alpha^(i (119 - j)) is a sum, so lane
+    // (codeword c = l & 7, byte group l >> 3 = 15 positions) adds its terms without any chain of dependent look-ups and
+    // three butterfly exchanges fold the eight groups (Horner's 119 dependent steps were the whole cost of this kernel).
+    for (int c0 = 0; c0 < s; c0 += 8) {
+        const int c = c0 + (t & 7), jg = t >> 3;
+        uint32_t syn[RS_NROOTS];
+#pragma unroll
+        for (int i = 0; i < RS_NROOTS; i++) syn[i] = 0;
+        if (c < s) {
+#pragma unroll 3
+            for (int jj = 0; jj < 15; jj++) {
+                const int j = jg * 15 + jj;
+                const uint32_t dj = s_sf[j * s + c];
+                const uint32_t k = (uint32_t)(RS_LEN - 1 - j);               // exponent step: x^(119 - j) at x = alpha^i
+                uint32_t ex = index_of[dj];                                  // 255 for dj = 0: the terms are masked below
+                syn[0] ^= dj;
+#pragma unroll
+                for (int i = 1; i < RS_NROOTS; i++) {
+                    ex += k; ex = ex >= RS_NN ? ex - RS_NN : ex;
+                    const uint32_t av = alpha_to[ex >= RS_NN ? ex - RS_NN : ex];
+                    syn[i] ^= dj ? av : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RS_NROOTS; i++) {
+            syn[i] ^= __shfl_xor(syn[i], 8); syn[i] ^= __shfl_xor(syn[i], 16); syn[i] ^= __shfl_xor(syn[i], 32);
+        }
+        if (jg == 0 && c < s) {
+            RsIo io; io.base = s_sf + c; io.pos_stride = (size_t)s;
+            const int n = rs_correct120(io, syn, alpha_to, index_of, s_ws + (t & 7) * RS_WS_BYTES);
+            if (n < 0) atomicOr(&sh.unc, 1); else if (n > 0) atomicAdd(&sh.corr, n);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {                                                          // CheckSync, :160-213
+        const uint8_t* sf = s_sf;
+        int sync = 0, num_aus = 0;
+        if (!(sf[3] == 0x00 && sf[4] == 0x00) && (uint16_t)(sf[0] << 8 | sf[1]) == crc16_msb(sf + 2, 9, false, false, 0x782F)) {
+            const int dac_rate = sf[2] & 0x40, sbr_flag = sf[2] & 0x20;
+            num_aus = dac_rate ? (sbr_flag ? 3 : 6) : (sbr_flag ? 2 : 4);
+            sh.au_start[0] = dac_rate ? (sbr_flag ? 6 : 11) : (sbr_flag ? 5 : 8);
+            sh.au_start[num_aus] = sf_len / 120 * 110;
+            sh.au_start[1] = sf[3] << 4 | sf[4] >> 4;
+            if (num_aus >= 3) sh.au_start[2] = (sf[4] & 0x0F) << 8 | sf[5];
+            if (num_aus >= 4) sh.au_start[3] = sf[6] << 4 | sf[7] >> 4;
+            if (num_aus == 6) { sh.au_start[4] = (sf[7] & 0x0F) << 8 | sf[8]; sh.au_start[5] = sf[9] << 4 | sf[10] >> 4; }
+            sync = 1;
+            for (int i = 0; i < num_aus; i++) if (sh.au_start[i] >= sh.au_start[i + 1]) sync = 0;
+        }
+        sh.sync = sync;
+        e = SfEvent{};
+        e.corrected = sh.corr; e.uncorrectable = sh.unc; e.sync = sync; e.sf_slot = -1;
+        if (sync) {
+            e.format = sf[2]; e.num_aus = num_aus;
+            for (int i = 0; i <= num_aus; i++) e.au_start[i] = sh.au_start[i];
+        }
+    }
+    __syncthreads();
+}
+
+// :122-131 AU CRC-16-CCITT of the first ne events of one (ensemble, member), one lane per access unit.  The verdicts do not steer the
+// state machine.  (Events and superframes were written by earlier kernels or, behind a barrier, by this work-group.)  Returns nothing:
+// failures are counted into *aubad (LDS).
+__device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t)
+{
+    for (int base = 0; base < ne * 6; base += 64) {
+        const int k = base + t, e_i = k / 6, au_i = k % 6;
+        if (e_i < ne && ev[e_i].sync && au_i < ev[e_i].num_aus) {
+            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
+            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
+            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
+            else atomicAdd(aubad, 1);
+        }
+    }
+}
+
+// ---- The wide pass.  A receiver in lock finds a superframe every five frames: all attempts of the batch are made at once, one
+// work-group per (member, ensemble, attempt q), each on the window the serial machine WOULD see if every earlier attempt of the batch
+// synchronises (sf_plan).  k_superframe_settle then accepts an (ensemble, member) iff all its attempts did -- in that case the serial
+// walk makes exactly these attempts on exactly these windows -- and does what the walk does at its end; every other (ensemble, member)
+// is walked by k_superframe from the untouched state, as before.  The state machine's 26 dependent attempts per batch were this
+// stage's whole time: 0.8 ms of a mostly idle device per step.
+template <int SF_MAX>
+__global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_sf[SF_MAX];
+    __shared__ __attribute__((aligned(16))) uint8_t alpha_to[256], index_of[256];
+    __shared__ SfShared sh;
+    __shared__ uint8_t s_ws[8 * RS_WS_BYTES];
+    const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x, q = (int)blockIdx.z;
+    const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
+    const size_t bm = (size_t)b * A.n_members + m;
+    const uint8_t* st = A.state + bm * A.state_stride;
+    const SfPlan p = sf_plan(A, b, st);
+    if (q >= p.nq) return;
+    sf_tables(A, alpha_to, index_of, nullptr, t);
+    for (int k = 0; k < 5; k++) {
+        const int g = 5 * q + k;                                               // frame g of (carried frames, then rows)
+        const uint8_t* src = g < p.cu ? st + 16 + (size_t)(p.fc - p.cu + g) * fb : A.out + (bm * A.n_cif + (p.r_first + g - p.cu)) * fb;
+        for (int i = t; i < fw; i += 64) reinterpret_cast<uint2*>(s_sf + k * fb)[i] = reinterpret_cast<const uint2*>(src)[i];
+    }
+    SfEvent e;
+    sf_attempt(s_sf, fb, A.s, alpha_to, index_of, s_ws, sh, e, t);
+    if (t == 0) {
+        e.cif = p.r_first + 5 * q + 4 - p.cu;                                  // the row whose arrival triggers the attempt
+        if (sh.sync) e.sf_slot = q;
+        A.events[bm * A.n_cif + q] = e;
+    }
+    if (sh.sync) {
+        uint8_t* gsf = A.sf + (bm * A.n_slots + q) * sf_len;
+        for (int i = t; i < 5 * fw; i += 64) reinterpret_cast<uint2*>(gsf)[i] = reinterpret_cast<const uint2*>(s_sf)[i];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
+{
+    __shared__ uint16_t s_crctab[256];
+    __shared__ int s_ok, s_corr, s_unc, s_aubad;
+    const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
+    const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
+    const size_t bm = (size_t)b * A.n_members + m;
+    uint8_t* st = A.state + bm * A.state_stride;
+    const SfPlan p = sf_plan(A, b, st);
+    SfEvent* ev = A.events + bm * A.n_cif;
+    for (int v = t; v < 256; v += 64) {
+        uint16_t c = (uint16_t)(v << 8);
+        for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1);
+        s_crctab[v] = c;
+    }
+    if (t == 0) { s_ok = p.nq >= 1; s_corr = 0; s_unc = 0; s_aubad = 0; }
+    __syncthreads();
+    for (int q = t; q < p.nq; q += 64) {
+        if (!ev[q].sync) s_ok = 0;                                  // (every writer stores the same value)
+        else { if (ev[q].corrected) atomicAdd(&s_corr, ev[q].corrected); if (ev[q].uncorrectable) atomicAdd(&s_unc, ev[q].uncorrectable); }
+    }
+    __syncthreads();
+    const int ok = s_ok;
+    if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }
+    if (!ok) return;
+    sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t);
+    // the frames behind the last attempt are the next batch's carried window (a hit empties it, dabplus_decoder.cpp:156)
+    const int n_left = p.cu + p.avail - 5 * p.nq;
+    for (int k = 0; k < n_left; k++) {
+        const uint8_t* src = A.out + (bm * A.n_cif + (p.n_rows - n_left + k)) * fb;
+        for (int i = t; i < fw; i += 64) reinterpret_cast<uint2*>(st + 16 + (size_t)k * fb)[i] = reinterpret_cast<const uint2*>(src)[i];
+    }
+    __syncthreads();
+    if (t == 0) {
+        *reinterpret_cast<int32_t*>(st) = n_left; A.n_events[bm] = p.nq;
+        if (A.stats) { atomicAdd(A.stats + 4 * b, p.nq); atomicAdd(A.stats + 4 * b + 1, s_corr); atomicAdd(A.stats + 4 * b + 2, s_unc); atomicAdd(A.stats + 4 * b + 3, s_aubad); }
+    }
+}
+
+// ---- The serial walk: SuperframeFilter::Feed / CheckSync (dabplus_decoder.cpp:50-213) for one sub-channel of one ensemble, frame by
+// frame with the reference's state machine -- 5-frame sliding window, Reed-Solomon on a copy, Fire-code / AU-table check, AU CRCs, and
+// after a hit a fresh window -- carrying frame_count + the raw window to the next batch.  Runs for what the wide pass did not settle.
 template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
 __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2) k_superframe(SfArgs A)
 {
     // LDS: the raw 5-frame window (a ring: `head` = oldest frame, nothing is ever shifted) and the working copy
     __shared__ __attribute__((aligned(16))) uint8_t s_dyn[2 * SF_MAX];
-    __shared__ uint8_t alpha_to[256], index_of[256];
-    __shared__ int s_corr, s_unc, s_sync, s_au_start[8], s_aubad;
+    __shared__ __attribute__((aligned(16))) uint8_t alpha_to[256], index_of[256];
+    __shared__ SfShared sh;
+    __shared__ int s_aubad;
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];                   // error-path workspaces of the eight code words decoded at a time
     __shared__ uint16_t s_crctab[256];                          // CRC-16-CCITT (0x1021), one byte per step: the AU checks
-    rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
-    for (int v = threadIdx.x; v < 256; v += 64) {
-        uint16_t c = (uint16_t)(v << 8);
-        for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1);
-        s_crctab[v] = c;
-    }
-    if (threadIdx.x == 0) s_aubad = 0;
     const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
+    const size_t bm = (size_t)b * A.n_members + m;
+    if (A.accepted && A.accepted[bm]) return;                  // settled by the wide pass
+    sf_tables(A, alpha_to, index_of, s_crctab, t);
+    if (t == 0) s_aubad = 0;
     const int fb = A.frame_bytes, sf_len = 5 * fb;
     uint8_t* const s_raw = s_dyn;
     uint8_t* const s_sf = s_dyn + SF_MAX;
-    const size_t bm = (size_t)b * A.n_members + m;
     uint8_t* st = A.state + bm * A.state_stride;
-    int frame_count = *reinterpret_cast<const int32_t*>(st);
+    const SfPlan p = sf_plan(A, b, st);
+    int frame_count = p.fc;
+    __syncthreads();
     for (int i = t; i < frame_count * fb; i += 64) s_raw[i] = st[16 + i];     // carried frames, oldest first
     int head = 0;                                                              // ring slot of the oldest frame
     int ne = 0, slot = 0;
     SfEvent* ev = A.events + bm * A.n_cif;
     int tot_sync = 0, tot_corr = 0, tot_unc = 0;
-    // Rows of the class output are packed: k_msc_gather lays the logical frames of an ensemble out in CIF order from the first frame
-    // number of the batch (c_glob = 4 * desc[b][0].frame_no + r), whatever slots the demodulated frames occupied -- rows
-    // [0, 4 * nv) are real, nv = frames with valid == 1; a slot whose window search failed leaves no gap.
-    int nv = 0;
-    for (int f = 0; f < A.n_frames; f++) nv += A.desc[(size_t)b * A.n_frames + f].valid == 1 ? 1 : 0;
-    const long long c0 = 4 * A.desc[(size_t)b * A.n_frames].frame_no;
     // A logical frame is fb = 24 * (bitrate / 8) bytes.  Rows travel HBM -> LDS by LDS-DMA, SF_PREFETCH rows ahead, into a ring of
-    // their own (no registers, nothing waits until the row is needed): a row per iteration used to be a round trip to HBM per iteration
-    // -- 128 dependent latencies per work-group and batch were most of this kernel's time.  Every row costs exactly ROW_DMA requests
-    // (lanes beyond the row re-fetch its last dword into the slot's padding), so "row r has landed" is a constant vmcnt.
+    // their own (no registers, nothing waits until the row is needed).  Every row costs exactly ROW_DMA requests (lanes beyond the row
+    // re-fetch its last dword into the slot's padding), so "row r has landed" is a constant vmcnt.
     constexpr int FB_MAX = SF_MAX / 5, ROW_DMA = (FB_MAX / 4 + 63) / 64, PRE_PITCH = ROW_DMA * 256;
     __shared__ __attribute__((aligned(16))) uint8_t s_pre[SF_PREFETCH * PRE_PITCH];
     const int fdw = fb >> 2;                                                   // dwords per row
-    const int n_rows = 4 * nv;
+    const int n_rows = p.n_rows, r_first = p.r_first;
     auto row_issue = [&](int r) {
         const uint8_t* src = A.out + (bm * A.n_cif + r) * fb;
         uint8_t* dst = s_pre + (r % SF_PREFETCH) * PRE_PITCH;
 #pragma unroll
         for (int i = 0; i < ROW_DMA; i++) { int w = t + 64 * i; w = w < fdw ? w : fdw - 1; lds_dma4(src + 4 * w, dst + 256 * i); }
     };
-    int r_first = 0;
-    while (r_first < n_rows && c0 + r_first < 16) r_first++;                   // frames before the 16-CIF fill of the time de-interleaver (dab-audio.cpp:146-149) are never emitted
     for (int i = 0; i < SF_PREFETCH; i++) if (r_first + i < n_rows) row_issue(r_first + i);
     for (int r = r_first; r < n_rows; r++) {
         if (r + SF_PREFETCH - 1 < n_rows) lds_dma_wait_but<(SF_PREFETCH - 1) * ROW_DMA>(); else lds_dma_wait();
@@ -324,101 +516,34 @@ __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2
         if (frame_count < 5) continue;
         for (int k = 0; k < 5; k++) {                                          // :97 decode on a copy, frames in age order
             int sl = head + k; if (sl >= 5) sl -= 5;
-            for (int i = t; i < fb; i += 64) s_sf[k * fb + i] = s_raw[sl * fb + i];
+            for (int i = t; i < fdw; i += 64) reinterpret_cast<uint32_t*>(s_sf + k * fb)[i] = reinterpret_cast<const uint32_t*>(s_raw + sl * fb)[i];
         }
-        if (t == 0) { s_corr = 0; s_unc = 0; }
-        __syncthreads();
-        // Syndromes, eight codewords at a time with the whole wave: S_i = XOR_j d_j alpha^(i (119 - j)) is a sum, so lane
-        // (codeword c = l & 7, byte group l >> 3 = 15 positions) adds its terms without any chain of dependent look-ups and
-        // three butterfly exchanges fold the eight groups (Horner's 119 dependent steps were the whole cost of this kernel).
-        for (int c0 = 0; c0 < A.s; c0 += 8) {
-            const int c = c0 + (t & 7), jg = t >> 3;
-            uint32_t syn[RS_NROOTS];
-#pragma unroll
-            for (int i = 0; i < RS_NROOTS; i++) syn[i] = 0;
-            if (c < A.s) {
-#pragma unroll 3
-                for (int jj = 0; jj < 15; jj++) {
-                    const int j = jg * 15 + jj;
-                    const uint32_t dj = s_sf[j * A.s + c];
-                    const uint32_t k = (uint32_t)(RS_LEN - 1 - j);               // exponent step: x^(119 - j) at x = alpha^i
-                    uint32_t e = index_of[dj];                                   // 255 for dj = 0: the terms are masked below
-                    syn[0] ^= dj;
-#pragma unroll
-                    for (int i = 1; i < RS_NROOTS; i++) {
-                        e += k; e = e >= RS_NN ? e - RS_NN : e;
-                        const uint32_t a = alpha_to[e >= RS_NN ? e - RS_NN : e];
-                        syn[i] ^= dj ? a : 0u;
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < RS_NROOTS; i++) {
-                syn[i] ^= __shfl_xor(syn[i], 8); syn[i] ^= __shfl_xor(syn[i], 16); syn[i] ^= __shfl_xor(syn[i], 32);
-            }
-            if (jg == 0 && c < A.s) {
-                RsIo io; io.base = s_sf + c; io.pos_stride = (size_t)A.s;
-                const int n = rs_correct120(io, syn, alpha_to, index_of, s_ws + (t & 7) * RS_WS_BYTES);
-                if (n < 0) atomicOr(&s_unc, 1); else if (n > 0) atomicAdd(&s_corr, n);
-            }
-        }
-        __syncthreads();
-        if (t == 0) {                                                          // CheckSync, :160-213
-            const uint8_t* sf = s_sf;
-            int sync = 0, num_aus = 0;
-            if (!(sf[3] == 0x00 && sf[4] == 0x00) && (uint16_t)(sf[0] << 8 | sf[1]) == crc16_msb(sf + 2, 9, false, false, 0x782F)) {
-                const int dac_rate = sf[2] & 0x40, sbr_flag = sf[2] & 0x20;
-                num_aus = dac_rate ? (sbr_flag ? 3 : 6) : (sbr_flag ? 2 : 4);
-                s_au_start[0] = dac_rate ? (sbr_flag ? 6 : 11) : (sbr_flag ? 5 : 8);
-                s_au_start[num_aus] = sf_len / 120 * 110;
-                s_au_start[1] = sf[3] << 4 | sf[4] >> 4;
-                if (num_aus >= 3) s_au_start[2] = (sf[4] & 0x0F) << 8 | sf[5];
-                if (num_aus >= 4) s_au_start[3] = sf[6] << 4 | sf[7] >> 4;
-                if (num_aus == 6) { s_au_start[4] = (sf[7] & 0x0F) << 8 | sf[8]; s_au_start[5] = sf[9] << 4 | sf[10] >> 4; }
-                sync = 1;
-                for (int i = 0; i < num_aus; i++) if (s_au_start[i] >= s_au_start[i + 1]) sync = 0;
-            }
-            s_sync = sync;
-            SfEvent e{};
-            e.cif = r; e.corrected = s_corr; e.uncorrectable = s_unc; e.sync = sync; e.sf_slot = -1;
-            if (sync) {
-                e.format = sf[2]; e.num_aus = num_aus; e.sf_slot = slot;
-                for (int i = 0; i <= num_aus; i++) e.au_start[i] = s_au_start[i];
-            }
+        SfEvent e;
+        sf_attempt(s_sf, fb, A.s, alpha_to, index_of, s_ws, sh, e, t);
+        if (t == 0) {
+            e.cif = r;
+            if (sh.sync) e.sf_slot = slot;
             ev[ne] = e;
         }
-        __syncthreads();
         ne++;
-        tot_corr += s_corr; tot_unc += s_unc;
-        if (s_sync) {
+        tot_corr += sh.corr; tot_unc += sh.unc;
+        if (sh.sync) {
             uint8_t* gsf = A.sf + (bm * A.n_slots + slot) * sf_len;             // only synchronised superframes are kept
-            for (int i = t; i < sf_len; i += 64) gsf[i] = s_sf[i];
+            for (int i = t; i < 5 * fdw; i += 64) reinterpret_cast<uint32_t*>(gsf)[i] = reinterpret_cast<const uint32_t*>(s_sf)[i];
             tot_sync++;
             frame_count = 0; head = 0; if (slot + 1 < A.n_slots) slot++;       // :156 wait for a complete new superframe
         }
     }
     __syncthreads();
-    // :122-131 AU CRC-16-CCITT.  The verdicts do not steer the state machine, so all access units of the batch are checked
-    // here side by side, one lane each (events and superframes were written by this work-group: visible after the barrier).
-    int tot_aubad = 0;
-    for (int base = 0; base < ne * 6; base += 64) {
-        const int k = base + t, e_i = k / 6, au_i = k % 6;
-        if (e_i < ne && ev[e_i].sync && au_i < ev[e_i].num_aus) {
-            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
-            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
-            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, s_crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
-            else atomicAdd(&s_aubad, 1);
-        }
-    }
+    sf_au_crcs(A, ev, bm, ne, sf_len, s_crctab, &s_aubad, t);
     __syncthreads();
     for (int i = t; i < frame_count * fb; i += 64) {                           // carry the window, oldest frame first
         int sl = head + i / fb; if (sl >= 5) sl -= 5;
         st[16 + i] = s_raw[sl * fb + i % fb];
     }
     if (t == 0) {
-        tot_aubad = s_aubad;
         *reinterpret_cast<int32_t*>(st) = frame_count; A.n_events[bm] = ne;
-        if (A.stats) { atomicAdd(A.stats + 4 * b, tot_sync); atomicAdd(A.stats + 4 * b + 1, tot_corr); atomicAdd(A.stats + 4 * b + 2, tot_unc); atomicAdd(A.stats + 4 * b + 3, tot_aubad); }
+        if (A.stats) { atomicAdd(A.stats + 4 * b, tot_sync); atomicAdd(A.stats + 4 * b + 1, tot_corr); atomicAdd(A.stats + 4 * b + 2, tot_unc); atomicAdd(A.stats + 4 * b + 3, s_aubad); }
     }
 }
 
@@ -426,6 +551,14 @@ void launch_superframe(const SfArgs& a, hipStream_t s)
 {
     const dim3 grid(a.member >= 0 ? 1 : a.n_members, a.ens_count > 0 ? a.ens_count : a.n_ens - a.ens0);
     const int sf_len = 5 * a.frame_bytes;
+    if (a.accepted) {
+        // the wide pass: every attempt a locked receiver makes in this batch at once, then the verdict per (ensemble, member)
+        const dim3 wide(grid.x, grid.y, (a.n_cif + 4) / 5);
+        if (sf_len <= 960) hipLaunchKernelGGL(k_superframe_wide<960>, wide, dim3(64), 0, s, a);
+        else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe_wide<2880>, wide, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(k_superframe_wide<5760>, wide, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_superframe_settle, grid, dim3(64), 0, s, a);
+    }
     if (sf_len <= 960) hipLaunchKernelGGL(k_superframe<960>, grid, dim3(64), 0, s, a);            // <= 64 kbit/s
     else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe<2880>, grid, dim3(64), 0, s, a);     // <= 192 kbit/s
     else hipLaunchKernelGGL(k_superframe<5760>, grid, dim3(64), 0, s, a);                         // <= 384 kbit/s
