@@ -126,6 +126,7 @@ struct FicGatherArgs {
     const FrameDesc* desc; int n_ens, n_frames;
     const int16_t* map;     // [3096] mother-code index -> index into the 2304 punctured bits, -1 = erasure
     VitClass c;
+    int frame_sel;          // 0: every frame of the batch, codeword (b F + f) 4 + q; f + 1: frame f only, codeword 4 b + q (c.n_cw = 4 B)
 };
 
 // Gather for one MSC sub-channel class: time de-interleave (dab-audio.cpp:138-143) + depuncture
@@ -167,6 +168,7 @@ struct CrcArgs {
     int disable_coarse;     // RadioReceiverOptions::disableCoarseCorrector as the synchroniser used it (k_fic_ratio checks the ratio it saw)
     int frame_first, frame_count;   // k_fic_ratio: walk only these frame slots (0 = all)
     int32_t* any_effective; // k_fic_ratio: set to 1 when a stale decision with a possible effect is found (optional)
+    int frame_sel;          // k_fib_crc: 0: fib = [B][F][12][32]; f + 1: fib = [B][12][32] holds frame f only (flags still land in ok[b][f][.])
 };
 
 // Gather from a plain [n_cw][in_stride] array of soft bits (the Viterbi::deconvolve / Protection::deconvolve seams)

@@ -124,7 +124,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // step, the first chunk(s) of the frame's symbols (PRS + the three FIC symbols), FIC decode of the class, ratio of frame f.  Everything else
         // of the batch follows below as in the first pass (the demod kernel writes the same soft bits again where nothing changed).
         SyncArgs sa = sync_args(h, cur, F, h->chain_valid[cur]);
+        // the FIC of ONE frame per step: a class of 4 B code words (frame_sel), decoded into the head of the FIB buffer -- the
+        // full-batch FIC pass below writes every FIB again
         VitClass c = fic_c;
+        c.n_cw = (int)(B * 4); c.n_groups = (c.n_cw + 63) / 64; c.g_begin = 0; c.g_end = c.n_groups;
         c.sym = h->fsym.as<uint32_t>(); c.dec = h->fdec.as<uint2>(); c.out = h->s_fib.as<uint8_t>();
         FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
@@ -137,10 +140,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             DemodArgs d1 = da; d1.frame_first = (int)f; d1.frame_count = 1; d1.con = nullptr; d1.osc_stats = nullptr;
             d1.chunk_count = (3 + da.chunk_len - 1) / da.chunk_len;          // the chunks that hold the FIC symbols 1..3 (demod_chunk may be 1 or 2)
             launch_demod(d1, (int)B, h->stream);
+            g.frame_sel = (int)f + 1; k.frame_sel = (int)f + 1;
             launch_fic_gather(g, h->stream);
             launch_viterbi(v, h->stream);
             launch_fib_crc(k, h->stream);
-            CrcArgs kf = k; kf.frame_first = (int)f; kf.frame_count = 1;
+            CrcArgs kf = k; kf.frame_sel = 0; kf.frame_first = (int)f; kf.frame_count = 1;
             launch_fic_ratio(kf, h->stream);
         }
     }

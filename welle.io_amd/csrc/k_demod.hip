@@ -125,19 +125,6 @@ __device__ __forceinline__ void load_half(cf32 (&x)[8], const cf32* __restrict__
     }
 }
 
-// ... or from the LDS stage an earlier LDS-DMA filled with the symbol's 2048 samples in natural order
-__device__ __forceinline__ void stage_half(cf32 (&x)[8], const cf32* stage, const SymCursor& c, const OscChain& k,
-                                           const cf32* __restrict__ nco, const MixSteps& st, int h, int mix, int t, bool checked)
-{
-#pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = stage[t + 128 * h + 256 * j];
-    if (mix) {
-        cf32 o[8]; osc_half(o, k, nco, c, st, h, checked);
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = pk_cmul(x[j], o[j]);
-    }
-}
-
 // Bins held by thread t after the transform: t + 128 j.  Carriers are k = +1..+768 (bins 1..768) and k = -768..-1 (bins
 // 1280..2047): j = 0..5 and 10..15 for every thread but thread 0, whose j = 0 is the unused DC bin and which owns bin 768
 // (j = 6) instead.  So every thread demaps exactly 12 carriers: slot q < 6 is j = q (thread 0, q = 0: j = 6), slot q >= 6
@@ -145,9 +132,6 @@ __device__ __forceinline__ void stage_half(cf32 (&x)[8], const cf32* stage, cons
 constexpr int N_SLOTS = 12;
 #ifndef DIV127_VARIANT
 #define DIV127_VARIANT 0
-#endif
-#ifndef DEMOD_STAGE
-#define DEMOD_STAGE 2
 #endif
 __device__ __forceinline__ void carrier_slots(cf32 (&c)[N_SLOTS], const cf32 (&v)[16], int t)
 {
@@ -164,19 +148,9 @@ __device__ __forceinline__ void carrier_slots(cf32 (&c)[N_SLOTS], const cf32 (&v
 template <bool CON>
 __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
 {
-#if DEMOD_STAGE == 2
     __shared__ __attribute__((aligned(16))) cf32 tile[FFT_INPLACE_TILE];
-#else
-    __shared__ __attribute__((aligned(16))) cf32 tile[T_U];
-#endif
     __shared__ __attribute__((aligned(16))) cf32 twB[FFT_TWB_ENTRIES];
-#if DEMOD_STAGE == 2
-    // (the next symbol's raw samples land in the exchange tile itself: 21 KiB per work-group, a third wave per SIMD)
-#elif DEMOD_STAGE
-    __shared__ __attribute__((aligned(16))) cf32 stage[T_U];      // next symbol's raw samples, filled by LDS-DMA
-#else
-    cf32* const stage = nullptr;
-#endif
+    // (the next symbol's raw samples land in the exchange tile itself: 24 KiB per work-group, 168 registers: three waves per SIMD)
     __shared__ __attribute__((aligned(16))) int8_t softbuf[SOFT_PER_SYM];
     __shared__ __attribute__((aligned(16))) dc64 s_symstep[L_SYM];   // exp(-j 2 pi k T_s f / RATE): symbol k of the chunk against its first
     const int t = threadIdx.x;
@@ -191,9 +165,8 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     if (s_begin >= L_SYM) return;
 
     FftTwiddles w; fft_load_twiddles(w, A.tab.tw, twB, t);
-    // soft-bit index (freq-interleaver.cpp:88-91 inverted) of each slot: twelve loop-invariant registers, or (three waves per SIMD:
-    // 168 registers) a 3 KiB LDS table read back slot by slot
-#if DEMOD_STAGE == 2
+    // soft-bit index (freq-interleaver.cpp:88-91 inverted) of each slot: a 3 KiB LDS table read back slot by slot (twelve loop-invariant
+    // registers would not fit beside three waves per SIMD)
     __shared__ uint16_t sidx_lds[N_SLOTS * FFT_THREADS];
 #pragma unroll
     for (int q = 0; q < N_SLOTS; q++) {
@@ -201,15 +174,6 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         sidx_lds[q * FFT_THREADS + t] = (uint16_t)A.tab.bin2soft[t + 128 * j];       // (read only by the thread that wrote it)
     }
     auto sidx_of = [&](int q) { return (int)sidx_lds[q * FFT_THREADS + t]; };
-#else
-    int sidx[N_SLOTS];
-#pragma unroll
-    for (int q = 0; q < N_SLOTS; q++) {
-        const int j = q >= 6 ? q + 4 : (q == 0 && t == 0) ? 6 : q;
-        sidx[q] = A.tab.bin2soft[t + 128 * j];
-    }
-    auto sidx_of = [&](int q) { return sidx[q]; };
-#endif
 
     // offset (from d.pos) of the useful part of symbol s: PRS at start_index; s >= 1 at J0 + (s-1) T_s + T_g.
     // Phase of the sample at offset j: j < J0: (L0 - (j+1) f_prs) mod RATE, else (L1 - (j-J0+1) f_sym) mod RATE.
@@ -241,13 +205,8 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         __syncthreads();
         const bool checked = hazard_bit(sref);
 #pragma unroll
-#if DEMOD_STAGE == 2
         for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, nco, ms, h, A.mix, checked); fft_round_a_inplace<false>(x, h, tile, w, t); }
         fft_rounds_bc_split<false>(v, tile, w, t);
-#else
-        for (int h = 0; h < 2; h++) { cf32 x[8]; load_half(x, iq, ring, c, osc, nco, ms, h, A.mix, checked); fft_round_a<false>(x, h, tile, w, t); }
-        fft_rounds_bc<false>(v, tile, w, t);
-#endif
         if (sref == 0 && A.prs_mag) {
             // |bin| of the PRS for the SNR estimate (ofdm-decoder.cpp:240-266): stored in bin order, summed by k_snr_frames
             float* pm = A.prs_mag + ((size_t)b * A.n_frames + f) * T_U;
@@ -268,8 +227,7 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
     // (once per ring revolution) takes the direct path instead.
     const int lane = t & 63, wv = t >> 6;
     uint32_t sym0 = (uint32_t)((d.pos + J0 + (int64_t)(s_begin - 1) * T_S + T_G) % A.ring);   // ring index of sample 0 (uniform)
-    auto dma_ok = [&](uint32_t a0) { return DEMOD_STAGE && a0 + (uint32_t)T_U <= ring; };
-#if DEMOD_STAGE == 2
+    auto dma_ok = [&](uint32_t a0) { return a0 + (uint32_t)T_U <= ring; };
     // ... into the tile itself, rows of 256 samples 32 bytes apart (fft2048.h, "k_demod's variant"): wave w fills rows 4w .. 4w+3,
     // two requests per row; the row's address is scalar arithmetic, the lanes keep one 32-bit offset
     const int wvu = uniform_i32(wv);
@@ -279,14 +237,6 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
 #pragma unroll
         for (int r = 0; r < 4; r++) { lds_dma16<0>(g + 2048 * r, l + FFT_RAW_PITCH * r); lds_dma16<1024>(g + 2048 * r, l + FFT_RAW_PITCH * r); }
     };
-#else
-    auto dma_issue = [&](uint32_t a0) {
-        const cf32* g = iq + a0 + 1024 * wv + 2 * lane;
-        cf32* l = stage + 1024 * wv;
-        lds_dma16<0>(g, l); lds_dma16<1024>(g, l); lds_dma16<2048>(g, l); lds_dma16<3072>(g, l);
-        lds_dma16<0>(g + 512, l + 512); lds_dma16<1024>(g + 512, l + 512); lds_dma16<2048>(g + 512, l + 512); lds_dma16<3072>(g + 512, l + 512);
-    };
-#endif
     bool staged = dma_ok(sym0);
     // Every symbol's base is ONE product of two osc_exp values (the thread's base at the chunk's first symbol and the wave-uniform step
     // to symbol k, from LDS), not a chain of k products: the unchecked conversion's error budget (osc_exact.h) counts on it.
@@ -315,7 +265,6 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         if (s > s_begin) store_soft(s - 1);
         uint32_t next0 = sym0 + T_S; if (next0 >= ring) next0 -= ring;
         const bool next_staged = (s + 1 < s_end) && dma_ok(next0);
-#if DEMOD_STAGE == 2
         // The samples lie in the tile (fft2048.h, "k_demod's variant"): a half is read, mixed, transformed and written back over
         // itself.  The next symbol's transfer starts behind this wave's round-C reads and is in flight during round C's arithmetic,
         // the demapper and the soft-bit stores -- and behind the other work-groups of the CU (three waves per SIMD).
@@ -327,15 +276,6 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
             fft_round_a_inplace<false>(x, h, tile, w, t);
         }
         fft_rounds_bc_split<false>(v, tile, w, t, [&]() { if (next_staged) dma_issue(next0); });
-#else
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            cf32 x[8];
-            if (staged) stage_half(x, stage, cur, osc, nco, ms, h, A.mix, t, checked); else load_half(x, iq, ring, cur, osc, nco, ms, h, A.mix, checked);
-            fft_round_a<false>(x, h, tile, w, t);
-        }
-        fft_rounds_bc<false>(v, tile, w, t, [&]() { if (next_staged) dma_issue(next0); });
-#endif
         sym0 = next0; staged = next_staged;
         cur.a += T_S; if (cur.a >= ring) cur.a -= ring;
         cur.ph -= ms.sTS; if (cur.ph < 0) cur.ph += INPUT_RATE;

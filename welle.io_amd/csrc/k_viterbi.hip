@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
     const int cw = g * 64 + lane;
     const int nsteps = A.c.nsteps;
     const bool live = cw < A.c.n_cw;
-    const int q = cw & 3, bf = cw >> 2;                    // bf = b * n_frames + f
+    const int q = cw & 3;
+    const int bf = A.frame_sel ? (cw >> 2) * A.n_frames + (A.frame_sel - 1) : cw >> 2;     // bf = b * n_frames + f
     const int b = live ? bf / A.n_frames : 0;
     const FrameDesc d = A.desc[live ? bf : 0];
     const int8_t* __restrict__ src = A.soft + ((size_t)b * A.soft_ring + (size_t)(d.frame_no % A.soft_ring)) * A.frame_stride + 2304 * q;
@@ -501,8 +502,9 @@ __global__ void __launch_bounds__(256) k_lin_gather(LinGatherArgs A)
 __global__ void k_fib_crc(CrcArgs A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = A.n_ens * A.n_frames * 12;
+    const int n = A.n_ens * (A.frame_sel ? 1 : A.n_frames) * 12;
     if (i >= n) return;
+    const int o = A.frame_sel ? ((i / 12) * A.n_frames + (A.frame_sel - 1)) * 12 + i % 12 : i;      // FIB index in [B][F][12]
     // the 32 bytes of a FIB as two 16-byte loads; bytes are consumed in transmission order (little-endian words)
     const uint4* p4 = reinterpret_cast<const uint4*>(A.fib + (size_t)i * 32);
     const uint4 qa = p4[0], qb = p4[1];
@@ -518,8 +520,8 @@ __global__ void k_fib_crc(CrcArgs A)
         for (int bit = 0; bit < 8; bit++) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
     }
     crc ^= 0xFFFF;
-    const bool valid = A.desc[i / 12].valid == 1;
-    A.ok[i] = (valid && crc == (((uint32_t)p[30] << 8) | p[31])) ? 1 : 0;
+    const bool valid = A.desc[o / 12].valid == 1;
+    A.ok[o] = (valid && crc == (((uint32_t)p[30] << 8) | p[31])) ? 1 : 0;
 }
 
 // saturating success counter (fic-handler.cpp:219-229), one thread per ensemble walks its FIBs in order
@@ -581,7 +583,7 @@ void launch_lin_gather(const LinGatherArgs& a, hipStream_t s)
 }
 void launch_fib_crc(const CrcArgs& a, hipStream_t s)
 {
-    const int n = a.n_ens * a.n_frames * 12;
+    const int n = a.n_ens * (a.frame_sel ? 1 : a.n_frames) * 12;
     hipLaunchKernelGGL(k_fib_crc, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_fic_ratio(const CrcArgs& a, hipStream_t s)
