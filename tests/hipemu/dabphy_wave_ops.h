@@ -25,6 +25,7 @@ static inline cf32 pk_add(cf32 a, cf32 b) { return cadd(a, b); }
 static inline cf32 pk_sub(cf32 a, cf32 b) { return csub(a, b); }
 static inline cf32 pk_cmul(cf32 a, cf32 b) { return cmul(a, b); }
 static inline cf32 pk_cmulc(cf32 a, cf32 b) { return cmul(a, cconj(b)); }
+static inline cf32 pk_cmul_unit(cf32 a, cf32 w) { return cmul(a, w); }
 static inline cf32 pk_sub_ib(cf32 a, cf32 b) { cf32 r; r.re = a.re + b.im; r.im = a.im - b.re; return r; }
 static inline cf32 pk_add_ib(cf32 a, cf32 b) { cf32 r; r.re = a.re - b.im; r.im = a.im + b.re; return r; }
 static inline int cvt_i32_trunc(float x)

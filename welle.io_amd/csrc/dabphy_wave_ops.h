@@ -55,6 +55,16 @@ __device__ __forceinline__ cf32 pk_cmulc(cf32 a, cf32 b)
     v2f r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
     return v2c(r);
 }
+// a * w for a twiddle w = (1, s) with s = +-0 (tw[0] of the KISS table is (1, -0)): (a.re * 1 - a.im * s, a.re * s + a.im * 1).  The
+// products by 1 are exact and a.im * s, a.re * s are exactly +-0 (or NaN), so ONE fused multiply-add per component returns the very
+// bits of the two multiplications and the addition -- zero signs, NaN and infinity included (fma rounds once, and nothing here rounds).
+// The host checks w.re == 1 when it builds the table.
+__device__ __forceinline__ cf32 pk_cmul_unit(cf32 a, cf32 w)
+{
+    v2f r; const v2f av = c2v(a), wv = c2v(w);
+    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(wv));
+    return v2c(r);
+}
 // a - i b = (a.re + b.im, a.im - b.re)   and   a + i b = (a.re - b.im, a.im + b.re)
 __device__ __forceinline__ cf32 pk_sub_ib(cf32 a, cf32 b)
 {

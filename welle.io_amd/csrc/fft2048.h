@@ -170,15 +170,38 @@ __device__ __forceinline__ void fft_raw_half(cf32 (&x)[8], const cf32* lds, int 
     for (int j = 0; j < 8; j++) x[j] = lds[fft_raw_index(t, h, j)];
 }
 
+// kf_bfly2 / kf_bfly4 with the unit twiddle tw[0] (the first two passes of the forward transform): same operations, the
+// multiplications by (1, -0) as one instruction each (pk_cmul_unit)
+__device__ __forceinline__ void bfly2_unit(cf32& f0, cf32& f1, cf32 tw)
+{
+    const cf32 t = pk_cmul_unit(f1, tw);
+    f1 = pk_sub(f0, t);
+    f0 = pk_add(f0, t);
+}
+__device__ __forceinline__ void bfly4_unit(cf32& f0, cf32& f1, cf32& f2, cf32& f3, cf32 tw)
+{
+    const cf32 s0 = pk_cmul_unit(f1, tw);
+    const cf32 s1 = pk_cmul_unit(f2, tw);
+    const cf32 s2 = pk_cmul_unit(f3, tw);
+    const cf32 s5 = pk_sub(f0, s1);
+    f0 = pk_add(f0, s1);
+    const cf32 s3 = pk_add(s0, s2);
+    const cf32 s4 = pk_sub(s0, s2);
+    f2 = pk_sub(f0, s3);
+    f0 = pk_add(f0, s3);
+    f1 = pk_sub_ib(s5, s4); f3 = pk_add_ib(s5, s4);
+}
+
 template <bool INV>
 __device__ __forceinline__ void fft_round_a_inplace(const cf32 (&x)[8], int h, cf32* lds, const FftTwiddles& w, int t)
 {
+    static_assert(!INV, "forward transform only (k_demod)");
     cf32 a[8];
 #pragma unroll
     for (int j5 = 0; j5 < 4; j5++) { a[2 * j5] = x[j5]; a[2 * j5 + 1] = x[j5 + 4]; }
 #pragma unroll
-    for (int j5 = 0; j5 < 4; j5++) bfly2<INV>(a[2 * j5], a[2 * j5 + 1], w.t0);
-    bfly4<INV>(a[0], a[2], a[4], a[6], w.t0, w.t0, w.t0);
+    for (int j5 = 0; j5 < 4; j5++) bfly2_unit(a[2 * j5], a[2 * j5 + 1], w.t0);
+    bfly4_unit(a[0], a[2], a[4], a[6], w.t0);
     bfly4<INV>(a[1], a[3], a[5], a[7], w.a1, w.a2, w.a3);
 #pragma unroll
     for (int r = 0; r < 8; r++) lds[fft_raw_index(t, h, r)] = a[r];
