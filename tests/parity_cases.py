@@ -296,7 +296,8 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, a
 
 
 # ---- DAB+ superframe filter on the device vs the oracle's (itself pinned to the real SuperframeFilter)
-def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True, auto_modes=(False, True), cfo=20, stats=None, min_synced=1):
+def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True, auto_modes=(False, True), cfo=20, stats=None, min_synced=1,
+                                ensemble=None, pick=(1, 6)):
     """superframes straddle the batches (12 logical frames per batch, 5 per superframe); the noise level makes the Viterbi
     output carry byte errors for Reed-Solomon to correct (no loss of lock: batch mode and the reference drop different
     frames then), and the transmitter damages some superframes beyond repair: a broken access unit, more byte errors than
@@ -314,8 +315,9 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
             if q == 8 and k == 0:
                 for j in range(4, 10): data[j * (sc.bitrate // 8)] ^= 0x81           # header column uncorrectable -> Fire code fails -> window slides
         return bytes(data)
-    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=50, return_tx=True, seed=seed, payload_fn=payload)
-    subs = [tx.subchs[1], tx.subchs[6]]
+    # ensemble: the sub-channels of the multiplex (default: 18 x 64 kbit/s); pick: the ones the filter is checked on
+    x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=50, return_tx=True, seed=seed, payload_fn=payload, subchs=ensemble)
+    subs = [tx.subchs[i] for i in pick]
     o = R.orc_receiver_run(x, subchs=subs)
     d = d_factory(n_ensembles=B, max_frames=F, want_constellation=False)
     try:

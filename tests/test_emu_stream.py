@@ -49,6 +49,14 @@ def test_superframe_filter(emu):
     assert any(e[0] > 0 for e in ev) and any(e[1] and e[2] and e[6] != 7 for e in ev) and any(not e[2] for e in ev[2:])   # corrections, a broken AU, a lost sync
 
 
+def test_superframe_filter_other_bit_rates(emu):
+    """the filter's other instances: 128 / 192 / 256 kbit/s (superframes of 1920 / 2880 / 3840 bytes: 16 - 32 code words, rows of more than
+    one LDS-DMA request) and 32 kbit/s (4 code words: half a syndrome round), damaged superframes included, both ways through a batch"""
+    from welle_io_amd import synth
+    ens = [synth.SubchannelCfg(1, 0, 128), synth.SubchannelCfg(2, 96, 192), synth.SubchannelCfg(3, 240, 256), synth.SubchannelCfg(4, 432, 32)]
+    P.check_superframes_vs_oracle(factory, nf=20, B=1, ensemble=ens, pick=(0, 1, 2, 3), auto_modes=(True,))
+
+
 def test_mixed_protection_classes(emu):
     P.check_mixed_ensemble(factory, expect_fused=False)
 
