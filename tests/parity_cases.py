@@ -689,7 +689,7 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
     return logs
 
 
-def check_demod_chunks(d_factory, chunks=(7, 25, 38, 75), snr_db=13, seed=2, early=150):
+def check_demod_chunks(d_factory, chunks=(1, 3, 7, 25, 38, 75), snr_db=13, seed=2, early=150):
     """explicit dabphy_config.demod_chunk values (work-groups of 7 / 25 / 75 data symbols; create() picks 25 for B x F >= 1024, the
     benchmark's case, and 15 otherwise): all 230 400 soft bits and the constellation taps equal the oracle's"""
     x = synth.make_stream(4, snr_db=snr_db, seed=seed)

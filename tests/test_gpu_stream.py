@@ -167,6 +167,14 @@ def test_exact_batch_mode(gpu, snr, cfo, F, seed, pipeline, replay):
     P.check_exact_batch(factory, snr, cfo, F, seed, pipeline_sync=pipeline, expect_replay=replay)
 
 
+@pytest.mark.parametrize("chunk", [1, 2])
+def test_exact_batch_mode_with_short_demod_chunks(gpu, chunk):
+    """the replay demodulates only the chunks that hold the FIC symbols 1 .. 3 of a frame: with one or two symbols per work-group that
+    is three or two chunks (a replay that took only the first one read stale soft bits: advisor, round 2); the batch must still equal
+    the oracle frame for frame and must have been decoded twice"""
+    P.check_exact_batch(lambda **kw: factory(demod_chunk=chunk, **kw), 3, -1000, 4, 5, pipeline_sync=False, expect_replay=True)
+
+
 def test_superframes_through_a_replayed_batch(gpu):
     """exact batch mode with the superframe filter: a 3.5 dB stream in which one batch has to be decoded a second time -- the filter's
     windows are put back with the rest of the state -- gives the oracle's superframe events, corrected superframes and totals whether
