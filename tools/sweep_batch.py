@@ -3,9 +3,12 @@ schedule, every stream through tests/parity_cases.check_stream_vs_oracle -- FIBs
 symbols, SNR reports and the MSC bytes of three sub-channels against the oracle, frame by frame; batch mode's documented deviation
 (a coarse-corrector decision taken with a stale FIC ratio) is tolerated only from the frame the library itself reports -- and reports
 how many frames came from the wide synchroniser pass and how many OFDM symbols took the unchecked / checked oscillator conversion.
-python tools/sweep_batch.py [n_streams] [seed] [exact]
+python tools/sweep_batch.py [n_streams] [seed] [exact | channels]
 With `exact` the library's default is swept instead -- exact batch mode, replay armed -- at 2-8 dB, and NO tolerance is given: every frame
-must equal the oracle's; the replayed batches are counted."""
+must equal the oracle's; the replayed batches are counted.
+With `channels` (exact batch mode too, 6-20 dB) every stream also passes a random channel: one to three echoes with complex gains and delays
+from -250 to 700 samples (pre-echoes, echoes beyond the guard interval), a sampling-clock offset of up to +-120 ppm, flat fading of
+10-40 % at 2-12 Hz -- each with probability 1/2 --, and a random FFT placement method: the signals that break the wide pass' prediction."""
 import os
 import sys
 
@@ -21,7 +24,8 @@ from welle_io_amd import capi  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = os.environ.get("DABPHY_LIB", GPU_LIB)
-exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
+chan = len(sys.argv) > 3 and sys.argv[3] == "channels"
+exact = (len(sys.argv) > 3 and sys.argv[3] == "exact") or chan
 
 
 def factory(**kw):
@@ -36,11 +40,24 @@ for it in range(n):
     nf = int(rng.choice([18, 26, 34]))
     if exact and rng.rand() < 0.5:
         cfo = float(rng.choice([-2400, -1000, 300, 1500, 2300, 17400]))
-    logs, o, _ = P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, False, B=2, F=F, pipeline_sync=pipe, seed=seed, ratio_lag_ok=not exact)
+    channel = None; placement = 2; desc = ""
+    if chan:
+        snr = float(rng.choice([6, 8, 10, 14, 20]))
+        channel = {}
+        if rng.rand() < 0.5:
+            channel["echoes"] = [(int(rng.randint(-250, 700)), complex(rng.uniform(0.2, 0.9) * np.exp(1j * rng.uniform(0, 2 * np.pi)))) for _ in range(int(rng.randint(1, 4)))]
+        if rng.rand() < 0.5:
+            channel["ppm"] = float(rng.uniform(-120, 120))
+        if rng.rand() < 0.5:
+            channel["fade"] = (float(rng.uniform(0.1, 0.4)), float(rng.uniform(2, 12)))
+        placement = int(rng.choice([0, 1, 2]))
+        desc = "  placement %d  channel %s" % (placement, {k: (["%d:%.2f%+.2fj" % (d_, g.real, g.imag) for d_, g in v] if k == "echoes" else v) for k, v in channel.items()})
+    logs, o, _ = P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, False, B=2, F=F, pipeline_sync=pipe, seed=seed, ratio_lag_ok=not exact,
+                                          fft_placement=placement, channel=channel or None)
     replayed += logs[0]["replayed"]
     L = logs[0]
     k = len(L["info"]); frames += k; wide += L["wide"][0]; fast += L["osc"][0]; checked += L["osc"][1]; lagged += int(L["ratio_lag"][0] > 0); effective += int(L["ratio_lag_effect"][0] > 0)
     print("stream %3d  snr %4.0f dB  cfo %7.1f Hz  delay %4d  F %d  schedule %d  frames %2d  from the wide pass %2d  oscillator symbols unchecked/checked %d/%d  ratio lag %s with an effect %s"
-          % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"], L["ratio_lag_effect"]), flush=True)
+          % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"], L["ratio_lag_effect"]) + desc, flush=True)
 print("streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  batches decoded twice %d  mismatches 0"
       % (n, frames, wide, fast, checked, lagged, effective, replayed))
