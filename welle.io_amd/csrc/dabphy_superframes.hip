@@ -22,11 +22,11 @@ int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t
     if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
     if ((r = ensure(h, h->sf_accept, sizeof(int32_t) * B * M))) return r;
     if (!h->sf_gf.p) {
-        // GF(256) of RS(120,110), generator polynomial 0x11D (init_rs.h:48-60): alpha_to[256], index_of[256]
-        static uint8_t gf[512];
-        int sr = 1;
-        gf[256 + 0] = 255; gf[255] = 0;
-        for (int i = 0; i < 255; i++) { gf[256 + sr] = (uint8_t)i; gf[i] = (uint8_t)sr; sr <<= 1; if (sr & 256) sr ^= 0x11D; sr &= 255; }
+        // GF(256) of RS(120,110), generator polynomial 0x11D (init_rs.h:48-60): alpha_to[256], index_of[256]  (built once, thread-safely:
+        // the node receiver creates its handles from several host threads)
+        struct Gf { uint8_t b[512]; Gf() { int sr = 1; memset(b, 0, sizeof b); b[256 + 0] = 255; b[255] = 0; for (int i = 0; i < 255; i++) { b[256 + sr] = (uint8_t)i; b[i] = (uint8_t)sr; sr <<= 1; if (sr & 256) sr ^= 0x11D; sr &= 255; } } };
+        static const Gf gf_tab;
+        const uint8_t (&gf)[512] = gf_tab.b;
         if ((r = ensure(h, h->sf_gf, sizeof gf + 2 * sizeof(unsigned long long)))) return r;      // + the wide pass' two counters
         HIPCHK(h, hipMemsetAsync(h->sf_gf.p, 0, sizeof gf + 2 * sizeof(unsigned long long), h->stream));
         HIPCHK(h, hipMemcpyAsync(h->sf_gf.p, gf, sizeof gf, hipMemcpyHostToDevice, h->stream));

@@ -11,6 +11,10 @@
 // bytes, the corrected-symbol count and the "uncorrectable" verdict equal the reference's also for words beyond the
 // correction capacity (miscorrections included: tests/golden rs vectors, random error patterns of weight 0 .. 12 against
 // the oracle, which is pinned to decode_rs_char itself).  GF tables live in LDS.
+//
+// Second half of the file: the DAB+ superframe filter (SuperframeFilter::Feed / CheckSync, dabplus_decoder.cpp:50-213) on the
+// class output of a batch -- k_superframe_wide + k_superframe_settle (every attempt a receiver in lock makes in the batch at once,
+// accepted per sub-channel iff all of them synchronise) and k_superframe (the reference's walk frame by frame, for what is left).
 #include "dabphy_kernels.h"
 #include <dabphy_wave_ops.h>
 
