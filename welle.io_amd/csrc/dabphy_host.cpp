@@ -45,7 +45,8 @@ static void build(HostTables& T)
         T.tw[i].re = (float)cos(phase);
         T.tw[i].im = (float)sin(phase);
     }
-    if (T.tw[0].re != 1.0f || T.tw[0].im != 0.0f) abort();      // pk_cmul_unit (k_demod's first two passes) counts on tw[0] = (1, +-0)
+    // pk_cmul_unit (k_demod's first two passes) counts on tw[0] = (1, +-0): cos(-0.0) and sin(-0.0) of any libm
+    if (T.tw[0].re != 1.0f || T.tw[0].im != 0.0f) { fprintf(stderr, "dabphy: this libm's cos(-0.0) / sin(-0.0) are not 1 / -0: the twiddle table cannot be used\n"); abort(); }
     T.nco.resize(INPUT_RATE);
     for (int i = 0; i < INPUT_RATE; i++) {
         T.nco[i].re = (float)cos(2.0 * M_PI * i / INPUT_RATE);
