@@ -356,6 +356,10 @@ int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
  * (ofdm-decoder.cpp:208 computes 127.0f / l1_norm): every float x in [2^-100, 2^100] is divided both ways on the device.
  * counts[0] = mismatches of the 4-instruction variant, counts[1] = of the 6-instruction variant, counts[2] = values tried. */
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts);
+/* Device self-test of the one-instruction product by the unit twiddle tw[0] = (1, +-0) in the first two passes of the demod kernel's
+ * FFT (kiss_fft.c:21-90 multiplies by it like by any other twiddle): 2^33 operand pairs -- every exponent, zeros, denormals, infinities
+ * and NaNs included -- through both forms.  counts[0] = results that differ in a bit (two NaNs count as equal), counts[1] = pairs tried. */
+int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
 
 #ifdef __cplusplus
 }

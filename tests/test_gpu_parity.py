@@ -62,6 +62,14 @@ def test_div127_exhaustive(gpu):
     assert bad4 == 0, "4-instruction variant (the one k_demod is built with): %d mismatches" % bad4
 
 
+def test_unit_twiddle_product_exhaustive(gpu):
+    """the fused product by tw[0] = (1, +-0) in the demod kernel's first two FFT passes returns the bits of the two multiplications and
+    the addition it replaces: zero signs, denormals, infinities, NaNs"""
+    bad, tried = gpu.selftest_unit_twiddle()
+    assert tried == 4 * 2 ** 32
+    assert bad == 0, "%d of %d products differ" % (bad, tried)
+
+
 def test_demod_zero_carriers(gpu):
     frames = np.zeros((1, 2048 + 75 * 2552), np.complex64)
     soft, con, _ = gpu.demod_frames(frames)

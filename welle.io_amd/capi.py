@@ -196,6 +196,11 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_tii(self.h, _p(ev), _p(n), m))
         return [ev[b, :min(int(n[b]), m)].copy() for b in range(B)], n
 
+    def selftest_unit_twiddle(self):
+        c = (C.c_uint64 * 2)()
+        self._chk(self.lib.dabphy_selftest_unit_twiddle(self.h, c))
+        return [int(x) for x in c]
+
     def selftest_div127(self):
         c = (C.c_uint64 * 3)()
         self._chk(self.lib.dabphy_selftest_div127(self.h, c))

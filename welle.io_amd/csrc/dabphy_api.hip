@@ -385,6 +385,22 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
     return DABPHY_OK;
 }
 
+int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts)
+{
+    DeviceBind dev_(h);
+    if (!h || !counts) return DABPHY_ERR_INVALID;
+    unsigned long long* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, 2 * sizeof *d));
+    HIPCHK(h, hipMemsetAsync(d, 0, 2 * sizeof *d, h->stream));
+    launch_selftest_unit_twiddle(d, h->stream);
+    unsigned long long host[2];
+    HIPCHK(h, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    const int r = sync(h);
+    (void)hipFree(d);
+    for (int i = 0; i < 2; i++) counts[i] = host[i];
+    return r;
+}
+
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)
 {
     DeviceBind dev_(h);

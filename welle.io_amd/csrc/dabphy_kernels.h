@@ -247,6 +247,7 @@ void launch_rs_msc(const RsMscArgs& a, hipStream_t s);
 void launch_demod(const DemodArgs& a, int n_ens, hipStream_t s);
 void launch_snr(const SnrArgs& a, hipStream_t s);
 void launch_selftest_div127(unsigned long long* out, hipStream_t s);
+void launch_selftest_unit_twiddle(unsigned long long* out, hipStream_t s);
 void launch_viterbi(const VitArgs& a, hipStream_t s);
 void launch_fic_gather(const FicGatherArgs& a, hipStream_t s);
 void launch_msc_gather(const MscGatherArgs& a, hipStream_t s);

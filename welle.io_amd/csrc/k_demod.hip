@@ -386,6 +386,40 @@ __global__ void k_selftest_div127(unsigned long long* out)
     if (bad1) atomicAdd(&out[1], bad1);
     if (tried) atomicAdd(&out[2], tried);
 }
+// pk_cmul_unit against the two multiplications and the addition it stands for (pk_cmul), on 2^32 pairs of float bit patterns per
+// twiddle sign: re = every exponent x sign x a sample of mantissas (zeros, denormals, infinities, NaNs included), im = a hash of it and,
+// for one thread in eight, one of the special values.  A mismatch = different bits, unless both results are NaN (payloads are nobody's
+// business: every later stage only asks whether a value is NaN).
+__device__ __forceinline__ bool same_float(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+__global__ void k_selftest_unit_twiddle(unsigned long long* out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;                        // 2^24 threads
+    const uint32_t special[8] = {0x00000000u, 0x80000000u, 0x7f800000u, 0xff800000u, 0x7fc00000u, 0x00000001u, 0x807fffffu, 0x7f7fffffu};
+    unsigned long long bad = 0, tried = 0;
+    for (uint32_t k = 0; k < 256; k++) {
+        const uint32_t n = i * 256u + k;
+        const uint32_t rb = (n << 23) | (n >> 9);                              // all 512 sign/exponent combinations x 2^23 mantissas over the run
+        uint32_t ib = rb * 2654435761u + 0x9e3779b9u; ib ^= ib >> 15; ib *= 2246822519u; ib ^= ib >> 13;
+        if ((n & 7u) == 3u) ib = special[(n >> 3) & 7u];
+        cf32 x; x.re = __uint_as_float(rb); x.im = __uint_as_float(ib);
+        for (int sgn = 0; sgn < 2; sgn++) {
+            cf32 w; w.re = __uint_as_float(opaque_vgpr(0x3f800000u)); w.im = __uint_as_float(opaque_vgpr(sgn ? 0x80000000u : 0u));   // (values the compiler cannot fold)
+            const cf32 a = pk_cmul(x, w), b = pk_cmul_unit(x, w);
+            bad += !(same_float(a.re, b.re) && same_float(a.im, b.im));
+            cf32 y; y.re = x.im; y.im = x.re;                                    // (and with the parts exchanged)
+            const cf32 c = pk_cmul(y, w), d = pk_cmul_unit(y, w);
+            bad += !(same_float(c.re, d.re) && same_float(c.im, d.im));
+            tried += 2;
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], tried);
+}
+void launch_selftest_unit_twiddle(unsigned long long* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_unit_twiddle, dim3(1u << 16), dim3(256), 0, s, out);
+}
+
 void launch_selftest_div127(unsigned long long* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_selftest_div127, dim3(1u << 16), dim3(256), 0, s, out);
