@@ -297,7 +297,7 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, a
 
 # ---- DAB+ superframe filter on the device vs the oracle's (itself pinned to the real SuperframeFilter)
 def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2, damage=True, auto_modes=(False, True), cfo=20, stats=None, min_synced=1,
-                                ensemble=None, pick=(1, 6)):
+                                ensemble=None, pick=(1, 6), damage_q=(6, 8)):
     """superframes straddle the batches (12 logical frames per batch, 5 per superframe); the noise level makes the Viterbi
     output carry byte errors for Reed-Solomon to correct (no loss of lock: batch mode and the reference drop different
     frames then), and the transmitter damages some superframes beyond repair: a broken access unit, more byte errors than
@@ -308,11 +308,11 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
         data = bytearray(base(sc, r))
         if damage:
             q, k = (r % 80) // 5, r % 5
-            if q == 6 and k == 2: data[40] ^= 0x5A                                   # inside an access unit of superframe 6: AU CRC fails after RS has nothing to say
-            if q == 6 and k == 2:
+            if q == damage_q[0] and k == 2: data[40] ^= 0x5A                         # inside an access unit of superframe 6: AU CRC fails after RS has nothing to say
+            if q == damage_q[0] and k == 2:
                 for j in range(12): data[3 + j * (sc.bitrate // 8)] ^= 0x33          # ... because codeword 3 is beyond repair
-            if q == 8 and k == 0: data[0] ^= 0xFF; data[sc.bitrate // 8] ^= 0xFF; data[2 * (sc.bitrate // 8)] ^= 1; data[3 * (sc.bitrate // 8)] ^= 7
-            if q == 8 and k == 0:
+            if q == damage_q[1] and k == 0: data[0] ^= 0xFF; data[sc.bitrate // 8] ^= 0xFF; data[2 * (sc.bitrate // 8)] ^= 1; data[3 * (sc.bitrate // 8)] ^= 7
+            if q == damage_q[1] and k == 0:
                 for j in range(4, 10): data[j * (sc.bitrate // 8)] ^= 0x81           # header column uncorrectable -> Fire code fails -> window slides
         return bytes(data)
     # ensemble: the sub-channels of the multiplex (default: 18 x 64 kbit/s); pick: the ones the filter is checked on
@@ -356,7 +356,7 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
         # both ways through the filter were taken: batches whose attempts all synchronised were settled by the wide pass, the damaged
         # ones (and the first, which only fills the window) were walked frame by frame
         settled, tried = d.wide_superframe_stats()
-        assert tried > 0 and (0 < settled < tried if damage and nf >= 16 else settled <= tried), (settled, tried)
+        assert tried > 0 and (0 < settled < tried if damage and nf >= 16 and damage_q == (6, 8) else settled <= tried), (settled, tried)
         if stats is not None:
             stats["sf_wide"] = (settled, tried)
     finally:

@@ -67,6 +67,13 @@ def test_superframe_filter(gpu):
     assert any(e[0] > 0 for e in ev) and any(e[1] and e[2] and e[6] != 7 for e in ev) and any(not e[2] for e in ev[2:])   # corrections, a broken AU, a lost sync
 
 
+@pytest.mark.parametrize("F,damage_q", [(2, (1, 7)), (3, (3, 9)), (5, (4, 12))])
+def test_superframe_filter_where_the_damage_falls(gpu, F, damage_q):
+    """a broken and a lost superframe at other places and other batch depths (F = 2 with superframe 7 lost: the wide pass starts from a full
+    window that had failed and is accepted): events, corrected superframes and totals still the oracle's"""
+    P.check_superframes_vs_oracle(factory, F=F, nf=22, B=1, damage_q=damage_q, auto_modes=(True,))
+
+
 def test_superframe_filter_other_bit_rates(gpu):
     """the filter's other instances: 128 / 192 / 256 kbit/s (superframes of 1920 / 2880 / 3840 bytes: 16 - 32 code words, rows of more than
     one LDS-DMA request) and 32 kbit/s (4 code words: half a syndrome round), damaged superframes included, both ways through a batch"""
