@@ -248,7 +248,9 @@ def raw_encode(x, fmt):
     return raw, (f[:, 0] + 1j * f[:, 1]).astype(np.complex64)
 
 
-def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, asynchronous=False):
+def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, asynchronous=False, ring_extra=0):
+    """ring_extra: the ring is 6 frames + this many samples long, so that the place where it wraps moves through the frame from revolution
+    to revolution (the demod kernel takes the symbol that straddles the end straight from HBM instead of through its LDS-DMA pipeline)"""
     T_F = 196608
     x, tx = synth.make_stream(nf, snr_db=snr_db, cfo_hz=cfo, delay=300, return_tx=True, seed=seed)
     subs = [tx.subchs[2], tx.subchs[11]]
@@ -256,7 +258,8 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, a
     o = R.orc_receiver_run(xf, subchs=subs)
     d = d_factory(n_ensembles=1, max_frames=1, want_constellation=False)
     try:
-        d.stream_open(6 * T_F)
+        ring = 6 * T_F + ring_extra
+        d.stream_open(ring)
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, d.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subs])
         fibs, oks, msc = [], [], [[] for _ in subs]
         wr = 0
@@ -282,7 +285,7 @@ def check_live_raw_vs_oracle(d_factory, fmt, nf=9, seed=5, snr_db=18, cfo=-35, a
                     m, fv = d.msc(i); msc[i].append(m[0, fv[0]:4].tobytes())
             else:
                 idle += 1
-            room = 6 * T_F - (wr - d.stream_consumed())
+            room = ring - (wr - d.stream_consumed())
             feed(min(room, T_F))
         n = len(fibs)
         assert n >= o["n_frames"] - 1, (n, o["n_frames"])

@@ -82,6 +82,14 @@ def test_other_freqsync_methods(emu, freqsync, cfo, snr):
     P.check_stream_vs_oracle(factory, snr, cfo, 250, 10, True, seed=50 + freqsync, freqsync=freqsync)
 
 
+@pytest.mark.parametrize("ring_extra", [44500, 77777])
+def test_live_ring_that_wraps_inside_the_frames(emu, ring_extra):
+    """a ring of 6 frames + 44 500 / 77 777 samples: its end falls on another OFDM symbol in every revolution -- the first symbol of a demod
+    work-group's chunk (its LDS-DMA pipeline starts one symbol late) and symbols in the middle of a chunk (the pipeline is interrupted and
+    picked up again); that symbol comes straight from HBM.  (Which symbols: seen by instrumenting the kernel once.)"""
+    P.check_live_raw_vs_oracle(factory, "s16le", nf=20, ring_extra=ring_extra)
+
+
 def test_live_ring_async_ingest(emu):
     """dabphy_stream_write_raw_async: copy + conversion on the copy stream, dabphy_process orders itself behind them"""
     P.check_live_raw_vs_oracle(factory, "u8", asynchronous=True)
