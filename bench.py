@@ -35,10 +35,11 @@ CLOCK_HZ = 2.4e9                                             # MI355X_MICROARCH.
 PARITY_SUBCH = (0, 7, 17)                                    # sub-channels whose MSC bytes the parity leg compares
 
 
-def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir, cwd=None):
-    """n_proc concurrent receiver processes, receiver i over recording recs[i % len(recs)]; returns their result records"""
+def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir, cwd=None, layout=None):
+    """n_proc concurrent receiver processes, receiver i over recording recs[i % len(recs)]; returns their result records
+    (layout: JSON file with the multiplex when it is not the canonical one)"""
     args = [sys.executable, os.path.join(ROOT, "tests", "cpu_baseline_worker.py")]
-    procs = [subprocess.Popen(args + [recs[i % len(recs)], str(n_loops), mode, os.path.join(out_dir, "%s_%d.npz" % (mode, i)) if i < len(recs) else "-"],
+    procs = [subprocess.Popen(args + [recs[i % len(recs)], str(n_loops), mode, os.path.join(out_dir, "%s_%d.npz" % (mode, i)) if i < len(recs) else "-"] + ([layout] if layout else []),
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=open(os.path.join(out_dir, "%s_err.txt" % mode), "w") if i == 0 else subprocess.DEVNULL, text=True, env=env, cwd=cwd) for i in range(n_proc)]
     for p in procs:
         if p.stdout.readline().strip() != "READY":
@@ -54,9 +55,9 @@ def _run_receivers(recs, n_proc, n_loops, mode, env, out_dir, cwd=None):
     return res
 
 
-def _compare_with_receivers(td, mode, ens_list, gpu_logs):
-    """FIB bytes + CRC flags and the MSC bytes of PARITY_SUBCH of every ensemble in ens_list: GPU log vs the files receiver i of `mode`
-    left in td; raises AssertionError on the first difference; returns (frames compared, MSC bytes compared per sub-channel)"""
+def _compare_with_receivers(td, mode, ens_list, gpu_logs, subch_idx=PARITY_SUBCH):
+    """FIB bytes + CRC flags and the MSC bytes of the sub-channels subch_idx of every ensemble in ens_list: GPU log vs the files receiver i
+    of `mode` left in td; raises AssertionError on the first difference; returns (frames compared, MSC bytes compared of the last sub-channel)"""
     n = m = 0
     for i, e in enumerate(ens_list):
         z = np.load(os.path.join(td, "%s_%d.npz" % (mode, i)))
@@ -67,7 +68,7 @@ def _compare_with_receivers(td, mode, ens_list, gpu_logs):
         ok = np.array_equal(np.array(g["ok"][:n]), zf[:, :, 0]) and np.array_equal(np.array(g["fib"][:n]), zf[:, :, 1:])
         if not ok:
             raise AssertionError("parity: FIBs of ensemble %d differ from the %s receiver's" % (e, mode))
-        for k, i_sub in enumerate(PARITY_SUBCH):
+        for k, i_sub in enumerate(subch_idx):
             got = b"".join(g["msc"][k]); want = z["msc%d" % i_sub].tobytes()
             m = min(len(got), len(want))
             if m == 0 or got[:m] != want[:m]:
@@ -170,6 +171,64 @@ def cpu_baseline(rows, n_loops, gpu_logs):
     return base, parity
 
 
+def hetero_leg(capi, workload, torch, lib_path, B, F, steps, local, sched):
+    """The same hot path over a multiplex as they are on air (workload.HETERO_LAYOUT: 15 sub-channels, 6 protection classes incl. EEP-B
+    and UEP, code words of 192 .. 3072 bits), B x F, timed after the headline; never `value`.  Parity of this very run: FIBs and the MSC
+    bytes of EVERY sub-channel of the first, a middle and the last ensemble against the oracle on the same rows."""
+    import tempfile
+    lib = capi.load_library(lib_path)
+    subchs = workload.hetero_subchannels(lib)
+    rec_frames = workload.rec_frames_for(F)
+    base = workload.make_base_streams(2, rec_frames, seed0=50, subchs=subchs)
+    iq, cfo_hz, base_np, txs = workload.make_batch(B, rank=7, device="cuda", base=base, rec_frames=rec_frames)
+    dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=sched)
+    out = {"workload": "%d ensembles x %d frames, %d sub-channels in %d protection classes: %s" % (
+        B, F, len(subchs), len({(s.bitrate, s.profile_b, s.level, s.uep is not None) for s in subchs}),
+        ", ".join("%dk %s" % (s.bitrate, ("UEP-%d" % s.level) if s.uep is not None else "EEP-%d%s" % (s.level, "B" if s.profile_b else "A")) for s in subchs))}
+    try:
+        check = sorted({0, B // 2, B - 1})
+        idx = list(range(len(subchs)))
+        logs = {e: dict(fib=[], ok=[], msc=[[] for _ in idx]) for e in check}
+        for W in range(3):
+            dev.process(F); sf = dev.superframes_stats()
+            if W * F < 64:
+                info = dev.frame_info(); fib, ok = dev.fibs(); mscs = [dev.msc(i) for i in idx]
+                for e in check:
+                    valid = [f for f in range(F) if info[e, f]["valid"] == 1]
+                    for f in valid:
+                        logs[e]["fib"].append(np.array(fib[e, f])); logs[e]["ok"].append(np.array(ok[e, f]))
+                    for k in idx:
+                        m, fv = mscs[k]
+                        logs[e]["msc"][k].append(m[e, fv[e]:4 * len(valid)].tobytes())
+        torch.cuda.synchronize(); t0 = time.perf_counter(); acc = {}
+        for _ in range(steps):
+            dev.process(F); sf = dev.superframes_stats(); fib, ok = dev.fibs_host()
+            for k, v in dev.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        assert np.asarray(ok).all(), "FIB CRC failures in the heterogeneous signal"
+        assert (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all() and (sf[:, 0] >= len(subchs) * (4 * F // 5)).all(), "superframe filter: %s" % sf[:4]
+        n_cw_steps = B * 4 * F * sum(24 * s.bitrate + 6 for s in subchs)
+        out.update(value=B * F * FRAME_S / dt, unit="x real-time", ms_per_step=dt * 1e3, stages_ms={k: v / steps for k, v in acc.items()},
+                   msc_viterbi_ms=acc.get("msc_viterbi", 0.0) / steps, demod_ms=acc.get("demod", 0.0) / steps,
+                   codeword_steps_per_s=n_cw_steps / (acc.get("msc_viterbi", 0.0) / steps * 1e-3) if acc.get("msc_viterbi") else None,
+                   launches="one fused launch for all classes and the FIC (dabphy_fused.hip: work list, longest code words first)")
+        with tempfile.TemporaryDirectory() as td:
+            recs = []
+            for e in check:
+                path = os.path.join(td, "rec%d.npy" % e); np.save(path, iq[e].cpu().numpy()); recs.append(path)
+            layout = os.path.join(td, "layout.json"); json.dump(workload.subchannels_to_json(subchs), open(layout, "w"))
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            _run_receivers(recs, len(recs), max(2, -(-80 // rec_frames)), "port", env, td, layout=layout)
+            n, m = _compare_with_receivers(td, "port", check, logs, subch_idx=idx)
+        out.update(parity=True, parity_detail="FIBs + CRC flags of %d frames and the MSC bytes of all %d sub-channels of ensembles %s equal the oracle's (C restatement, same rows)" % (n, len(subchs), check))
+    except AssertionError as ex:
+        out.update(parity=False, parity_error=str(ex))
+    finally:
+        dev.close()
+    return out
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -224,7 +283,7 @@ def main():
     ap.add_argument("--cfo-max-hz", type=float, default=60.0, help="per-ensemble carrier frequency offsets are drawn from +-this (small enough for DQPSK to decode from the first frame on, so every ensemble keeps the same frame count; the oscillator cost does not depend on the value)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and with it the parity check of this run)")
     ap.add_argument("--no-alt-schedule", action="store_true", help="skip the extra (untimed) pass with the other pipelined schedule")
-    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements behind the timed region (single-ensemble facade latency, host-u8 PCIe-inclusive rate)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements behind the timed region (heterogeneous multiplex, single-ensemble facade latency, host-u8 PCIe-inclusive rate)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -266,7 +325,15 @@ def main():
 
     B, F = args.ensembles, args.frames
     rec_frames = workload.rec_frames_for(F)                # the looping recording is at least one batch long: a step reads every sample once
+    # (every rank builds its own recordings on its host cores before the first barrier: bounded like the rendezvous, so that a rank that
+    # never arrives says so instead of leaving the others in a collective until its timeout)
+    import threading
+
+    def _slow_signal():
+        sys.stderr.write("bench.py rank %d/%d: building the synthetic signal took more than 900 s -- giving up\n" % (rank, world)); sys.stderr.flush(); os._exit(4)
+    dog2 = threading.Timer(900.0, _slow_signal); dog2.daemon = True; dog2.start()
     iq, cfo_hz, base, txs = workload.make_batch(B, rank=rank, cfo_max_hz=args.cfo_max_hz, device="cuda", rec_frames=rec_frames)
+    dog2.cancel()
     N = iq.shape[1]
     torch.cuda.synchronize()
     subchs = txs[0].subchs
@@ -347,10 +414,15 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    demod_ms_ranks = None
     if dist is not None:
         tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # the FFT stage's kernel time of every rank (HIP events of each rank's own launches): the roofline is quoted on the slowest
+        td_ = torch.zeros(world, device=tt.device, dtype=torch.float64); td_[rank] = stage_acc.get("demod", 0.0) / args.steps
+        dist.all_reduce(td_, op=dist.ReduceOp.SUM)
+        demod_ms_ranks = [float(v) for v in td_.cpu()]
 
     # ---- multi-rank runs: every rank proves ITS shard (outside the timed region): the first and the last ensemble of the shard through
     # the oracle on this host, FIBs + CRC flags + MSC bytes of three sub-channels from the very first frame on; the verdicts are summed
@@ -379,7 +451,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = world * B * F * FRAME_S / (dt / args.steps)
         stages = {k: v / args.steps for k, v in stage_acc.items()}
-        demod_ms = stages["demod"]
+        demod_ms = max(demod_ms_ranks) if demod_ms_ranks else stages["demod"]
         ach = B * F * ALG_BYTES_DEMOD_PER_FRAME / (demod_ms * 1e-3) / 1e9
         stale = []
         pj = _static_profile("demod_hbm_traffic.json", B, F, lib_path, stale)
@@ -396,6 +468,7 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": pj.get("hbm_bytes_per_launch") if pj else None,
                          "traffic_source": ("static: profiles/demod_hbm_traffic.json (FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh on this command; not measured by this run)" if pj else None),
                          "algorithmic_bytes_per_launch": B * F * ALG_BYTES_DEMOD_PER_FRAME, "kernel_ms": demod_ms,
+                         "kernel_ms_per_rank": demod_ms_ranks, "kernel_ms_note": ("per launch, HIP events on the launch's stream; with ranks: the SLOWEST rank's (each rank launches the kernel on its own %d x %d shard)" % (B, F)) if demod_ms_ranks else "per launch, HIP events on the launch's stream",
                          "classic_c2c_GBps": B * F * ALG_BYTES_FFT_CLASSIC_PER_FRAME / (demod_ms * 1e-3) / 1e9,
                          "survey_8d_fused_GBps": B * F * (196608 * 8 + 75 * 3072) / (demod_ms * 1e-3) / 1e9},
             "stages_ms": stages,
@@ -436,8 +509,14 @@ def main():
         line["profile_build"] = dict(lib_sha_note, stale_profile=stale or None,
                                      note="static counter figures (roofline.traffic, roofline_viterbi.hbm_bytes / valu_insts / lds_*) are reported only when the profile's src_sha256 equals this build's (tools/make_profiles.sh + tools/collect_profiles.py regenerate them)")
         # what a plain device-to-device copy moves on this box (read + write), for scale next to the 8 TB/s specification the fraction is
-        # taken against ("measure the denominator"); never used as `peak`
+        # taken against ("measure the denominator"); never used as `peak`.  The library's own float4 grid-stride copy
+        # (dabphy_time_copy, the recipe MI355X_MICROARCH.md quotes 6.29 TB/s for; tools/ubench/copy_f4.hip sweeps it), 2 GiB in + 2 GiB out
+        # per pass; torch's copy_ beside it (round 3's denominator: it flattered)
         try:
+            cg = dev.time_copy(2 << 30, 0, 5)
+            line["roofline"]["measured_copy_GBps"] = cg
+            line["roofline"]["frac_of_achievable"] = ach / cg
+            line["roofline"]["measured_copy_note"] = "float4 grid-stride device copy of 2 GiB (read + write counted), 16 work-groups per CU, after this run's timed region on the same device (dabphy_time_copy)"
             src = iq[: max(1, B // 2)]; dst = torch.empty_like(src)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             dst.copy_(src); torch.cuda.synchronize()
@@ -445,11 +524,10 @@ def main():
             for _ in range(3):
                 dst.copy_(src)
             e1.record(); torch.cuda.synchronize()
-            line["roofline"]["measured_copy_GBps"] = 3 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            line["roofline"]["frac_of_measured_copy"] = ach / line["roofline"]["measured_copy_GBps"]
+            line["roofline"]["torch_copy_GBps"] = 3 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
             del dst
-        except Exception:
-            pass
+        except Exception as ex:
+            line["roofline"]["measured_copy_error"] = "%s: %s" % (type(ex).__name__, ex)
         line["config"]["schedule"] = {0: "serial synchroniser", 1: "pipelined: the next batch's synchroniser starts behind this batch's demod kernel",
                                       2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)",
                                       3: "pipelined two batches ahead: the synchroniser of batch k + 2 starts behind batch k's demod kernel"}[sched]
@@ -473,13 +551,21 @@ def main():
                                               "roofline_frac": B * F * ALG_BYTES_DEMOD_PER_FRAME / (dm * 1e-3) / 1e9 / HBM_PEAK_GBPS})
                 dev2.close()
             line["alt_schedule"] = line["alt_schedules"][0]
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, after the timed region, whatever the number of ranks (the other ranks wait at the final barrier):
+            # the same bounded sample, over the rows rank 0 logged -- its parity leg against the real reference backend and the oracle
+            if dev is not None and world > 1:
+                pass                                     # (the handle stays open: nothing of the baseline runs on the device)
             rows = {e: iq[e].cpu().numpy() for e in check}
-            line["cpu_baseline"], line["parity_check"] = cpu_baseline(rows, n_loops=max(1, 240 // rec_frames), gpu_logs=logs)
-            line["parity_check"].update(ranks_ok=1, ranks=1)
+            line["cpu_baseline"], pc = cpu_baseline(rows, n_loops=max(1, 240 // rec_frames), gpu_logs=logs)
+            if world == 1:
+                line["parity_check"] = pc
+                line["parity_check"].update(ranks_ok=1, ranks=1)
         if world > 1:
             line["parity_check"] = {"ranks_ok": ranks_ok, "ranks": world, "per_rank": "ensembles %s of the rank's own shard: FIBs + CRC flags + MSC bytes of sub-channels %s from the first frame on vs the oracle (C restatement) on the same rows, outside the timed region" % (check, list(PARITY_SUBCH)),
                                     "fib_equal": ranks_ok == world, "msc_equal": ranks_ok == world, "rank0_error": rank_err}
+            if not args.no_cpu_baseline:
+                line["parity_check"]["rank0_against"] = pc.get("against")
         if world == 1 and not args.no_extras:
             # BASELINE configs 2-3 and the PCIe-inclusive path, measured in this run (own processes, own handles, after the timed region;
             # never `value`): the drop-in facade over one ensemble, one frame per call, every getter copied out, the reference's
@@ -487,6 +573,12 @@ def main():
             if dev is not None:
                 dev.close(); dev = None
             del iq; torch.cuda.empty_cache()
+            # a multiplex as they are on air instead of 18 identical sub-channels: same batch geometry, own parity leg
+            try:
+                line["extras"] = {"hetero": hetero_leg(capi, workload, torch, lib_path, B, F, args.steps, local, sched)}
+            except Exception as ex:
+                line["extras"] = {"hetero": {"error": "%s: %s" % (type(ex).__name__, ex)}}
+            torch.cuda.empty_cache()
             line["facade"] = _extra([os.path.join(ROOT, "tools", "bench_facade.py"), "--json"], {}, 240)
             line["host_u8"] = _extra([os.path.join(ROOT, "tools", "bench_host_u8.py")], {"HOSTU8_B": str(B), "HOSTU8_F": str(F), "HOSTU8_STEPS": "3"}, 300)
         print(json.dumps(line), flush=True)

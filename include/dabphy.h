@@ -32,10 +32,19 @@ typedef enum {
     DABPHY_ERR_STATE = -5           /* call sequence error (e.g. process before bind) */
 } dabphy_status;
 
+/* Limits of the batch geometry (dabphy_create returns DABPHY_ERR_INVALID beyond them).  The reference has none -- any number of
+ * receivers decode correctly, msc-handler.cpp:129-158 -- and neither has the batch below them: no offset on the decode path is
+ * narrower than the range it has to cover.  (Round 3 addressed the soft-bit ring of the fused MSC decode with 32-bit offsets from
+ * the START of the ring: n_ensembles * (max_frames + 5) > 18 641 wrapped silently.  The offsets are now relative to the ring slice
+ * of the first ensemble a wavefront decodes, a span of a few ensembles that dabphy_process checks against 4 GiB per class -- a
+ * class that would exceed it is decoded through the two-kernel path with 64-bit addresses -- see DESIGN.md 4.2.) */
+#define DABPHY_MAX_FRAMES 4096u                   /* max_frames: frames per call and ensemble */
+#define DABPHY_MAX_ENSEMBLE_FRAMES (1u << 22)     /* n_ensembles * max_frames: code word counts stay inside 31 bits with 64 sub-channels */
+
 /* RadioReceiverOptions (src/backend/radio-receiver-options.h:66-84) + batch geometry */
 typedef struct {
-    uint32_t n_ensembles;           /* independent ensembles (streams) decoded in lock step; >= 1 */
-    uint32_t max_frames;            /* transmission frames per dabphy_process call and ensemble; >= 1 */
+    uint32_t n_ensembles;           /* independent ensembles (streams) decoded in lock step; >= 1, n_ensembles * max_frames <= DABPHY_MAX_ENSEMBLE_FRAMES */
+    uint32_t max_frames;            /* transmission frames per dabphy_process call and ensemble; 1 .. DABPHY_MAX_FRAMES */
     int32_t device;                 /* HIP device ordinal */
     int32_t fft_placement;          /* FFTPlacementMethod: 2 = ThresholdBeforePeak (default), 1 = EarliestPeakWithBinning, 0 = StrongestPeak */
     int32_t disable_coarse;         /* RadioReceiverOptions::disableCoarseCorrector */
@@ -100,6 +109,9 @@ int dabphy_protection_fic(dabphy_protection* p);
 int dabphy_protection_eep(dabphy_protection* p, int bitrate, int profile_b, int level);     /* eep-protection.cpp:32-113 */
 int dabphy_protection_uep(dabphy_protection* p, int bitrate, int level);                    /* uep-protection.cpp:120-167 */
 int dabphy_protection_input_bits(const dabphy_protection* p);                               /* punctured soft bits consumed */
+/* row `table_index` (0 .. 63, the 6-bit index a short-form FIG 0/1 carries) of the UEP table: sub-channel size in CUs, protection level
+ * 1 .. 5, bit rate (fib-processor.cpp:496-503 reads the same triple from ProtLevel, dab-constants.cpp:75-142) */
+int dabphy_uep_table_entry(int table_index, int* size_cu, int* level, int* bitrate);
 
 /* ---- seam 1: OfdmDecoder::pushAllSymbols (ofdm-decoder.cpp:132-139) -> processPRS + 75 x decodeDataSymbol --------
  * frames: n_frames x (2048 + 75*2552) complex floats, [PRS useful part][75 symbols incl. cyclic prefix], already
@@ -244,7 +256,8 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
 /* the wide pass of the DAB+ superframe filter since dabphy_create (either pointer may be NULL): (ensemble, sub-channel) batches whose
  * superframe attempts were all made at once and accepted -- the rest were walked frame by frame as SuperframeFilter::Feed does
- * (dabplus_decoder.cpp:50-158); results are identical either way -- and batches it was tried on */
+ * (dabplus_decoder.cpp:50-158); results are identical either way -- and batches it was tried on (those with at least one full
+ * five-frame window).  Counts passes, not batches: the second pass of a batch that exact batch mode decodes twice counts again. */
 int dabphy_get_wide_superframe_stats(dabphy_handle* h, uint64_t* settled, uint64_t* tried);
 /* batches decoded a second time (see dabphy_config.no_batch_replay) since dabphy_reset / dabphy_create */
 int dabphy_get_replayed_batches(dabphy_handle* h, uint64_t* batches);
@@ -340,26 +353,7 @@ int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, ui
 int dabphy_set_profiling(dabphy_handle* h, int32_t on);
 int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);
 
-/* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
- * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
- *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.
- * dabphy_time_viterbi: decodes n_codewords random-content codewords of nbits `iters` times; *ms_gather / *ms_decode.
- * dabphy_time_fused_msc: re-runs the fused MSC decode of the last dabphy_process batch (first protection class) `iters` times
- *   with nothing else on the device; *ms = mean kernel time.  DABPHY_ERR_STATE before the first such batch. */
-int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
-                      int32_t mix, int32_t f_hz, uint32_t iters, float* ms);
-int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
-                        float* ms_decode);
-int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
-
-/* Device self-test of the reciprocal-based 127/x the demapper uses in place of the IEEE division sequence
- * (ofdm-decoder.cpp:208 computes 127.0f / l1_norm): every float x in [2^-100, 2^100] is divided both ways on the device.
- * counts[0] = mismatches of the 4-instruction variant, counts[1] = of the 6-instruction variant, counts[2] = values tried. */
-int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts);
-/* Device self-test of the one-instruction product by the unit twiddle tw[0] = (1, +-0) in the first two passes of the demod kernel's
- * FFT (kiss_fft.c:21-90 multiplies by it like by any other twiddle): 2^33 operand pairs -- every exponent, zeros, denormals, infinities
- * and NaNs included -- through both forms.  counts[0] = results that differ in a bit (two NaNs count as equal), counts[1] = pairs tried. */
-int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
+/* (Timing drivers and device self-tests used by tests/ and tools/ are declared in include/dabphy_test.h: not part of the receiver API.) */
 
 #ifdef __cplusplus
 }

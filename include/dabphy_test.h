@@ -1,0 +1,44 @@
+/* include/dabphy_test.h -- test and measurement entry points of libdabphy_hip.so: timing drivers that run ONE stage alone on
+ * device-resident data, and exhaustive device self-tests of two arithmetic shortcuts of the demod kernel.  tests/, tools/ and
+ * bench.py's side measurements call them; a receiver needs only include/dabphy.h. */
+#ifndef DABPHY_TEST_H
+#define DABPHY_TEST_H
+
+#include "dabphy.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
+ * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
+ *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.
+ * dabphy_time_viterbi: decodes n_codewords random-content codewords of nbits `iters` times; *ms_gather / *ms_decode.
+ * dabphy_time_fused_msc: re-runs the fused decode launch of the last dabphy_process batch (every class it held, the FIC included)
+ *   `iters` times with nothing else on the device; *ms = mean kernel time.  DABPHY_ERR_STATE before the first such batch and after
+ *   anything that replaced a buffer the launch names (dabphy_set_subchannels, a larger batch, another seam's scratch). */
+int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
+                      int32_t mix, int32_t f_hz, uint32_t iters, float* ms);
+int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
+                        float* ms_decode);
+int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
+/* dabphy_time_copy: a plain device-to-device copy of `bytes` bytes (16 bytes per lane and request, grid-stride, blocks_per_cu work-groups
+ *   of 256 threads per compute unit, 0 = 16), `iters` passes after three warm-up passes; *gbytes_per_s = bytes read + bytes written per
+ *   second.  What the device's HBM delivers to the simplest possible kernel on this box: the measured denominator bench.py prints
+ *   next to the 8 TB/s specification (tools/ubench/copy_f4.hip is the stand-alone sweep of the same kernel). */
+int dabphy_time_copy(dabphy_handle* h, uint64_t bytes, uint32_t blocks_per_cu, uint32_t iters, float* gbytes_per_s);
+
+/* Device self-test of the reciprocal-based 127/x the demapper uses in place of the IEEE division sequence
+ * (ofdm-decoder.cpp:208 computes 127.0f / l1_norm): every float x in [2^-100, 2^100] is divided both ways on the device.
+ * counts[0] = mismatches of the 4-instruction variant, counts[1] = of the 6-instruction variant, counts[2] = values tried. */
+int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts);
+/* Device self-test of the one-instruction product by the unit twiddle tw[0] = (1, +-0) in the first two passes of the demod kernel's
+ * FFT (kiss_fft.c:21-90 multiplies by it like by any other twiddle): 2^33 operand pairs -- every exponent, zeros, denormals, infinities
+ * and NaNs included -- through both forms.  counts[0] = results that differ in a bit (two NaNs count as equal), counts[1] = pairs tried. */
+int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* DABPHY_TEST_H */

@@ -54,8 +54,8 @@ static inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { retur
 // buffer addressing model: the resource is the base pointer
 typedef char* BufRsrc;
 static inline BufRsrc buf_rsrc(const void* base) { return (char*)base; }
-static inline uint2 buf_load_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes) { uint2 v; memcpy(&v, r + lane_bytes + uniform_bytes, 8); return v; }
-static inline void buf_store_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint2 v) { memcpy(r + lane_bytes + uniform_bytes, &v, 8); }
+template <int AUX = 0> static inline uint2 buf_load_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes) { uint2 v; memcpy(&v, r + lane_bytes + uniform_bytes, 8); return v; }
+template <int AUX = 0> static inline void buf_store_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint2 v) { memcpy(r + lane_bytes + uniform_bytes, &v, 8); }
 static inline void buf_store_b32(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint32_t v) { memcpy(r + lane_bytes + uniform_bytes, &v, 4); }
 static inline BufRsrc buf_rsrc_4g(const void* base) { return (char*)base; }
 static inline void buf_dma4(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu_lane(), r + lane_bytes + uniform_bytes, 4); }

@@ -107,10 +107,12 @@ def dev_prot(d, s):
     return d.protection_uep(s.bitrate, s.level) if getattr(s, "uep", None) is not None else d.protection_eep(s.bitrate, s.profile_b, s.level)
 
 
-def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2, stage_log=None, serial_sync=False, exact_batch=True):
-    """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames"""
+def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1, pipeline_sync=False, con=True, fft_placement=2, freqsync=2, stage_log=None, serial_sync=False, exact_batch=True,
+               max_frames=None, log_ens=None):
+    """drive the streaming receiver over the same stream for B ensembles; returns per-ensemble logs of valid frames (max_frames: the
+    handle's batch depth when it is to differ from the F frames per call; log_ens: log only these ensembles)"""
     from welle_io_amd import capi  # noqa: F401
-    d = d_factory(n_ensembles=B, max_frames=F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync, serial_sync=serial_sync, exact_batch=exact_batch)
+    d = d_factory(n_ensembles=B, max_frames=max_frames or F, disable_coarse=disable_coarse, pipeline_sync=pipeline_sync, want_constellation=con, fft_placement=fft_placement, freqsync_method=freqsync, serial_sync=serial_sync, exact_batch=exact_batch)
     try:
         d.stream_upload(np.tile(np.asarray(x, np.complex64), (B, 1)))
         d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subs])
@@ -123,7 +125,7 @@ def run_stream(d_factory, x, subs, F, n_frames_total, disable_coarse=False, B=1,
             info = d.frame_info(); fb, ok = d.fibs(); cn = d.constellation() if con else np.zeros((B, F, 1200), np.complex64)
             nl = d.null_symbols()
             mscs = [d.msc(i) for i in range(len(subs))]
-            for b in range(B):
+            for b in (range(B) if log_ens is None else log_ens):
                 nv = 0
                 for f in range(F):
                     if info[b, f]["valid"] == 1:
@@ -388,37 +390,48 @@ def check_superframes_vs_oracle(d_factory, F=3, nf=16, snr_db=5.0, seed=12, B=2,
     return got
 
 
-def check_mixed_ensemble(d_factory, F=4, nf=11, snr_db=12, seed=31, expect_fused=None):
-    """an ensemble whose sub-channels all differ: bit rates 8..192 kbit/s, EEP profiles A and B, levels 1..4 -- one Viterbi
-    class (one gather + decode launch pair) per sub-channel, code words of 192..4608 bits, groups of 64 code words that
-    straddle ensembles"""
-    cfgs = [(1, 32, False, 1), (2, 128, False, 2), (3, 64, True, 3), (4, 48, False, 4), (5, 8, False, 3), (6, 192, False, 3), (7, 32, True, 1)]
+MIXED_CFGS = [(1, 32, False, 1), (2, 128, False, 2), (3, 64, True, 3), (4, 48, False, 4), (5, 8, False, 3), (6, 192, False, 3), (7, 32, True, 1)]
+
+
+def mixed_subchannels(cfgs=MIXED_CFGS, uep=((8, 80, 1), (9, 384, 5))):
+    """an ensemble whose sub-channels all differ: bit rates 8..192 kbit/s, EEP profiles A and B, levels 1..4; short-form (UEP)
+    sub-channels through the streaming path: 80 kbit/s level 1 (the reference's table row with PI2 = 7, uep-protection.cpp:66) and the
+    longest code word there is, 384 kbit/s (9216 bits, level 5)"""
     subchs = []; cu = 0
     for sid, br, pb, lvl in cfgs:
         sc = synth.SubchannelCfg(sid, cu, br, pb, lvl, dabplus=False); subchs.append(sc); cu += sc.size_cu
-    # short-form (UEP) sub-channels through the streaming path: 80 kbit/s level 1 (the reference's table row with PI2 = 7,
-    # uep-protection.cpp:66) and the longest code word there is, 384 kbit/s (9216 bits, level 5)
-    for sid, br, lvl in ((8, 80, 1), (9, 384, 5)):
+    for sid, br, lvl in uep:
         sc = R.uep_subchannel(synth, sid, cu, br, lvl); subchs.append(sc); cu += sc.size_cu
     assert cu <= 864
+    return subchs
+
+
+def check_mixed_ensemble(d_factory, F=4, nf=11, snr_db=12, seed=31, expect_fused=None, B=2, max_frames=None, subchs=None, check_ens=None):
+    """an ensemble whose sub-channels all differ -- one Viterbi class per sub-channel, code words of 192..9216 bits, groups of 64 code
+    words that straddle sub-channels and ensembles -- B copies side by side, each against the oracle.  expect_fused: whether every
+    class went through the fused kernel (no separate gather stage) or none did.  max_frames: batch depth of the handle (ring slices of
+    max_frames + 6 frames per ensemble) when it is to differ from the F frames per call; check_ens: the ensembles to compare (all)"""
+    if subchs is None:
+        subchs = mixed_subchannels()
     x, tx = synth.make_stream(nf, subchs=subchs, snr_db=snr_db, cfo_hz=-55, delay=123, return_tx=True, seed=seed)
     # (the coarse corrector is off when F is large: a first batch of 16 frames would consult the start-up FIC ratio for all of them,
     # the documented batch-mode deviation that test_low_snr_batches_with_coarse_corrector pins)
     o = R.orc_receiver_run(x, subchs=subchs, disable_coarse=F > 4)
     seen = {}
-    logs = run_stream(d_factory, x, subchs, F, o["n_frames"], B=2, stage_log=seen, disable_coarse=F > 4)
+    ens = list(range(B)) if check_ens is None else list(check_ens)
+    logs = run_stream(d_factory, x, subchs, F, o["n_frames"], B=B, stage_log=seen, disable_coarse=F > 4, max_frames=max_frames, log_ens=ens, con=B <= 2)
     if expect_fused is not None:
         # the fused kernel (gather inside the Viterbi kernel) leaves no separate gather stage
         assert (seen["times"]["msc_gather"] == 0.0) == expect_fused, seen["times"]
-    for b in range(2):
+    for b in ens:
         L = logs[b]
         n = min(len(L["fib"]), len(o["fib"]) // 12)
         assert n >= o["n_frames"] - F
         ofib = o["fib"][:12 * n].reshape(n, 12, 33)
-        assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]) and np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:])
+        assert np.array_equal(np.array(L["ok"][:n]), ofib[:, :, 0]) and np.array_equal(np.array(L["fib"][:n]), ofib[:, :, 1:]), "ensemble %d: FIBs differ" % b
         for i in range(len(subchs)):
             got = b"".join(L["msc"][i])
-            assert len(got) > 0 and got == bytes(o["msc"][i])[:len(got)], "MSC bytes of sub-channel %d (%d kbit/s) differ" % (i, subchs[i].bitrate)
+            assert len(got) > 0 and got == bytes(o["msc"][i])[:len(got)], "ensemble %d: MSC bytes of sub-channel %d (%d kbit/s) differ" % (b, i, subchs[i].bitrate)
 
 
 def tii_pairs(x, n, early=100):

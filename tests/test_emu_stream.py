@@ -66,8 +66,27 @@ def test_superframe_filter_other_bit_rates(emu):
     P.check_superframes_vs_oracle(factory, nf=20, B=1, ensemble=ens, pick=(0, 1, 2, 3), auto_modes=(True,))
 
 
-def test_mixed_protection_classes(emu):
-    P.check_mixed_ensemble(factory, expect_fused=False)
+@pytest.mark.parametrize("F,nf", [(4, 11), (1, 7), (3, 10)])
+def test_mixed_protection_classes(emu, F, nf):
+    """4 / 1 / 3 frames per call = 16 / 4 / 12 CIFs per sub-channel: a wave's 64 code words span up to 5 / 17 / 7 (ensemble,
+    sub-channel) pairs -- the 144- and 324-row builds of the fused kernel; no separate gather stage at any batch depth"""
+    P.check_mixed_ensemble(factory, F=F, nf=nf, expect_fused=True)
+
+
+def test_two_kernel_decode_beyond_the_fused_kernels_reach(emu):
+    """a handle with ring slices of 4102 frames (945 MB) per ensemble, 4 frames per call: the 5 + 1 ensembles a wave of a one-member
+    class could span lie 5.7 GB apart -- beyond the 32-bit offsets of the fused kernel's buffer resource -- so every class and the FIC
+    go through k_msc_gather / k_fic_gather + k_viterbi (64-bit addresses), and decode the same bytes"""
+    P.check_mixed_ensemble(factory, F=4, nf=11, max_frames=4096, expect_fused=False)
+
+
+def test_fused_decode_of_ensembles_beyond_4_gib(emu):
+    """six ensembles whose ring slices are 945 MB apart: ensemble 5's soft bits start 4.7 GB behind the ring's -- round 3's fused
+    kernel addressed them with 32-bit offsets from the START of the ring and decoded ensemble 5 from ensemble 0's rows.  16 frames per
+    call (two segments per wave: the 96-row build), two narrow sub-channels"""
+    from welle_io_amd import synth
+    subchs = [synth.SubchannelCfg(1, 0, 32, False, 3, dabplus=False), synth.SubchannelCfg(2, 24, 8, False, 2, dabplus=False)]
+    P.check_mixed_ensemble(factory, F=16, nf=36, B=6, max_frames=4096, subchs=subchs, expect_fused=True, check_ens=(0, 4, 5))
 
 
 @pytest.mark.parametrize("method,snr,cfo", [(1, 15, 90), (1, None, -300), (0, 12, 40)])
@@ -124,6 +143,19 @@ def test_benchmark_handle_configuration_small(emu):
                          base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=0), expect_chunk=25)
 
 
+def test_heterogeneous_multiplex_small(emu):
+    """bench.py's `hetero` leg (workload.HETERO_LAYOUT: 15 sub-channels, 6 protection classes incl. EEP-B and UEP, all DAB+) through the
+    handle bench.py opens, at a size the execution model finishes: one fused launch for all classes and the FIC, every sub-channel's
+    bytes and the superframe totals against the oracle"""
+    from welle_io_amd import workload
+    lib = capi.load_library(EMU_LIB)
+    subchs = workload.hetero_subchannels(lib)
+    assert len(subchs) == 15 and sum(s.size_cu for s in subchs) <= 864
+    assert workload.subchannels_to_json(workload.subchannels_from_json(workload.subchannels_to_json(subchs))) == workload.subchannels_to_json(subchs)
+    P.check_bench_config(capi, EMU_LIB, 2, 4, 1, check_ens=[0, 1], n_steps=4, demod_chunk=25, device="cpu", subs_idx=tuple(range(15)),
+                         base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=50, subchs=subchs), expect_chunk=25)
+
+
 @pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
 def test_ingest_vs_reference_crawfile(emu, fmt, tmp_path):
     """k_ingest pinned to the real CRAWFile::convertSamples (input/raw_file.cpp:324-366, compiled into oracle/_ref)"""
@@ -146,8 +178,8 @@ def test_dropout_in_batch_mode(emu):
 
 
 def test_mixed_protection_classes_fused_decode(emu):
-    """16 frames per call = 64 CIFs per sub-channel: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel -- the MSC
-    gather inside the Viterbi kernel (k_viterbi_msc: LDS window ring fed by LDS-DMA, per-step descriptors from the depuncturing map)"""
+    """16 frames per call = 64 CIFs per sub-channel: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel's 96-row build -- the MSC
+    gather inside the Viterbi kernel (k_viterbi_fused: LDS window ring fed by LDS-DMA, per-step descriptors from the depuncturing map)"""
     P.check_mixed_ensemble(factory, F=16, nf=36, expect_fused=True)
 
 

@@ -41,5 +41,30 @@ def test_benchmarked_configuration_one_work_group_per_frame(gpu):
     P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 129, 255], n_steps=2, base=base_streams(32), expect_chunk=75, demod_chunk=75)
 
 
+def test_batch_beyond_18641_frame_slots(gpu):
+    """520 ensembles x 32 frames: 520 x (32 + 6) frame slots of soft bits = 4.55 GB.  Round 3's fused kernel addressed that ring with
+    32-bit offsets from its start and decoded every ensemble from 504 on from the rows of the first ones (18 641 x 230 400 = 2^32); the
+    offsets now start at the ring slice of the wave's first ensemble.  Ensembles on both sides of the old limit and the last one, the
+    whole check of the benchmarked configuration (FIBs, correctors, soft bits, MSC bytes, superframe totals of all 18 sub-channels)"""
+    P.check_bench_config(capi, GPU_LIB, 520, 32, 1, check_ens=[0, 503, 504, 519], n_steps=2, base=base_streams(32), expect_chunk=25)
+
+
+def hetero_base(frames_per_step):
+    lib = capi.load_library(GPU_LIB)
+    n = workload.rec_frames_for(frames_per_step)
+    key = ("hetero", n)
+    if key not in _base:
+        _base[key] = workload.make_base_streams(2, n, seed0=50, subchs=workload.hetero_subchannels(lib))
+    return _base[key]
+
+
+def test_heterogeneous_multiplex_at_the_benchmarked_geometry(gpu):
+    """bench.py's `hetero` leg: 256 ensembles x 32 frames of a multiplex as they are on air (15 sub-channels, 6 protection classes incl.
+    EEP-B and UEP, code words of 192 .. 3072 bits): all classes and the FIC in ONE fused launch, code word groups that straddle
+    sub-channels and ensembles in several classes at once.  Every sub-channel's bytes of the first, two middle and the last ensemble
+    (and FIBs, correctors, soft bits, superframe totals) against the oracle"""
+    P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 127, 128, 255], n_steps=2, base=hetero_base(32), expect_chunk=25, subs_idx=tuple(range(15)))
+
+
 def test_demod_chunk_sizes(gpu):
     P.check_demod_chunks(lambda **kw: capi.DabPhy(lib_path=GPU_LIB, **kw))

@@ -37,6 +37,10 @@ def test_single_gpu_line_and_parity_leg(gpu):
         assert j["cpu_baseline"]["stage_ms"] and "ProcessSymbol" in j["cpu_baseline"]["stage_ms"] and "DADeconvolve" in j["cpu_baseline"]["stage_ms"]
         assert j["cpu_baseline"]["o3"] is None or j["cpu_baseline"]["o3"].get("value", 1) > 0
     assert "facade" in j and "host_u8" in j and j["host_u8"].get("x_real_time", 0) > 0
+    # the heterogeneous multiplex behind the headline: its own throughput, Viterbi stage time and parity leg (every sub-channel)
+    het = j["extras"]["hetero"]
+    assert het.get("parity") is True and het["value"] > 0 and het["msc_viterbi_ms"] > 0, het
+    assert j["roofline"]["measured_copy_GBps"] > 1000 and 0 < j["roofline"]["frac_of_achievable"] < 1.2
     assert j["profile_build"]["src_sha256"] and j["profile_build"]["lib_sha256"]
 
 
@@ -51,8 +55,13 @@ def test_gpus_2_starts_its_ranks(gpu):
     env = dict(env, **{k: "" for k in ()})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         os.environ.pop(k, None)
-    j = run_bench(["--gpus", "2", "--steps", "1", "--ensembles", "4", "--frames", "10", "--no-alt-schedule", "--no-cpu-baseline"], env)
+    j = run_bench(["--gpus", "2", "--steps", "1", "--ensembles", "4", "--frames", "10", "--no-alt-schedule"], env)
     assert j["n_gpus"] == 2 and j["config"]["ensembles_per_gpu"] == 4
     assert j["rccl_ranks"] == (2 if torch.cuda.device_count() >= 2 else 0)
+    # the multi-rank line is as complete as the single-GPU one: roofline of the slowest rank (per-rank kernel times beside it) and the
+    # CPU baseline, timed on rank 0's host cores after the timed region
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and len(j["roofline"]["kernel_ms_per_rank"]) == 2
+    assert j["roofline"]["kernel_ms"] == max(j["roofline"]["kernel_ms_per_rank"])
+    assert j["cpu_baseline"]["kind"] in ("reference", "port") and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
     # every rank proved its own shard against the oracle outside the timed region
     assert j["parity_check"]["ranks_ok"] == 2 and j["parity_check"]["fib_equal"] and j["parity_check"]["msc_equal"], j["parity_check"]

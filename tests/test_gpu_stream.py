@@ -82,12 +82,30 @@ def test_superframe_filter_other_bit_rates(gpu):
     P.check_superframes_vs_oracle(factory, nf=20, B=1, ensemble=ens, pick=(0, 1, 2, 3), auto_modes=(True,))
 
 
-def test_mixed_protection_classes(gpu):
-    P.check_mixed_ensemble(factory, expect_fused=False)
+@pytest.mark.parametrize("F,nf", [(4, 11), (1, 7), (2, 9), (3, 10), (5, 14), (8, 19), (15, 33)])
+def test_mixed_protection_classes(gpu, F, nf):
+    """1 .. 15 frames per call = 4 .. 60 CIFs per sub-channel: a wave's 64 code words span up to 17 (ensemble, sub-channel) pairs -- the
+    144- and 324-row builds of the fused kernel; no separate gather stage at any batch depth"""
+    P.check_mixed_ensemble(factory, F=F, nf=nf, expect_fused=True)
+
+
+def test_two_kernel_decode_beyond_the_fused_kernels_reach(gpu):
+    """a handle with ring slices of 4102 frames (945 MB) per ensemble, 4 frames per call: the 5 + 1 ensembles a wave of a one-member
+    class could span lie 5.7 GB apart -- beyond the 32-bit offsets of the fused kernel's buffer resource -- so every class and the FIC
+    go through k_msc_gather / k_fic_gather + k_viterbi (64-bit addresses), and decode the same bytes"""
+    P.check_mixed_ensemble(factory, F=4, nf=11, max_frames=4096, expect_fused=False)
+
+
+def test_fused_decode_of_ensembles_beyond_4_gib(gpu):
+    """six ensembles whose ring slices are 945 MB apart: ensemble 5's soft bits start 4.7 GB behind the ring's (round 3's fused kernel
+    addressed them with 32-bit offsets from the START of the ring).  16 frames per call, two narrow sub-channels; the emulator runs
+    the same case"""
+    subchs = [synth.SubchannelCfg(1, 0, 32, False, 3, dabplus=False), synth.SubchannelCfg(2, 24, 8, False, 2, dabplus=False)]
+    P.check_mixed_ensemble(factory, F=16, nf=36, B=6, max_frames=4096, subchs=subchs, expect_fused=True, check_ens=(0, 4, 5))
 
 
 def test_mixed_protection_classes_fused_decode(gpu):
-    """16 / 20 frames per call: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel (k_viterbi_msc)"""
+    """16 / 20 frames per call: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel's 96-row build (k_viterbi_fused)"""
     P.check_mixed_ensemble(factory, F=16, nf=36, expect_fused=True)
     P.check_mixed_ensemble(factory, F=20, nf=45, seed=32, snr_db=9, expect_fused=True)
 

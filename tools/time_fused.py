@@ -1,5 +1,5 @@
-"""Not a test: times k_viterbi_msc ALONE on the benchmark batch (dabphy_time_fused_msc: the fused MSC decode of the last batch re-run
-with nothing else on the device) for A/B runs on the GPU box.  usage: python tools/time_fused.py [B] [F] ; DABPHY_LIB selects the library."""
+"""Not a test: times the fused decode launch (k_viterbi_fused: every MSC class + the FIC) ALONE on the benchmark batch (dabphy_time_fused_msc:
+the launch of the last batch re-run with nothing else on the device) for A/B runs on the GPU box.  usage: python tools/time_fused.py [B] [F] ; DABPHY_LIB selects the library."""
 import os
 import sys
 
@@ -23,5 +23,5 @@ torch.cuda.synchronize()
 ms = dev.time_fused_msc(5)
 groups = B * 18 * 4 * F // 64
 steps = 1542
-print("k_viterbi_msc alone: %.3f ms per launch (%d x %d, %d groups); %.0f cycles per trellis step and SIMD at 2.4 GHz" % (ms, B, F, groups, ms * 1e-3 * 2.4e9 / (groups * steps / 1024.0)))
+print("k_viterbi_fused alone (%s): %.3f ms per launch (%d x %d, %d MSC groups + the FIC class if fused); %.0f cycles per MSC trellis step and SIMD at 2.4 GHz" % (os.path.basename(lib), ms, B, F, groups, ms * 1e-3 * 2.4e9 / (groups * steps / 1024.0)))
 dev.close()

@@ -10,10 +10,10 @@ ROOT = os.path.dirname(PKG_DIR)
 
 
 def source_sha256():
-    """SHA-256 over the kernel and host sources of the library (csrc/*.hip, *.h, *.cpp, the Makefile and include/dabphy.h), in name order"""
+    """SHA-256 over the kernel and host sources of the library (csrc/*.hip, *.h, *.cpp, the Makefile and include/dabphy*.h), in name order"""
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")) + glob.glob(os.path.join(PKG_DIR, "csrc", "*.h")) +
-                   glob.glob(os.path.join(PKG_DIR, "csrc", "*.cpp")) + [os.path.join(PKG_DIR, "csrc", "Makefile"), os.path.join(ROOT, "include", "dabphy.h")])
+                   glob.glob(os.path.join(PKG_DIR, "csrc", "*.cpp")) + [os.path.join(PKG_DIR, "csrc", "Makefile"), os.path.join(ROOT, "include", "dabphy.h"), os.path.join(ROOT, "include", "dabphy_test.h")])
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())

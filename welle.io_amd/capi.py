@@ -211,6 +211,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_time_viterbi(self.h, nbits, n_codewords, iters, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def time_copy(self, nbytes=2 << 30, blocks_per_cu=0, iters=5):
+        """GB/s (read + write) of a plain float4 device copy of nbytes (dabphy_time_copy)"""
+        a = C.c_float(0)
+        self._chk(self.lib.dabphy_time_copy(self.h, C.c_uint64(nbytes), blocks_per_cu, iters, C.byref(a)))
+        return a.value
+
     def time_fused_msc(self, iters=3):
         a = C.c_float(0)
         self._chk(self.lib.dabphy_time_fused_msc(self.h, iters, C.byref(a)))

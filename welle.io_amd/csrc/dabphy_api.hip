@@ -7,6 +7,8 @@ extern "C" {
 int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
 {
     if (!cfg || !out || cfg->n_ensembles < 1 || cfg->max_frames < 1) return DABPHY_ERR_INVALID;
+    // include/dabphy.h "limits": frame and code word counts are 32-bit quantities in the kernels' argument blocks
+    if (cfg->max_frames > DABPHY_MAX_FRAMES || (uint64_t)cfg->n_ensembles * cfg->max_frames > DABPHY_MAX_ENSEMBLE_FRAMES) return DABPHY_ERR_INVALID;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return DABPHY_ERR_NO_DEVICE;
@@ -61,6 +63,8 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_ingest[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_chain_gate, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipEventCreateWithFlags(&h->ev_fused_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if ((r = fused_class_tables(h, pf, true, h->fic_steps, h->fic_windows))) return fail(r);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreateWithFlags(&h->ev_wide_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     {
@@ -102,6 +106,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
 #endif
 #ifdef DABPHY_EXPERIMENTS
     if (const char* e = getenv("DABPHY_FUSED_MSC")) h->fused_msc = atoi(e) != 0;
+    if (const char* e = getenv("DABPHY_FUSED_FIC")) h->fused_fic = atoi(e) != 0;
 #endif
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
@@ -114,7 +119,7 @@ namespace {
 void free_class(dabphy_handle::MscClass& c)
 {
     hipError_t e = hipSuccess;
-    DevBuf* bufs[] = {&c.map, &c.start_bits, &c.tiles, &c.out, &c.steps, &c.sf_state, &c.sf_snap};
+    DevBuf* bufs[] = {&c.map, &c.start_bits, &c.tiles, &c.out, &c.steps[0], &c.steps[1], &c.steps[2], &c.sf_state, &c.sf_snap};
     for (DevBuf* b : bufs) if (b->p) { e = hipFree(b->p); b->p = nullptr; b->cap = 0; }
     (void)e;
 }
@@ -144,6 +149,8 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->snap_dec.p) e = hipFree(h->snap_dec.p);
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
+    if (h->ev_fused_done) e = hipEventDestroy(h->ev_fused_done);
+    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2]}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
@@ -191,6 +198,11 @@ int dabphy_protection_eep(dabphy_protection* p, int bitrate, int profile_b, int 
     return protection_eep(p, bitrate, profile_b, level) ? DABPHY_ERR_INVALID : DABPHY_OK;
 }
 int dabphy_protection_uep(dabphy_protection* p, int bitrate, int level) { return p ? protection_uep(p, bitrate, level) : DABPHY_ERR_INVALID; }
+int dabphy_uep_table_entry(int table_index, int* size_cu, int* level, int* bitrate)
+{
+    if (!size_cu || !level || !bitrate) return DABPHY_ERR_INVALID;
+    return uep_table_entry(table_index, size_cu, level, bitrate) ? DABPHY_ERR_INVALID : DABPHY_OK;
+}
 int dabphy_protection_input_bits(const dabphy_protection* p) { return p ? protection_input_bits(p) : DABPHY_ERR_INVALID; }
 
 int dabphy_demod_frames(dabphy_handle* h, const float* frames, uint32_t n_frames, int8_t* soft, float* constellation, float* snr)
@@ -303,6 +315,7 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
     }
     for (auto& c : h->classes) free_class(c);
     h->classes.clear();
+    h->fplan.valid = false; h->fplan.launched = false; h->buf_gen++;          // the plan names the classes' buffers
     h->last_frames = 0; h->last_desc = nullptr; h->sf_stats_ready = false;     // the class outputs of the last batch are gone with the classes
     h->subch.assign(list, list + n);
     for (uint32_t i = 0; i < n; i++) {
@@ -333,54 +346,8 @@ int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint
         }
         if ((r = ensure(h, c.tiles, tl.size() * sizeof(int32_t)))) return r;
         HIPCHK(h, hipMemcpy(c.tiles.p, tl.data(), tl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        // fused decode: what every trellis step reads, in terms of the wave's window ring (k_viterbi_msc).  Source byte u sits in
-        // window u >> 4 (slot (u >> 4) & 1), column u & 15, map16[u & 15] rows below the lane's row base.
-        {
-            static const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-            constexpr int PITCH = MSC_ROW_PITCH, SLOT = MSC_SLOT_BYTES, ZERO = MSC_ZERO_OFF;
-            constexpr int PADDING = 6;                        // the kernel requests descriptors one block of six steps ahead
-            std::vector<MscStep> st((size_t)nsteps + PADDING);
-            std::vector<int> wlo((size_t)nsteps, -1), whi((size_t)nsteps, -1);
-            for (int q = 0; q < nsteps; q++) {
-                uint32_t off[4];
-                for (int j = 0; j < 4; j++) {
-                    const int u = m[4 * q + j];
-                    if (u < 0) { off[j] = ZERO; continue; }
-                    const int w = u >> 4, col = u & 15;
-                    off[j] = (uint32_t)((w & 1) * SLOT + map16[col] * PITCH + col);
-                    if (wlo[q] < 0) wlo[q] = w;
-                    whi[q] = w;
-                }
-                st[q].off01 = off[0] | (off[1] << 16); st[q].off23 = off[2] | (off[3] << 16);
-            }
-            for (int q = nsteps; q < nsteps + PADDING; q++) st[(size_t)q].off01 = st[(size_t)q].off23 = ZERO | (ZERO << 16);
-            const int n_in = protection_input_bits(&c.prot);
-            c.n_windows = (n_in + 15) / 16;
-            // lowest window any LATER step reads: when it moves up, the window below it has died and its slot takes the window after the next
-            std::vector<int> low_after((size_t)nsteps, c.n_windows);
-            for (int q = nsteps - 2, low = c.n_windows; q >= 0; q--) { if (wlo[q + 1] >= 0) low = wlo[q + 1]; low_after[q] = low; }
-            int seen = 1, prev_low = 0;
-            std::vector<int> load_step((size_t)c.n_windows + 2, -10);
-            bool ok = nsteps % 6 == 0; int why = ok ? 0 : 8;    // (the kernel walks the trellis in blocks of six steps: true for every 24 * bitrate + 6)
-            for (int q = 0; q < nsteps; q++) {
-                if (whi[q] > seen) {
-                    st[q].off01 |= MSC_FIRST_USE; seen = whi[q];
-                    // the step BEFORE q waits for the window with s_waitcnt vmcnt(2): its load must be older than two decision stores
-                    if (q - 1 - load_step[seen] < 2) { ok = false; why |= 1; }
-                }
-                if (whi[q] >= 0 && whi[q] - wlo[q] > 1) { ok = false; why |= 2; }
-                if (low_after[q] > prev_low) {
-                    if (low_after[q] != prev_low + 1 && low_after[q] < c.n_windows) { ok = false; why |= 4; }
-                    prev_low = low_after[q];
-                    if (prev_low + 1 < c.n_windows) { st[q].off01 |= MSC_LOAD_NEXT; load_step[prev_low + 1] = q; }
-                }
-            }
-            if (!ok && debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class nbits %d: no fused decode (window schedule, reason %d)\n", c.prot.nbits, why);
-            if (!ok) c.n_windows = 0;             // (never for the profiles of EN 300 401; the two-kernel path decodes such a class)
-            if ((r = ensure(h, c.steps, st.size() * sizeof(MscStep)))) return r;
-            HIPCHK(h, hipMemcpy(c.steps.p, st.data(), st.size() * sizeof(MscStep), hipMemcpyHostToDevice));
-
-        }
+        // fused decode: what every trellis step reads, in terms of the wave's window ring, for each build of the kernel (dabphy_fused.hip)
+        if ((r = fused_class_tables(h, c.prot, false, c.steps, c.n_windows))) return r;
     }
     return DABPHY_OK;
 }
@@ -457,6 +424,37 @@ int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uin
     return sync(h);
 }
 
+int dabphy_time_copy(dabphy_handle* h, uint64_t bytes, uint32_t blocks_per_cu, uint32_t iters, float* gbytes_per_s)
+{
+    DeviceBind dev_(h);
+    if (!h || !gbytes_per_s || bytes < 4096 || iters == 0) return DABPHY_ERR_INVALID;
+    hipDeviceProp_t p;
+    HIPCHK(h, hipGetDeviceProperties(&p, h->cfg.device));
+    const int blocks = p.multiProcessorCount * (int)(blocks_per_cu ? blocks_per_cu : 16);
+    void *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, bytes) != hipSuccess) { h->err = "hipMalloc failed (copy source)"; return DABPHY_ERR_NOMEM; }
+    if (hipMalloc(&dst, bytes) != hipSuccess) { (void)hipFree(src); h->err = "hipMalloc failed (copy destination)"; return DABPHY_ERR_NOMEM; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMemsetAsync(src, 1, bytes, h->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float t = 0;
+    if (e == hipSuccess) {
+        for (int w = 0; w < 3; w++) launch_copy_f4(src, dst, bytes / 16, blocks, h->stream);      // clocks up, pages touched
+        e = hipEventRecord(e0, h->stream);
+        for (uint32_t i = 0; i < iters; i++) launch_copy_f4(src, dst, bytes / 16, blocks, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(dst);
+    if (e != hipSuccess) { h->err = std::string("dabphy_time_copy: ") + hipGetErrorString(e); return DABPHY_ERR_HIP; }
+    *gbytes_per_s = (float)(2.0 * (double)(bytes / 16 * 16) * iters / ((double)t * 1e-3) / 1e9);
+    return sync(h);
+}
+
 int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather, float* ms_decode)
 {
     DeviceBind dev_(h);
@@ -498,17 +496,24 @@ int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
 {
     DeviceBind dev_(h);
     if (!h || !ms || iters == 0) return DABPHY_ERR_INVALID;
-    if (!h->have_last_fused) { h->err = "no batch has been decoded by the fused MSC kernel yet"; return DABPHY_ERR_STATE; }
+    // the launch as the last batch queued it -- only while every buffer it names is still the one it named (sub-channel changes,
+    // resets and reallocations bump buf_gen)
+    const auto& P = h->fplan;
+    if (!P.valid || !P.launched || P.buf_gen != h->buf_gen || P.args.n_work == 0) { h->err = "no batch has been decoded by the fused kernel with the present buffers"; return DABPHY_ERR_STATE; }
     HIPCHK(h, hipDeviceSynchronize());                       // alone on the device: nothing of the pipeline beside it
-    hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-    launch_viterbi_msc(h->last_fused, h->stream);            // (same inputs, same outputs: the launch is idempotent)
-    HIPCHK(h, hipEventRecord(e0, h->stream));
-    for (uint32_t i = 0; i < iters; i++) launch_viterbi_msc(h->last_fused, h->stream);
-    HIPCHK(h, hipEventRecord(e1, h->stream));
-    HIPCHK(h, hipEventSynchronize(e1));
-    float t = 0; HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(h, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); h->err = "hipEventCreate failed"; return DABPHY_ERR_HIP; }
+    launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream);            // (same inputs, same outputs: the launch is idempotent)
+    hipError_t e = hipEventRecord(e0, h->stream);
+    for (uint32_t i = 0; i < iters; i++) launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float t = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess) { h->err = std::string("dabphy_time_fused_msc: ") + hipGetErrorString(e); return DABPHY_ERR_HIP; }
     *ms = t / iters;
-    HIPCHK(h, hipEventDestroy(e0)); HIPCHK(h, hipEventDestroy(e1));
     return sync(h);
 }
 

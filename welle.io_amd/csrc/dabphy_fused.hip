@@ -1,0 +1,167 @@
+// welle.io_amd/csrc/dabphy_fused.hip -- host side of the fused decode (k_viterbi_fused, k_viterbi.hip): the per-class step tables and the
+// launch plan.  No arithmetic of the hot path happens here: the tables restate the depuncturing maps (eep-protection.cpp:32-152,
+// uep-protection.cpp:27-239, fic-handler.cpp:158-191) in terms of the kernel's LDS window ring.
+#include "dabphy_internal.h"
+
+namespace {
+
+// What every trellis step reads, in terms of a wave's window ring of `rows` rows.  Source byte u of the punctured stream sits in window
+// u >> 4 (slot (u >> 4) & 1), column u & 15 -- and, for an MSC class, map16[u & 15] rows below the lane's row base (the time
+// de-interleaver, dab-audio.cpp:138-143; the FIC has none).  Returns false when the kernel's window schedule cannot follow the map.
+bool step_table(const std::vector<int16_t>& m, int nsteps, int n_in, int rows, bool skew, std::vector<MscStep>& st, int& n_windows, int& why)
+{
+    static const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+    const int PITCH = MSC_ROW_PITCH, SLOT = rows * MSC_ROW_PITCH, ZERO = 2 * SLOT;
+    constexpr int PADDING = 6;                        // the kernel requests descriptors one block of six steps ahead
+    st.assign((size_t)nsteps + PADDING, MscStep{0, 0});
+    std::vector<int> wlo((size_t)nsteps, -1), whi((size_t)nsteps, -1);
+    for (int q = 0; q < nsteps; q++) {
+        uint32_t off[4];
+        for (int j = 0; j < 4; j++) {
+            const int u = m[4 * q + j];
+            if (u < 0) { off[j] = (uint32_t)ZERO; continue; }
+            const int w = u >> 4, col = u & 15;
+            off[j] = (uint32_t)((w & 1) * SLOT + (skew ? map16[col] : 0) * PITCH + col);
+            if (wlo[q] < 0) wlo[q] = w;
+            whi[q] = w;
+        }
+        st[q].off01 = off[0] | (off[1] << 16); st[q].off23 = off[2] | (off[3] << 16);
+    }
+    for (int q = nsteps; q < nsteps + PADDING; q++) st[(size_t)q].off01 = st[(size_t)q].off23 = (uint32_t)ZERO | ((uint32_t)ZERO << 16);
+    n_windows = (n_in + 15) / 16;
+    // lowest window any LATER step reads: when it moves up, the window below it has died and its slot takes the window after the next
+    std::vector<int> low_after((size_t)nsteps, n_windows);
+    for (int q = nsteps - 2, low = n_windows; q >= 0; q--) { if (wlo[q + 1] >= 0) low = wlo[q + 1]; low_after[q] = low; }
+    int seen = 1, prev_low = 0;
+    std::vector<int> load_step((size_t)n_windows + 2, -10);
+    bool ok = nsteps % 6 == 0; why = ok ? 0 : 8;    // (the kernel walks the trellis in blocks of six steps: true for every 24 * bitrate + 6 and for the FIC's 774)
+    for (int q = 0; q < nsteps; q++) {
+        if (whi[q] > seen) {
+            st[q].off01 |= MSC_FIRST_USE; seen = whi[q];
+            // the step BEFORE q waits for the window with s_waitcnt vmcnt(2): its load must be older than two decision stores
+            if (q - 1 - load_step[seen] < 2) { ok = false; why |= 1; }
+        }
+        if (whi[q] >= 0 && whi[q] - wlo[q] > 1) { ok = false; why |= 2; }
+        if (low_after[q] > prev_low) {
+            if (low_after[q] != prev_low + 1 && low_after[q] < n_windows) { ok = false; why |= 4; }
+            prev_low = low_after[q];
+            if (prev_low + 1 < n_windows) { st[q].off01 |= MSC_LOAD_NEXT; load_step[prev_low + 1] = q; }
+        }
+    }
+    return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t soft_ens_stride(const dabphy_handle* h)
+{
+    // [max_frames + 5 frame slots][one frame of zeros]: what the fused decode loads for CIFs that do not exist yet sits behind every
+    // ensemble's own slice, inside the reach of a buffer resource based at that slice
+    return ((size_t)h->cfg.max_frames + 5 + 1) * SOFT_PER_FRAME;
+}
+
+int fused_class_tables(dabphy_handle* h, const dabphy_protection& prot, bool fic, DevBuf (&steps)[FUSED_VARIANTS], int (&n_windows)[FUSED_VARIANTS])
+{
+    const std::vector<int16_t> m = depuncture_map(&prot);
+    const int nsteps = prot.nbits + 6, n_in = protection_input_bits(&prot);
+    for (int v = 0; v < FUSED_VARIANTS; v++) {
+        std::vector<MscStep> st; int nw = 0, why = 0;
+        const bool ok = step_table(m, nsteps, n_in, FUSED_ROWS[v], !fic, st, nw, why);
+        if (!ok && debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class nbits %d: no fused decode (window schedule, reason %d)\n", prot.nbits, why);
+        n_windows[v] = ok ? nw : 0;                   // (never 0 for the profiles of EN 300 401; the two-kernel path decodes such a class)
+        int r;
+        if ((r = ensure(h, steps[v], st.size() * sizeof(MscStep)))) return r;
+        HIPCHK(h, hipMemcpy(steps[v].p, st.data(), st.size() * sizeof(MscStep), hipMemcpyHostToDevice));
+    }
+    return DABPHY_OK;
+}
+
+// The launch plan of one batch depth: which build of the kernel (how many (ensemble, sub-channel) pairs the 64 code words of a wave can
+// span), which classes it decodes, their descriptors and the work list.  Called from dabphy_process's allocation phase (every buffer
+// it names exists by then); uploads happen on the handle's stream, in order with the launches that read them, and only when
+// something changed.
+int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
+{
+    auto& P = h->fplan;
+    const uint32_t B = h->cfg.n_ensembles;
+    const int R = 4 * (int)F;
+    const int v = R >= FUSED_MIN_CIFS[0] ? 0 : R >= FUSED_MIN_CIFS[1] ? 1 : 2;
+    const size_t ens_stride = soft_ens_stride(h);
+    // A wave's sources are addressed with 32-bit offsets from the ring slice of its first ensemble.  Its code words span at most
+    // nseg (ensemble, sub-channel) pairs (64 + 15 nseg <= rows), i.e. ceil(nseg / members) + 1 ensembles; the FIC's 64 code words
+    // = 16 frames, ceil(16 / F) + 1 ensembles.  A class whose span leaves the 4 GiB takes the two-kernel path (64-bit addresses).
+    const int nseg = (FUSED_ROWS[v] - 64) / 15;
+    auto reach_ok = [&](int n_ens_spanned) { return (uint64_t)n_ens_spanned * ens_stride <= 0xffffffffull; };
+    std::vector<FusedClass> cls; std::vector<int> idx;
+    struct Item { int nsteps, ci, n_groups; };
+    std::vector<Item> items;
+    size_t max_steps = 0;
+    for (size_t i = 0; i < h->classes.size(); i++) {
+        auto& c = h->classes[i];
+        const int M = (int)c.members.size();
+        if (!h->fused_msc || c.n_windows[v] <= 0 || !reach_ok((nseg + M - 1) / M + 1)) continue;
+        FusedClass fc{};
+        fc.steps = c.steps[v].as<MscStep>(); fc.start_bit = c.start_bits.as<int32_t>(); fc.out = c.out.as<uint8_t>();
+        fc.nbits = c.prot.nbits; fc.nsteps = fc.nbits + 6; fc.n_windows = c.n_windows[v]; fc.n_cw = (int32_t)(B * 4 * F * M);
+        fc.n_members = M; fc.kind = 0; fc.dedisperse = 1; fc.frame_sel = 0;
+        items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
+        cls.push_back(fc); idx.push_back((int)i);
+        max_steps = std::max(max_steps, (size_t)fc.nsteps);
+    }
+    bool fic_in = false;
+    if (want_fic && h->fused_fic && h->fic_windows[v] > 0 && reach_ok((16 + (int)F - 1) / (int)F + 1)) {
+        FusedClass fc{};
+        fc.steps = h->fic_steps[v].as<MscStep>(); fc.start_bit = nullptr; fc.out = h->s_fib.as<uint8_t>();
+        fc.nbits = 768; fc.nsteps = 774; fc.n_windows = h->fic_windows[v]; fc.n_cw = (int32_t)(B * F * 4);
+        fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1; fc.frame_sel = 0;
+        items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
+        cls.push_back(fc);
+        max_steps = std::max(max_steps, (size_t)fc.nsteps);
+        fic_in = true;
+    }
+    if (cls.size() > 255) { h->err = "more than 255 protection classes"; return DABPHY_ERR_INVALID; }
+    // longest code words first: the waves that pull the long groups start them while every slot is still busy, the short ones fill the end
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.nsteps > b.nsteps; });
+    std::vector<uint32_t> work;
+    for (const Item& it : items) {
+        if (it.n_groups > 0xffffff) { h->err = "class too large for the fused decode's work list"; return DABPHY_ERR_INVALID; }
+        for (int g = 0; g < it.n_groups; g++) work.push_back(((uint32_t)it.ci << 24) | (uint32_t)g);
+    }
+    const int slots = fused_wave_slots(v);
+    const int n_slots = (int)std::min<size_t>(work.size(), (size_t)slots);
+    int r;
+    if (!work.empty()) {
+        if ((r = ensure(h, h->vdec, (size_t)n_slots * max_steps * 64 * sizeof(uint2)))) return r;
+        if ((r = ensure(h, h->fused_cls, cls.size() * sizeof(FusedClass)))) return r;
+        if ((r = ensure(h, h->fused_work, work.size() * sizeof(uint32_t)))) return r;
+        if (!h->d_fused_next) {
+            void* p = nullptr;
+            if (hipMalloc(&p, sizeof(uint32_t)) != hipSuccess) { h->err = "hipMalloc failed (work cursor)"; return DABPHY_ERR_NOMEM; }
+            h->owned.push_back(p); h->d_fused_next = reinterpret_cast<uint32_t*>(p);
+        }
+    }
+    const bool same_cls = P.valid && P.buf_gen == h->buf_gen && P.host_cls.size() == cls.size() &&
+                          (cls.empty() || !memcmp(P.host_cls.data(), cls.data(), cls.size() * sizeof(FusedClass)));
+    const bool same_work = P.valid && P.buf_gen == h->buf_gen && P.host_work == work;
+    if (!same_cls) {
+        P.host_cls = cls;                              // (the plan's own storage: it outlives the copy, which the stream orders before the launch)
+        if (!cls.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_cls.p, P.host_cls.data(), cls.size() * sizeof(FusedClass), hipMemcpyHostToDevice, h->stream));
+    }
+    if (!same_work) {
+        P.host_work = work;
+        if (!work.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_work.p, P.host_work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    P.valid = true; P.F = F; P.want_fic = want_fic; P.fic_in = fic_in; P.variant = v; P.n_slots = n_slots;
+    P.dec_slot_cells = max_steps * 64; P.class_idx = idx; P.buf_gen = h->buf_gen;
+    FusedArgs a{};
+    a.soft = h->s_soft.as<int8_t>(); a.ens_stride = ens_stride; a.soft_ring = (int)h->cfg.max_frames + 5; a.n_ens = (int)B; a.n_frames = (int)F;
+    a.desc = nullptr;                                  // (set per batch: the descriptor buffers rotate)
+    a.cls = h->fused_cls.as<FusedClass>(); a.work = h->fused_work.as<uint32_t>(); a.n_work = (uint32_t)work.size(); a.next = h->d_fused_next;
+    a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = P.dec_slot_cells; a.prbs_words = h->d_prbs_words;
+    P.args = a;
+    return DABPHY_OK;
+}
+
+} // extern "C"

@@ -227,7 +227,7 @@ int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, in
     if (!h || !out || ensemble >= h->cfg.n_ensembles || frame >= h->last_frames) return DABPHY_ERR_INVALID;
     const FrameDesc& d = h->h_desc[(size_t)ensemble * h->last_frames + frame];
     const size_t slot = (size_t)(d.frame_no % h->soft_ring);
-    HIPCHK(h, hipMemcpyAsync(out, h->s_soft.as<int8_t>() + ((size_t)ensemble * h->soft_ring + slot) * SOFT_PER_FRAME, SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, h->s_soft.as<int8_t>() + (size_t)ensemble * soft_ens_stride(h) + slot * SOFT_PER_FRAME, SOFT_PER_FRAME, hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
 

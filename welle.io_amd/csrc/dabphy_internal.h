@@ -3,10 +3,12 @@
 //   dabphy_api.hip          create / destroy / options / sub-channel classes, the stateless seams (demod, Viterbi, FIC, RS) and the timing drivers
 //   dabphy_stream.hip       sample rings (bind / upload / write / raw formats), the synchroniser's chain and wide pass, reset
 //   dabphy_process.hip      dabphy_process: the pipelined schedules, exact batch mode (replay), the decode of one batch
+//   dabphy_fused.hip        the fused decode's host side: per-class step tables, the launch plan (build, classes, work list)
 //   dabphy_superframes.hip  Reed-Solomon seams and the DAB+ superframe filter
 //   dabphy_getters.hip      everything a caller reads back after a batch, profiling, TII
 #pragma once
 #include "../../include/dabphy.h"
+#include "../../include/dabphy_test.h"
 #include "dabphy_kernels.h"
 #include "dabphy_host.h"
 #include "osc_exact.h"
@@ -66,7 +68,7 @@ struct dabphy_handle {
         dabphy_protection prot{};
         std::vector<int> members;     // indices into subch
         DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
-        DevBuf steps; int n_windows = 0;     // fused decode (k_viterbi_msc): per-step window-ring descriptors, 16-byte windows of the punctured stream
+        DevBuf steps[FUSED_VARIANTS]; int n_windows[FUSED_VARIANTS] = {0, 0, 0};   // fused decode (k_viterbi_fused): per-step window-ring descriptors for each row-count build (0 windows: not decodable that way)
         DevBuf sf_state;                     // SuperframeFilter window of every (ensemble, member)
         DevBuf sf_snap;                      // ... as it was in front of the current batch (exact batch mode)
     };
@@ -85,8 +87,22 @@ struct dabphy_handle {
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
-    FusedMscArgs last_fused{}; bool have_last_fused = false;   // the fused decode launch of the last batch (dabphy_time_fused_msc re-runs it alone)
-    bool fused_msc = true;                               // MSC classes with >= 64 CIFs per batch: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
+    // fused decode (k_viterbi_fused): every class of the batch (and the FIC) in one launch.  The plan = which build, which classes, the
+    // work list; rebuilt when the batch depth, the class set or a buffer address changes (dabphy_fused.hip)
+    struct FusedPlan {
+        bool valid = false; uint32_t F = 0; bool want_fic = false; bool fic_in = false;
+        int variant = 0, n_slots = 0; size_t dec_slot_cells = 0;
+        std::vector<int> class_idx;                      // classes decoded by the fused launch (the others take k_msc_gather + k_viterbi)
+        std::vector<FusedClass> host_cls; std::vector<uint32_t> host_work;
+        FusedArgs args{}; uint64_t buf_gen = 0;          // the launch as it was last queued (dabphy_time_fused_msc re-runs it alone while buf_gen is current)
+        bool launched = false;
+    } fplan;
+    DevBuf fused_cls, fused_work; uint32_t* d_fused_next = nullptr;
+    DevBuf fic_steps[FUSED_VARIANTS]; int fic_windows[FUSED_VARIANTS] = {0, 0, 0};
+    hipEvent_t ev_fused_done = nullptr;
+    uint64_t buf_gen = 1;                                // bumped whenever a device buffer is reallocated or a class is rebuilt
+    bool fused_msc = true;                               // MSC classes: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
+    bool fused_fic = true;                               // the FIC rides in the same launch (DABPHY_FUSED_FIC=0: k_fic_gather + k_viterbi on the auxiliary stream)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
     // wide synchroniser pass (all frames of a batch at once, k_sync_find_wide/_finish_wide/_validate) and its serial fall-back
     bool wide_sync = true;            // cfg.serial_sync == 0 (DABPHY_SYNC_WIDE overrides)
@@ -150,6 +166,7 @@ inline int ensure(dabphy_handle* h, DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    h->buf_gen++;
     bytes = (bytes + 4095) & ~(size_t)4095;
     if (hipMalloc(&b.p, bytes) != hipSuccess) { h->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; b.p = nullptr; return DABPHY_ERR_NOMEM; }
     b.cap = bytes;
@@ -173,7 +190,8 @@ inline int sync(dabphy_handle* h)
     return 0;
 }
 
-// Fill a VitClass for n_cw codewords of nbits and make sure its device buffers exist.
+// Fill a VitClass for n_cw codewords of nbits and make sure its device buffers exist.  (h->vdec is also the decision scratch of the
+// fused decode: grow-only, so a buffer that is large enough for one of the two users is never shrunk under the other.)
 inline int prepare_class(dabphy_handle* h, VitClass& c, int nbits, int n_cw, int dedisperse)
 {
     c.nbits = nbits; c.nsteps = nbits + 6; c.n_cw = n_cw; c.n_groups = (n_cw + 63) / 64; c.dedisperse = dedisperse; c.g_begin = 0; c.g_end = c.n_groups;
@@ -199,4 +217,7 @@ DABPHY_INTERNAL int resolve_chain(dabphy_handle* h, int sel);
 DABPHY_INTERNAL int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F);       // dabphy_superframes.hip
 DABPHY_INTERNAL int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st = nullptr, int ens0 = 0, int ens_count = 0);
 DABPHY_INTERNAL int launch_superframe_stats(dabphy_handle* h);
+DABPHY_INTERNAL int fused_class_tables(dabphy_handle* h, const dabphy_protection& prot, bool fic, DevBuf (&steps)[FUSED_VARIANTS], int (&n_windows)[FUSED_VARIANTS]);   // dabphy_fused.hip
+DABPHY_INTERNAL int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic);
+DABPHY_INTERNAL size_t soft_ens_stride(const dabphy_handle* h);                                   // bytes between the soft-bit ring slices of two ensembles
 }

@@ -90,7 +90,8 @@ struct DemodArgs {
     const FrameDesc* desc; int n_frames;
     int chunk_len;                                        // data symbols per work-group
     int mix;                                              // 1: apply the NCO (streaming path); 0: input already mixed
-    int8_t* soft; int soft_ring;                          // [B][soft_ring][75][3072]
+    int8_t* soft; int soft_ring;                          // [B][soft_ring (+ 1 zero frame in the streaming receiver)][75][3072]
+    size_t soft_ens_stride;                               // bytes between the ring slices of two ensembles (0: soft_ring * SOFT_PER_FRAME)
     cf32* con;                                            // optional [B][n_frames][1200]
     float* prs_mag;                                       // optional [B][n_frames][2048]
     unsigned long long* osc_stats;                        // optional [2]: symbols mixed with the unchecked / the checked oscillator conversion
@@ -123,6 +124,7 @@ struct VitArgs { VitClass c; const uint32_t* prbs_words; };
 // Gather for the FIC: soft bits of symbols 1..3 of frame (b,f) -> 4 codewords, depunctured (fic-handler.cpp:158-191)
 struct FicGatherArgs {
     const int8_t* soft; int soft_ring; size_t frame_stride;   // bytes between frame slots (SOFT_PER_FRAME in the ring)
+    size_t soft_ens_stride;                                   // bytes between ensembles (0: soft_ring * frame_stride)
     const FrameDesc* desc; int n_ens, n_frames;
     const int16_t* map;     // [3096] mother-code index -> index into the 2304 punctured bits, -1 = erasure
     VitClass c;
@@ -133,6 +135,7 @@ struct FicGatherArgs {
 // (eep-protection.cpp:127-148) fused into one indexed read of the soft-bit ring.
 struct MscGatherArgs {
     const int8_t* soft; int soft_ring; const RxState* state; int n_ens, n_frames;
+    size_t soft_ens_stride;   // bytes between ensembles (0: soft_ring * SOFT_PER_FRAME)
     const int16_t* map;     // [4*nbits+24] -> index into the sub-channel's length*64 soft bits, -1 = erasure
     const int32_t* start_bit; // [n_subch_in_class] startAddr*64 per member sub-channel
     const int32_t* tiles;     // [ceil(nsteps/56)][2]: first source byte (4-aligned) and dwords per row of each step tile
@@ -141,25 +144,44 @@ struct MscGatherArgs {
     VitClass c;
 };
 
-// Fused MSC decode (k_viterbi_msc): the MSC gather inside the Viterbi kernel.  MscStep = what one trellis step needs, identical for
-// all code words of a class: byte offsets of its four soft bits in the wave's LDS window ring (relative to the lane's row base;
-// an erasure points into the zero slot), whether it is the first step to read a window, and which window to load once it has read.
+// Fused decode (k_viterbi_fused): the MSC gather (time de-interleave + depuncture) and the FIC gather inside the Viterbi kernel.
+// MscStep = what one trellis step needs, identical for all code words of a class: byte offsets of its four soft bits in the wave's
+// LDS window ring (relative to the lane's row base; an erasure points into the zero slot), whether it is the first step to read a
+// window, and which window to load once it has read.
 // (8 bytes per step: off0 | off1 << 16, off2 | off3 << 16 with two flags in the spare top bits -- bit 15 of off01: first step to read
 // a new window, wait for its load; bit 31 of off01: once this step has read, load the next window (they are loaded in order 2, 3, ...))
 struct MscStep { uint32_t off01, off23; };
-// geometry of the window ring (k_viterbi.hip: FM_*): 96 rows of 20 bytes per slot (16 window bytes + 4 bytes of padding: a pitch of five
-// dwords keeps the byte reads of consecutive rows on different LDS banks), slots 0 / 1 = windows, slot 2 = zeros (erasures)
-constexpr int MSC_ROW_PITCH = 20, MSC_SLOT_BYTES = 96 * MSC_ROW_PITCH, MSC_ZERO_OFF = 2 * MSC_SLOT_BYTES;
+// geometry of the window ring (k_viterbi.hip: FM_*): ROWS rows of 20 bytes per slot (16 window bytes + 4 bytes of padding: a pitch of
+// five dwords keeps the byte reads of consecutive rows on different LDS banks), slots 0 / 1 = windows, slot 2 = zeros (erasures).
+// ROWS depends on how many (ensemble, sub-channel) pairs the 64 code words of a wave can span, i.e. on the batch depth: the kernel is
+// built for three row counts and the per-step tables (whose offsets contain the slot size) once per variant.
+constexpr int MSC_ROW_PITCH = 20;
+constexpr int FUSED_VARIANTS = 3;
+constexpr int FUSED_ROWS[FUSED_VARIANTS] = {96, 144, 324};      // >= 64 + 15 * segments: 2 segments (>= 64 CIFs per batch), 5 (>= 16), 17 (>= 4)
+constexpr int FUSED_MIN_CIFS[FUSED_VARIANTS] = {64, 16, 4};
 constexpr uint32_t MSC_FIRST_USE = 1u << 15, MSC_LOAD_NEXT = 1u << 31, MSC_OFF_MASK = 0x7fffu;
-struct FusedMscArgs {
-    const int8_t* soft; int soft_ring; int n_ens, n_frames;
-    const MscStep* steps;     // [nsteps]
-    int n_windows;            // 16-byte windows of the punctured bit stream
-    const int32_t* start_bit; int n_members; const FrameDesc* desc;
-    uint32_t zero_off16;      // (byte offset / 16) of >= 16 * n_windows zero bytes behind the soft-bit ring: what a row without a source CIF loads
-    VitClass c; const uint32_t* prbs_words;
+// One class of a fused launch (read through the constant address space).  kind 0 = an MSC protection class: code word
+// cw = (b * n_members + m) * R + r (ensemble b, member sub-channel m, CIF r of this batch, R = 4 * n_frames); kind 1 = the FIC:
+// code word (b * n_frames + f) * 4 + q, or 4 b + q of frame frame_sel - 1 alone (the replay of exact batch mode).
+struct FusedClass {
+    const MscStep* steps;     // [nsteps + 6] for the launch's row-count variant
+    const int32_t* start_bit; // MSC: [n_members] startAddr * 64
+    uint8_t* out;             // [n_cw][nbits / 8]
+    int32_t nsteps, nbits, n_windows, n_cw, n_members, kind, dedisperse, frame_sel;
 };
-void launch_viterbi_msc(const FusedMscArgs& a, hipStream_t s);
+static_assert(sizeof(FusedClass) == 56, "FusedClass layout");
+struct FusedArgs {
+    const int8_t* soft; size_t ens_stride; int soft_ring; int n_ens, n_frames;
+    const FrameDesc* desc;
+    const FusedClass* cls;
+    const uint32_t* work; uint32_t n_work;     // work list: class << 24 | group of 64 code words, longest code words first
+    uint32_t* next;                            // its dynamic cursor (zeroed by the launcher)
+    uint2* dec; size_t dec_slot_cells;         // decision scratch of work-group i: dec + i * dec_slot_cells ([step][64 lanes] cells)
+    const uint32_t* prbs_words;
+};
+// variant = index into FUSED_ROWS; n_slots = work-groups (one wave each) to launch
+void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s);
+int fused_wave_slots(int variant);             // resident waves of that variant on the current device
 
 struct CrcArgs {
     const uint8_t* fib;     // [B][F][12][32]
@@ -210,6 +232,7 @@ struct IngestArgs {
     int format;                                           // dabphy_sample_format
 };
 void launch_ingest(const IngestArgs& a, int n_ens, hipStream_t s);
+void launch_copy_f4(const void* src, void* dst, size_t n16, int blocks, hipStream_t s);
 
 // Reed-Solomon (k_rs.hip)
 struct RsArgs {            // contiguous superframes [n_sf][sf_stride], s = bitrate/8 codewords each

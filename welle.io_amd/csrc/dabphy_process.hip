@@ -27,11 +27,13 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->exact_batch && (r = ensure(h, h->snap_state[k], (size_t)B * sizeof(RxState)))) return r;
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
-    {   // + a tail of zeros (one sub-channel's worth: 864 CU x 64 bits) that the fused MSC decode loads for CIFs that do not exist yet
-        const size_t ring_bytes = (size_t)B * ring_frames * SOFT_PER_FRAME, tail = 864 * 64 + 64;
-        if (h->s_soft.cap < ring_bytes + tail) {
-            if ((r = ensure(h, h->s_soft, ring_bytes + tail))) return r;
-            HIPCHK(h, hipMemsetAsync(h->s_soft.as<int8_t>() + ring_bytes, 0, tail, h->stream));
+    const size_t ens_stride = soft_ens_stride(h);
+    {   // [B][ring_frames frame slots + one frame of zeros]: the zeros are what the fused decode loads for CIFs that do not exist yet
+        // (nothing ever writes them; one sub-channel's worth -- 864 CU x 64 bits -- is the most a row needs)
+        const size_t ring_bytes = (size_t)B * ens_stride;
+        if (h->s_soft.cap < ring_bytes) {
+            if ((r = ensure(h, h->s_soft, ring_bytes))) return r;
+            for (uint32_t b = 0; b < B; b++) HIPCHK(h, hipMemsetAsync(h->s_soft.as<int8_t>() + (size_t)b * ens_stride + (size_t)ring_frames * SOFT_PER_FRAME, 0, SOFT_PER_FRAME, h->stream));
         }
     }
     if ((r = ensure(h, h->s_hist, (size_t)B * HIST_CAP * sizeof(FrameDesc)))) return r;
@@ -45,9 +47,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     VitClass fic_c{};
     {
         fic_c.nbits = 768; fic_c.nsteps = 774; fic_c.n_cw = (int)(B * F * 4); fic_c.n_groups = (fic_c.n_cw + 63) / 64; fic_c.dedisperse = 1; fic_c.g_begin = 0; fic_c.g_end = fic_c.n_groups;
-        const size_t cells = (size_t)fic_c.n_groups * fic_c.nsteps * 64;
-        if ((r = ensure(h, h->fsym, cells * sizeof(uint32_t)))) return r;
-        if ((r = ensure(h, h->fdec, cells * sizeof(uint2)))) return r;
         if ((r = ensure(h, h->s_fib, (size_t)fic_c.n_groups * 64 * 96))) return r;      // the class output holds whole groups of 64 codewords
         if (h->tii_on) {
             if ((r = ensure(h, h->tii_err, (size_t)B * F * TII_MAX_LIKELY * TII_NERR * sizeof(float)))) return r;
@@ -56,10 +55,27 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if ((r = ensure(h, h->tii_nev, (size_t)B * sizeof(int32_t)))) return r;
         }
         for (auto& cls : h->classes) {
-            VitClass c{};
-            if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * cls.members.size()), 1))) return r;
-            if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
+            const size_t n_groups = ((size_t)B * 4 * F * cls.members.size() + 63) / 64;
+            if ((r = ensure(h, cls.out, n_groups * 64 * (cls.prot.nbits / 8)))) return r;
             if (h->sf_auto && (r = prepare_superframes(h, cls, F))) return r;
+        }
+        // the fused decode of this batch depth: which classes (and whether the FIC) ride in the one launch; its decision scratch
+        if ((r = fused_plan(h, F, true))) return r;
+        {   // what is left for the two-kernel path: Viterbi scratch of the largest such class; the FIC's own (the replay of exact batch
+            // mode decodes one frame's 4 B code words at a time through it even when the batch's FIC is fused)
+            size_t ci = 0;
+            for (auto& cls : h->classes) {
+                const bool fused = std::find(h->fplan.class_idx.begin(), h->fplan.class_idx.end(), (int)ci) != h->fplan.class_idx.end();
+                ci++;
+                if (fused) continue;
+                VitClass c{};
+                if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * cls.members.size()), 1))) return r;
+            }
+            const size_t fic_groups = h->fplan.fic_in ? ((size_t)B * 4 + 63) / 64 : (size_t)fic_c.n_groups;
+            if (!h->fplan.fic_in || h->exact_batch) {
+                if ((r = ensure(h, h->fsym, fic_groups * fic_c.nsteps * 64 * sizeof(uint32_t)))) return r;
+                if ((r = ensure(h, h->fdec, fic_groups * fic_c.nsteps * 64 * sizeof(uint2)))) return r;
+            }
         }
         if (h->sf_auto && (r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
         if (h->exact_batch) {
@@ -67,6 +83,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if (h->tii_state.p && (r = ensure(h, h->snap_tii, h->tii_state.cap))) return r;
             for (auto& cls : h->classes) if (cls.sf_state.p && (r = ensure(h, cls.sf_snap, cls.sf_state.cap))) return r;
         }
+        // (an ensure() above may have moved a buffer the plan names: then it is stale -- plan again, nothing moves the second time)
+        if (h->fplan.buf_gen != h->buf_gen && (r = fused_plan(h, F, true))) return r;
     }
     h->soft_ring = ring_frames;
 
@@ -115,7 +133,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     DemodArgs da{};
     da.tab = h->tab; da.iq = h->s_iq; da.iq_stride = h->s_stride; da.ring = (int64_t)h->s_ring;
     da.desc = d_desc; da.n_frames = (int)F; da.chunk_len = h->cfg.demod_chunk; da.mix = 1;
-    da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames;
+    da.soft = h->s_soft.as<int8_t>(); da.soft_ring = ring_frames; da.soft_ens_stride = ens_stride;
     da.con = h->cfg.want_constellation ? h->s_con.as<cf32>() : nullptr; da.prs_mag = h->s_mag.as<float>();
     da.osc_stats = h->d_osc_stats;
     if (replay) {
@@ -129,7 +147,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         VitClass c = fic_c;
         c.n_cw = (int)(B * 4); c.n_groups = (c.n_cw + 63) / 64; c.g_begin = 0; c.g_end = c.n_groups;
         c.sym = h->fsym.as<uint32_t>(); c.dec = h->fdec.as<uint2>(); c.out = h->s_fib.as<uint8_t>();
-        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
+        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.soft_ens_stride = ens_stride; g.desc = d_desc;
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
@@ -155,35 +173,31 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     if (!replay && (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3)) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
 
-    // SNR + FIC: 4 codewords per frame.  Only B*F/16 wavefronts of 774 serial trellis steps: it runs on its own stream beside the
-    // MSC classes (own Viterbi scratch), filling execution slots instead of holding the whole device for a latency-bound tail.
+    // SNR + FIC + TII beside the MSC decode, on the auxiliary stream.  The FIC's 4 code words per frame ride in the fused launch
+    // (dabphy_fused.hip) unless that is switched off; then -- B*F/16 wavefronts of 774 serial trellis steps -- they are decoded here,
+    // by their own gather + Viterbi pair that fills execution slots beside the MSC classes.
+    const bool fic_fused = h->fplan.fic_in;
+    hipStream_t fs = h->aux_stream;
+    VitClass ficc = fic_c;
+    ficc.sym = h->fsym.as<uint32_t>(); ficc.dec = h->fdec.as<uint2>(); ficc.out = h->s_fib.as<uint8_t>();
     {
-        VitClass c = fic_c;
-        c.sym = h->fsym.as<uint32_t>(); c.dec = h->fdec.as<uint2>(); c.out = h->s_fib.as<uint8_t>();
-        FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.desc = d_desc;
-        g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
-        hipStream_t fs = h->aux_stream;
         HIPCHK(h, hipEventRecord(h->ev_demod_done, h->stream));
         HIPCHK(h, hipStreamWaitEvent(fs, h->ev_demod_done, 0));
-        // the SNR estimate (8192 threads of serial float sums over the PRS magnitudes) feeds nothing on the device: off the main stream,
-        // so that the MSC decode starts the moment the demod kernel ends
+        // the SNR estimate feeds nothing on the device: off the main stream, so that the MSC decode starts the moment the demod kernel ends
         mark(dabphy_handle::ST_SNR, false, fs);
         launch_snr(sn, fs);
         mark(dabphy_handle::ST_SNR, true, fs);
-        mark(dabphy_handle::ST_FIC, false, fs);
-        launch_fic_gather(g, fs);
-        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
-        launch_viterbi(v, fs);
-        CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
-        launch_fib_crc(k, fs);
-        k.any_effective = h->d_any_eff;
-        if (!replay) launch_fic_ratio(k, fs);                    // (the second pass of exact batch mode has advanced the ratio frame by frame)
-        HIPCHK(h, hipMemcpyAsync(h->h_any_eff, h->d_any_eff, sizeof(int32_t), hipMemcpyDeviceToHost, fs));
-        mark(dabphy_handle::ST_FIC, true, fs);
+        if (!fic_fused) {
+            FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.soft_ens_stride = ens_stride; g.desc = d_desc;
+            g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = ficc;
+            mark(dabphy_handle::ST_FIC, false, fs);
+            launch_fic_gather(g, fs);
+            VitArgs v{}; v.c = ficc; v.prbs_words = h->d_prbs_words;
+            launch_viterbi(v, fs);
+        }
         h->tii_ran = false;
         if (h->tii_on) {
-            // TII side path (ofdm-processor.cpp:462-466 -> TIIDecoder): needs only the samples and the frame descriptors, rides behind
-            // the FIC on the auxiliary stream
+            // TII side path (ofdm-processor.cpp:462-466 -> TIIDecoder): needs only the samples and the frame descriptors
             h->tii_max_events = TII_MAX_LIKELY * h->cfg.max_frames;
             TiiArgs ta{};
             ta.tab = h->tab; ta.iq = h->s_iq; ta.iq_stride = h->s_stride; ta.ring = (int64_t)h->s_ring; ta.desc = d_desc; ta.n_ens = (int)B; ta.n_frames = (int)F;
@@ -197,42 +211,52 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // the host's copies of the descriptors and SNR reports leave here, beside the decoder, instead of behind the step's last kernel
         HIPCHK(h, hipMemcpyAsync(h->h_desc, d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
+    }
+    // MSC (+ FIC): every class the plan holds in ONE launch; the stage events bracket all of it
+    h->last_frames = F;
+    h->sf_stats_ready = false; h->h_sf_stats_valid = false;
+    if (h->fplan.args.n_work > 0) {
+        FusedArgs fa = h->fplan.args; fa.desc = d_desc;
+        h->fplan.args = fa; h->fplan.launched = true;
+        mark(dabphy_handle::ST_MSC_VITERBI, false);
+        launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream);
+        mark(dabphy_handle::ST_MSC_VITERBI, true);
+        if (fic_fused) HIPCHK(h, hipEventRecord(h->ev_fused_done, h->stream));
+    }
+    {
+        // FIB CRCs, the FIC success ratio (and with it the verdict of exact batch mode), the host's copies of both
+        if (fic_fused) { HIPCHK(h, hipStreamWaitEvent(fs, h->ev_fused_done, 0)); mark(dabphy_handle::ST_FIC, false, fs); }
+        CrcArgs k{}; k.fib = ficc.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
+        launch_fib_crc(k, fs);
+        k.any_effective = h->d_any_eff;
+        if (!replay) launch_fic_ratio(k, fs);                    // (the second pass of exact batch mode has advanced the ratio frame by frame)
+        HIPCHK(h, hipMemcpyAsync(h->h_any_eff, h->d_any_eff, sizeof(int32_t), hipMemcpyDeviceToHost, fs));
+        mark(dabphy_handle::ST_FIC, true, fs);
         HIPCHK(h, hipMemcpyAsync(h->h_fib, h->s_fib.p, (size_t)B * F * 384, hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipMemcpyAsync(h->h_ok, h->s_ok.p, (size_t)B * F * 12, hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
-    // MSC: one decode per protection class (stage events bracket the first class only: one class in the canonical ensemble).
-    h->last_frames = F;
-    h->sf_stats_ready = false; h->h_sf_stats_valid = false;
-    for (auto& cls : h->classes) {
-        VitClass c{};
-        const int M = (int)cls.members.size();
-        const int n_cw = (int)(B * 4 * F * M);
-        if ((r = prepare_class(h, c, cls.prot.nbits, n_cw, 1))) return r;
-        if ((r = ensure(h, cls.out, (size_t)c.n_groups * 64 * (cls.prot.nbits / 8)))) return r;
-        c.out = cls.out.as<uint8_t>();
-        const bool first_cls = (&cls == &h->classes.front());
-        if (h->fused_msc && cls.n_windows > 0 && 4 * F >= 64) {
-            // fused: the gather happens inside the Viterbi kernel (needs >= 64 CIFs per sub-channel and batch: a wave then spans at
-            // most two (ensemble, sub-channel) pairs)
-            FusedMscArgs fa{}; fa.soft = da.soft; fa.soft_ring = ring_frames; fa.n_ens = (int)B; fa.n_frames = (int)F;
-            fa.steps = cls.steps.as<MscStep>(); fa.n_windows = cls.n_windows; fa.start_bit = cls.start_bits.as<int32_t>(); fa.n_members = M; fa.desc = d_desc; fa.zero_off16 = (uint32_t)(((size_t)B * ring_frames * SOFT_PER_FRAME) >> 4);
-            fa.c = c; fa.prbs_words = h->d_prbs_words;
-            if (first_cls) { h->last_fused = fa; h->have_last_fused = true; }
-            if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, false);
-            launch_viterbi_msc(fa, h->stream);
-            if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
-            continue;
+    // classes the fused launch does not take (DABPHY_FUSED_MSC=0, a window schedule the kernel cannot follow, a span beyond 4 GiB): two
+    // kernels each, one class after the other (they share the Viterbi scratch)
+    {
+        bool first_two = true; size_t ci = 0;
+        for (auto& cls : h->classes) {
+            const bool fused = std::find(h->fplan.class_idx.begin(), h->fplan.class_idx.end(), (int)ci) != h->fplan.class_idx.end();
+            ci++;
+            if (fused) continue;
+            VitClass c{};
+            const int M = (int)cls.members.size();
+            if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * M), 1))) return r;
+            c.out = cls.out.as<uint8_t>();
+            MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.soft_ens_stride = ens_stride; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
+            g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
+            if (first_two) mark(dabphy_handle::ST_MSC_GATHER, false);
+            launch_msc_gather(g, h->stream);
+            VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+            launch_viterbi(v, h->stream);
+            first_two = false;
         }
-        // batches of fewer than 64 CIFs per sub-channel (and classes whose window schedule the fused kernel cannot follow): two kernels
-        MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
-        g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
-        if (first_cls) mark(dabphy_handle::ST_MSC_GATHER, false);
-        launch_msc_gather(g, h->stream);
-        if (first_cls) { mark(dabphy_handle::ST_MSC_GATHER, true); mark(dabphy_handle::ST_MSC_VITERBI, false); }
-        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
-        launch_viterbi(v, h->stream);
-        if (first_cls) mark(dabphy_handle::ST_MSC_VITERBI, true);
+        if (!first_two) mark(dabphy_handle::ST_MSC_GATHER, true);       // (gather + decode pairs of all such classes)
     }
     if (h->sf_auto) {
         if ((r = launch_superframe_stats(h))) return r;

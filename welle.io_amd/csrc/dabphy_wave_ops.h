@@ -135,19 +135,22 @@ __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef unsigned int buf_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ BufRsrc buf_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); }
+// AUX = the instruction's cache-policy bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1; MI355X_MICROARCH.md "stores of each flavour")
+template <int AUX = 0>
 __device__ __forceinline__ uint2 buf_load_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes)
 {
-    const buf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0); return make_uint2(v.x, v.y);
+    const buf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, AUX); return make_uint2(v.x, v.y);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store_b64(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint2 v)
 {
-    buf_u32x2 w; w.x = v.x; w.y = v.y; __builtin_amdgcn_raw_buffer_store_b64(w, r, lane_bytes, uniform_bytes, 0);
+    buf_u32x2 w; w.x = v.x; w.y = v.y; __builtin_amdgcn_raw_buffer_store_b64(w, r, lane_bytes, uniform_bytes, AUX);
 }
 __device__ __forceinline__ void buf_store_b32(BufRsrc r, uint32_t lane_bytes, uint32_t uniform_bytes, uint32_t v)
 {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_bytes, uniform_bytes, 0);
 }
-// ... with a range of 4 GiB from the base (LDS-DMA sources: the soft-bit ring of a 256-ensemble batch is 2.2 GB)
+// ... with a range of 4 GiB from the base (LDS-DMA sources of the fused decode: the ring slices of the few ensembles a wave spans)
 __device__ __forceinline__ BufRsrc buf_rsrc_4g(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000); }
 // LDS-DMA through a buffer resource: the dword at base + lane_bytes + uniform_bytes lands at lds_wave_base + 4 * lane (inactive lanes
 // transfer nothing); no 64-bit address arithmetic, no VGPR pair per request.  Completion is tracked by vmcnt like lds_dma4.

@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
     }
     __syncthreads();
     const int ok = s_ok;
-    if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }
+    if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats && p.nq >= 1) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }   // (a batch without a full window has nothing the wide pass could settle: not counted as tried)
     if (!ok) return;
     sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t);
     // the frames behind the last attempt are the next batch's carried window (a hit empties it, dabplus_decoder.cpp:156)

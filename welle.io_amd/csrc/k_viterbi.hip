@@ -42,20 +42,21 @@ __device__ __forceinline__ uint2 step_from_word(uint32_t (&M)[32], uint32_t w, u
 // Traceback of one codeword from state 0, skipping the 6 tail steps (chainback_viterbi, viterbi.cpp:313-339); bits are packed MSB
 // first (decoder_adapter.cpp:61-67) into little-endian 32-bit words and XORed with the energy-dispersal sequence when asked to
 // (fic-handler.cpp:206-208, energy_dispersal.h:51-53).  The decision words do not depend on the path, so 8 steps are fetched at a
-// time and resolved from registers (acs::back: four instructions per step).  dec_lane = this lane's column of the group's decisions.
-__device__ __forceinline__ void traceback(const uint2* __restrict__ dec_g, uint32_t lane, int nbits, uint32_t* __restrict__ out, bool live,
+// time and resolved from registers (acs::back: four instructions per step).  load_dec(step) = this lane's decision word of that trellis step.
+template <typename LoadDec>
+__device__ __forceinline__ void traceback(LoadDec&& load_dec, int nbits, uint32_t* __restrict__ out, bool live,
                                           int dedisperse, const uint32_t* __restrict__ prbs_words)
 {
     uint32_t J = 0, outw = 0;
     uint32_t rho = (uint32_t)acs::dec_rot((nbits - 1) % 6);       // step t = n + 6 ran in layout t % 6 = n % 6
     uint2 dq[8], dn[8];                                           // this iteration's decision words and the next one's (already in flight)
 #pragma unroll
-    for (int k = 0; k < 8; k++) dq[k] = dec_g[(uint32_t)((nbits - 1 - k + 6) * 64) + lane];
+    for (int k = 0; k < 8; k++) dq[k] = load_dec(nbits - 1 - k + 6);
     for (int n = nbits - 1; n >= 0; n -= 8) {
         {
             const int m = n >= 8 ? n - 8 : n;                     // the last iteration re-reads its own words
 #pragma unroll
-            for (int k = 0; k < 8; k++) dn[k] = dec_g[(uint32_t)((m - k + 6) * 64) + lane];
+            for (int k = 0; k < 8; k++) dn[k] = load_dec(m - k + 6);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(64, VIT_OCC) k_viterbi(VitArgs A)
     if (s < nsteps) { dec[(size_t)s * 64] = step_from_word<4>(M, sym[(size_t)s * 64], ones); s++; }
 
     const int cw = g * 64 + lane;
-    traceback(A.c.dec + (size_t)g * nsteps * 64, (uint32_t)lane, nbits, reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32),
+    traceback([&](int st) { return dec[(uint32_t)(st * 64)]; }, nbits, reinterpret_cast<uint32_t*>(A.c.out) + (size_t)cw * (nbits / 32),
               cw < A.c.n_cw, A.c.dedisperse, A.prbs_words);
   }
 }
@@ -143,7 +144,8 @@ __global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
     const int bf = A.frame_sel ? (cw >> 2) * A.n_frames + (A.frame_sel - 1) : cw >> 2;     // bf = b * n_frames + f
     const int b = live ? bf / A.n_frames : 0;
     const FrameDesc d = A.desc[live ? bf : 0];
-    const int8_t* __restrict__ src = A.soft + ((size_t)b * A.soft_ring + (size_t)(d.frame_no % A.soft_ring)) * A.frame_stride + 2304 * q;
+    const size_t ens_stride = A.soft_ens_stride ? A.soft_ens_stride : (size_t)A.soft_ring * A.frame_stride;
+    const int8_t* __restrict__ src = A.soft + (size_t)b * ens_stride + (size_t)(d.frame_no % A.soft_ring) * A.frame_stride + 2304 * q;
     uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
     for (int s = blockIdx.y * 4 + wave; s < nsteps; s += gridDim.y * 4) {
         uint32_t word = 0;
@@ -190,7 +192,8 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
     const int pair = live ? cw / R : -1, r = live ? cw % R : 0;
     const int b = live ? pair / A.n_members : 0, m = live ? pair % A.n_members : 0;
     const long long c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;   // CIF whose arrival emits this logical frame
-    const size_t ens_base = (size_t)b * A.soft_ring * SOFT_PER_FRAME + A.start_bit[m];
+    const size_t ens_stride = A.soft_ens_stride ? A.soft_ens_stride : (size_t)A.soft_ring * SOFT_PER_FRAME;
+    const size_t ens_base = (size_t)b * ens_stride + A.start_bit[m];
     const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
     uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
 
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
             if (s_pair[l] < 0) { for (int k = l; k <= e; k++) s_rowbase[k] = -1; l = e + 1; continue; }
             if (nrows + need > GT_MAXROWS) { nrows = -1; break; }
             const int pb = s_pair[l] / A.n_members, pm = s_pair[l] % A.n_members;
-            const long long pbase = (long long)pb * A.soft_ring * SOFT_PER_FRAME + A.start_bit[pm];
+            const long long pbase = (long long)pb * (long long)ens_stride + A.start_bit[pm];
             for (int k = 0; k < need; k++) {
                 const long long c_src = s_c[l] - 16 + k;
                 long long src = -1;
@@ -284,98 +287,166 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
     }
 }
 
-// ------------------------------------------------------------------------------------------ fused MSC decode
-// k_viterbi_msc = k_msc_gather + k_viterbi in one kernel: the step-word array (4 bytes per trellis step and code word written by the
-// gather and read back by the decoder: 2 x 2.27 GB per 256 x 20 batch) never exists.  A wavefront (64 code words = consecutive CIFs of
-// at most two (ensemble, sub-channel) pairs) keeps in LDS a sliding WINDOW of the soft-bit rows it decodes from:
-//   rows    the source CIFs of its code words, 64 + 15 per (b, m) segment (time de-interleaver: byte u of the frame emitted at CIF c
-//           comes from CIF c - 16 + map16[u & 15], dab-audio.cpp:113,138-143), <= 94;
-//   columns 16-byte windows of the sub-channel's punctured bit stream: window w = bytes [16 w, 16 w + 16).  Two windows are resident
-//           (slot w & 1), the next one travels HBM -> LDS by LDS-DMA (6 requests of 64 x 4 bytes, no VGPRs) while the current ones are
-//           consumed; u & 15 is the column inside a window, so the de-interleaver's row skew is a function of the column.
+// ------------------------------------------------------------------------------------------ fused decode
+// k_viterbi_fused = k_msc_gather / k_fic_gather + k_viterbi in one kernel, for EVERY class of a batch in one launch: the step-word
+// array (4 bytes per trellis step and code word written by a gather and read back by the decoder) never exists, and the classes of a
+// heterogeneous multiplex share one grid instead of queueing one partly filled launch each.
+//
+// Work: a list of (class, group of 64 code words), longest code words first, handed out through an atomic cursor -- every
+// work-group is ONE wave that lives for the whole launch (one per resident wave slot) and pulls the next group when it has finished
+// one, so SIMDs stay evenly loaded whatever the mix of code word lengths.  Its decision scratch is per work-group, not per group.
+//
+// A wave (64 code words) keeps in LDS a sliding WINDOW of the soft-bit rows it decodes from:
+//   rows    MSC class: the source CIFs of its code words.  Code words are consecutive CIFs of consecutive (ensemble, sub-channel)
+//           pairs; byte u of the frame emitted at CIF c comes from CIF c - 16 + map16[u & 15] (time de-interleaver,
+//           dab-audio.cpp:113,138-143), so a run of n lanes of one pair (a segment) needs n + 15 rows: 64 + 15 * segments in all.
+//           Batches of >= 64 CIFs per sub-channel give <= 2 segments (96 rows), >= 16 CIFs <= 5 (144 rows), >= 4 CIFs <= 17 (324
+//           rows): three builds of the kernel.  FIC: one row per code word (its 2304 punctured bits, fic-handler.cpp:158-191), no skew.
+//   columns 16-byte windows of the punctured bit stream: window w = bytes [16 w, 16 w + 16).  Two windows are resident (slot w & 1),
+//           the next one travels HBM -> LDS by LDS-DMA (requests of 12 rows x 4 dwords, no VGPRs) while the current ones are consumed;
+//           u & 15 is the column inside a window, so the de-interleaver's row skew is a function of the column.
+// Sources are addressed through a buffer resource that starts at the ring slice of the wave's FIRST ensemble (a wave spans a handful
+// of consecutive ensembles; the host checks that span against the 4 GiB a 32-bit offset reaches -- whole-ring offsets wrapped for
+// B x (F + 5) > 18 641 frame slots in round 3); rows without a source CIF point at that ensemble's zero frame.
 // Everything that depends only on the step -- which of the 4 mother-code bits are punctured, where the others lie in the window ring,
 // when a window dies -- is the same for all lanes and comes from a per-class table (MscStep, built on the host from the depuncturing
 // map) through scalar loads.  Per step a lane adds its row base to four uniform offsets, reads four bytes from LDS (an erasure
 // reads a zero from a third, never written slot) and forms the branch metrics; the trellis and the traceback are k_viterbi's.
-constexpr int FM_ROWS = 96;                       // 12-row blocks of the LDS-DMA requests; 64 + 2 * 15 = 94 rows used at most
 constexpr int FM_PITCH = MSC_ROW_PITCH;           // bytes per row of a window slot: 16 window bytes + 4 of padding.  FIVE dwords per row, so the
                                                   // byte reads of 32 consecutive rows (lanes) at one column fall into 32 different banks; with
                                                   // the 16-byte pitch of round 2 they were 4-way conflicted (SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.72)
-constexpr int FM_SLOT = FM_ROWS * FM_PITCH;       // bytes per window slot: [row][20]
-constexpr int FM_ZERO = 2 * FM_SLOT;              // third slot: zeros (erasures, viterbi.cpp:233-238 maps soft value 0 to symbol 127)
-constexpr int FM_ROWPTR = 3 * FM_SLOT;            // then the rows' sources: byte offset / 16 into the soft-bit ring (rows without a source CIF point at the zeros behind the ring)
-constexpr int FM_LDS = FM_ROWPTR + FM_ROWS * 4;
 constexpr int FM_REQ_ROWS = 12;                   // rows per LDS-DMA request: 12 x 5 = 60 lanes, lane l moves dword (l % 5) of row l / 5 (dword 4 = the padding: idle)
-static_assert(FM_ZERO == MSC_ZERO_OFF && FM_SLOT == MSC_SLOT_BYTES, "window ring layout: host table (dabphy_api.hip) and kernel");
+template <int ROWS> struct FmGeom {
+    static constexpr int SLOT = ROWS * FM_PITCH;  // bytes per window slot: [row][20]
+    static constexpr int ZERO = 2 * SLOT;         // third slot: zeros (erasures, viterbi.cpp:233-238 maps soft value 0 to symbol 127)
+    static constexpr int ROWPTR = 3 * SLOT;       // then the rows' sources: byte offset / 16 from the wave's base
+    static constexpr int LDS = ROWPTR + ROWS * 4;
+    static constexpr int NREQ = ROWS / FM_REQ_ROWS;
+    static_assert(ROWS % FM_REQ_ROWS == 0 && 3 * SLOT + 64 * FM_PITCH <= (int)MSC_OFF_MASK, "window ring geometry");
+};
+// cache policy of the decision traffic (8 bytes per trellis step and code word, written once, read once ~a millisecond later by the
+// same wave): timing experiments, profiles/r04_viterbi_cache_policy.txt
+#ifndef FM_DEC_STORE_AUX
+#define FM_DEC_STORE_AUX 0
+#endif
+#ifndef FM_DEC_LOAD_AUX
+#define FM_DEC_LOAD_AUX 0
+#endif
 
 #ifndef VITM_OCC
 #define VITM_OCC 5
 #endif
-__global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
+template <int ROWS, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[FM_LDS];
+  using G = FmGeom<ROWS>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[G::LDS];
   const int lane = threadIdx.x;
-  const int nsteps = A.c.nsteps, nbits = A.c.nbits, R = 4 * A.n_frames;
-  uint32_t* const out_words = reinterpret_cast<uint32_t*>(A.c.out);
-  const int words_per_cw = nbits / 32;
+  const int F = A.n_frames, R = 4 * F;
   const uint32_t lane8 = (uint32_t)lane * 8u;                       // byte offset of this lane in a decision row
+  // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
+  uint2* const dec_g = A.dec + (size_t)blockIdx.x * A.dec_slot_cells;
+  const BufRsrc dec_rs = buf_rsrc(dec_g);
+  const DABPHY_CONST_AS FusedClass* const classes = as_constant(A.cls);
+  const DABPHY_CONST_AS uint32_t* const work = as_constant(A.work);
+  uint32_t* const rowptr = reinterpret_cast<uint32_t*>(lds + G::ROWPTR);
 #pragma unroll 1
-  for (int g = A.c.g_begin + blockIdx.x; g < A.c.g_end; g += gridDim.x) {
-    // ---- which rows this wave needs: segments = runs of lanes with the same (b, m) (their CIFs are consecutive by construction)
-    const int cw = g * 64 + lane;
-    const bool live = cw < A.c.n_cw;
-    const int pair = live ? cw / R : -1, r = live ? cw % R : 0;
-    const int b = live ? pair / A.n_members : 0;
-    const int pair0 = __shfl(pair, 0);
-    const unsigned long long in0 = __ballot(pair == pair0);                              // segment 0 = the leading lanes of pair0
-    const int n0 = __popcll(in0);
-    const int seg = (pair == pair0) ? 0 : 1;                                             // (dead lanes ride in segment 1: their output is dropped)
-    const int rb = lane + 15 * seg;                                                      // row of CIF c_glob - 16
-    const int first1 = n0 < 64 ? n0 : 63;
-    const int pair1 = __shfl(pair, first1);
-    const long long c_a0 = 4 * A.desc[(size_t)__shfl(b, 0) * A.n_frames].frame_no + __shfl(r, 0);            // first CIF of segment 0 ...
-    const long long c_a1 = 4 * A.desc[(size_t)__shfl(b, first1) * A.n_frames].frame_no + __shfl(r, first1);  // ... and of segment 1
-    const int nrows = (n0 < 64 && pair1 >= 0) ? 64 + 30 : n0 + 15;
+  for (;;) {
+    uint32_t item = 0;
+    if (lane == 0) item = atomicAdd(A.next, 1u);
+    item = (uint32_t)uniform_i32(__shfl((int)item, 0));
+    if (item >= A.n_work) break;
+    const uint32_t wk = work[item];
+    const DABPHY_CONST_AS FusedClass& C = classes[wk >> 24];
+    const int g = (int)(wk & 0xffffffu);
+    const int nsteps = C.nsteps, nbits = C.nbits, n_cw = C.n_cw, n_windows = C.n_windows;
+    const long long cw0 = (long long)g * 64;
+    const int cw = (int)cw0 + lane;
+    const uint32_t zero16 = (uint32_t)(((size_t)A.soft_ring * SOFT_PER_FRAME) >> 4);     // the zero frame behind the wave's first ensemble's ring slice
     __syncthreads();                                                                     // (one wave per work-group: orders the LDS reuse between groups)
-    // zero the window slots and the erasure slot; row pointers
-    for (int i = lane; i < FM_ROWPTR / 16; i += 64) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
-    for (int row = lane; row < FM_ROWS; row += 64) {
-        uint32_t src = A.zero_off16;                   // no such CIF yet (start of a stream) / row not used by this wave
-        if (row < nrows) {
-            const bool s1 = row >= n0 + 15;
-            const int pr = s1 ? pair1 : pair0;
-            const long long c_src = (s1 ? c_a1 : c_a0) - 16 + (s1 ? row - (n0 + 15) : row);
-            if (pr >= 0 && c_src >= 0) {
-                const int pb = pr / A.n_members, pm = pr % A.n_members;
-                src = (uint32_t)(((long long)pb * A.soft_ring * SOFT_PER_FRAME + A.start_bit[pm] +
-                                  ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM) >> 4);     // (start_bit is a multiple of 64)
+    // zero the window slots and the erasure slot
+    for (int i = lane; i < G::ROWPTR / 16; i += 64) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    // ---- which rows this wave needs, and where they lie
+    int rb, nrows, pb0;
+    if (C.kind == 0) {
+        // segments = runs of lanes with the same (b, m) pair: pair0, pair0 + 1, ...; the first one starts at CIF r0 of its pair, the
+        // others at CIF 0.  Segment j >= 1 begins at lane n0 + (j - 1) R and at row n0 + 15 + (j - 1) (R + 15).
+        const int M = C.n_members;
+        const int pair0 = (int)(cw0 / R), r0 = (int)(cw0 - (long long)pair0 * R);
+        const int n0 = R - r0;
+        const long long cw_last = cw0 + 63 < n_cw ? cw0 + 63 : (long long)n_cw - 1;
+        const int nseg = (int)(cw_last / R) - pair0 + 1;
+        nrows = 64 + 15 * nseg;
+        pb0 = pair0 / M;
+        int seg = cw / R - pair0; if (seg > nseg - 1) seg = nseg - 1;                    // (dead lanes ride in the last segment: their output is dropped)
+        rb = lane + 15 * seg;                                                            // row of CIF c_glob - 16
+        const int32_t* __restrict__ start_bit = C.start_bit;
+        for (int row = lane; row < ROWS; row += 64) {
+            uint32_t src = zero16;                     // no such CIF yet (start of a stream) / row not used by this wave
+            if (row < nrows) {
+                int j = 0, idx = row;
+                if (row >= n0 + 15) { const int q = row - (n0 + 15); j = 1 + q / (R + 15); idx = q - (j - 1) * (R + 15); }
+                const int pr = pair0 + j;
+                if (j == 0 || (long long)pr * R < n_cw) {
+                    const int pb = pr / M, pm = pr - pb * M;
+                    const long long c_src = 4 * A.desc[(size_t)pb * F].frame_no + (j == 0 ? r0 : 0) - 16 + idx;
+                    if (c_src >= 0)
+                        src = (uint32_t)(((size_t)(pb - pb0) * A.ens_stride + (size_t)start_bit[pm] +
+                                          ((size_t)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM) >> 4);     // (start_bit is a multiple of 64)
+                }
             }
+            rowptr[row] = src;
         }
-        reinterpret_cast<uint32_t*>(lds + FM_ROWPTR)[row] = src;
+    } else {
+        // FIC: code word -> (ensemble, frame slot, quarter); one row per code word: the 2304 soft bits of that quarter of symbols 1..3
+        const int fsel = C.frame_sel;
+        auto bf_of = [&](int c) { return fsel ? (c >> 2) * F + (fsel - 1) : c >> 2; };
+        nrows = 64; rb = lane;
+        pb0 = bf_of((int)cw0) / F;
+        for (int row = lane; row < ROWS; row += 64) {
+            uint32_t src = zero16;
+            const int cwr = (int)cw0 + row;
+            if (row < 64 && cwr < n_cw) {
+                const int bf = bf_of(cwr), b = bf / F;
+                const FrameDesc& d = A.desc[bf];
+                if (d.valid == 1)
+                    src = (uint32_t)(((size_t)(b - pb0) * A.ens_stride + (size_t)(d.frame_no % A.soft_ring) * SOFT_PER_FRAME + (size_t)2304 * (cwr & 3)) >> 4);
+            }
+            rowptr[row] = src;
+        }
     }
     __syncthreads();
-    // window w -> slot w & 1: 8 requests of 12 rows x 5 dwords (60 lanes; the fifth dword of a row is padding and its lane stays idle).
-    // All eight row addresses are read first, then the requests go out back to back: no LDS round trip between them.  Sources are
-    // addressed through a buffer resource on the soft-bit ring: row offset (one VGPR) + the window's column (one SGPR).
-    const BufRsrc soft_rs = buf_rsrc_4g(A.soft);
+    // window w -> slot w & 1: requests of 12 rows x 5 dwords (60 lanes; the fifth dword of a row is padding and its lane stays idle).
+    // The row addresses are read first, then the requests go out back to back: no LDS round trip between them.  Sources are
+    // addressed through a buffer resource on the first ensemble's ring slice: row offset (one VGPR) + the window's column (one SGPR).
+    const BufRsrc soft_rs = buf_rsrc_4g(A.soft + (size_t)uniform_i32(pb0) * A.ens_stride);
+    const int nreq = uniform_i32((nrows + FM_REQ_ROWS - 1) / FM_REQ_ROWS);
     auto load_window = [&](int w) {
-        uint8_t* slot = lds + (w & 1) * FM_SLOT;
+        uint8_t* slot = lds + (w & 1) * G::SLOT;
         const uint32_t l = opaque_vgpr((uint32_t)lane);             // (nothing of this may be hoisted out of the step loop)
         const uint32_t r5 = (l * 205u) >> 10, q5 = l - 5u * r5;     // l / 5, l % 5 for l < 64
         if (q5 < 4u && l < 5u * FM_REQ_ROWS) {
-            uint32_t src[FM_ROWS / FM_REQ_ROWS];
+            if constexpr (G::NREQ == 8) {
+                uint32_t src[8];
 #pragma unroll
-            for (int k = 0; k < FM_ROWS / FM_REQ_ROWS; k++) src[k] = reinterpret_cast<const uint32_t*>(lds + FM_ROWPTR)[FM_REQ_ROWS * k + r5];
+                for (int k = 0; k < 8; k++) src[k] = rowptr[FM_REQ_ROWS * k + r5];
 #pragma unroll
-            for (int k = 0; k < FM_ROWS / FM_REQ_ROWS; k++) buf_dma4(soft_rs, (src[k] << 4) + 4u * q5, 16u * (uint32_t)w, slot + FM_REQ_ROWS * FM_PITCH * k);
+                for (int k = 0; k < 8; k++) buf_dma4(soft_rs, (src[k] << 4) + 4u * q5, 16u * (uint32_t)w, slot + FM_REQ_ROWS * FM_PITCH * k);
+            } else {
+#pragma unroll 1
+                for (int k0 = 0; k0 < nreq; k0 += 3) {              // (G::NREQ is a multiple of three)
+                    uint32_t src[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) src[k] = rowptr[FM_REQ_ROWS * (k0 + k) + r5];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) if (k0 + k < nreq) buf_dma4(soft_rs, (src[k] << 4) + 4u * q5, 16u * (uint32_t)w, slot + FM_REQ_ROWS * FM_PITCH * (k0 + k));
+                }
+            }
         }
     };
     load_window(0);
-    if (A.n_windows > 1) load_window(1);
+    if (n_windows > 1) load_window(1);
 
-    // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
-    uint2* __restrict__ const dec_g = A.c.dec + (size_t)g * nsteps * 64;
-    const BufRsrc dec_rs = buf_rsrc(dec_g);
     const uint32_t ones = opaque_sgpr(0x01010101u);
     uint32_t M[32];
     acs::init(M);
@@ -404,21 +475,21 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     // stores (the host checks that when it builds the table), so the newest stores stay in flight.
     // Descriptors come through the constant address space (scalar loads), six steps ahead (six entries of padding end the table).  Scalar loads share the LDS counter and return out of order, so any wait for LDS bytes also waits for them: they are
     // issued right AFTER the first such wait of a block and have a whole step to arrive.
-    const DABPHY_CONST_AS MscStep* steps = as_constant(A.steps);
+    const DABPHY_CONST_AS MscStep* steps = as_constant(C.steps);
     auto desc_at = [&](int i) { MscStep d; d.off01 = steps[i].off01; d.off23 = steps[i].off23; return d; };
     auto one_step = [&](auto fc, int s, const MscStep& d_cur, const MscStep& d_next, auto&& after_wait) {
-        constexpr int F = decltype(fc)::value;
+        constexpr int FL = decltype(fc)::value;
         int x0 = cur[0] + cur[3], v1 = cur[1], v2 = cur[2];
         asm volatile("" : "+v"(x0), "+v"(v1), "+v"(v2));                  // this step's LDS reads have been consumed here ...
         after_wait();
 #ifndef FM_EXP_NODMA             // (timing experiment only)
         if (d_cur.off01 & MSC_LOAD_NEXT) { wave_converge(); load_window(next_window); next_window++; }     // ... by every lane, before the dying window's slot is refilled
 #endif
-        const uint2 dd = acs::step<F>(M, x0, v1, v2, ones);
+        const uint2 dd = acs::step<FL>(M, x0, v1, v2, ones);
 #ifdef FM_EXP_NOSTORE            // (timing experiment only)
-        if (dd.x == 0x12345u && dd.y == 0x777u) buf_store_b64(dec_rs, lane8, (uint32_t)s * 512u, dd);
+        if (dd.x == 0x12345u && dd.y == 0x777u) buf_store_b64<FM_DEC_STORE_AUX>(dec_rs, lane8, (uint32_t)s * 512u, dd);
 #else
-        buf_store_b64(dec_rs, lane8, (uint32_t)s * 512u, dd);
+        buf_store_b64<FM_DEC_STORE_AUX>(dec_rs, lane8, (uint32_t)s * 512u, dd);
 #endif
 #ifndef FM_EXP_NOWAIT            // (timing experiment only)
         if (d_next.off01 & MSC_FIRST_USE) lds_dma_wait_but<2>();
@@ -429,7 +500,7 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     MscStep d0 = desc_at(0), d1 = desc_at(1), d2 = desc_at(2), d3 = desc_at(3), d4 = desc_at(4), d5 = desc_at(5);
     fetch(d0, cur);
     int since_renorm = 0;
-    for (int s = 0; s < nsteps; s += 6) {                            // (nsteps is a multiple of six for every sub-channel size: 24 * bitrate + 6)
+    for (int s = 0; s < nsteps; s += 6) {                            // (nsteps is a multiple of six for every sub-channel size and the FIC: 24 * bitrate + 6, 774)
         // the descriptors of the next block arrive pair by pair (four scalar registers in flight, not twelve: the loop is short of them)
         MscStep ea, eb;
         one_step(std::integral_constant<int, 0>{}, s, d0, d1, [&]() { ea = desc_at(s + 6); eb = desc_at(s + 7); });
@@ -446,31 +517,41 @@ __global__ void __launch_bounds__(64, VITM_OCC) k_viterbi_msc(FusedMscArgs A)
     lds_dma_wait();                                                  // (no load may still be in flight when the next group reuses the slots)
 
 #ifndef FM_EXP_NOTRACE            // (timing experiment only)
-    // traceback: as in k_viterbi
+    // traceback: as in k_viterbi, the decision words through the same buffer resource the stores took
     const int cw_out = g * 64 + lane;                                // (recomputed: nothing but the trellis lives across the step loop)
-    traceback(dec_g, (uint32_t)lane, nbits, out_words + (size_t)cw_out * words_per_cw, cw_out < A.c.n_cw, A.c.dedisperse, A.prbs_words);
+    traceback([&](int st) { return buf_load_b64<FM_DEC_LOAD_AUX>(dec_rs, lane8, (uint32_t)st * 512u); }, nbits,
+              reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_out * (nbits / 32), cw_out < n_cw, C.dedisperse, A.prbs_words);
 #endif
   }
 }
 
-void launch_viterbi_msc(const FusedMscArgs& a, hipStream_t s)
+static int device_simds()
 {
     static int n_simd = 0;
     if (!n_simd) {
         int dev = 0; hipDeviceProp_t p;
         n_simd = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? 4 * p.multiProcessorCount : 1024;
     }
-    const int n = a.c.g_end - a.c.g_begin;
-    if (n <= 0) return;
-    // One work-group (= one wave) per resident wave slot: VITM_OCC per SIMD.  With more groups than slots work-group i walks groups
-    // i, i + grid, ... (the kernel's loop), so every SIMD gets the same number of groups to within one -- 9216 groups on 5120 slots:
-    // four waves with two groups and one with one on every SIMD, instead of SIMDs with five and SIMDs with four two-group waves.
-    int occ = VITM_OCC;
+    return n_simd;
+}
+// waves per SIMD of the three builds: 96 rows -- 6.1 KiB of LDS, 96 VGPRs: five; 144 rows -- 9 KiB: four; 324 rows -- 20.3 KiB: seven per CU
+constexpr int FUSED_OCC[FUSED_VARIANTS] = {VITM_OCC, 4, 1};
+int fused_wave_slots(int variant)
+{
+    int occ = FUSED_OCC[variant];
 #ifdef DABPHY_EXPERIMENTS
     { const char* e = getenv("DABPHY_VITM_SLOTS"); if (e && atoi(e) > 0) occ = atoi(e); }
 #endif
-    const int grid = n < occ * n_simd ? n : occ * n_simd;
-    hipLaunchKernelGGL(k_viterbi_msc, dim3(grid), dim3(64), 0, s, a);
+    return occ * device_simds();
+}
+void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s)
+{
+    if (a.n_work == 0 || n_slots <= 0) return;
+    // One work-group (= one wave) per resident wave slot, or fewer when there is less work; the groups are pulled from the list.
+    hipError_t e = hipMemsetAsync(a.next, 0, sizeof(uint32_t), s); (void)e;
+    if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0]>), dim3(n_slots), dim3(64), 0, s, a);
+    else if (variant == 1) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[1], FUSED_OCC[1]>), dim3(n_slots), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[2], FUSED_OCC[2]>), dim3(n_slots), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------ linear gather

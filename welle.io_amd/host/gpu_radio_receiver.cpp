@@ -78,13 +78,15 @@ GpuRadioReceiver::Stream::~Stream()
     if (thread.joinable()) thread.join();           // frames already queued are still delivered (a file ends with its last frames decoded)
 }
 
-void GpuRadioReceiver::Stream::push(const uint8_t* p)
+void GpuRadioReceiver::Stream::push(const uint8_t* p, const std::atomic<bool>& receiver_running)
 {
     {
         // a full queue holds the channel decoder back (an unthrottled file input would otherwise run arbitrarily far ahead of the audio
-        // decoder): DabAudio::process waits the same way on its ring buffer (dab-audio.cpp:99-106)
+        // decoder): DabAudio::process waits the same way on its ring buffer (dab-audio.cpp:99-106).  The wait is bounded: a receiver
+        // that is being stopped must not sit behind a stalled audio decoder (the frame is then dropped with the receiver)
         std::unique_lock<std::mutex> lock(m);
-        cv_space.wait(lock, [&] { return closing || q.size() < kMaxQueued; });
+        while (!cv_space.wait_for(lock, std::chrono::milliseconds(50), [&] { return closing || q.size() < kMaxQueued; }))
+            if (!receiver_running) return;
         if (closing) return;
         q.emplace_back(p, p + frame_bytes);
     }
@@ -152,7 +154,12 @@ void GpuRadioReceiver::restart_decoder()
 
 void GpuRadioReceiver::stop()
 {
-    running = false;
+    {
+        // under the mutex wait_until_released() evaluates its predicate under: a waiter that has just seen `running` true is inside
+        // wait() by the time the flag flips, so the notification cannot fall between its check and its sleep
+        std::lock_guard<std::mutex> lock(mutex);
+        running = false;
+    }
     sub_cv.notify_all();                                                // (nobody waits for a worker that is going away)
     // onInputFailure() runs on the worker and controllers answer it with stop() (ofdm-processor.cpp:497): never join ourselves
     if (worker.joinable() && worker.get_id() != std::this_thread::get_id()) worker.join();
@@ -361,7 +368,7 @@ bool GpuRadioReceiver::decode_one_frame()
         std::vector<uint8_t> out(4 * (size_t)st.frame_bytes);
         int32_t first_valid = 0, n_rows = 0;
         if (dabphy_get_msc(phy, (uint32_t)idx, out.data(), out.size(), &first_valid, &n_rows) != DABPHY_OK) continue;
-        for (int c = first_valid; c < n_rows; c++) st.push(out.data() + (size_t)c * st.frame_bytes);
+        for (int c = first_valid; c < n_rows; c++) st.push(out.data() + (size_t)c * st.frame_bytes, running);
     }
     // onFrequencyCorrectorChange every INPUT_RATE/5 samples (ofdm-processor.cpp:218-223)
     sample_count += 196608;

@@ -89,7 +89,7 @@ class GpuRadioReceiver {
         struct Stream {
             Stream(ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& sub);
             ~Stream();
-            void push(const uint8_t* frame_bytes_msb_first);            // one logical frame (3 * bitrate bytes)
+            void push(const uint8_t* frame_bytes_msb_first, const std::atomic<bool>& receiver_running);   // one logical frame (3 * bitrate bytes)
             Subchannel sub;
             int frame_bytes;
           private:

@@ -21,6 +21,53 @@ def rec_frames_for(frames_per_step):
 RATE = 2048000.0
 
 
+def uep_subchannel(lib, subch_id, start_cu, bitrate, level, dabplus=True):
+    """a short-form (UEP) synth.SubchannelCfg: table row, size and (L_i, PI_i) segments from the library's own protection helpers (pure
+    host functions of the C ABI: no device, no handle)"""
+    import ctypes as C
+    from .capi import Protection
+    p = Protection(); assert lib.dabphy_protection_uep(C.byref(p), bitrate, level) == 0
+    for idx in range(64):
+        size = C.c_int(0); lvl = C.c_int(0); br = C.c_int(0)
+        assert lib.dabphy_uep_table_entry(idx, C.byref(size), C.byref(lvl), C.byref(br)) == 0
+        if br.value == bitrate and lvl.value == level:
+            segs = [(p.L[i], p.PI[i]) for i in range(4) if p.PI[i] > 0 and p.L[i] > 0]
+            return synth.SubchannelCfg(subch_id, start_cu, bitrate, level=level, dabplus=dabplus, uep=(idx, size.value, segs))
+    raise ValueError("no UEP table row for %d kbit/s level %d" % (bitrate, level))
+
+
+# A multiplex as they are on air (bench.py's `hetero` leg, tests/test_gpu_bench_config.py): 15 sub-channels in 6 protection classes --
+# (bit rate, EEP profile B?, level) or ("uep", bit rate, level) -- 128 kbit/s 3-A, 6 x 64 kbit/s 3-A, 4 x 48 kbit/s 2-A, 2 x 32 kbit/s
+# 3-B, 80 kbit/s UEP-3, 8 kbit/s 3-A: code words of 192 .. 3072 bits, 676 of the 864 capacity units.  All carry DAB+ superframes
+# (what the reference's SuperframeFilter, dabplus_decoder.cpp:50-213, is fed): the filter runs on every one of them as in the headline.
+HETERO_LAYOUT = [(128, False, 3)] + [(64, False, 3)] * 6 + [(48, False, 2)] * 4 + [(32, True, 3)] * 2 + [("uep", 80, 3), (8, False, 3)]
+
+
+def hetero_subchannels(lib, layout=None):
+    subchs = []; cu = 0
+    for i, ent in enumerate(layout or HETERO_LAYOUT):
+        sc = uep_subchannel(lib, i + 1, cu, ent[1], ent[2]) if ent[0] == "uep" else synth.SubchannelCfg(i + 1, cu, ent[0], ent[1], ent[2])
+        subchs.append(sc); cu += sc.size_cu
+    assert cu <= 864, cu
+    return subchs
+
+
+def subchannels_to_json(subchs):
+    """plain-data form of a sub-channel list (for a CPU receiver in another process: tests/cpu_baseline_worker.py)"""
+    return [dict(subch_id=s.subch_id, start_cu=s.start_cu, bitrate=s.bitrate, profile_b=bool(s.profile_b), level=s.level, dabplus=bool(s.dabplus),
+                 uep=None if s.uep is None else [s.uep[0], s.uep[1], [list(x) for x in s.uep[2]]]) for s in subchs]
+
+
+def subchannels_from_json(rows):
+    return [synth.SubchannelCfg(r["subch_id"], r["start_cu"], r["bitrate"], r["profile_b"], r["level"], r["dabplus"],
+                                uep=None if r["uep"] is None else (r["uep"][0], r["uep"][1], [tuple(x) for x in r["uep"][2]])) for r in rows]
+
+
+def dev_protection(dev, s):
+    """device protection record of a synth.SubchannelCfg"""
+    return dev.protection_uep(s.bitrate, s.level) if s.uep is not None else dev.protection_eep(s.bitrate, s.profile_b, s.level)
+
+
 def make_base_streams(n_distinct, n_frames=REC_FRAMES, seed0=0, subchs=None):
     out, txs = [], []
     for e in range(n_distinct):
@@ -63,7 +110,7 @@ def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demo
         dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=loop)
     else:
         dev.stream_upload(iq.numpy(), loop=loop)
-    dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev.protection_eep(s.bitrate, s.profile_b, s.level)) for s in subchs])
+    dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_protection(dev, s)) for s in subchs])
     if profiling:
         dev.set_profiling(True)
     dev.set_auto_superframes(True)
