@@ -36,6 +36,10 @@ int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts);
  * FFT (kiss_fft.c:21-90 multiplies by it like by any other twiddle): 2^33 operand pairs -- every exponent, zeros, denormals, infinities
  * and NaNs included -- through both forms.  counts[0] = results that differ in a bit (two NaNs count as equal), counts[1] = pairs tried. */
 int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
+/* Device self-test of the lane exchanges of the state-parallel Viterbi kernel (k_viterbi_sp.hip: v_permlane32_swap, v_permlane16_swap,
+ * bank-masked row DPP moves, quad_perm DPP reads, v_readlane) against plain shuffles: the forms the
+ * GPU-less execution model of tests/hipemu stands in for.  counts[0] = mismatches, counts[1] = values checked. */
+int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts);
 
 #ifdef __cplusplus
 }

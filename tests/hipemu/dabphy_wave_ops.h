@@ -49,6 +49,15 @@ static inline uint32_t pk_sign_bytes(u16x2 a, u16x2 b)
 }
 
 static inline int mul_i24(int x, int m) { return (int)((uint32_t)x * (uint32_t)m); }
+static inline int mad_i24(int x, int m, int acc) { return (int)((uint32_t)x * (uint32_t)m + (uint32_t)acc); }
+// lanes = trellis states: pairs differ in lane bit B; x = the value of the pair's lane with bit B clear, y = of the lane with it set
+template <int B> static inline void pair_values(uint32_t m, uint32_t& x, uint32_t& y)
+{
+    const int lane = hipemu_lane();
+    x = hipemu_wave_exchange(m, lane & ~(1 << B), true);
+    y = hipemu_wave_exchange(m, lane | (1 << B), true);
+}
+static inline uint32_t lane_get(uint32_t v, uint32_t idx) { return hipemu_wave_exchange(v, (int)(idx & 63), true); }
 static inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
 
 // buffer addressing model: the resource is the base pointer

@@ -636,7 +636,7 @@ def check_error_behaviour(d_factory):
 # ---- the configuration bench.py times (welle_io_amd/workload.py): B x F batch, looping ring, coarse corrector enabled, pipelined
 # synchroniser, all 18 sub-channels, superframe filter inside process() -- against the oracle on the very same samples
 def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_steps=3, demod_chunk=0, device="cuda", subs_idx=(0, 7, 17),
-                       base=None, expect_chunk=None, channels=None, min_wide_fallbacks=None):
+                       base=None, expect_chunk=None, channels=None, min_wide_fallbacks=None, decode_shape=0):
     """channels: one channel (synth.apply_channel) per distinct recording -- the recordings then run through it ONCE over the whole test
     (a drifting sampling clock has no seamless loop point) and the ring does not loop.  min_wide_fallbacks: the wide synchroniser pass
     must have handed at least that many batches back to the frame-by-frame chain (what per-ensemble drift does in every batch)"""
@@ -650,7 +650,7 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
         base = (np.stack(rows).astype(np.complex64), txs)
     iq, cfo, base_np, txs = workload.make_batch(B, device=device, base=base)
     subchs = txs[0].subchs
-    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False, loop=loop)
+    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False, loop=loop, decode_shape=decode_shape)
     logs = {b: dict(fib=[], ok=[], corr=[], soft=[], msc=[[] for _ in subs_idx], sf=np.zeros(4, np.int64), n_logical=0) for b in check_ens}
     try:
         if expect_chunk is not None:

@@ -12,6 +12,16 @@ def factory(**kw):
     return capi.DabPhy(lib_path=EMU_LIB, **kw)
 
 
+def factory_lane_per_codeword(**kw):
+    """dabphy_config.decode_shape = 1: the throughput kernel (k_viterbi_fused) also for batches the default would decode state-parallel"""
+    return capi.DabPhy(lib_path=EMU_LIB, decode_shape=1, **kw)
+
+
+def factory_state_parallel(**kw):
+    """dabphy_config.decode_shape = 2: one wavefront per code word (k_viterbi_sp) whatever the batch size"""
+    return capi.DabPhy(lib_path=EMU_LIB, decode_shape=2, **kw)
+
+
 @pytest.mark.parametrize("snr,cfo,delay,nf,lockstep", [(25, 0, 0, 10, False), (13, 137, 1000, 8, True), (20, 2300, 0, 8, True), (20, -400, 333, 8, True)])
 def test_stream(emu, snr, cfo, delay, nf, lockstep):
     P.check_stream_vs_oracle(factory, snr, cfo, delay, nf, lockstep)
@@ -70,14 +80,29 @@ def test_superframe_filter_other_bit_rates(emu):
 def test_mixed_protection_classes(emu, F, nf):
     """4 / 1 / 3 frames per call = 16 / 4 / 12 CIFs per sub-channel: a wave's 64 code words span up to 5 / 17 / 7 (ensemble,
     sub-channel) pairs -- the 144- and 324-row builds of the fused kernel; no separate gather stage at any batch depth"""
-    P.check_mixed_ensemble(factory, F=F, nf=nf, expect_fused=True)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=F, nf=nf, expect_fused=True)
+
+
+@pytest.mark.parametrize("F,nf", [(4, 11), (16, 36), (1, 7)])
+def test_mixed_protection_classes_state_parallel(emu, F, nf):
+    """the same ensemble (EEP A/B, UEP, 8 .. 384 kbit/s: code words of 192 .. 9216 bits, all three LDS sizes of the kernel) through
+    k_viterbi_sp: one wavefront per code word, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
+    stream test of this file runs small batches too, hence this kernel: the default picks it below 16 384 code words per call.)"""
+    P.check_mixed_ensemble(factory_state_parallel, F=F, nf=nf, expect_fused=True)
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+def test_stream_with_either_decoder(emu, shape):
+    """the canonical ensemble through both Viterbi kernels explicitly (soft bits, FIBs, MSC bytes of all 18 sub-channels vs the oracle)"""
+    f = factory_lane_per_codeword if shape == 1 else factory_state_parallel
+    P.check_stream_vs_oracle(f, 11, 80, 250, 9, False, F=3)
 
 
 def test_two_kernel_decode_beyond_the_fused_kernels_reach(emu):
     """a handle with ring slices of 4102 frames (945 MB) per ensemble, 4 frames per call: the 5 + 1 ensembles a wave of a one-member
     class could span lie 5.7 GB apart -- beyond the 32-bit offsets of the fused kernel's buffer resource -- so every class and the FIC
     go through k_msc_gather / k_fic_gather + k_viterbi (64-bit addresses), and decode the same bytes"""
-    P.check_mixed_ensemble(factory, F=4, nf=11, max_frames=4096, expect_fused=False)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=4, nf=11, max_frames=4096, expect_fused=False)
 
 
 def test_fused_decode_of_ensembles_beyond_4_gib(emu):
@@ -86,7 +111,7 @@ def test_fused_decode_of_ensembles_beyond_4_gib(emu):
     call (two segments per wave: the 96-row build), two narrow sub-channels"""
     from welle_io_amd import synth
     subchs = [synth.SubchannelCfg(1, 0, 32, False, 3, dabplus=False), synth.SubchannelCfg(2, 24, 8, False, 2, dabplus=False)]
-    P.check_mixed_ensemble(factory, F=16, nf=36, B=6, max_frames=4096, subchs=subchs, expect_fused=True, check_ens=(0, 4, 5))
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=16, nf=36, B=6, max_frames=4096, subchs=subchs, expect_fused=True, check_ens=(0, 4, 5))
 
 
 @pytest.mark.parametrize("method,snr,cfo", [(1, 15, 90), (1, None, -300), (0, 12, 40)])
@@ -139,8 +164,10 @@ def test_benchmark_handle_configuration_small(emu):
     """the handle bench.py opens (looping ring, coarse corrector on, pipelined synchroniser, all 18 sub-channels, superframe filter
     inside process(), 25-symbol demod chunks), at a size the execution model finishes: against the oracle on the same samples"""
     from welle_io_amd import workload
-    P.check_bench_config(capi, EMU_LIB, 3, 3, 1, check_ens=[0, 1, 2], n_steps=5, demod_chunk=25, device="cpu", subs_idx=(0, 7, 17),
-                         base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=0), expect_chunk=25)
+    base = workload.make_base_streams(2, workload.REC_FRAMES, seed0=0)
+    for shape in (1, 2):              # lane-per-code-word as the benchmark runs it, and state-parallel (what this size would get by default)
+        P.check_bench_config(capi, EMU_LIB, 3, 3, 1, check_ens=[0, 1, 2], n_steps=5, demod_chunk=25, device="cpu", subs_idx=(0, 7, 17),
+                             base=base, expect_chunk=25, decode_shape=shape)
 
 
 def test_heterogeneous_multiplex_small(emu):
@@ -153,7 +180,7 @@ def test_heterogeneous_multiplex_small(emu):
     assert len(subchs) == 15 and sum(s.size_cu for s in subchs) <= 864
     assert workload.subchannels_to_json(workload.subchannels_from_json(workload.subchannels_to_json(subchs))) == workload.subchannels_to_json(subchs)
     P.check_bench_config(capi, EMU_LIB, 2, 4, 1, check_ens=[0, 1], n_steps=4, demod_chunk=25, device="cpu", subs_idx=tuple(range(15)),
-                         base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=50, subchs=subchs), expect_chunk=25)
+                         base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=50, subchs=subchs), expect_chunk=25, decode_shape=1)
 
 
 @pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
@@ -180,7 +207,7 @@ def test_dropout_in_batch_mode(emu):
 def test_mixed_protection_classes_fused_decode(emu):
     """16 frames per call = 64 CIFs per sub-channel: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel's 96-row build -- the MSC
     gather inside the Viterbi kernel (k_viterbi_fused: LDS window ring fed by LDS-DMA, per-step descriptors from the depuncturing map)"""
-    P.check_mixed_ensemble(factory, F=16, nf=36, expect_fused=True)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=16, nf=36, expect_fused=True)
 
 
 def test_receiver_options_at_run_time(emu):

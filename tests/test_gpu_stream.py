@@ -14,6 +14,16 @@ def factory(**kw):
     return capi.DabPhy(lib_path=GPU_LIB, **kw)
 
 
+def factory_lane_per_codeword(**kw):
+    """dabphy_config.decode_shape = 1: the throughput kernel (k_viterbi_fused) also for batches the default would decode state-parallel"""
+    return capi.DabPhy(lib_path=GPU_LIB, decode_shape=1, **kw)
+
+
+def factory_state_parallel(**kw):
+    """dabphy_config.decode_shape = 2: one wavefront per code word (k_viterbi_sp) whatever the batch size"""
+    return capi.DabPhy(lib_path=GPU_LIB, decode_shape=2, **kw)
+
+
 @pytest.mark.parametrize("snr,cfo,delay,nf,lockstep", [(25, 0, 0, 22, False), (None, 0, 0, 9, False), (13, 137, 1000, 14, True), (20, 2300, 0, 12, True),
                                                      (20, -400, 333, 10, True), (None, 17400, 0, 8, True), (10, -1000, 0, 8, True), (8, 60, 77, 12, False)])
 def test_stream(gpu, snr, cfo, delay, nf, lockstep):
@@ -86,14 +96,42 @@ def test_superframe_filter_other_bit_rates(gpu):
 def test_mixed_protection_classes(gpu, F, nf):
     """1 .. 15 frames per call = 4 .. 60 CIFs per sub-channel: a wave's 64 code words span up to 17 (ensemble, sub-channel) pairs -- the
     144- and 324-row builds of the fused kernel; no separate gather stage at any batch depth"""
-    P.check_mixed_ensemble(factory, F=F, nf=nf, expect_fused=True)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=F, nf=nf, expect_fused=True)
+
+
+@pytest.mark.parametrize("F,nf", [(4, 11), (16, 36), (1, 7), (7, 17)])
+def test_mixed_protection_classes_state_parallel(gpu, F, nf):
+    """the same ensemble (EEP A/B, UEP, 8 .. 384 kbit/s: code words of 192 .. 9216 bits, all three LDS sizes of the kernel) through
+    k_viterbi_sp: one wavefront per code word, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
+    stream test of this file runs small batches too, hence this kernel: the default picks it below 16 384 code words per call.)"""
+    P.check_mixed_ensemble(factory_state_parallel, F=F, nf=nf, expect_fused=True)
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+def test_stream_with_either_decoder(gpu, shape):
+    """the canonical ensemble through both Viterbi kernels explicitly (soft bits, FIBs, MSC bytes of all 18 sub-channels vs the oracle)"""
+    f = factory_lane_per_codeword if shape == 1 else factory_state_parallel
+    P.check_stream_vs_oracle(f, 11, 80, 250, 9, False, F=3)
+
+
+def test_lane_exchanges_of_the_state_parallel_kernel(gpu):
+    """v_permlane32_swap / v_permlane16_swap / bank-masked row DPP / quad_perm DPP / v_readlane as k_viterbi_sp uses them, against plain
+    shuffles on the device (the GPU-less execution model stands in for exactly these forms)"""
+    bad, n = gpu.selftest_pair_exchange()
+    assert bad == 0 and n == 8 * 64 * 16 * 13, (bad, n)
+
+
+def test_shallow_batch_above_the_state_parallel_limit(gpu):
+    """128 ensembles x 4 frames of the mixed ensemble = 20 480 code words per call: too many for the state-parallel kernel's default
+    limit, too shallow for the 96-row build: the 144-row build of the fused kernel as the DEFAULT choice"""
+    P.check_mixed_ensemble(factory, F=4, nf=11, B=128, expect_fused=True, check_ens=(0, 63, 127))
 
 
 def test_two_kernel_decode_beyond_the_fused_kernels_reach(gpu):
     """a handle with ring slices of 4102 frames (945 MB) per ensemble, 4 frames per call: the 5 + 1 ensembles a wave of a one-member
     class could span lie 5.7 GB apart -- beyond the 32-bit offsets of the fused kernel's buffer resource -- so every class and the FIC
     go through k_msc_gather / k_fic_gather + k_viterbi (64-bit addresses), and decode the same bytes"""
-    P.check_mixed_ensemble(factory, F=4, nf=11, max_frames=4096, expect_fused=False)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=4, nf=11, max_frames=4096, expect_fused=False)
 
 
 def test_fused_decode_of_ensembles_beyond_4_gib(gpu):
@@ -101,13 +139,13 @@ def test_fused_decode_of_ensembles_beyond_4_gib(gpu):
     addressed them with 32-bit offsets from the START of the ring).  16 frames per call, two narrow sub-channels; the emulator runs
     the same case"""
     subchs = [synth.SubchannelCfg(1, 0, 32, False, 3, dabplus=False), synth.SubchannelCfg(2, 24, 8, False, 2, dabplus=False)]
-    P.check_mixed_ensemble(factory, F=16, nf=36, B=6, max_frames=4096, subchs=subchs, expect_fused=True, check_ens=(0, 4, 5))
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=16, nf=36, B=6, max_frames=4096, subchs=subchs, expect_fused=True, check_ens=(0, 4, 5))
 
 
 def test_mixed_protection_classes_fused_decode(gpu):
     """16 / 20 frames per call: every class (EEP A/B, UEP, 8 .. 384 kbit/s) takes the fused kernel's 96-row build (k_viterbi_fused)"""
-    P.check_mixed_ensemble(factory, F=16, nf=36, expect_fused=True)
-    P.check_mixed_ensemble(factory, F=20, nf=45, seed=32, snr_db=9, expect_fused=True)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=16, nf=36, expect_fused=True)
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=20, nf=45, seed=32, snr_db=9, expect_fused=True)
 
 
 @pytest.mark.parametrize("method,snr,cfo", [(1, 15, 90), (1, None, -300), (0, 12, 40)])

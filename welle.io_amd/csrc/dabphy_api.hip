@@ -25,7 +25,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
-    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3) return fail(DABPHY_ERR_INVALID);
+    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 2) return fail(DABPHY_ERR_INVALID);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
@@ -107,6 +107,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
 #ifdef DABPHY_EXPERIMENTS
     if (const char* e = getenv("DABPHY_FUSED_MSC")) h->fused_msc = atoi(e) != 0;
     if (const char* e = getenv("DABPHY_FUSED_FIC")) h->fused_fic = atoi(e) != 0;
+    if (const char* e = getenv("DABPHY_SP_MAX_CW")) h->sp_max_codewords = (uint32_t)atoll(e);
 #endif
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
@@ -368,6 +369,22 @@ int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts)
     return r;
 }
 
+int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts)
+{
+    DeviceBind dev_(h);
+    if (!h || !counts) return DABPHY_ERR_INVALID;
+    unsigned* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, 2 * sizeof *d));
+    HIPCHK(h, hipMemsetAsync(d, 0, 2 * sizeof *d, h->stream));
+    launch_selftest_pair_exchange(d, h->stream);
+    unsigned host[2];
+    HIPCHK(h, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    const int r = sync(h);
+    (void)hipFree(d);
+    for (int i = 0; i < 2; i++) counts[i] = host[i];
+    return r;
+}
+
 int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts)
 {
     DeviceBind dev_(h);
@@ -504,9 +521,10 @@ int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(h, hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); h->err = "hipEventCreate failed"; return DABPHY_ERR_HIP; }
-    launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream);            // (same inputs, same outputs: the launch is idempotent)
+    auto again = [&]() { if (P.use_sp) launch_viterbi_sp(P.args, P.sp_variant, h->stream); else launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream); };
+    again();                                                                  // (same inputs, same outputs: the launch is idempotent)
     hipError_t e = hipEventRecord(e0, h->stream);
-    for (uint32_t i = 0; i < iters; i++) launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream);
+    for (uint32_t i = 0; i < iters; i++) again();
     if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float t = 0;

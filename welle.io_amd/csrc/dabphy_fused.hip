@@ -98,12 +98,18 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     struct Item { int nsteps, ci, n_groups; };
     std::vector<Item> items;
     size_t max_steps = 0;
+    // A small batch -- fewer code words than the device has lanes to give them -- is decoded STATE-PARALLEL: one wavefront per code word
+    // (k_viterbi_sp.hip), every class and the FIC, whatever their window schedules and spans (it addresses with 64-bit pointers).
+    uint64_t total_cw = (uint64_t)B * F * 4 * (want_fic && h->fused_fic ? 1 : 0);
+    bool sp_ok = h->fused_msc && h->cfg.decode_shape != 1 && (h->sp_max_codewords > 0 || h->cfg.decode_shape == 2);
+    for (auto& c : h->classes) { total_cw += (uint64_t)B * 4 * F * c.members.size(); sp_ok = sp_ok && (c.prot.nbits + 6) % 6 == 0 && c.prot.nbits + 6 <= SP_MAXSTEPS[SP_VARIANTS - 1]; }
+    const bool use_sp = sp_ok && (h->cfg.decode_shape == 2 || total_cw <= h->sp_max_codewords);
     for (size_t i = 0; i < h->classes.size(); i++) {
         auto& c = h->classes[i];
         const int M = (int)c.members.size();
-        if (!h->fused_msc || c.n_windows[v] <= 0 || !reach_ok((nseg + M - 1) / M + 1)) continue;
+        if (!h->fused_msc || (!use_sp && (c.n_windows[v] <= 0 || !reach_ok((nseg + M - 1) / M + 1)))) continue;
         FusedClass fc{};
-        fc.steps = c.steps[v].as<MscStep>(); fc.start_bit = c.start_bits.as<int32_t>(); fc.out = c.out.as<uint8_t>();
+        fc.steps = c.steps[v].as<MscStep>(); fc.start_bit = c.start_bits.as<int32_t>(); fc.map = c.map.as<int16_t>(); fc.out = c.out.as<uint8_t>();
         fc.nbits = c.prot.nbits; fc.nsteps = fc.nbits + 6; fc.n_windows = c.n_windows[v]; fc.n_cw = (int32_t)(B * 4 * F * M);
         fc.n_members = M; fc.kind = 0; fc.dedisperse = 1; fc.frame_sel = 0;
         items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
@@ -111,9 +117,9 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         max_steps = std::max(max_steps, (size_t)fc.nsteps);
     }
     bool fic_in = false;
-    if (want_fic && h->fused_fic && h->fic_windows[v] > 0 && reach_ok((16 + (int)F - 1) / (int)F + 1)) {
+    if (want_fic && h->fused_fic && (use_sp || (h->fic_windows[v] > 0 && reach_ok((16 + (int)F - 1) / (int)F + 1)))) {
         FusedClass fc{};
-        fc.steps = h->fic_steps[v].as<MscStep>(); fc.start_bit = nullptr; fc.out = h->s_fib.as<uint8_t>();
+        fc.steps = h->fic_steps[v].as<MscStep>(); fc.start_bit = nullptr; fc.map = h->d_fic_map; fc.out = h->s_fib.as<uint8_t>();
         fc.nbits = 768; fc.nsteps = 774; fc.n_windows = h->fic_windows[v]; fc.n_cw = (int32_t)(B * F * 4);
         fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1; fc.frame_sel = 0;
         items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
@@ -130,10 +136,13 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         for (int g = 0; g < it.n_groups; g++) work.push_back(((uint32_t)it.ci << 24) | (uint32_t)g);
     }
     const int slots = fused_wave_slots(v);
-    const int n_slots = (int)std::min<size_t>(work.size(), (size_t)slots);
+    // (state-parallel: one work-group per code word slot of every listed group, each with its own decision scratch)
+    const int n_slots = use_sp ? (int)work.size() * 64 : (int)std::min<size_t>(work.size(), (size_t)slots);
+    int sp_variant = 0;
+    while (sp_variant + 1 < SP_VARIANTS && (size_t)SP_MAXSTEPS[sp_variant] < max_steps) sp_variant++;
     int r;
     if (!work.empty()) {
-        if ((r = ensure(h, h->vdec, (size_t)n_slots * max_steps * 64 * sizeof(uint2)))) return r;
+        if ((r = ensure(h, h->vdec, (size_t)n_slots * (use_sp ? ((max_steps + 31) / 32) * 32 : max_steps * 64) * sizeof(uint2)))) return r;
         if ((r = ensure(h, h->fused_cls, cls.size() * sizeof(FusedClass)))) return r;
         if ((r = ensure(h, h->fused_work, work.size() * sizeof(uint32_t)))) return r;
         if (!h->d_fused_next) {
@@ -154,7 +163,8 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         if (!work.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_work.p, P.host_work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     }
     P.valid = true; P.F = F; P.want_fic = want_fic; P.fic_in = fic_in; P.variant = v; P.n_slots = n_slots;
-    P.dec_slot_cells = max_steps * 64; P.class_idx = idx; P.buf_gen = h->buf_gen;
+    P.use_sp = use_sp; P.sp_variant = sp_variant;
+    P.dec_slot_cells = use_sp ? ((max_steps + 31) / 32) * 32 : max_steps * 64; P.class_idx = idx; P.buf_gen = h->buf_gen;
     FusedArgs a{};
     a.soft = h->s_soft.as<int8_t>(); a.ens_stride = ens_stride; a.soft_ring = (int)h->cfg.max_frames + 5; a.n_ens = (int)B; a.n_frames = (int)F;
     a.desc = nullptr;                                  // (set per batch: the descriptor buffers rotate)

@@ -166,10 +166,11 @@ constexpr uint32_t MSC_FIRST_USE = 1u << 15, MSC_LOAD_NEXT = 1u << 31, MSC_OFF_M
 struct FusedClass {
     const MscStep* steps;     // [nsteps + 6] for the launch's row-count variant
     const int32_t* start_bit; // MSC: [n_members] startAddr * 64
+    const int16_t* map;       // [4 * nsteps] mother-code index -> index into the class's punctured bit stream, -1 = erasure (k_viterbi_sp gathers by it)
     uint8_t* out;             // [n_cw][nbits / 8]
     int32_t nsteps, nbits, n_windows, n_cw, n_members, kind, dedisperse, frame_sel;
 };
-static_assert(sizeof(FusedClass) == 56, "FusedClass layout");
+static_assert(sizeof(FusedClass) == 64, "FusedClass layout");
 struct FusedArgs {
     const int8_t* soft; size_t ens_stride; int soft_ring; int n_ens, n_frames;
     const FrameDesc* desc;
@@ -182,6 +183,13 @@ struct FusedArgs {
 // variant = index into FUSED_ROWS; n_slots = work-groups (one wave each) to launch
 void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s);
 int fused_wave_slots(int variant);             // resident waves of that variant on the current device
+// State-parallel decode of the same work (k_viterbi_sp.hip): one wavefront per CODE WORD, lanes = the 64 trellis states -- the shape for
+// batches too small to fill the device with 64-code-word waves.  lds_variant = index into SP_MAXSTEPS (the longest code word of the launch);
+// one work-group per code word slot: a.n_work * 64 of them; a.dec holds a.dec_slot_cells decision words per work-group.
+constexpr int SP_VARIANTS = 3;
+constexpr int SP_MAXSTEPS[SP_VARIANTS] = {1542, 3078, 9222};     // <= 64, <= 128, <= 384 kbit/s (24 * bitrate + 6 trellis steps)
+void launch_viterbi_sp(const FusedArgs& a, int lds_variant, hipStream_t s);
+void launch_selftest_pair_exchange(unsigned* out, hipStream_t s);
 
 struct CrcArgs {
     const uint8_t* fib;     // [B][F][12][32]

@@ -219,7 +219,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         FusedArgs fa = h->fplan.args; fa.desc = d_desc;
         h->fplan.args = fa; h->fplan.launched = true;
         mark(dabphy_handle::ST_MSC_VITERBI, false);
-        launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream);
+        if (h->fplan.use_sp) launch_viterbi_sp(fa, h->fplan.sp_variant, h->stream);
+        else launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream);
         mark(dabphy_handle::ST_MSC_VITERBI, true);
         if (fic_fused) HIPCHK(h, hipEventRecord(h->ev_fused_done, h->stream));
     }

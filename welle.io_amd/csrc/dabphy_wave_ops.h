@@ -129,6 +129,27 @@ __device__ __forceinline__ int mul_i24(int x, int m) { int r; asm("v_mul_i32_i24
 // ({hi, lo} >> sh) & 0xffffffff, 0 <= sh <= 31 (v_alignbit_b32)
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
+// x * m + acc for |x|, |m| < 2^23, m wave-uniform (v_mad_i32_i24)
+__device__ __forceinline__ int mad_i24(int x, int m, int acc) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "s"(m), "v"(x), "v"(acc)); return r; }
+
+// ---- lanes = trellis states (k_viterbi_sp.hip).  The 64 lanes form 32 pairs that differ in lane bit B; every lane of a pair gets
+// x = the value held by the pair's lane with bit B clear and y = the value of the lane with bit B set.  B = 5, 4: v_permlane32_swap /
+// v_permlane16_swap of the register with a copy of itself (gfx950); B = 3, 2: row_shr / row_shl DPP moves under a bank mask (the other
+// lanes keep their own value); B = 1, 0: quad_perm DPP reads, which the compiler folds into the consuming addition.
+typedef unsigned int pair_u32x2 __attribute__((ext_vector_type(2)));
+template <int B> __device__ __forceinline__ void pair_values(uint32_t m, uint32_t& x, uint32_t& y)
+{
+    static_assert(B >= 0 && B <= 5, "lane bit");
+    if constexpr (B == 5) { const pair_u32x2 r = __builtin_amdgcn_permlane32_swap(m, m, false, false); x = r[0]; y = r[1]; }
+    else if constexpr (B == 4) { const pair_u32x2 r = __builtin_amdgcn_permlane16_swap(m, m, false, false); x = r[0]; y = r[1]; }
+    else if constexpr (B == 3) { x = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x118, 0xf, 0xC, false); y = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x108, 0xf, 0x3, false); }
+    else if constexpr (B == 2) { x = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x114, 0xf, 0xA, false); y = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x104, 0xf, 0x5, false); }
+    else if constexpr (B == 1) { x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x44, 0xf, 0xf, false); y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xEE, 0xf, 0xf, false); }
+    else { x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xA0, 0xf, 0xf, false); y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xF5, 0xf, 0xf, false); }
+}
+// the value lane `idx` (wave-uniform) holds, as a wave-uniform value (v_readlane_b32)
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
+
 // ---- buffer addressing: (wave-uniform base in a 128-bit scalar resource) + (per-lane byte offset, one VGPR) + (wave-uniform byte offset,
 // one SGPR).  Global loads and stores of the form uniform_pointer[lane] otherwise cost a 64-bit VGPR address pair per array and a 64-bit
 // add per access in a loop that is short of registers.  Raw buffer (stride 0), range = 2 GiB from the base.

@@ -325,12 +325,13 @@ template <int ROWS> struct FmGeom {
     static_assert(ROWS % FM_REQ_ROWS == 0 && 3 * SLOT + 64 * FM_PITCH <= (int)MSC_OFF_MASK, "window ring geometry");
 };
 // cache policy of the decision traffic (8 bytes per trellis step and code word, written once, read once ~a millisecond later by the
-// same wave): timing experiments, profiles/r04_viterbi_cache_policy.txt
+// same wave), measured in round 4 (profiles/r04_viterbi_cache_policy.txt): `nt` on the traceback's loads -2.4 % on the launch alone and
+// -1 ... -2.5 % on the step; `nt` on the stores +1.4 % alone (and no gain in the step), both together = neither.  2 = nt, 16 = sc1.
 #ifndef FM_DEC_STORE_AUX
 #define FM_DEC_STORE_AUX 0
 #endif
 #ifndef FM_DEC_LOAD_AUX
-#define FM_DEC_LOAD_AUX 0
+#define FM_DEC_LOAD_AUX 2
 #endif
 
 #ifndef VITM_OCC

@@ -1,0 +1,191 @@
+// welle.io_amd/csrc/k_viterbi_sp.hip -- K = 7 Viterbi decoder, STATE-PARALLEL: one wavefront per code word, lanes = the 64 trellis states.
+//
+// Replaces (reference file:line, relative to src/backend) exactly what k_viterbi_fused replaces -- Viterbi::deconvolve / BFLY /
+// chainback_viterbi (viterbi.cpp:227-339), the depuncturing of EEPProtection / UEPProtection::deconvolve (eep-protection.cpp:115-152,
+// uep-protection.cpp:169-239) and FicHandler::processFicInput (fic-handler.cpp:144-204), DabAudio's time de-interleaver
+// (dab-audio.cpp:113-149), energy dispersal and bit packing -- for the batches k_viterbi_fused is the wrong shape for.
+//
+// Why a second decoder.  k_viterbi_fused gives every LANE a code word: three VALU instructions per code word and trellis step, nothing
+// cheaper exists on this machine -- but a wavefront then needs 64 code words and ~1 000 cycles per step, so one transmission frame of one
+// ensemble (72 MSC + 4 FIC code words) is two waves that walk 1542 dependent steps for half a millisecond on an otherwise idle device:
+// the latency regime (the live receiver behind GpuRadioReceiver, BASELINE configs 2-3).  Here the 64 path metrics of ONE code word are
+// the 64 lanes of a wavefront: ~12 VALU instructions per step, four times the work per code word -- and a hundredth of the latency,
+// because 76 code words are 76 wavefronts on 76 SIMDs.  dabphy_fused.hip picks this kernel while the batch has fewer code words than the
+// device has lanes to give them (profiles/r04_viterbi_state_parallel.txt has the crossover).
+//
+// The trellis in place.  Lane l holds the metric of state rotl6(l, f) at a step in layout f = t % 6, so the two inputs k and k + 32 of a
+// butterfly are the lanes of a pair that differs in lane bit 5 - f, and its outputs 2k and 2k + 1 stay in those two lanes (the new
+// layout is f + 1).  Both lanes of a pair fetch X = M[k] and Y = M[k + 32] (pair_values: v_permlane32_swap, v_permlane16_swap, masked
+// row DPP moves, quad_perm DPP reads, as the bit asks) and each computes its own output min(X + b, Y - b), where b = +-(bm(p_k) - 510)
+// -- the sign flips for the lane that computes 2k + 1, and bm(p) + bm(~p) = 1020 (viterbi.cpp:170-177) lets every step drop the common
+// 510.  Branch metrics: the soft bits of a step are the same for all lanes (scalar registers), b is three multiply-adds with per-lane
+// constants +-1.  Metrics are int32, doubled (the +-1/2 of the mapping viterbi.cpp:233-238 become integers), never renormalised:
+// |b| <= 1020 per step, 9222 steps.  Decisions: the sign of (Y - b) - (X + b) is "m0 > m1" with the reference's tie-break for BOTH lanes of
+// a pair (both compare the X path against the Y path); one v_alignbit_b32 shifts it into the lane's own 32-step history, and 32 steps
+// leave as one coalesced 256-byte store: 8 bytes per step and code word as in the other kernels, no cross-lane packing at all.
+//
+// Traceback on the scalar unit: the walk from state 0 carries the LANE index of the current state; one step back replaces one bit of it
+// -- position (5 - f) mod 6 -- by the decision it has just read (the same algebra as viterbi_acs.h, with the identity as decision
+// index).  Histories come back 32 steps per load, one word per lane; a step reads the word of lane l with v_readlane.
+//
+// Gather.  The soft bits of a code word are fetched once, up front, by all 64 lanes (lane j: steps j, j + 64, ...) straight from the
+// soft-bit ring -- time de-interleaver as an address computation, depuncturing by the class's map -- and parked in LDS as one packed
+// word per step (x0 = v0 + v3, v1, v2: outputs 0 and 3 share a generator).
+#include "dabphy_kernels.h"
+#include <dabphy_wave_ops.h>
+#include "viterbi_acs.h"
+
+namespace dabphy {
+
+namespace sp {
+__device__ __forceinline__ int rotl6(int x, int r) { r %= 6; return r == 0 ? x : (((x << r) | (x >> (6 - r))) & 63); }
+__device__ __forceinline__ int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }   // = map16[i] of dab-audio.cpp:113
+}
+
+template <int MAXSTEPS, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
+{
+    __shared__ uint32_t sym[MAXSTEPS + 2];
+    __shared__ long long s_rowoff[16];
+    const int lane = threadIdx.x;
+    const int F = A.n_frames, R = 4 * F;
+    const uint32_t wk = as_constant(A.work)[blockIdx.x >> 6];
+    const DABPHY_CONST_AS FusedClass& C = as_constant(A.cls)[wk >> 24];
+    const int cw = (int)(wk & 0xffffffu) * 64 + (int)(blockIdx.x & 63u);
+    const int nsteps = C.nsteps, nbits = C.nbits;
+    if (cw >= C.n_cw || nsteps > MAXSTEPS) return;
+
+    // ---- where this code word's soft bits lie: 16 row offsets (one per column u & 15 of the time de-interleaver), -1 = no such CIF
+    const int8_t* base;
+    if (C.kind == 0) {
+        const int M = C.n_members;
+        const int pair = cw / R, r = cw - pair * R, b = pair / M, m = pair - b * M;
+        base = A.soft + (size_t)b * A.ens_stride + (size_t)C.start_bit[m];
+        if (lane < 16) {
+            const long long c_src = 4 * A.desc[(size_t)b * F].frame_no + r - 16 + sp::brev4(lane);      // dab-audio.cpp:113,138-143
+            s_rowoff[lane] = c_src >= 0 ? ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM : -1;
+        }
+    } else {
+        const int fsel = C.frame_sel;
+        const int bf = fsel ? (cw >> 2) * F + (fsel - 1) : cw >> 2, b = bf / F;
+        const FrameDesc& d = A.desc[bf];
+        base = A.soft + (size_t)b * A.ens_stride + (size_t)(d.frame_no % A.soft_ring) * SOFT_PER_FRAME + (size_t)2304 * (cw & 3);
+        if (lane < 16) s_rowoff[lane] = d.valid == 1 ? 0 : -1;
+    }
+    __syncthreads();
+    {
+        const int16_t* __restrict__ map = C.map;
+        for (int s = lane; s < nsteps; s += 64) {
+            const uint2 mm = *reinterpret_cast<const uint2*>(map + 4 * s);                 // four map entries
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = (int)(int16_t)(((j < 2 ? mm.x : mm.y) >> (16 * (j & 1))) & 0xffffu);
+                long long off = -1;
+                if (u >= 0) off = s_rowoff[u & 15];
+                v[j] = off >= 0 ? (int)base[off + u] : 0;
+            }
+            sym[s] = ((uint32_t)(v[0] + v[3]) & 0xffffu) | (((uint32_t)v[1] & 0xffu) << 16) | ((uint32_t)v[2] << 24);
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane constants: for each layout f the signs of the three branch-metric terms of this lane's butterfly output
+    int E[6][3];
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+        const int st = sp::rotl6(lane, f), p = acs::pat(st & 31), sg = (st >> 5) ? -1 : 1;
+#pragma unroll
+        for (int j = 0; j < 3; j++) E[f][j] = ((p >> j) & 1) ? -sg : sg;
+    }
+    int Mx = lane == 0 ? 0 : 126;                                        // init_viterbi (viterbi.cpp:342-354): all 63, start state 0 at 0; doubled
+    // decisions: lane l keeps the decisions of ITS new states, newest in bit 0; 32 steps leave as one coalesced 256-byte store
+    uint32_t* __restrict__ const dec_g = reinterpret_cast<uint32_t*>(A.dec + (size_t)blockIdx.x * A.dec_slot_cells);
+    uint32_t acc = 0;
+    auto one_step = [&](auto fc, int t) {
+        constexpr int FL = decltype(fc)::value;
+        const uint32_t w = (uint32_t)uniform_i32((int)sym[t]);
+        const int a0 = 2 * (int)(int16_t)(w & 0xffffu) - 2, a1 = 2 * (int)(int8_t)((w >> 16) & 0xffu) - 1, a2 = 2 * ((int)w >> 24) - 1;
+        const int beta = mad_i24(E[FL][0], a0, mad_i24(E[FL][1], a1, mul_i24(E[FL][2], a2)));
+        uint32_t X, Y;
+        pair_values<5 - FL>((uint32_t)Mx, X, Y);
+        const int cX = (int)X + beta, cY = (int)Y - beta;
+        acc = funnel_shr(acc, (uint32_t)(cY - cX), 31);                 // acc << 1 | (m0 > m1): ties keep the m0 branch (viterbi.cpp:263-268)
+        Mx = cX < cY ? cX : cY;
+        if ((t & 31) == 31) dec_g[(t >> 5) * 64 + lane] = acc;
+    };
+    for (int t = 0; t < nsteps; t += 6) {                               // (nsteps is a multiple of six: dabphy_fused.hip plans nothing else)
+        one_step(std::integral_constant<int, 0>{}, t);
+        one_step(std::integral_constant<int, 1>{}, t + 1);
+        one_step(std::integral_constant<int, 2>{}, t + 2);
+        one_step(std::integral_constant<int, 3>{}, t + 3);
+        one_step(std::integral_constant<int, 4>{}, t + 4);
+        one_step(std::integral_constant<int, 5>{}, t + 5);
+    }
+    if (nsteps & 31) dec_g[(nsteps >> 5) * 64 + lane] = acc << (32 - (nsteps & 31));    // the last, partial block: its first step in bit 31 like the others
+    __syncthreads();                                                    // (one wave: the wait it implies orders the stores above before the loads below)
+
+    // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339): l = lane that computed the current state when its step ran
+    uint32_t* __restrict__ const out = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw * (nbits / 32);
+    const uint32_t* __restrict__ prbs = A.prbs_words;
+    const int dedisperse = C.dedisperse;
+    uint32_t l = 0, outw = 0, rho = 0;                                 // step nsteps - 1 ran in layout 5: bit (5 - 5) is replaced first
+    int t = nsteps - 1;
+    uint32_t cur = dec_g[(t >> 5) * 64 + lane];
+    while (t >= 6) {
+        const int blk = t >> 5;
+        uint32_t nxt = cur;
+        if (blk >= 1) nxt = dec_g[(blk - 1) * 64 + lane];               // the block below, in flight while this one is walked
+        for (int j = t & 31; j >= 0 && t >= 6; j--, t--) {
+            const uint32_t d = (lane_get(cur, l) >> (31 - j)) & 1u;    // the decoded bit IS the decision
+            outw = (outw >> 1) | (d << 31);
+            l = (l & ~(1u << rho)) | (d << rho);
+            rho = rho == 5 ? 0 : rho + 1;
+            const int n = t - 6;
+            if ((n & 31) == 0) {
+                const uint32_t word = acs::back_word(outw);             // bytes packed MSB first (decoder_adapter.cpp:61-67)
+                if (lane == 0) out[n >> 5] = dedisperse ? word ^ prbs[n >> 5] : word;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// pair_values against plain shuffles, all six lane bits: out[0] = mismatching lanes, out[1] = lanes checked (device self-test of the
+// instruction forms the execution model of tests/hipemu stands in for)
+__global__ void __launch_bounds__(64) k_selftest_pair_exchange(unsigned* out)
+{
+    const int lane = threadIdx.x;
+    unsigned bad = 0, n = 0;
+    for (unsigned round = 0; round < 16; round++) {
+        const uint32_t m = (uint32_t)lane * 2654435761u + round * 40503u + (blockIdx.x << 20);
+        auto chk = [&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            uint32_t x, y; pair_values<B>(m, x, y);
+            const uint32_t wx = (uint32_t)__shfl((int)m, lane & ~(1 << B)), wy = (uint32_t)__shfl((int)m, lane | (1 << B));
+            bad += (x != wx) + (y != wy); n += 2;
+        };
+        chk(std::integral_constant<int, 0>{}); chk(std::integral_constant<int, 1>{}); chk(std::integral_constant<int, 2>{});
+        chk(std::integral_constant<int, 3>{}); chk(std::integral_constant<int, 4>{}); chk(std::integral_constant<int, 5>{});
+        const uint32_t own = lane_get(m, (round * 5u + 7u) & 63u);
+        bad += (own != (uint32_t)__shfl((int)m, (int)((round * 5u + 7u) & 63u))); n += 1;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], n);
+}
+void launch_selftest_pair_exchange(unsigned* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_pair_exchange, dim3(8), dim3(64), 0, s, out);
+}
+
+void launch_viterbi_sp(const FusedArgs& a, int lds_variant, hipStream_t s)
+{
+    if (a.n_work == 0) return;
+    const dim3 grid(a.n_work * 64u);
+    // LDS: one packed word per trellis step of the longest code word: 6 / 12 / 36 KiB -- 8 / 8 / 4 work-groups per compute unit
+    if (lds_variant == 0) hipLaunchKernelGGL((k_viterbi_sp<SP_MAXSTEPS[0], 2>), grid, dim3(64), 0, s, a);
+    else if (lds_variant == 1) hipLaunchKernelGGL((k_viterbi_sp<SP_MAXSTEPS[1], 2>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_viterbi_sp<SP_MAXSTEPS[2], 1>), grid, dim3(64), 0, s, a);
+}
+
+} // namespace dabphy
