@@ -513,10 +513,11 @@ def main():
         # (dabphy_time_copy, the recipe MI355X_MICROARCH.md quotes 6.29 TB/s for; tools/ubench/copy_f4.hip sweeps it), 2 GiB in + 2 GiB out
         # per pass; torch's copy_ beside it (round 3's denominator: it flattered)
         try:
-            cg = dev.time_copy(2 << 30, 0, 5)
+            sweep = {k: dev.time_copy(2 << 30, k, 5) for k in (2, 4, 8, 16)}
+            cg = max(sweep.values())
             line["roofline"]["measured_copy_GBps"] = cg
             line["roofline"]["frac_of_achievable"] = ach / cg
-            line["roofline"]["measured_copy_note"] = "float4 grid-stride device copy of 2 GiB (read + write counted), 16 work-groups per CU, after this run's timed region on the same device (dabphy_time_copy)"
+            line["roofline"]["measured_copy_note"] = "float4 grid-stride device copy of 2 GiB (read + write counted), best of 2 / 4 / 8 / 16 work-groups per CU (%s), after this run's timed region on the same device (dabphy_time_copy; tools/ubench/copy_f4.hip is the full sweep, profiles/r04_copy_f4.txt)" % ", ".join("%d: %.0f" % kv for kv in sorted(sweep.items()))
             src = iq[: max(1, B // 2)]; dst = torch.empty_like(src)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             dst.copy_(src); torch.cuda.synchronize()

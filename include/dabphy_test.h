@@ -23,7 +23,7 @@ int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, 
                         float* ms_decode);
 int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
 /* dabphy_time_copy: a plain device-to-device copy of `bytes` bytes (16 bytes per lane and request, grid-stride, blocks_per_cu work-groups
- *   of 256 threads per compute unit, 0 = 16), `iters` passes after three warm-up passes; *gbytes_per_s = bytes read + bytes written per
+ *   of 256 threads per compute unit, 0 = 4), `iters` passes after three warm-up passes; *gbytes_per_s = bytes read + bytes written per
  *   second.  What the device's HBM delivers to the simplest possible kernel on this box: the measured denominator bench.py prints
  *   next to the 8 TB/s specification (tools/ubench/copy_f4.hip is the stand-alone sweep of the same kernel). */
 int dabphy_time_copy(dabphy_handle* h, uint64_t bytes, uint32_t blocks_per_cu, uint32_t iters, float* gbytes_per_s);

@@ -447,7 +447,7 @@ int dabphy_time_copy(dabphy_handle* h, uint64_t bytes, uint32_t blocks_per_cu, u
     if (!h || !gbytes_per_s || bytes < 4096 || iters == 0) return DABPHY_ERR_INVALID;
     hipDeviceProp_t p;
     HIPCHK(h, hipGetDeviceProperties(&p, h->cfg.device));
-    const int blocks = p.multiProcessorCount * (int)(blocks_per_cu ? blocks_per_cu : 16);
+    const int blocks = p.multiProcessorCount * (int)(blocks_per_cu ? blocks_per_cu : 4);
     void *src = nullptr, *dst = nullptr;
     if (hipMalloc(&src, bytes) != hipSuccess) { h->err = "hipMalloc failed (copy source)"; return DABPHY_ERR_NOMEM; }
     if (hipMalloc(&dst, bytes) != hipSuccess) { (void)hipFree(src); h->err = "hipMalloc failed (copy destination)"; return DABPHY_ERR_NOMEM; }

@@ -60,17 +60,13 @@ void launch_null_symbols(const NullArgs& a, int n_ens, hipStream_t s)
     hipLaunchKernelGGL(k_null_symbols, dim3(4, a.n_frames, n_ens), dim3(256), 0, s, a);
 }
 
-// Plain device copy, 16 bytes per lane and request, four requests in flight per lane, grid-stride: the measured denominator of the
-// FFT stage's roofline figures (dabphy_time_copy, include/dabphy_test.h; tools/ubench/copy_f4.hip sweeps its parameters).
+// Plain device copy, 16 bytes per lane and request, grid-stride, one request per lane and iteration: the measured denominator of the
+// FFT stage's roofline figures (dabphy_time_copy, include/dabphy_test.h).  tools/ubench/copy_f4.hip sweeps grid size and unroll depth:
+// on the boxes of this pool FEWER work-groups and no unrolling are fastest (profiles/r04_copy_f4.txt).
 __global__ void __launch_bounds__(256) k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 void launch_copy_f4(const void* src, void* dst, size_t n16, int blocks, hipStream_t s)
 {
