@@ -481,10 +481,10 @@ def main():
             ub = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
         except Exception:
             ub = None
-        rv = {"kernel": "k_viterbi_msc, MSC class (lane = codeword, 64 states in 32 VGPRs of u16 pairs; SWAR additions in a six-layout rotating state pairing, viterbi_acs.h; de-interleave + depuncture gather fused in through an LDS window ring)", "bound": "valu",
-              "kernel_ms": vit_ms, "kernel_ms_note": "HIP events around the launch inside the pipelined step: the FIC class and the next batch's synchroniser run beside it",
-              "codeword_steps_per_s": B * F * 72 * 1542 / (vit_ms * 1e-3) if vit_ms > 0 else None,
-              "algorithmic_bytes": B * F * 72 * (4 * 1542 + 1536 // 8), "hbm_bytes": vj.get("hbm_bytes_per_launch") if vj else None,
+        rv = {"kernel": "k_viterbi_fused: all 18 sub-channels and the FIC in one launch (lane = codeword, 64 states in 32 VGPRs of u16 pairs; SWAR additions in a six-layout rotating state pairing, viterbi_acs.h; de-interleave + depuncture gather fused in through an LDS window ring; work list pulled by persistent waves)", "bound": "valu",
+              "kernel_ms": vit_ms, "kernel_ms_note": "HIP events around the launch inside the pipelined step: the next batch's synchroniser and the SNR sums run beside it",
+              "codeword_steps_per_s": n_cw_steps / (vit_ms * 1e-3) if vit_ms > 0 else None,
+              "algorithmic_bytes": B * F * (72 * (4 * 1542 + 1536 // 8) + 4 * (4 * 774 + 768 // 8)), "hbm_bytes": vj.get("hbm_bytes_per_launch") if vj else None,
               "hbm_bytes_if_narrow_requests_are_tallied_in_full": vj.get("hbm_bytes_if_narrow_requests_are_tallied_in_full") if vj else None,
               "decision_bytes_written_plus_read": vj.get("decision_bytes_written_plus_read") if vj else None,
               "hbm_note": "the decision array (8 bytes per trellis step and code word, written by the forward pass, read back by the traceback) is 3.9 x the algorithmic bytes on its own: what bounds this kernel now (DESIGN.md 4.2)",
@@ -502,7 +502,7 @@ def main():
             # north star: "LDS-bank efficiency for Viterbi ACS".  The ACS itself touches no LDS (path metrics are register-resident); the
             # kernel's LDS traffic is the byte gather from its de-interleaver window ring
             rv.update(lds_bank_efficiency=1.0 - vj["lds_bank_conflict_cycles"] / vj["lds_idx_active_cycles"],
-                      lds_insts_per_trellis_step=vj["lds_insts_per_launch"] / (B * F * 72 * 1542 / 64.0) if vj.get("lds_insts_per_launch") else None,
+                      lds_insts_per_trellis_step=vj["lds_insts_per_launch"] / (n_cw_steps / 64.0) if vj.get("lds_insts_per_launch") else None,
                       lds_note="1 - SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the launch (static, profiles/viterbi_counters.json): the window ring's rows are 20 bytes (five dwords) apart, so the byte reads of consecutive rows fall on different banks (round 2, 16-byte pitch: 0.28); the add-compare-select itself runs in VGPRs (DESIGN.md 4.2)")
         line["roofline_viterbi"] = rv
         # which build this line was measured on, and which committed counter profiles were NOT reported because they belong to another one
@@ -580,6 +580,8 @@ def main():
             except Exception as ex:
                 line["extras"] = {"hetero": {"error": "%s: %s" % (type(ex).__name__, ex)}}
             torch.cuda.empty_cache()
+            # the latency regime: ONE ensemble, 1 / 4 / 8 / 16 frames per call, both Viterbi kernels (the default picks the state-parallel one here)
+            line["extras"]["short_batches"] = _extra([os.path.join(ROOT, "tools", "sweep_decode_shape.py"), "--json"], {}, 300)
             line["facade"] = _extra([os.path.join(ROOT, "tools", "bench_facade.py"), "--json"], {}, 240)
             line["host_u8"] = _extra([os.path.join(ROOT, "tools", "bench_host_u8.py")], {"HOSTU8_B": str(B), "HOSTU8_F": str(F), "HOSTU8_STEPS": "3"}, 300)
         print(json.dumps(line), flush=True)

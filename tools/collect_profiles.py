@@ -88,7 +88,7 @@ def is_msc_launch(r):
     """the fused MSC decode (any grid: a work-group walks several 64-codeword groups when there are more groups than wave slots), or
     the MSC launch of the two-kernel path (the FIC class uses the same k_viterbi with a smaller grid)"""
     name = r["Kernel_Name"]
-    return "k_viterbi_msc" in name or ("k_viterbi(" in name and int(r["Grid_Size"]) == vit_grid)
+    return "k_viterbi_fused" in name or "k_viterbi_msc" in name or ("k_viterbi(" in name and int(r["Grid_Size"]) == vit_grid)
 
 
 if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
@@ -104,19 +104,19 @@ if os.path.exists(os.path.join(SRC, "pmc_vit_counter_collection.csv")):
     wg = [float(r["Counter_Value"]) for r in rows("pmc_write_counter_collection.csv") if r["Counter_Name"] == "WRITE_SIZE" and "k_msc_gather" in r["Kernel_Name"]]
     mid = lambda v: sorted(v)[len(v) // 2] if v else 0.0
     json.dump({
-        "kernel": "dabphy::k_viterbi_msc (MSC class launch: gather fused into the Viterbi kernel)", "ensembles": B, "frames": F,
+        "kernel": "dabphy::k_viterbi_fused (all MSC classes + the FIC in one launch: gathers fused into the Viterbi kernel)", "ensembles": B, "frames": F,
         "valu_insts_per_launch": med.get("SQ_INSTS_VALU"), "lds_insts_per_launch": med.get("SQ_INSTS_LDS"), "vmem_insts_per_launch": med.get("SQ_INSTS_VMEM"),
         "waves": med.get("SQ_WAVES"), "lds_bank_conflict_cycles": med.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": med.get("SQ_LDS_IDX_ACTIVE"),
         "fetch_size_kb_raw": mid(fv), "write_size_kb_raw": mid(wv),
         "hbm_bytes_per_launch": int(mid(fv) * 1024 * 2 + mid(wv) * 1024),
         "gather_fetch_size_kb_raw": mid(fg), "gather_write_size_kb_raw": mid(wg), "gather_hbm_bytes_per_launch": int(mid(fg) * 1024 * 2 + mid(wg) * 1024),
-        "algorithmic_bytes_per_launch": B * F * 72 * (4 * 1542 + 1536 // 8),
+        "algorithmic_bytes_per_launch": B * F * (72 * (4 * 1542 + 1536 // 8) + 4 * (4 * 774 + 768 // 8)),
         # what is known without counters: the decision array, 8 bytes per trellis step and code word, written once and read back once
-        "decision_bytes_written_plus_read": 2 * (B * F * 72 // 64) * 1542 * 512,
+        "decision_bytes_written_plus_read": 2 * ((B * F * 72 // 64) * 1542 + (B * F * 4 // 64) * 774) * 512,
         # the guide calibrates the doubling for WIDE coalesced reads (128-byte requests tallied at 64): the decision reads are such reads,
         # the soft-bit windows are 4-byte-per-lane LDS-DMA requests.  If those are tallied at their true 64 bytes: reads = decisions
         # (known) + (raw FETCH - decisions / 2)
-        "hbm_bytes_if_narrow_requests_are_tallied_in_full": int((B * F * 72 // 64) * 1542 * 512 + (mid(fv) * 1024 - (B * F * 72 // 64) * 1542 * 512 / 2) + mid(wv) * 1024),
+        "hbm_bytes_if_narrow_requests_are_tallied_in_full": int(((B * F * 72 // 64) * 1542 + (B * F * 4 // 64) * 774) * 512 + (mid(fv) * 1024 - ((B * F * 72 // 64) * 1542 + (B * F * 4 // 64) * 774) * 512 / 2) + mid(wv) * 1024),
         "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported; median launch",
         "source": "profiles/%s_pmc_sq_viterbi_gather.csv, profiles/%s_pmc_fetch_size.csv, profiles/%s_pmc_write_size.csv" % (TAG, TAG, TAG), **BUILD,
     }, open(os.path.join(DST, "viterbi_counters.json"), "w"), indent=1)

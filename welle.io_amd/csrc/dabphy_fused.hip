@@ -142,7 +142,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     while (sp_variant + 1 < SP_VARIANTS && (size_t)SP_MAXSTEPS[sp_variant] < max_steps) sp_variant++;
     int r;
     if (!work.empty()) {
-        if ((r = ensure(h, h->vdec, (size_t)n_slots * (use_sp ? ((max_steps + 31) / 32) * 32 : max_steps * 64) * sizeof(uint2)))) return r;
+        if ((r = ensure(h, h->vdec, (size_t)n_slots * (use_sp ? (max_steps / 30 + 1) * 32 : max_steps * 64) * sizeof(uint2)))) return r;
         if ((r = ensure(h, h->fused_cls, cls.size() * sizeof(FusedClass)))) return r;
         if ((r = ensure(h, h->fused_work, work.size() * sizeof(uint32_t)))) return r;
         if (!h->d_fused_next) {
@@ -162,9 +162,11 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         P.host_work = work;
         if (!work.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_work.p, P.host_work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     }
+    if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: decode plan for %u frames per call: %s, %zu of %zu classes%s, %zu groups, %d work-groups\n", F, use_sp ? "state-parallel" : "lane-per-code-word", idx.size(), h->classes.size(), fic_in ? " + FIC" : "", work.size(), n_slots);
     P.valid = true; P.F = F; P.want_fic = want_fic; P.fic_in = fic_in; P.variant = v; P.n_slots = n_slots;
     P.use_sp = use_sp; P.sp_variant = sp_variant;
-    P.dec_slot_cells = use_sp ? ((max_steps + 31) / 32) * 32 : max_steps * 64; P.class_idx = idx; P.buf_gen = h->buf_gen;
+    P.dec_slot_cells = use_sp ? (max_steps / 30 + 1) * 32 : max_steps * 64;      // (state-parallel: one 256-byte row of history words per 30 steps)
+    P.class_idx = idx; P.buf_gen = h->buf_gen;
     FusedArgs a{};
     a.soft = h->s_soft.as<int8_t>(); a.ens_stride = ens_stride; a.soft_ring = (int)h->cfg.max_frames + 5; a.n_ens = (int)B; a.n_frames = (int)F;
     a.desc = nullptr;                                  // (set per batch: the descriptor buffers rotate)

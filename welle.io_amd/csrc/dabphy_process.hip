@@ -245,6 +245,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             const bool fused = std::find(h->fplan.class_idx.begin(), h->fplan.class_idx.end(), (int)ci) != h->fplan.class_idx.end();
             ci++;
             if (fused) continue;
+            if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class %zu (%d bits) through k_msc_gather + k_viterbi\n", ci - 1, cls.prot.nbits);
             VitClass c{};
             const int M = (int)cls.members.size();
             if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * M), 1))) return r;

@@ -21,12 +21,13 @@
 // 510.  Branch metrics: the soft bits of a step are the same for all lanes (scalar registers), b is three multiply-adds with per-lane
 // constants +-1.  Metrics are int32, doubled (the +-1/2 of the mapping viterbi.cpp:233-238 become integers), never renormalised:
 // |b| <= 1020 per step, 9222 steps.  Decisions: the sign of (Y - b) - (X + b) is "m0 > m1" with the reference's tie-break for BOTH lanes of
-// a pair (both compare the X path against the Y path); one v_alignbit_b32 shifts it into the lane's own 32-step history, and 32 steps
-// leave as one coalesced 256-byte store: 8 bytes per step and code word as in the other kernels, no cross-lane packing at all.
+// a pair (both compare the X path against the Y path); one v_alignbit_b32 shifts it into the lane's own history, and 30 steps (five
+// turns through the layouts: straight-line code) leave as one coalesced 256-byte store: 8.5 bytes per step and code word, no cross-lane
+// packing at all.
 //
 // Traceback on the scalar unit: the walk from state 0 carries the LANE index of the current state; one step back replaces one bit of it
 // -- position (5 - f) mod 6 -- by the decision it has just read (the same algebra as viterbi_acs.h, with the identity as decision
-// index).  Histories come back 32 steps per load, one word per lane; a step reads the word of lane l with v_readlane.
+// index).  Histories come back 30 steps per load, one word per lane; a step reads the word of lane l with v_readlane.
 //
 // Gather.  The soft bits of a code word are fetched once, up front, by all 64 lanes (lane j: steps j, j + 64, ...) straight from the
 // soft-bit ring -- time de-interleaver as an address computation, depuncturing by the class's map -- and parked in LDS as one packed
@@ -37,6 +38,7 @@
 
 namespace dabphy {
 
+constexpr int SP_HIST = 30;                       // trellis steps per decision history word (k_viterbi_sp)
 namespace sp {
 __device__ __forceinline__ int rotl6(int x, int r) { r %= 6; return r == 0 ? x : (((x << r) | (x >> (6 - r))) & 63); }
 __device__ __forceinline__ int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }   // = map16[i] of dab-audio.cpp:113
@@ -45,7 +47,7 @@ __device__ __forceinline__ int brev4(int i) { return ((i & 1) << 3) | ((i & 2) <
 template <int MAXSTEPS, int OCC>
 __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
 {
-    __shared__ uint32_t sym[MAXSTEPS + 2];
+    __shared__ uint32_t sym[MAXSTEPS + 2 * SP_HIST];
     __shared__ long long s_rowoff[16];
     const int lane = threadIdx.x;
     const int F = A.n_frames, R = 4 * F;
@@ -99,12 +101,14 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
         for (int j = 0; j < 3; j++) E[f][j] = ((p >> j) & 1) ? -sg : sg;
     }
     int Mx = lane == 0 ? 0 : 126;                                        // init_viterbi (viterbi.cpp:342-354): all 63, start state 0 at 0; doubled
-    // decisions: lane l keeps the decisions of ITS new states, newest in bit 0; 32 steps leave as one coalesced 256-byte store
+    // decisions: lane l keeps the decisions of ITS new states, newest in bit 0; SP_HIST steps leave as one coalesced 256-byte store.
+    // (30, not 32: a multiple of the six layouts, so a block of steps is straight-line code with one store at its end.)
     uint32_t* __restrict__ const dec_g = reinterpret_cast<uint32_t*>(A.dec + (size_t)blockIdx.x * A.dec_slot_cells);
     uint32_t acc = 0;
-    auto one_step = [&](auto fc, int t) {
+    // the packed soft bits of a block, one step per lane (lane k: step t0 + k), fetched from LDS a block ahead; a step takes its
+    // word with v_readlane (constant lane): no LDS round trip inside the dependent chain of the trellis
+    auto one_step = [&](auto fc, uint32_t w) {
         constexpr int FL = decltype(fc)::value;
-        const uint32_t w = (uint32_t)uniform_i32((int)sym[t]);
         const int a0 = 2 * (int)(int16_t)(w & 0xffffu) - 2, a1 = 2 * (int)(int8_t)((w >> 16) & 0xffu) - 1, a2 = 2 * ((int)w >> 24) - 1;
         const int beta = mad_i24(E[FL][0], a0, mad_i24(E[FL][1], a1, mul_i24(E[FL][2], a2)));
         uint32_t X, Y;
@@ -112,17 +116,30 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
         const int cX = (int)X + beta, cY = (int)Y - beta;
         acc = funnel_shr(acc, (uint32_t)(cY - cX), 31);                 // acc << 1 | (m0 > m1): ties keep the m0 branch (viterbi.cpp:263-268)
         Mx = cX < cY ? cX : cY;
-        if ((t & 31) == 31) dec_g[(t >> 5) * 64 + lane] = acc;
     };
-    for (int t = 0; t < nsteps; t += 6) {                               // (nsteps is a multiple of six: dabphy_fused.hip plans nothing else)
-        one_step(std::integral_constant<int, 0>{}, t);
-        one_step(std::integral_constant<int, 1>{}, t + 1);
-        one_step(std::integral_constant<int, 2>{}, t + 2);
-        one_step(std::integral_constant<int, 3>{}, t + 3);
-        one_step(std::integral_constant<int, 4>{}, t + 4);
-        one_step(std::integral_constant<int, 5>{}, t + 5);
+    auto six_steps = [&](uint32_t wv, auto kc) {
+        constexpr int K = decltype(kc)::value;
+        one_step(std::integral_constant<int, 0>{}, lane_get(wv, K + 0)); one_step(std::integral_constant<int, 1>{}, lane_get(wv, K + 1));
+        one_step(std::integral_constant<int, 2>{}, lane_get(wv, K + 2)); one_step(std::integral_constant<int, 3>{}, lane_get(wv, K + 3));
+        one_step(std::integral_constant<int, 4>{}, lane_get(wv, K + 4)); one_step(std::integral_constant<int, 5>{}, lane_get(wv, K + 5));
+    };
+    const int nfull = nsteps / SP_HIST;
+    uint32_t wv = sym[lane < SP_HIST ? lane : 0];                        // (sym has SP_HIST words of slack behind nsteps)
+    for (int blk = 0; blk < nfull; blk++) {
+        const uint32_t wn = sym[(blk + 1) * SP_HIST + (lane < SP_HIST ? lane : 0)];
+        six_steps(wv, std::integral_constant<int, 0>{}); six_steps(wv, std::integral_constant<int, 6>{}); six_steps(wv, std::integral_constant<int, 12>{});
+        six_steps(wv, std::integral_constant<int, 18>{}); six_steps(wv, std::integral_constant<int, 24>{});
+        dec_g[blk * 64 + lane] = acc;
+        wv = wn;
     }
-    if (nsteps & 31) dec_g[(nsteps >> 5) * 64 + lane] = acc << (32 - (nsteps & 31));    // the last, partial block: its first step in bit 31 like the others
+    {   // the last, partial block (nsteps is a multiple of six): its first step in bit SP_HIST - 1 like the others
+        const int rem = nsteps - nfull * SP_HIST;
+        if (rem >= 6) six_steps(wv, std::integral_constant<int, 0>{});
+        if (rem >= 12) six_steps(wv, std::integral_constant<int, 6>{});
+        if (rem >= 18) six_steps(wv, std::integral_constant<int, 12>{});
+        if (rem >= 24) six_steps(wv, std::integral_constant<int, 18>{});
+        if (rem) dec_g[nfull * 64 + lane] = acc << (SP_HIST - rem);
+    }
     __syncthreads();                                                    // (one wave: the wait it implies orders the stores above before the loads below)
 
     // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339): l = lane that computed the current state when its step ran
@@ -131,13 +148,13 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
     const int dedisperse = C.dedisperse;
     uint32_t l = 0, outw = 0, rho = 0;                                 // step nsteps - 1 ran in layout 5: bit (5 - 5) is replaced first
     int t = nsteps - 1;
-    uint32_t cur = dec_g[(t >> 5) * 64 + lane];
+    int blk = t / SP_HIST;
+    uint32_t cur = dec_g[blk * 64 + lane];
     while (t >= 6) {
-        const int blk = t >> 5;
         uint32_t nxt = cur;
         if (blk >= 1) nxt = dec_g[(blk - 1) * 64 + lane];               // the block below, in flight while this one is walked
-        for (int j = t & 31; j >= 0 && t >= 6; j--, t--) {
-            const uint32_t d = (lane_get(cur, l) >> (31 - j)) & 1u;    // the decoded bit IS the decision
+        for (int j = t - blk * SP_HIST; j >= 0 && t >= 6; j--, t--) {
+            const uint32_t d = (lane_get(cur, l) >> (SP_HIST - 1 - j)) & 1u;    // the decoded bit IS the decision
             outw = (outw >> 1) | (d << 31);
             l = (l & ~(1u << rho)) | (d << rho);
             rho = rho == 5 ? 0 : rho + 1;
@@ -147,7 +164,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
                 if (lane == 0) out[n >> 5] = dedisperse ? word ^ prbs[n >> 5] : word;
             }
         }
-        cur = nxt;
+        cur = nxt; blk--;
     }
 }
 
