@@ -25,6 +25,13 @@ def load_package():
 
 load_package()
 
+# The CPU execution model runs a wavefront as 64 fibres that meet at every cross-lane operation: the state-parallel Viterbi kernel
+# (k_viterbi_sp: a few exchanges per trellis step) costs it seconds per frame.  The GPU-less suite therefore lets the library's automatic
+# choice fall on the lane-per-code-word kernel (the experiments build of tests/hipemu reads DABPHY_SP_MAX_CW; the product library reads no
+# environment at all) and runs the state-parallel kernel in the tests that ask for it (decode_shape = 2); the automatic choice itself is
+# covered on the device (every small-batch test of the -m gpu suite) and by tests/test_emu_product_build.py.
+os.environ.setdefault("DABPHY_SP_MAX_CW", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")

@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
                 if (u >= 0) off = s_rowoff[u & 15];
                 v[j] = off >= 0 ? (int)base[off + u] : 0;
             }
-            sym[s] = ((uint32_t)(v[0] + v[3]) & 0xffffu) | (((uint32_t)v[1] & 0xffu) << 16) | ((uint32_t)v[2] << 24);
+            // the three branch-metric inputs of the step, doubled and biased as the trellis takes them (viterbi.cpp:233-238 puts the symbol
+            // levels at v + 127: bm(p) = 510 + e0 (x0 - 1) + e1 (v1 - 1/2) + e2 (v2 - 1/2), x0 = v0 + v3): 12 + 10 + 10 signed bits
+            sym[s] = ((uint32_t)(2 * (v[0] + v[3]) - 2) & 0xfffu) | (((uint32_t)(2 * v[1] - 1) & 0x3ffu) << 12) | ((uint32_t)(2 * v[2] - 1) << 22);
         }
     }
     __syncthreads();
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
     // word with v_readlane (constant lane): no LDS round trip inside the dependent chain of the trellis
     auto one_step = [&](auto fc, uint32_t w) {
         constexpr int FL = decltype(fc)::value;
-        const int a0 = 2 * (int)(int16_t)(w & 0xffffu) - 2, a1 = 2 * (int)(int8_t)((w >> 16) & 0xffu) - 1, a2 = 2 * ((int)w >> 24) - 1;
+        const int a0 = (int)(w << 20) >> 20, a1 = (int)(w << 10) >> 22, a2 = (int)w >> 22;
         const int beta = mad_i24(E[FL][0], a0, mad_i24(E[FL][1], a1, mul_i24(E[FL][2], a2)));
         uint32_t X, Y;
         pair_values<5 - FL>((uint32_t)Mx, X, Y);
@@ -142,29 +144,48 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
     }
     __syncthreads();                                                    // (one wave: the wait it implies orders the stores above before the loads below)
 
-    // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339): l = lane that computed the current state when its step ran
+    // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339): l = lane that computed the current state when its step ran.
+    // All of it is wave-uniform (scalar unit + one v_readlane per step).  The decoded bits -- the decisions themselves -- are shifted
+    // into the top of a 64-bit register, newest first; whenever 32 of them have gathered the oldest 32 leave as one output word
+    // (bytes packed MSB first, decoder_adapter.cpp:61-67; the first bit read is data bit nbits - 1, and nbits is a multiple of 32).
     uint32_t* __restrict__ const out = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw * (nbits / 32);
     const uint32_t* __restrict__ prbs = A.prbs_words;
     const int dedisperse = C.dedisperse;
-    uint32_t l = 0, outw = 0, rho = 0;                                 // step nsteps - 1 ran in layout 5: bit (5 - 5) is replaced first
-    int t = nsteps - 1;
-    int blk = t / SP_HIST;
-    uint32_t cur = dec_g[blk * 64 + lane];
-    while (t >= 6) {
-        uint32_t nxt = cur;
-        if (blk >= 1) nxt = dec_g[(blk - 1) * 64 + lane];               // the block below, in flight while this one is walked
-        for (int j = t - blk * SP_HIST; j >= 0 && t >= 6; j--, t--) {
-            const uint32_t d = (lane_get(cur, l) >> (SP_HIST - 1 - j)) & 1u;    // the decoded bit IS the decision
-            outw = (outw >> 1) | (d << 31);
-            l = (l & ~(1u << rho)) | (d << rho);
-            rho = rho == 5 ? 0 : rho + 1;
-            const int n = t - 6;
-            if ((n & 31) == 0) {
-                const uint32_t word = acs::back_word(outw);             // bytes packed MSB first (decoder_adapter.cpp:61-67)
-                if (lane == 0) out[n >> 5] = dedisperse ? word ^ prbs[n >> 5] : word;
-            }
+    uint32_t l = 0;
+    unsigned long long bits = 0; int cnt = 0, wi = nbits / 32;
+    auto take = [&](uint32_t d, uint32_t rho) {
+        bits = (bits >> 1) | ((unsigned long long)d << 63);
+        l = (l & ~(1u << rho)) | (d << rho);
+    };
+    auto emit = [&]() {
+        if (cnt >= 32) {
+            const uint32_t word = acs::back_word((uint32_t)(bits >> (64 - cnt)));
+            wi--; cnt -= 32;
+            if (lane == 0) out[wi] = dedisperse ? word ^ prbs[wi] : word;
         }
-        cur = nxt; blk--;
+    };
+    const int rem = nsteps - nfull * SP_HIST;                           // steps in the top, partial block (a multiple of six)
+    if (rem) {
+        const uint32_t cur = dec_g[nfull * 64 + lane];
+        uint32_t rho = 0;                                               // step nsteps - 1 ran in layout 5: bit (5 - 5) is replaced first
+        for (int j = rem - 1; j >= 0; j--) {
+            take((lane_get(cur, l) >> (SP_HIST - 1 - j)) & 1u, rho);
+            rho = rho == 5 ? 0 : rho + 1;
+        }
+        cnt += rem; emit();
+    }
+    uint32_t cur = nfull ? dec_g[(nfull - 1) * 64 + lane] : 0u;
+    for (int blk = nfull - 1; blk >= 1; blk--) {                        // whole blocks above the first: 30 steps of straight-line code
+        const uint32_t nxt = dec_g[(blk - 1) * 64 + lane];              // the block below, in flight while this one is walked
+#pragma unroll
+        for (int j = SP_HIST - 1; j >= 0; j--) take((lane_get(cur, l) >> (SP_HIST - 1 - j)) & 1u, (uint32_t)((5 - j % 6) % 6));
+        cnt += SP_HIST; emit();
+        cur = nxt;
+    }
+    if (nfull) {                                                        // block 0: its first six steps decide nothing that is kept
+#pragma unroll
+        for (int j = SP_HIST - 1; j >= 6; j--) take((lane_get(cur, l) >> (SP_HIST - 1 - j)) & 1u, (uint32_t)((5 - j % 6) % 6));
+        cnt += SP_HIST - 6; emit();
     }
 }
 
