@@ -85,6 +85,8 @@ int fused_class_tables(dabphy_handle* h, const dabphy_protection& prot, bool fic
 int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
 {
     auto& P = h->fplan;
+    // (everything below is a function of the batch depth, the class set and the buffers' addresses: buf_gen moves with the last two)
+    if (P.valid && P.F == F && P.want_fic == want_fic && P.buf_gen == h->buf_gen) return DABPHY_OK;
     const uint32_t B = h->cfg.n_ensembles;
     const int R = 4 * (int)F;
     const int v = R >= FUSED_MIN_CIFS[0] ? 0 : R >= FUSED_MIN_CIFS[1] ? 1 : 2;

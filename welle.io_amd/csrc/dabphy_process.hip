@@ -171,6 +171,12 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     tick(2);
     mark(dabphy_handle::ST_DEMOD, true);
     if (!replay && (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3)) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
+    if (!replay && depth && h->chain_early) {
+        // the next batch's synchroniser is handed to the device BEFORE this batch's decoder (whose persistent waves would otherwise hold
+        // every wave slot until the end of the step: the synchroniser then runs in the step's tail)
+        if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
+        for (; h->ahead < 1 + depth; h->ahead++) if ((r = queue_chain(h, (cur + h->ahead) % ND, F))) return r;
+    }
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
 
     // SNR + FIC + TII beside the MSC decode, on the auxiliary stream.  The FIC's 4 code words per frame ride in the fused launch
