@@ -71,7 +71,7 @@ typedef struct {
                                        (a few MB, device to device) and, in such a batch, about three times its normal time.
                                        1: report only (round 1's behaviour) */
     int32_t decode_shape;           /* which Viterbi kernel decodes the FIC and the sub-channels.  0 (default): by batch size -- small batches (at
-                                       most 6144 code words per call: e.g. one ensemble, up to 80 frames of 18 sub-channels) one WAVEFRONT per
+                                       most 16 384 code words per call: e.g. one ensemble of 18 sub-channels, any batch depth; 16 ensembles x 8 frames) one WAVEFRONT per
                                        code word, lanes = the 64 trellis states (k_viterbi_sp: four times the instructions per code word, a
                                        hundredth of the latency); larger ones one LANE per code word (k_viterbi_fused: the throughput shape).
                                        1: always lane-per-code-word; 2: always state-parallel.  Same bytes either way. */

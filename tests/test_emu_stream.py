@@ -87,7 +87,7 @@ def test_mixed_protection_classes(emu, F, nf):
 def test_mixed_protection_classes_state_parallel(emu, F, nf):
     """the same ensemble (EEP A/B, UEP, 8 .. 384 kbit/s: code words of 192 .. 9216 bits, all three LDS sizes of the kernel) through
     k_viterbi_sp: one wavefront per code word, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
-    stream test of this file runs small batches too, hence this kernel: the default picks it below 6144 code words per call.)"""
+    stream test of this file runs small batches too, hence this kernel: the default picks it below 16 384 code words per call.)"""
     P.check_mixed_ensemble(factory_state_parallel, F=F, nf=nf, expect_fused=True)
 
 

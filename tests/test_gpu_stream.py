@@ -103,7 +103,7 @@ def test_mixed_protection_classes(gpu, F, nf):
 def test_mixed_protection_classes_state_parallel(gpu, F, nf):
     """the same ensemble (EEP A/B, UEP, 8 .. 384 kbit/s: code words of 192 .. 9216 bits, all three LDS sizes of the kernel) through
     k_viterbi_sp: one wavefront per code word, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
-    stream test of this file runs small batches too, hence this kernel: the default picks it below 6144 code words per call.)"""
+    stream test of this file runs small batches too, hence this kernel: the default picks it below 16 384 code words per call.)"""
     P.check_mixed_ensemble(factory_state_parallel, F=F, nf=nf, expect_fused=True)
 
 
@@ -122,9 +122,9 @@ def test_lane_exchanges_of_the_state_parallel_kernel(gpu):
 
 
 def test_shallow_batch_above_the_state_parallel_limit(gpu):
-    """64 ensembles x 4 frames of the mixed ensemble = 10 240 code words per call: too many for the state-parallel kernel's default
+    """128 ensembles x 4 frames of the mixed ensemble = 20 480 code words per call: too many for the state-parallel kernel's default
     limit, too shallow for the 96-row build: the 144-row build of the fused kernel as the DEFAULT choice"""
-    P.check_mixed_ensemble(factory, F=4, nf=11, B=64, expect_fused=True, check_ens=(0, 31, 63))
+    P.check_mixed_ensemble(factory, F=4, nf=11, B=128, expect_fused=True, check_ens=(0, 63, 127))
 
 
 def test_two_kernel_decode_beyond_the_fused_kernels_reach(gpu):
