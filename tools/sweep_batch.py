@@ -28,8 +28,11 @@ chan = len(sys.argv) > 3 and sys.argv[3] == "channels"
 exact = (len(sys.argv) > 3 and sys.argv[3] == "exact") or chan
 
 
+SHAPE = int(os.environ.get("SWEEP_DECODE_SHAPE", "0"))      # dabphy_config.decode_shape: 0 = the default (these small batches: state-parallel kernel), 1 = lane per code word (the fused kernel's 144- / 324-row builds at 2 ... 8 frames per call)
+
+
 def factory(**kw):
-    return capi.DabPhy(lib_path=lib, **kw)
+    return capi.DabPhy(lib_path=lib, decode_shape=SHAPE, **kw)
 
 
 frames = wide = fast = checked = lagged = effective = replayed = 0
@@ -59,5 +62,5 @@ for it in range(n):
     k = len(L["info"]); frames += k; wide += L["wide"][0]; fast += L["osc"][0]; checked += L["osc"][1]; lagged += int(L["ratio_lag"][0] > 0); effective += int(L["ratio_lag_effect"][0] > 0)
     print("stream %3d  snr %4.0f dB  cfo %7.1f Hz  delay %4d  F %d  schedule %d  frames %2d  from the wide pass %2d  oscillator symbols unchecked/checked %d/%d  ratio lag %s with an effect %s"
           % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"], L["ratio_lag_effect"]) + desc, flush=True)
-print("streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  batches decoded twice %d  mismatches 0"
-      % (n, frames, wide, fast, checked, lagged, effective, replayed))
+print("decode_shape %d  streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  batches decoded twice %d  mismatches 0"
+      % (SHAPE, n, frames, wide, fast, checked, lagged, effective, replayed))
