@@ -642,6 +642,35 @@ def check_error_behaviour(d_factory):
         d.close()
 
 
+def check_timing_driver_refuses_a_stale_launch(d_factory):
+    """dabphy_time_fused_msc re-runs the decode launch of the last batch; once a buffer that launch names has been replaced (new sub-channel
+    classes, a reallocation) it must say so (DABPHY_ERR_STATE) instead of launching on freed memory"""
+    from welle_io_amd.capi import DabPhyError
+    subchs = synth.default_subchannels(3)
+    x = synth.make_stream(5, subchs=subchs, snr_db=20, seed=4)
+    d = d_factory(n_ensembles=1, max_frames=2)
+    try:
+        def refused():
+            try:
+                d.time_fused_msc(1)
+            except DabPhyError as e:
+                assert "status -5" in str(e), str(e)
+                return True
+            return False
+        assert refused()                                                          # nothing decoded yet
+        d.stream_upload(np.asarray(x, np.complex64)[None, :])
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subchs])
+        d.process(2)
+        assert d.time_fused_msc(1) > 0.0
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s)) for s in subchs[:2]])      # frees the classes' buffers
+        assert refused()
+        d.process(2)
+        assert d.time_fused_msc(1) > 0.0
+        assert d.time_copy(1 << 22, 0, 1) > 0.0                                   # the copy denominator's entry point (4 MiB: any device, the execution model too)
+    finally:
+        d.close()
+
+
 # ---- the configuration bench.py times (welle_io_amd/workload.py): B x F batch, looping ring, coarse corrector enabled, pipelined
 # synchroniser, all 18 sub-channels, superframe filter inside process() -- against the oracle on the very same samples
 def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_steps=3, demod_chunk=0, device="cuda", subs_idx=(0, 7, 17),

@@ -41,6 +41,12 @@ def test_error_behaviour(emu):
     P.check_error_behaviour(lambda **kw: capi.DabPhy(lib_path=conftest.EMU_LIB, **kw))
 
 
+def test_timing_driver_refuses_a_stale_launch(emu):
+    from welle_io_amd import capi
+    import conftest
+    P.check_timing_driver_refuses_a_stale_launch(lambda **kw: capi.DabPhy(lib_path=conftest.EMU_LIB, **kw))
+
+
 def test_demod_chunk_sizes(emu):
     from welle_io_amd import capi
     import conftest

@@ -95,5 +95,11 @@ def test_error_behaviour(gpu):
     P.check_error_behaviour(lambda **kw: capi.DabPhy(lib_path=conftest.GPU_LIB, **kw))
 
 
+def test_timing_driver_refuses_a_stale_launch(gpu):
+    from welle_io_amd import capi
+    import conftest
+    P.check_timing_driver_refuses_a_stale_launch(lambda **kw: capi.DabPhy(lib_path=conftest.GPU_LIB, **kw))
+
+
 def test_reed_solomon_random_error_patterns(gpu):
     P.check_rs_random(gpu, n_sf=600)
