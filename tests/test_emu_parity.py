@@ -35,6 +35,26 @@ def test_demod_zero_carriers(emu):
     assert not soft.any()
 
 
+def test_seams_state_parallel(emu):
+    """the seams of INTEGRATION.md level 2 (Viterbi::deconvolve, Protection::deconvolve, FicHandler::processFicBlock) decode small calls
+    with one wavefront per code word (k_viterbi_sp, kinds 1 and 2; dabphy_config.decode_shape = 2 here, the default's choice on the device):
+    arbitrary int8 input incl. -128 (the clamp of viterbi.cpp:233-236), every EEP / UEP profile kind, the FIC"""
+    from welle_io_amd import capi
+    import conftest
+    d = capi.DabPhy(lib_path=conftest.EMU_LIB, decode_shape=2)
+    try:
+        P.check_viterbi(d, 768, 9, seed=5, kind="uniform")
+        P.check_viterbi(d, 192, 70, seed=6, kind="extreme")
+        P.check_viterbi(d, 2304, 3, seed=7, kind="coded")
+        P.check_viterbi(d, 32, 5, seed=8, kind="uniform")                 # 38 trellis steps: not a multiple of six -> the lane-per-code-word kernel
+        P.check_msc_deconvolve(d, "eep", 64, 0, 3, 5, seed=9)
+        P.check_msc_deconvolve(d, "eep", 32, 1, 1, 4, seed=10)
+        P.check_msc_deconvolve(d, "uep", 80, 1, 0, 3, seed=11)
+        assert P.check_fic(d, 3, 14, seed=12) > 0
+    finally:
+        d.close()
+
+
 def test_error_behaviour(emu):
     from welle_io_amd import capi
     import conftest

@@ -228,6 +228,12 @@ def test_exact_batch_mode(emu, snr, cfo, F, seed, pipeline, replay):
     P.check_exact_batch(factory, snr, cfo, F, seed, pipeline_sync=pipeline, expect_replay=replay)
 
 
+def test_exact_batch_mode_state_parallel(emu):
+    """the replay's frame-by-frame FIC decode through the one-class state-parallel launch (frame selector in the launch arguments), and the
+    batch's own decode state-parallel too: the stream that is known to need the second pass"""
+    P.check_exact_batch(factory_state_parallel, 3, -1000, 4, 5, pipeline_sync=False, expect_replay=True)
+
+
 @pytest.mark.parametrize("chunk", [1, 2])
 def test_exact_batch_mode_with_short_demod_chunks(emu, chunk):
     """the replay demodulates only the chunks that hold the FIC symbols 1 .. 3 of a frame: with one or two symbols per work-group that

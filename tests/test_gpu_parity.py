@@ -89,6 +89,25 @@ def test_demod_then_fic_roundtrip_full_batch(gpu):
     assert np.array_equal(fib, sent)
 
 
+@pytest.mark.parametrize("shape", [1, 2])
+def test_seams_with_either_decoder(gpu, shape):
+    """the seams of INTEGRATION.md level 2 with both Viterbi kernels forced (the default decodes these small calls state-parallel: every
+    other seam test of this file): arbitrary int8 input incl. -128, EEP / UEP profiles, the FIC"""
+    from welle_io_amd import capi
+    import conftest
+    d = capi.DabPhy(lib_path=conftest.GPU_LIB, decode_shape=shape)
+    try:
+        P.check_viterbi(d, 768, 90, seed=5, kind="uniform")
+        P.check_viterbi(d, 192, 700, seed=6, kind="extreme")
+        P.check_viterbi(d, 9216, 5, seed=7, kind="coded")
+        P.check_viterbi(d, 32, 5, seed=8, kind="uniform")
+        P.check_msc_deconvolve(d, "eep", 64, 0, 3, 40, seed=9)
+        P.check_msc_deconvolve(d, "uep", 80, 1, 0, 30, seed=11)
+        assert P.check_fic(d, 5, 14, seed=12) > 0
+    finally:
+        d.close()
+
+
 def test_error_behaviour(gpu):
     from welle_io_amd import capi
     import conftest

@@ -152,7 +152,8 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     if (h->ev_fused_done) e = hipEventDestroy(h->ev_fused_done);
-    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2]}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2], &h->sp1_cls, &h->sp1_work}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
+    if (h->h_sp1) e = hipHostFree(h->h_sp1);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
@@ -248,6 +249,15 @@ static int run_lin_decode(dabphy_handle* h, const int8_t* in, size_t in_stride, 
     VitClass c{};
     if ((r = prepare_class(h, c, nbits, (int)n_cw, dedisperse))) return r;
     HIPCHK(h, hipMemcpyAsync(h->in8.p, in, in_stride * n_cw, hipMemcpyHostToDevice, h->stream));
+    if (sp_single_ok(h, n_cw, c.nsteps)) {
+        // a small call (the per-frame seams of INTEGRATION.md level 2: a few code words): one wavefront per code word
+        FusedClass fc{}; fc.map = d_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = nbits; fc.n_cw = (int32_t)n_cw; fc.n_members = 1; fc.kind = 2; fc.dedisperse = dedisperse;
+        FusedArgs a{}; a.n_ens = 1; a.n_frames = 1; a.lin_in = h->in8.as<int8_t>(); a.lin_stride = in_stride;
+        if ((r = sp_single_prepare(h, fc, a, h->stream))) return r;
+        launch_viterbi_sp(a, sp_variant_for(c.nsteps), h->stream);
+        HIPCHK(h, hipMemcpyAsync(out, c.out, (size_t)n_cw * (nbits / 8), hipMemcpyDeviceToHost, h->stream));
+        return sync(h);
+    }
     LinGatherArgs g{}; g.in = h->in8.as<int8_t>(); g.in_stride = in_stride; g.map = d_map; g.c = c;
     launch_lin_gather(g, h->stream);
     VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
@@ -291,9 +301,17 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
     HIPCHK(h, hipMemcpyAsync(h->desc.p, d.data(), n_frames * sizeof(FrameDesc), hipMemcpyHostToDevice, h->stream));
     FicGatherArgs g{}; g.soft = h->in8.as<int8_t>(); g.soft_ring = (int)n_frames; g.frame_stride = 9216; g.desc = h->desc.as<FrameDesc>();
     g.n_ens = 1; g.n_frames = (int)n_frames; g.map = h->d_fic_map; g.c = c;
-    launch_fic_gather(g, h->stream);
-    VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
-    launch_viterbi(v, h->stream);
+    if (sp_single_ok(h, (uint64_t)n_frames * 4, c.nsteps)) {
+        // (FicHandler::processFicBlock bound per frame: four code words a call)
+        FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = (int32_t)(n_frames * 4); fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1;
+        FusedArgs a{}; a.soft = g.soft; a.ens_stride = (size_t)n_frames * 9216; a.soft_ring = (int)n_frames; a.n_ens = 1; a.n_frames = (int)n_frames; a.desc = g.desc; a.fic_frame_stride = 9216;
+        if ((r = sp_single_prepare(h, fc, a, h->stream))) return r;
+        launch_viterbi_sp(a, sp_variant_for(c.nsteps), h->stream);
+    } else {
+        launch_fic_gather(g, h->stream);
+        VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
+        launch_viterbi(v, h->stream);
+    }
     CrcArgs k{}; k.fib = c.out; k.ok = h->ok.as<uint8_t>(); k.state = h->d_dec; k.desc = g.desc; k.n_ens = 1; k.n_frames = (int)n_frames; k.disable_coarse = 1;   // (no synchroniser behind this seam)
     launch_fib_crc(k, h->stream);
     launch_fic_ratio(k, h->stream);

@@ -113,7 +113,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         FusedClass fc{};
         fc.steps = c.steps[v].as<MscStep>(); fc.start_bit = c.start_bits.as<int32_t>(); fc.map = c.map.as<int16_t>(); fc.out = c.out.as<uint8_t>();
         fc.nbits = c.prot.nbits; fc.nsteps = fc.nbits + 6; fc.n_windows = c.n_windows[v]; fc.n_cw = (int32_t)(B * 4 * F * M);
-        fc.n_members = M; fc.kind = 0; fc.dedisperse = 1; fc.frame_sel = 0;
+        fc.n_members = M; fc.kind = 0; fc.dedisperse = 1;
         items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
         cls.push_back(fc); idx.push_back((int)i);
         max_steps = std::max(max_steps, (size_t)fc.nsteps);
@@ -123,7 +123,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         FusedClass fc{};
         fc.steps = h->fic_steps[v].as<MscStep>(); fc.start_bit = nullptr; fc.map = h->d_fic_map; fc.out = h->s_fib.as<uint8_t>();
         fc.nbits = 768; fc.nsteps = 774; fc.n_windows = h->fic_windows[v]; fc.n_cw = (int32_t)(B * F * 4);
-        fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1; fc.frame_sel = 0;
+        fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1;
         items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
         cls.push_back(fc);
         max_steps = std::max(max_steps, (size_t)fc.nsteps);
@@ -140,8 +140,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     const int slots = fused_wave_slots(v);
     // (state-parallel: one work-group per code word slot of every listed group, each with its own decision scratch)
     const int n_slots = use_sp ? (int)work.size() * 64 : (int)std::min<size_t>(work.size(), (size_t)slots);
-    int sp_variant = 0;
-    while (sp_variant + 1 < SP_VARIANTS && (size_t)SP_MAXSTEPS[sp_variant] < max_steps) sp_variant++;
+    const int sp_variant = sp_variant_for((int)max_steps);
     int r;
     if (!work.empty()) {
         if ((r = ensure(h, h->vdec, (size_t)n_slots * (use_sp ? (max_steps / 30 + 1) * 32 : max_steps * 64) * sizeof(uint2)))) return r;
@@ -176,6 +175,57 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = P.dec_slot_cells; a.prbs_words = h->d_prbs_words;
     P.args = a;
     return DABPHY_OK;
+}
+
+// Whether a stand-alone class of n_cw code words (a seam's call, the replay's one-frame FIC) is decoded state-parallel: the same rule
+// as for a batch (dabphy_config.decode_shape, the code word limit), and the kernel's own conditions (blocks of six steps, its LDS sizes).
+bool sp_single_ok(const dabphy_handle* h, uint64_t n_cw, int nsteps)
+{
+    if (!h->fused_msc || h->cfg.decode_shape == 1 || nsteps % 6 != 0 || nsteps > SP_MAXSTEPS[SP_VARIANTS - 1]) return false;
+    return h->cfg.decode_shape == 2 || (h->sp_max_codewords > 0 && n_cw <= h->sp_max_codewords);
+}
+
+// One class through k_viterbi_sp on stream st: descriptor and work list go up through a small page-locked staging area (the copies are
+// ordered with the launch by the stream; the caller does not reuse the staging before it has synchronised or queued its last launch of
+// this class), decision scratch = the handle's (the stream orders it with every other user).  `a` carries what the class kind reads
+// (soft / desc / strides, or lin_in / lin_stride); cls, work, dec are filled in here and returned in `a` for further launches.
+// every buffer such a launch needs, so that a caller in the middle of a submission (the replay inside dabphy_process) allocates nothing
+int sp_single_reserve(dabphy_handle* h, uint64_t n_cw, int nsteps)
+{
+    const uint64_t n_groups = (n_cw + 63) / 64;
+    int r;
+    if (n_groups > 4096) { h->err = "one-class state-parallel launch: too many groups"; return DABPHY_ERR_INVALID; }
+    if (!h->h_sp1) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(FusedClass) + 4096 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc failed (one-class staging)"; return DABPHY_ERR_NOMEM; }
+        h->h_sp1 = p;
+    }
+    const size_t cells = ((size_t)nsteps / 30 + 1) * 32;
+    if ((r = ensure(h, h->sp1_cls, sizeof(FusedClass)))) return r;
+    if ((r = ensure(h, h->sp1_work, 4096 * sizeof(uint32_t)))) return r;
+    return ensure(h, h->vdec, (size_t)n_groups * 64 * cells * sizeof(uint2));
+}
+int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipStream_t st)
+{
+    const uint32_t n_groups = (uint32_t)((fc.n_cw + 63) / 64);
+    int r;
+    if ((r = sp_single_reserve(h, (uint64_t)fc.n_cw, fc.nsteps))) return r;
+    const size_t cells = ((size_t)fc.nsteps / 30 + 1) * 32;
+    FusedClass* hc = reinterpret_cast<FusedClass*>(h->h_sp1);
+    uint32_t* hw = reinterpret_cast<uint32_t*>(hc + 1);
+    *hc = fc;
+    for (uint32_t g = 0; g < n_groups; g++) hw[g] = g;                 // class 0, group g
+    HIPCHK(h, hipMemcpyAsync(h->sp1_cls.p, hc, sizeof(FusedClass), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->sp1_work.p, hw, n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    a.cls = h->sp1_cls.as<FusedClass>(); a.work = h->sp1_work.as<uint32_t>(); a.n_work = n_groups; a.next = nullptr;
+    a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = cells; a.prbs_words = h->d_prbs_words;
+    return DABPHY_OK;
+}
+int sp_variant_for(int nsteps)
+{
+    int v = 0;
+    while (v + 1 < SP_VARIANTS && SP_MAXSTEPS[v] < nsteps) v++;
+    return v;
 }
 
 } // extern "C"

@@ -99,6 +99,7 @@ struct dabphy_handle {
         bool launched = false;
     } fplan;
     DevBuf fused_cls, fused_work; uint32_t* d_fused_next = nullptr;
+    DevBuf sp1_cls, sp1_work; void* h_sp1 = nullptr;     // one-class state-parallel launches (the seams, the replay's one-frame FIC): descriptor + work list, page-locked staging
     DevBuf fic_steps[FUSED_VARIANTS]; int fic_windows[FUSED_VARIANTS] = {0, 0, 0};
     hipEvent_t ev_fused_done = nullptr;
     uint64_t buf_gen = 1;                                // bumped whenever a device buffer is reallocated or a class is rebuilt
@@ -222,5 +223,9 @@ DABPHY_INTERNAL int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& c
 DABPHY_INTERNAL int launch_superframe_stats(dabphy_handle* h);
 DABPHY_INTERNAL int fused_class_tables(dabphy_handle* h, const dabphy_protection& prot, bool fic, DevBuf (&steps)[FUSED_VARIANTS], int (&n_windows)[FUSED_VARIANTS]);   // dabphy_fused.hip
 DABPHY_INTERNAL int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic);
+DABPHY_INTERNAL bool sp_single_ok(const dabphy_handle* h, uint64_t n_cw, int nsteps);
+DABPHY_INTERNAL int sp_single_reserve(dabphy_handle* h, uint64_t n_cw, int nsteps);
+DABPHY_INTERNAL int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipStream_t st);
+DABPHY_INTERNAL int sp_variant_for(int nsteps);
 DABPHY_INTERNAL size_t soft_ens_stride(const dabphy_handle* h);                                   // bytes between the soft-bit ring slices of two ensembles
 }

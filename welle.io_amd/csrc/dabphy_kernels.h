@@ -162,13 +162,15 @@ constexpr int FUSED_MIN_CIFS[FUSED_VARIANTS] = {64, 16, 4};
 constexpr uint32_t MSC_FIRST_USE = 1u << 15, MSC_LOAD_NEXT = 1u << 31, MSC_OFF_MASK = 0x7fffu;
 // One class of a fused launch (read through the constant address space).  kind 0 = an MSC protection class: code word
 // cw = (b * n_members + m) * R + r (ensemble b, member sub-channel m, CIF r of this batch, R = 4 * n_frames); kind 1 = the FIC:
-// code word (b * n_frames + f) * 4 + q, or 4 b + q of frame frame_sel - 1 alone (the replay of exact batch mode).
+// code word (b * n_frames + f) * 4 + q -- or, k_viterbi_sp only, 4 b + q of frame FusedArgs::fic_frame_sel - 1 alone (the replay of exact
+// batch mode); kind 2 (k_viterbi_sp only) = code words that lie one after the other in a plain array (the Viterbi::deconvolve /
+// Protection::deconvolve seams): FusedArgs::lin_in + cw * lin_stride, depunctured through `map` when there is one.
 struct FusedClass {
     const MscStep* steps;     // [nsteps + 6] for the launch's row-count variant
     const int32_t* start_bit; // MSC: [n_members] startAddr * 64
     const int16_t* map;       // [4 * nsteps] mother-code index -> index into the class's punctured bit stream, -1 = erasure (k_viterbi_sp gathers by it)
     uint8_t* out;             // [n_cw][nbits / 8]
-    int32_t nsteps, nbits, n_windows, n_cw, n_members, kind, dedisperse, frame_sel;
+    int32_t nsteps, nbits, n_windows, n_cw, n_members, kind, dedisperse, reserved_;
 };
 static_assert(sizeof(FusedClass) == 64, "FusedClass layout");
 struct FusedArgs {
@@ -179,6 +181,10 @@ struct FusedArgs {
     uint32_t* next;                            // its dynamic cursor (zeroed by the launcher)
     uint2* dec; size_t dec_slot_cells;         // decision scratch of work-group i: dec + i * dec_slot_cells ([step][64 lanes] cells)
     const uint32_t* prbs_words;
+    // k_viterbi_sp's one-class launches (dabphy_fused.hip: sp_single): the replay's one-frame FIC, the linear seams
+    int fic_frame_sel;                         // kind 1: 0 = every frame of the batch; f + 1 = frame f only (n_cw = 4 B)
+    size_t fic_frame_stride;                   // kind 1: bytes between frame slots of `soft` (0: SOFT_PER_FRAME, the ring)
+    const int8_t* lin_in; size_t lin_stride;   // kind 2
 };
 // variant = index into FUSED_ROWS; n_slots = work-groups (one wave each) to launch
 void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s);

@@ -59,6 +59,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if ((r = ensure(h, cls.out, n_groups * 64 * (cls.prot.nbits / 8)))) return r;
             if (h->sf_auto && (r = prepare_superframes(h, cls, F))) return r;
         }
+        // (the replay of exact batch mode decodes one frame's FIC at a time, state-parallel when 4 B code words are few: its buffers now)
+        if (h->exact_batch && F > 1 && sp_single_ok(h, (uint64_t)B * 4, fic_c.nsteps) && (r = sp_single_reserve(h, (uint64_t)B * 4, fic_c.nsteps))) return r;
         // the fused decode of this batch depth: which classes (and whether the FIC) ride in the one launch; its decision scratch
         if ((r = fused_plan(h, F, true))) return r;
         {   // what is left for the two-kernel path: Viterbi scratch of the largest such class; the FIC's own (the replay of exact batch
@@ -151,6 +153,15 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = c;
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
         CrcArgs k{}; k.fib = c.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
+        // ... state-parallel when the batch of 4 B code words is small enough (one wavefront per code word: a replayed frame then costs a
+        // twentieth of a 774-step lane-per-code-word launch); the class is the same for every frame, only the frame selector moves
+        const bool fic_sp = sp_single_ok(h, (uint64_t)B * 4, c.nsteps);
+        FusedArgs spa{};
+        if (fic_sp) {
+            FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = c.n_cw; fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1;
+            spa.soft = da.soft; spa.ens_stride = ens_stride; spa.soft_ring = ring_frames; spa.n_ens = (int)B; spa.n_frames = (int)F; spa.desc = d_desc;
+            if ((r = sp_single_prepare(h, fc, spa, h->stream))) return r;
+        }
         for (uint32_t f = 0; f < F; f++) {
             sa.frame = (int)f;
             launch_sync_find(sa, h->stream);
@@ -159,8 +170,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             d1.chunk_count = (3 + da.chunk_len - 1) / da.chunk_len;          // the chunks that hold the FIC symbols 1..3 (demod_chunk may be 1 or 2)
             launch_demod(d1, (int)B, h->stream);
             g.frame_sel = (int)f + 1; k.frame_sel = (int)f + 1;
-            launch_fic_gather(g, h->stream);
-            launch_viterbi(v, h->stream);
+            if (fic_sp) { spa.fic_frame_sel = (int)f + 1; launch_viterbi_sp(spa, sp_variant_for(c.nsteps), h->stream); }
+            else { launch_fic_gather(g, h->stream); launch_viterbi(v, h->stream); }
             launch_fib_crc(k, h->stream);
             CrcArgs kf = k; kf.frame_sel = 0; kf.frame_first = (int)f; kf.frame_count = 1;
             launch_fic_ratio(kf, h->stream);

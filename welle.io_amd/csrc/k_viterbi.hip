@@ -400,8 +400,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
         }
     } else {
         // FIC: code word -> (ensemble, frame slot, quarter); one row per code word: the 2304 soft bits of that quarter of symbols 1..3
-        const int fsel = C.frame_sel;
-        auto bf_of = [&](int c) { return fsel ? (c >> 2) * F + (fsel - 1) : c >> 2; };
+        auto bf_of = [&](int c) { return c >> 2; };
         nrows = 64; rb = lane;
         pb0 = bf_of((int)cw0) / F;
         for (int row = lane; row < ROWS; row += 64) {

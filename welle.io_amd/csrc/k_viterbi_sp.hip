@@ -67,25 +67,32 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
             const long long c_src = 4 * A.desc[(size_t)b * F].frame_no + r - 16 + sp::brev4(lane);      // dab-audio.cpp:113,138-143
             s_rowoff[lane] = c_src >= 0 ? ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM : -1;
         }
-    } else {
-        const int fsel = C.frame_sel;
+    } else if (C.kind == 1) {
+        const int fsel = A.fic_frame_sel;
         const int bf = fsel ? (cw >> 2) * F + (fsel - 1) : cw >> 2, b = bf / F;
         const FrameDesc& d = A.desc[bf];
-        base = A.soft + (size_t)b * A.ens_stride + (size_t)(d.frame_no % A.soft_ring) * SOFT_PER_FRAME + (size_t)2304 * (cw & 3);
+        const size_t fstride = A.fic_frame_stride ? A.fic_frame_stride : (size_t)SOFT_PER_FRAME;
+        base = A.soft + (size_t)b * A.ens_stride + (size_t)(d.frame_no % A.soft_ring) * fstride + (size_t)2304 * (cw & 3);
         if (lane < 16) s_rowoff[lane] = d.valid == 1 ? 0 : -1;
+    } else {
+        base = A.lin_in + (size_t)cw * A.lin_stride;                     // a code word of the linear seams: no de-interleaver
+        if (lane < 16) s_rowoff[lane] = 0;
     }
     __syncthreads();
     {
         const int16_t* __restrict__ map = C.map;
+        const bool clamp = C.kind == 2;                                     // the seams take any int8: -128 maps to symbol 0 like -127 (viterbi.cpp:233-236)
         for (int s = lane; s < nsteps; s += 64) {
-            const uint2 mm = *reinterpret_cast<const uint2*>(map + 4 * s);                 // four map entries
+            uint2 mm = make_uint2(0, 0);
+            if (map) mm = *reinterpret_cast<const uint2*>(map + 4 * s);                    // four map entries
             int v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int u = (int)(int16_t)(((j < 2 ? mm.x : mm.y) >> (16 * (j & 1))) & 0xffffu);
+                const int u = map ? (int)(int16_t)(((j < 2 ? mm.x : mm.y) >> (16 * (j & 1))) & 0xffffu) : 4 * s + j;
                 long long off = -1;
                 if (u >= 0) off = s_rowoff[u & 15];
                 v[j] = off >= 0 ? (int)base[off + u] : 0;
+                if (clamp && v[j] < -127) v[j] = -127;
             }
             // the three branch-metric inputs of the step, doubled and biased as the trellis takes them (viterbi.cpp:233-238 puts the symbol
             // levels at v + 127: bm(p) = 510 + e0 (x0 - 1) + e1 (v1 - 1/2) + e2 (v2 - 1/2), x0 = v0 + v3): 12 + 10 + 10 signed bits
