@@ -259,29 +259,24 @@ __device__ __forceinline__ uint16_t crc16_msb_tab(const uint8_t* data, int len, 
 }
 
 // CRC-16-CCITT four bytes per step ("slicing by four"): T[k][v] = the register after byte v and k zero bytes from a zero register, so
-// four bytes cost four INDEPENDENT look-ups instead of four dependent ones.  crc4tab_build fills T (1024 entries, LDS); every lane
-// derives its own entries of T[1..3] from T[0], which must be complete: one barrier inside.
-__device__ __forceinline__ void crc4tab_build(uint16_t (*T)[256], int t)
+// four bytes cost four INDEPENDENT look-ups instead of four dependent ones.  The host builds T once (dabphy_superframes.hip) behind the
+// GF(256) tables; a work-group copies its 2 KiB into LDS.
+__device__ __forceinline__ void crc4tab_load(const SfArgs& A, uint16_t (*T)[256], int t)
 {
-    for (int v = t; v < 256; v += 64) {
-        uint16_t c = (uint16_t)(v << 8);
-        for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1);
-        T[0][v] = c;
-    }
-    __syncthreads();
-    for (int v = t; v < 256; v += 64) {
-        uint32_t c = T[0][v];
-        for (int k = 1; k < 4; k++) { c = ((c << 8) & 0xFFFFu) ^ T[0][c >> 8]; T[k][v] = (uint16_t)c; }
-    }
+    const uint4* src = reinterpret_cast<const uint4*>(A.gf + SF_CRC4_OFFSET);
+    for (int i = t; i < 4 * 256 * 2 / 16; i += 64) reinterpret_cast<uint4*>(&T[0][0])[i] = src[i];
 }
-// ... of `len` bytes at `data` (LDS), preset to ones, result inverted (CalcCRC, tools.cpp:41-72 with initial_invert = final_invert = true)
+// ... of `len` bytes at `data` (HBM: the corrected superframes), preset to ones, result inverted (CalcCRC, tools.cpp:41-72 with
+// initial_invert = final_invert = true): bytes up to the first 4-byte boundary one at a time, then one aligned dword load per step
 __device__ __forceinline__ uint16_t crc16_ccitt_by4(const uint8_t* data, int len, const uint16_t (*T)[256])
 {
     uint32_t crc = 0xFFFFu;
     int o = 0;
+    for (; o < len && ((uintptr_t)(data + o) & 3u); o++) crc = ((crc << 8) & 0xFFFFu) ^ T[0][(crc >> 8) ^ data[o]];
     for (; o + 4 <= len; o += 4) {
-        const uint32_t x = crc ^ ((uint32_t)data[o] << 8 | data[o + 1]);
-        crc = (uint32_t)T[3][x >> 8] ^ T[2][x & 0xFFu] ^ T[1][data[o + 2]] ^ T[0][data[o + 3]];
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(data + o);          // bytes o .. o + 3, lowest address in the low byte
+        const uint32_t x = crc ^ (((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu));
+        crc = (uint32_t)T[3][x >> 8] ^ T[2][x & 0xFFu] ^ T[1][(w >> 16) & 0xFFu] ^ T[0][w >> 24];
     }
     for (; o < len; o++) crc = ((crc << 8) & 0xFFFFu) ^ T[0][(crc >> 8) ^ data[o]];
     return (uint16_t)~crc;
@@ -326,7 +321,7 @@ __device__ __forceinline__ SfPlan sf_plan(const SfArgs& A, int b, const uint8_t*
 
 // One attempt on the 5-frame copy in s_sf: Reed-Solomon over its s code words, then CheckSync (dabplus_decoder.cpp:97-213).
 // Thread 0 gets the attempt's event (cif and sf_slot are the caller's); sh.sync / corr / unc are valid for all threads on return.
-struct SfShared { int corr, unc, sync, au_start[8], num_aus, au_ok; };
+struct SfShared { int corr, unc, sync, au_start[8]; };
 __device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const uint8_t* alpha_to, const uint8_t* index_of, uint8_t* s_ws,
                                            SfShared& sh, SfEvent& e, int t)
 {
@@ -383,7 +378,7 @@ __device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const u
             sync = 1;
             for (int i = 0; i < num_aus; i++) if (sh.au_start[i] >= sh.au_start[i + 1]) sync = 0;
         }
-        sh.sync = sync; sh.num_aus = sync ? num_aus : 0; sh.au_ok = 0;
+        sh.sync = sync;
         e = SfEvent{};
         e.corrected = sh.corr; e.uncorrectable = sh.unc; e.sync = sync; e.sf_slot = -1;
         if (sync) {
@@ -423,7 +418,6 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
     __shared__ __attribute__((aligned(16))) uint8_t alpha_to[256], index_of[256];
     __shared__ SfShared sh;
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];
-    __shared__ uint16_t s_crc4[4][256];
     const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x, q = (int)blockIdx.z;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
     const size_t bm = (size_t)b * A.n_members + m;
@@ -431,7 +425,6 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
     const SfPlan p = sf_plan(A, b, st);
     if (q >= p.nq) return;
     sf_tables(A, alpha_to, index_of, nullptr, t);
-    crc4tab_build(s_crc4, t);
     for (int k = 0; k < 5; k++) {
         const int g = 5 * q + k;                                               // frame g of (carried frames, then rows)
         const uint8_t* src = g < p.cu ? st + 16 + (size_t)(p.fc - p.cu + g) * fb : A.out + (bm * A.n_cif + (p.r_first + g - p.cu)) * fb;
@@ -439,17 +432,9 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
     }
     SfEvent e;
     sf_attempt(s_sf, fb, A.s, alpha_to, index_of, s_ws, sh, e, t);
-    // :122-131 the access units' CRCs while the corrected superframe is still in LDS, one lane per access unit, four bytes per step
-    // (round 3 left them to the verdict kernel: one byte per load from HBM, 0.2-0.35 ms of the step's critical path).  The verdicts do
-    // not steer the state machine; k_superframe_settle counts the failures of what it accepts.
-    if (sh.sync && t < sh.num_aus) {
-        const int a0 = sh.au_start[t], au_len = sh.au_start[t + 1] - a0;
-        if (au_len >= 2 && (uint16_t)(s_sf[a0 + au_len - 2] << 8 | s_sf[a0 + au_len - 1]) == crc16_ccitt_by4(s_sf + a0, au_len - 2, s_crc4)) atomicOr(&sh.au_ok, 1 << t);
-    }
-    __syncthreads();
     if (t == 0) {
         e.cif = p.r_first + 5 * q + 4 - p.cu;                                  // the row whose arrival triggers the attempt
-        if (sh.sync) { e.sf_slot = q; e.au_crc_ok = sh.au_ok; }
+        if (sh.sync) e.sf_slot = q;
         A.events[bm * A.n_cif + q] = e;
     }
     if (sh.sync) {
@@ -460,6 +445,7 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
 
 __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
 {
+    __shared__ __attribute__((aligned(16))) uint16_t s_crc4[4][256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
     const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
     const int fb = A.frame_bytes, fw = fb >> 3;
@@ -467,21 +453,29 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
     uint8_t* st = A.state + bm * A.state_stride;
     const SfPlan p = sf_plan(A, b, st);
     SfEvent* ev = A.events + bm * A.n_cif;
+    crc4tab_load(A, s_crc4, t);
     if (t == 0) { s_ok = p.nq >= 1; s_corr = 0; s_unc = 0; s_aubad = 0; }
     __syncthreads();
     for (int q = t; q < p.nq; q += 64) {
         if (!ev[q].sync) s_ok = 0;                                  // (every writer stores the same value)
-        else {
-            if (ev[q].corrected) atomicAdd(&s_corr, ev[q].corrected);
-            if (ev[q].uncorrectable) atomicAdd(&s_unc, ev[q].uncorrectable);
-            const int bad = ev[q].num_aus - __popc((unsigned)ev[q].au_crc_ok & ((1u << ev[q].num_aus) - 1u));     // the wide pass checked the access units' CRCs
-            if (bad) atomicAdd(&s_aubad, bad);
-        }
+        else { if (ev[q].corrected) atomicAdd(&s_corr, ev[q].corrected); if (ev[q].uncorrectable) atomicAdd(&s_unc, ev[q].uncorrectable); }
     }
     __syncthreads();
     const int ok = s_ok;
     if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats && p.nq >= 1) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }   // (a batch without a full window has nothing the wide pass could settle: not counted as tried)
     if (!ok) return;
+    // :122-131 the access units' CRCs, one lane per access unit, FOUR bytes per step (one aligned dword load, four independent table
+    // look-ups: round 3 took a byte per load and a dependent look-up per byte, 0.2-0.35 ms of the step's critical path)
+    const int sf_len = 5 * fb;
+    for (int base = 0; base < p.nq * 6; base += 64) {
+        const int k = base + t, e_i = k / 6, au_i = k % 6;
+        if (e_i < p.nq && au_i < ev[e_i].num_aus) {
+            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
+            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
+            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_ccitt_by4(au, au_len - 2, s_crc4)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
+            else atomicAdd(&s_aubad, 1);
+        }
+    }
     // the frames behind the last attempt are the next batch's carried window (a hit empties it, dabplus_decoder.cpp:156)
     const int n_left = p.cu + p.avail - 5 * p.nq;
     for (int k = 0; k < n_left; k++) {
