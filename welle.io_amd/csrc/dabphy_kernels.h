@@ -263,7 +263,6 @@ struct RsMscArgs {         // superframes inside a class's MSC output [B][n_memb
 struct SfEvent {           // = dabphy_sf_event (include/dabphy.h)
     int32_t cif, corrected, uncorrectable, sync, format, num_aus, au_start[7], au_crc_ok, sf_slot;
 };
-constexpr int SF_CRC4_OFFSET = 1024;
 struct SfArgs {
     const uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s;    // class output [B][members][n_cif][frame_bytes]
     int member;                                   // >= 0: only this member (grid (1, B)); -1: every member (grid (members, B))
@@ -273,8 +272,7 @@ struct SfArgs {
     uint8_t* sf; int n_slots;                     // [B][members][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
     int32_t* stats;                               // optional [B][4]: synchronised superframes, corrected symbols, uncorrectable attempts, AUs failing their CRC
     int ens0, ens_count;                          // this launch walks ensembles [ens0, ens0 + ens_count); ens_count = 0: all of them
-    const uint8_t* gf;                            // alpha_to[256], index_of[256] of GF(256) / 0x11D (init_rs.h:48-60); at + 512 the wide pass' counters; at + SF_CRC4_OFFSET
-                                                  // uint16 T[4][256]: CRC-16-CCITT by four bytes (T[k][v] = register after byte v and k zero bytes)
+    const uint8_t* gf;                            // alpha_to[256], index_of[256] of GF(256) / 0x11D (init_rs.h:48-60)
     int32_t* accepted;                            // [B][members]: set by the wide pass for what it settled (nullptr: serial walk only)
     unsigned long long* wide_stats;               // [2]: (ensemble, member) batches the wide pass settled / was tried on
 };

@@ -27,14 +27,9 @@ int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t
         struct Gf { uint8_t b[512]; Gf() { int sr = 1; memset(b, 0, sizeof b); b[256 + 0] = 255; b[255] = 0; for (int i = 0; i < 255; i++) { b[256 + sr] = (uint8_t)i; b[i] = (uint8_t)sr; sr <<= 1; if (sr & 256) sr ^= 0x11D; sr &= 255; } } };
         static const Gf gf_tab;
         const uint8_t (&gf)[512] = gf_tab.b;
-        // ... and CRC-16-CCITT (0x1021) by four bytes: T[k][v] = the register after byte v and k zero bytes from a zero register (tools.cpp:41-72 bit by bit)
-        struct Crc4 { uint16_t t[4][256]; Crc4() { for (int v = 0; v < 256; v++) { uint16_t c = (uint16_t)(v << 8); for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1); t[0][v] = c; }
-                                                           for (int k = 1; k < 4; k++) for (int v = 0; v < 256; v++) { const uint16_t c = t[k - 1][v]; t[k][v] = (uint16_t)((c << 8) ^ t[0][c >> 8]); } } };
-        static const Crc4 crc4_tab;
-        if ((r = ensure(h, h->sf_gf, SF_CRC4_OFFSET + sizeof crc4_tab.t))) return r;      // GF tables, the wide pass' two counters at + 512, the CRC tables at + 1024
-        HIPCHK(h, hipMemsetAsync(h->sf_gf.p, 0, SF_CRC4_OFFSET + sizeof crc4_tab.t, h->stream));
+        if ((r = ensure(h, h->sf_gf, sizeof gf + 2 * sizeof(unsigned long long)))) return r;      // + the wide pass' two counters
+        HIPCHK(h, hipMemsetAsync(h->sf_gf.p, 0, sizeof gf + 2 * sizeof(unsigned long long), h->stream));
         HIPCHK(h, hipMemcpyAsync(h->sf_gf.p, gf, sizeof gf, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->sf_gf.as<uint8_t>() + SF_CRC4_OFFSET, crc4_tab.t, sizeof crc4_tab.t, hipMemcpyHostToDevice, h->stream));
     }
     return 0;
 }

@@ -258,30 +258,6 @@ __device__ __forceinline__ uint16_t crc16_msb_tab(const uint8_t* data, int len, 
     return (uint16_t)(final_invert ? ~crc : crc);
 }
 
-// CRC-16-CCITT four bytes per step ("slicing by four"): T[k][v] = the register after byte v and k zero bytes from a zero register, so
-// four bytes cost four INDEPENDENT look-ups instead of four dependent ones.  The host builds T once (dabphy_superframes.hip) behind the
-// GF(256) tables; a work-group copies its 2 KiB into LDS.
-__device__ __forceinline__ void crc4tab_load(const SfArgs& A, uint16_t (*T)[256], int t)
-{
-    const uint4* src = reinterpret_cast<const uint4*>(A.gf + SF_CRC4_OFFSET);
-    for (int i = t; i < 4 * 256 * 2 / 16; i += 64) reinterpret_cast<uint4*>(&T[0][0])[i] = src[i];
-}
-// ... of `len` bytes at `data` (HBM: the corrected superframes), preset to ones, result inverted (CalcCRC, tools.cpp:41-72 with
-// initial_invert = final_invert = true): bytes up to the first 4-byte boundary one at a time, then one aligned dword load per step
-__device__ __forceinline__ uint16_t crc16_ccitt_by4(const uint8_t* data, int len, const uint16_t (*T)[256])
-{
-    uint32_t crc = 0xFFFFu;
-    int o = 0;
-    for (; o < len && ((uintptr_t)(data + o) & 3u); o++) crc = ((crc << 8) & 0xFFFFu) ^ T[0][(crc >> 8) ^ data[o]];
-    for (; o + 4 <= len; o += 4) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(data + o);          // bytes o .. o + 3, lowest address in the low byte
-        const uint32_t x = crc ^ (((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu));
-        crc = (uint32_t)T[3][x >> 8] ^ T[2][x & 0xFFu] ^ T[1][(w >> 16) & 0xFFu] ^ T[0][w >> 24];
-    }
-    for (; o < len; o++) crc = ((crc << 8) & 0xFFFFu) ^ T[0][(crc >> 8) ^ data[o]];
-    return (uint16_t)~crc;
-}
-
 constexpr int SF_PREFETCH = 6;      // rows of the class output in flight per work-group (serial walk)
 
 // GF(256) tables of the code (init_rs.h:48-60) from the copy the host uploaded, and the byte-wise table of CRC-16-CCITT (0x1021)
@@ -445,15 +421,19 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
 
 __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_crc4[4][256];
+    __shared__ uint16_t s_crctab[256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
     const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
-    const int fb = A.frame_bytes, fw = fb >> 3;
+    const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
     const size_t bm = (size_t)b * A.n_members + m;
     uint8_t* st = A.state + bm * A.state_stride;
     const SfPlan p = sf_plan(A, b, st);
     SfEvent* ev = A.events + bm * A.n_cif;
-    crc4tab_load(A, s_crc4, t);
+    for (int v = t; v < 256; v += 64) {
+        uint16_t c = (uint16_t)(v << 8);
+        for (int i = 0; i < 8; i++) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x1021) : (uint16_t)(c << 1);
+        s_crctab[v] = c;
+    }
     if (t == 0) { s_ok = p.nq >= 1; s_corr = 0; s_unc = 0; s_aubad = 0; }
     __syncthreads();
     for (int q = t; q < p.nq; q += 64) {
@@ -464,18 +444,7 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
     const int ok = s_ok;
     if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats && p.nq >= 1) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }   // (a batch without a full window has nothing the wide pass could settle: not counted as tried)
     if (!ok) return;
-    // :122-131 the access units' CRCs, one lane per access unit, FOUR bytes per step (one aligned dword load, four independent table
-    // look-ups: round 3 took a byte per load and a dependent look-up per byte, 0.2-0.35 ms of the step's critical path)
-    const int sf_len = 5 * fb;
-    for (int base = 0; base < p.nq * 6; base += 64) {
-        const int k = base + t, e_i = k / 6, au_i = k % 6;
-        if (e_i < p.nq && au_i < ev[e_i].num_aus) {
-            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
-            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
-            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_ccitt_by4(au, au_len - 2, s_crc4)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
-            else atomicAdd(&s_aubad, 1);
-        }
-    }
+    sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t);
     // the frames behind the last attempt are the next batch's carried window (a hit empties it, dabplus_decoder.cpp:156)
     const int n_left = p.cu + p.avail - 5 * p.nq;
     for (int k = 0; k < n_left; k++) {
