@@ -155,6 +155,9 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     const bool same_cls = P.valid && P.buf_gen == h->buf_gen && P.host_cls.size() == cls.size() &&
                           (cls.empty() || !memcmp(P.host_cls.data(), cls.data(), cls.size() * sizeof(FusedClass)));
     const bool same_work = P.valid && P.buf_gen == h->buf_gen && P.host_work == work;
+    // (an earlier upload may still be reading the plan's host vectors -- a pageable source is not always staged before the call returns --:
+    // nothing is replaced under it.  The stream is idle here except inside a call that plans twice.)
+    if (P.valid && (!same_cls || !same_work)) HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!same_cls) {
         P.host_cls = cls;                              // (the plan's own storage: it outlives the copy, which the stream orders before the launch)
         if (!cls.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_cls.p, P.host_cls.data(), cls.size() * sizeof(FusedClass), hipMemcpyHostToDevice, h->stream));

@@ -31,7 +31,13 @@
 //
 // Gather.  The soft bits of a code word are fetched once, up front, by all 64 lanes (lane j: steps j, j + 64, ...) straight from the
 // soft-bit ring -- time de-interleaver as an address computation, depuncturing by the class's map -- and parked in LDS as one packed
-// word per step (x0 = v0 + v3, v1, v2: outputs 0 and 3 share a generator).
+// word per step (the three branch-metric inputs, doubled and biased: x0 = v0 + v3 because outputs 0 and 3 share a generator).
+//
+// Who launches it (dabphy_fused.hip).  A batch of at most 16 384 code words: every MSC class and the FIC of the batch, kinds 0 and 1 of
+// FusedClass, through the same work list as k_viterbi_fused.  And stand-alone classes (sp_single_*): the one-frame FIC of exact batch
+// mode's replay (kind 1 with FusedArgs::fic_frame_sel) and small calls of the level-2 seams -- dabphy_viterbi_batch,
+// dabphy_msc_deconvolve (kind 2: code words one after the other in a plain array, arbitrary int8 with the clamp of viterbi.cpp:233-236)
+// and dabphy_fic_decode (kind 1 with its own frame stride).
 #include "dabphy_kernels.h"
 #include <dabphy_wave_ops.h>
 #include "viterbi_acs.h"
