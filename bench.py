@@ -469,6 +469,7 @@ def main():
                          "traffic_source": ("static: profiles/demod_hbm_traffic.json (FETCH_SIZE / WRITE_SIZE passes of tools/make_profiles.sh on this command; not measured by this run)" if pj else None),
                          "algorithmic_bytes_per_launch": B * F * ALG_BYTES_DEMOD_PER_FRAME, "kernel_ms": demod_ms,
                          "kernel_ms_per_rank": demod_ms_ranks, "kernel_ms_note": ("per launch, HIP events on the launch's stream; with ranks: the SLOWEST rank's (each rank launches the kernel on its own %d x %d shard)" % (B, F)) if demod_ms_ranks else "per launch, HIP events on the launch's stream",
+                         "bound_note": "the HBM roofline is what BASELINE.json's metric asks this stage to be measured against; the kernel itself spends about three quarters of its time on arithmetic, LDS traffic and barriers (642 VALU instructions per thread and symbol of bit-exact KISS butterflies, demapper and double-precision oscillator: DESIGN.md 4.1), at the package power limit",
                          "classic_c2c_GBps": B * F * ALG_BYTES_FFT_CLASSIC_PER_FRAME / (demod_ms * 1e-3) / 1e9,
                          "survey_8d_fused_GBps": B * F * (196608 * 8 + 75 * 3072) / (demod_ms * 1e-3) / 1e9},
             "stages_ms": stages,
