@@ -199,10 +199,21 @@ void dabphy_host_free(void* p);
 /* OFDMProcessor::restart (ofdm-processor.cpp:115-132): correctors, phase, sync state, FIC counter, SNR filter cleared */
 int dabphy_reset(dabphy_handle* h);
 
-/* MscHandler::addSubchannel (msc-handler.cpp:61-103) for every ensemble of the handle; n = 0 clears the list
- * (MscHandler::stopProcessing).  Must be called before the first dabphy_process of a stream for the time
- * de-interleaver to see all CIFs, exactly as in the reference. */
+/* Sub-channel selection.  Every receiver of the reference selects its own services (radio-receiver.cpp:120-137 -> MscHandler::
+ * addSubchannel / removeSubchannel / stopProcessing, msc-handler.cpp:61-127), so every ensemble of a batch has its OWN list:
+ *   dabphy_set_subchannels_ensemble   the list of ONE ensemble (at most 64 entries; n = 0: none).  Takes effect with the next
+ *                                     dabphy_process; the results of the last batch stay readable until then.
+ *   dabphy_set_subchannels            the same list for every ensemble of the handle (applied at once).
+ * A list REPLACES the ensemble's previous one.  A sub-channel that is in both (same subch_id, start_cu, size_cu and protection) is a
+ * service that keeps playing: its time de-interleaver and its DAB+ superframe window (dabphy_superframes*) are not disturbed, whatever
+ * else is added or removed, in its own or in any other ensemble -- as in the reference, where addSubchannel touches no other stream.
+ * A sub-channel that is new starts with an empty time de-interleaver: like DabAudio (dab-audio.cpp:146-149) it emits its first
+ * logical frame on the 17th CIF after it was selected (first_valid of dabphy_get_msc).
+ * subch_index in the getters below = position in the ensemble's list. */
 int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n);
+int dabphy_set_subchannels_ensemble(dabphy_handle* h, uint32_t ensemble, const dabphy_subchannel* list, uint32_t n);
+/* entries of the ensemble's list as last set */
+int dabphy_get_subchannel_count(dabphy_handle* h, uint32_t ensemble, uint32_t* n);
 
 /* Decode the next n_frames (<= max_frames) transmission frames of every ensemble: acquisition (null-symbol
  * search) where an ensemble is not synchronised, PRS time sync, coarse/fine frequency tracking, demodulation,
@@ -280,14 +291,17 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
  * after every frame instead (about 3 ms of one GPU lane per frame and ensemble): always exact, meant for the real-time
  * single-ensemble receiver whose ring holds only a few frames. */
 int dabphy_set_track_slevel(dabphy_handle* h, int32_t on);
-/* decoded logical frames of sub-channel `subch_index` (order of dabphy_set_subchannels):
+/* decoded logical frames of sub-channel `subch_index` (position in the list) of EVERY ensemble -- all of them must have a sub-channel
+ * of the same bit rate there (DABPHY_ERR_INVALID otherwise: read such batches per ensemble, dabphy_get_msc_ensemble):
  * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file (out_capacity = size of
  * `out` in bytes; DABPHY_ERR_INVALID when it is too small).  Row layout: the logical frames of an ensemble are packed in CIF order
  * from row 0 on, whatever slots of the batch its demodulated frames occupied (a slot that failed its window search leaves no gap):
  * rows [first_valid[b], n_rows[b]) are this batch's frames, n_rows[b] = 4 x (frames of ensemble b with valid == 1), rows beyond it
  * are undefined.  first_valid[b] = number of leading rows that carry no frame yet (the de-interleaver emits its first frame on the
- * 17th CIF, dab-audio.cpp:146-149).  first_valid / n_rows may be NULL. */
+ * 17th CIF after the sub-channel was selected, dab-audio.cpp:146-149).  first_valid / n_rows may be NULL. */
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
+/* ... of ONE ensemble: out [4*n_frames][nbits/8], first_valid / n_rows single values */
+int dabphy_get_msc_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
 int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_frames][2048] */);      /* onNewImpulseResponse */
 /* onNewNullSymbol (ofdm-processor.cpp:462-469): the 2656 oscillator-corrected samples of the null symbol that follows each
  * demodulated frame of the last batch, out[n_ensembles][n_frames][2656][2] (zeros where valid != 1).  Computed on request. */
@@ -300,7 +314,8 @@ int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, in
  * corrected symbols in superframe i (total_corr_count), uncorrectable[i] != 0 when any of its codewords failed. */
 int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint32_t n_sf, int32_t* corrected,
                           int32_t* uncorrectable);
-/* The same on the MSC output of the last dabphy_process, in HBM.  subch_index < 0: every sub-channel.
+/* The same on the MSC output of the last dabphy_process, in HBM.  subch_index < 0: every sub-channel; >= 0: the sub-channel at that
+ * position of every ensemble that has one.
  * first_cif[b]: CIF slot of this batch (0..4*n_frames-1, may be negative) where ensemble b's first superframe
  * starts -- the alignment SuperframeFilter::CheckSync (dabplus_decoder.cpp:171-215) finds on the host.  Only
  * superframes lying entirely inside the batch are decoded.  corrected / uncorrectable (may be NULL): per ensemble sums. */
@@ -328,6 +343,9 @@ typedef struct {
     int32_t sf_slot;                     /* index into sf, -1 when not synchronised */
 } dabphy_sf_event;
 int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf);
+/* ... for sub-channel subch_index of ONE ensemble (its own list position): events [4 * n_frames], n_events [1], sf [n_slots][120 * bitrate/8].
+ * dabphy_superframes needs the same bit rate at that position in every ensemble. */
+int dabphy_superframes_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf);
 /* The same filter over EVERY DAB+ sub-channel of every ensemble in one launch per protection class (instead of, not in
  * addition to, dabphy_superframes for this batch); nothing but totals leaves the device:
  * stats [n_ensembles][4] = synchronised superframes, corrected symbols, uncorrectable attempts, access units failing their CRC */

@@ -245,8 +245,33 @@ class DabPhy:
         arr = (Subchannel * max(1, len(subs)))()
         for i, (sid, start, size, prot) in enumerate(subs):
             arr[i].subch_id = sid; arr[i].start_cu = start; arr[i].size_cu = size; arr[i].prot = prot
-        self._n_sub = len(subs); self._sub_bytes = [s[3].nbits // 8 for s in subs]
+        self._n_sub = len(subs); self._sub_bytes = [s[3].nbits // 8 for s in subs]; self._ens_bytes = {}
         self._chk(self.lib.dabphy_set_subchannels(self.h, arr, len(subs)))
+
+    def set_subchannels_ensemble(self, ensemble, subs):
+        """the list of ONE ensemble of the batch (dabphy_set_subchannels_ensemble): takes effect with the next process()"""
+        arr = (Subchannel * max(1, len(subs)))()
+        for i, (sid, start, size, prot) in enumerate(subs):
+            arr[i].subch_id = sid; arr[i].start_cu = start; arr[i].size_cu = size; arr[i].prot = prot
+        self._ens_bytes = getattr(self, "_ens_bytes", {})
+        self._ens_bytes[ensemble] = [s[3].nbits // 8 for s in subs]
+        self._chk(self.lib.dabphy_set_subchannels_ensemble(self.h, ensemble, arr, len(subs)))
+
+    def msc_ensemble(self, ensemble, idx):
+        """-> (out [4F][bytes], first_valid, n_rows) of sub-channel idx (position in ITS list) of one ensemble"""
+        F = self._last
+        nb = self._ens_bytes[ensemble][idx] if ensemble in getattr(self, "_ens_bytes", {}) else self._sub_bytes[idx]
+        out = np.zeros((4 * F, nb), np.uint8); fv = C.c_int32(0); nr = C.c_int32(0)
+        self._chk(self.lib.dabphy_get_msc_ensemble(self.h, ensemble, idx, _p(out), C.c_size_t(out.nbytes), C.byref(fv), C.byref(nr)))
+        return out, fv.value, nr.value
+
+    def superframes_ensemble(self, ensemble, idx, bitrate):
+        """-> (events [4F], n_events, corrected superframes [n_slots][120*bitrate/8]) of one ensemble's sub-channel idx"""
+        F = self._last
+        ev = np.zeros(4 * F, SF_EVENT_DTYPE); ne = C.c_int32(0)
+        sf = np.zeros((4 * F // 5 + 1, 15 * bitrate), np.uint8)
+        self._chk(self.lib.dabphy_superframes_ensemble(self.h, ensemble, idx, _p(ev), C.byref(ne), _p(sf)))
+        return ev, ne.value, sf
 
     def host_alloc(self, shape, dtype):
         """page-locked numpy array (dabphy_host_alloc); release with host_free(arr)"""

@@ -18,6 +18,7 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipSetDevice(cfg->device) != hipSuccess) return DABPHY_ERR_NO_DEVICE;
     dabphy_handle* h = new dabphy_handle();
     h->cfg = *cfg;
+    h->subch_e.resize(cfg->n_ensembles); h->subch_next.resize(cfg->n_ensembles); h->where.resize(cfg->n_ensembles);
     // big batches: fewer reference-symbol transforms; small ones: more work-groups.  (Longer chunks -- 38, 75 symbols -- are 2-3 %
     // faster when the kernel runs alone, dabphy_time_demod, and 1-4 % slower inside the pipelined step: measured, round 2.)
     if (h->cfg.demod_chunk <= 0) h->cfg.demod_chunk = ((int64_t)h->cfg.n_ensembles * h->cfg.max_frames >= 1024) ? 25 : 15;
@@ -116,15 +117,13 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     return DABPHY_OK;
 }
 
-namespace {
-// every device buffer of one protection class (dabphy_set_subchannels replaces the classes, dabphy_destroy ends them)
+// every device buffer of one protection class (apply_subchannels replaces the classes, dabphy_destroy ends them)
 void free_class(dabphy_handle::MscClass& c)
 {
     hipError_t e = hipSuccess;
-    DevBuf* bufs[] = {&c.map, &c.start_bits, &c.tiles, &c.out, &c.steps[0], &c.steps[1], &c.steps[2], &c.sf_state, &c.sf_snap};
+    DevBuf* bufs[] = {&c.map, &c.pair_tab, &c.tiles, &c.out, &c.steps[0], &c.steps[1], &c.steps[2], &c.sf_state, &c.sf_snap};
     for (DevBuf* b : bufs) if (b->p) { e = hipFree(b->p); b->p = nullptr; b->cap = 0; }
     (void)e;
-}
 }
 
 void dabphy_destroy(dabphy_handle* h)
@@ -160,7 +159,7 @@ void dabphy_destroy(dabphy_handle* h)
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
     DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_desc2[2], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_cir2[2], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
-    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats, &h->sf_gf, &h->sf_accept}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats, &h->sf_gf, &h->sf_accept, &h->sf_run}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     { DevBuf* tb[] = {&h->s_hist, &h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) free_class(c);
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};
@@ -251,7 +250,7 @@ static int run_lin_decode(dabphy_handle* h, const int8_t* in, size_t in_stride, 
     HIPCHK(h, hipMemcpyAsync(h->in8.p, in, in_stride * n_cw, hipMemcpyHostToDevice, h->stream));
     if (sp_single_ok(h, n_cw, c.nsteps)) {
         // a small call (the per-frame seams of INTEGRATION.md level 2: a few code words): one wavefront per code word
-        FusedClass fc{}; fc.map = d_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = nbits; fc.n_cw = (int32_t)n_cw; fc.n_members = 1; fc.kind = 2; fc.dedisperse = dedisperse;
+        FusedClass fc{}; fc.map = d_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = nbits; fc.n_cw = (int32_t)n_cw; fc.n_pairs = 1; fc.kind = 2; fc.dedisperse = dedisperse;
         FusedArgs a{}; a.n_ens = 1; a.n_frames = 1; a.lin_in = h->in8.as<int8_t>(); a.lin_stride = in_stride;
         if ((r = sp_single_prepare(h, fc, a, h->stream))) return r;
         launch_viterbi_sp(a, sp_variant_for(c.nsteps), h->stream);
@@ -303,7 +302,7 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
     g.n_ens = 1; g.n_frames = (int)n_frames; g.map = h->d_fic_map; g.c = c;
     if (sp_single_ok(h, (uint64_t)n_frames * 4, c.nsteps)) {
         // (FicHandler::processFicBlock bound per frame: four code words a call)
-        FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = (int32_t)(n_frames * 4); fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1;
+        FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = (int32_t)(n_frames * 4); fc.n_pairs = 1; fc.kind = 1; fc.dedisperse = 1;
         FusedArgs a{}; a.soft = g.soft; a.ens_stride = (size_t)n_frames * 9216; a.soft_ring = (int)n_frames; a.n_ens = 1; a.n_frames = (int)n_frames; a.desc = g.desc; a.fic_frame_stride = 9216;
         if ((r = sp_single_prepare(h, fc, a, h->stream))) return r;
         launch_viterbi_sp(a, sp_variant_for(c.nsteps), h->stream);
@@ -324,51 +323,164 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
     return DABPHY_OK;
 }
 
-int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n)
+namespace {
+int check_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n)
 {
-    DeviceBind dev_(h);
-    if (!h || (n && !list)) return DABPHY_ERR_INVALID;
+    if (n > 64) { h->err = "more than 64 sub-channels in one ensemble"; return DABPHY_ERR_INVALID; }      // SubChId is a 6-bit field (fib-processor.cpp:331)
     for (uint32_t i = 0; i < n; i++) {
         const dabphy_subchannel& s = list[i];
         if (!protection_valid(&s.prot) || s.prot.nbits > PRBS_MAX_BITS || s.start_cu < 0 || s.size_cu <= 0 || s.start_cu + s.size_cu > 864 ||
             protection_input_bits(&s.prot) > s.size_cu * 64) { h->err = "invalid sub-channel " + std::to_string(i); return DABPHY_ERR_INVALID; }
     }
-    for (auto& c : h->classes) free_class(c);
-    h->classes.clear();
+    return DABPHY_OK;
+}
+}
+
+// MscHandler::addSubchannel / removeSubchannel / stopProcessing (msc-handler.cpp:61-127) for EVERY ensemble of the handle at once
+int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n)
+{
+    DeviceBind dev_(h);
+    if (!h || (n && !list)) return DABPHY_ERR_INVALID;
+    int r;
+    if ((r = check_subchannels(h, list, n))) return r;
+    for (auto& l : h->subch_next) l.assign(list, list + n);
+    h->subch_dirty = true;
+    return apply_subchannels(h);
+}
+
+// ... and for ONE ensemble of the batch, as each receiver of the reference does for itself (radio-receiver.cpp:120-137: playSingleProgramme /
+// addServiceToDecode / removeServiceToDecode drive its own MscHandler).  Takes effect with the next dabphy_process, which rebuilds the
+// protection classes once for all the ensembles that changed.
+int dabphy_set_subchannels_ensemble(dabphy_handle* h, uint32_t ensemble, const dabphy_subchannel* list, uint32_t n)
+{
+    DeviceBind dev_(h);
+    if (!h || (n && !list) || ensemble >= h->cfg.n_ensembles) return DABPHY_ERR_INVALID;
+    int r;
+    if ((r = check_subchannels(h, list, n))) return r;
+    h->subch_next[ensemble].assign(list, list + n);
+    h->subch_dirty = true;
+    return DABPHY_OK;
+}
+
+int dabphy_get_subchannel_count(dabphy_handle* h, uint32_t ensemble, uint32_t* n)
+{
+    if (!h || !n || ensemble >= h->cfg.n_ensembles) return DABPHY_ERR_INVALID;
+    *n = (uint32_t)h->subch_next[ensemble].size();
+    return DABPHY_OK;
+}
+
+int upload_pairs(dabphy_handle* h, dabphy_handle::MscClass& c)
+{
+    int r;
+    if ((r = ensure(h, c.pair_tab, c.pairs.size() * sizeof(MscPair)))) return r;
+    HIPCHK(h, hipMemcpy(c.pair_tab.p, c.pairs.data(), c.pairs.size() * sizeof(MscPair), hipMemcpyHostToDevice));
+    c.cif0_pending = false;
+    for (const MscPair& p : c.pairs) if (p.cif0 < 0) c.cif0_pending = true;
+    return DABPHY_OK;
+}
+
+// The classes of the batch from the per-ensemble lists.  A service that stays -- same ensemble, same SubChId, same place and protection
+// -- keeps what it carries from batch to batch: the CIF count its time de-interleaver started at and its SuperframeFilter window
+// (the reference's addSubchannel / removeSubchannel touch no other stream, msc-handler.cpp:61-127); a new one starts empty.
+int apply_subchannels(dabphy_handle* h)
+{
+    if (!h->subch_dirty) return DABPHY_OK;
+    const uint32_t B = h->cfg.n_ensembles;
+    int r;
+    HIPCHK(h, hipStreamSynchronize(h->stream));              // nothing queued still reads the classes that are about to go
+    HIPCHK(h, hipStreamSynchronize(h->aux_stream));
+    std::vector<dabphy_handle::MscClass> old;
+    old.swap(h->classes);
+    const std::vector<std::vector<dabphy_handle::PairRef>> old_where = h->where;
+    const std::vector<std::vector<dabphy_subchannel>> old_lists = h->subch_e;
     h->fplan.valid = false; h->fplan.launched = false; h->buf_gen++;          // the plan names the classes' buffers
-    h->last_frames = 0; h->last_desc = nullptr; h->sf_stats_ready = false;     // the class outputs of the last batch are gone with the classes
-    h->subch.assign(list, list + n);
-    for (uint32_t i = 0; i < n; i++) {
-        dabphy_handle::MscClass* cls = nullptr;
-        for (auto& c : h->classes) if (!memcmp(&c.prot, &list[i].prot, sizeof(dabphy_protection))) { cls = &c; break; }
-        if (!cls) { h->classes.emplace_back(); cls = &h->classes.back(); cls->prot = list[i].prot; }
-        cls->members.push_back((int)i);
-    }
-    for (auto& c : h->classes) {
-        const std::vector<int16_t> m = depuncture_map(&c.prot);
-        std::vector<int32_t> sb;
-        for (int i : c.members) sb.push_back(h->subch[i].start_cu * 64);
-        int r;
-        if ((r = ensure(h, c.map, m.size() * sizeof(int16_t)))) return r;
-        if ((r = ensure(h, c.start_bits, sb.size() * sizeof(int32_t)))) return r;
-        HIPCHK(h, hipMemcpy(c.map.p, m.data(), m.size() * sizeof(int16_t), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(c.start_bits.p, sb.data(), sb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        // step tiles of the MSC gather kernel (56 trellis steps each): source byte range of every tile
-        std::vector<int32_t> tl;
-        const int nsteps = c.prot.nbits + 6;
-        for (int s0 = 0; s0 < nsteps; s0 += 56) {
-            const int s1 = std::min(nsteps, s0 + 56);
-            int lo = -1, hi = -1;
-            for (int v = 4 * s0; v < 4 * s1; v++) if (m[v] >= 0) { if (lo < 0) lo = m[v]; hi = m[v]; }
-            if (lo < 0) { tl.push_back(0); tl.push_back(0); continue; }
-            const int lo_al = lo & ~3;
-            tl.push_back(lo_al); tl.push_back((hi - lo_al) / 4 + 1);
+    h->last_frames = 0; h->last_desc = nullptr; h->sf_stats_ready = false; h->h_sf_stats_valid = false;   // the class outputs of the last batch go with the classes
+    h->subch_e = h->subch_next;
+    h->subch_dirty = false;
+    auto fail = [&](int code) {                             // nothing half-built stays: the handle then decodes no sub-channel at all
+        for (auto& c : old) free_class(c);
+        for (auto& c : h->classes) free_class(c);
+        h->classes.clear();
+        for (uint32_t b = 0; b < B; b++) { h->subch_e[b].clear(); h->where[b].clear(); }
+        return code;
+    };
+    struct Carry { int old_cls, old_pair; };
+    std::vector<std::vector<Carry>> carry;                   // per new class, per pair: where its state lies now (-1: nowhere)
+    for (uint32_t b = 0; b < B; b++) {
+        h->where[b].assign(h->subch_e[b].size(), dabphy_handle::PairRef{});
+        std::vector<char> taken(old_lists[b].size(), 0);
+        for (size_t i = 0; i < h->subch_e[b].size(); i++) {
+            const dabphy_subchannel& sc = h->subch_e[b][i];
+            int ci = -1;
+            for (size_t k = 0; k < h->classes.size(); k++) if (!memcmp(&h->classes[k].prot, &sc.prot, sizeof(dabphy_protection))) { ci = (int)k; break; }
+            if (ci < 0) {
+                if (h->classes.size() >= 255) { h->err = "more than 255 protection classes"; return fail(DABPHY_ERR_INVALID); }
+                ci = (int)h->classes.size(); h->classes.emplace_back(); h->classes.back().prot = sc.prot; carry.emplace_back();
+            }
+            auto& c = h->classes[ci];
+            MscPair p{}; p.ens = (int32_t)b; p.start_bit = sc.start_cu * 64; p.cif0 = -1; p.idx = (int32_t)i;
+            Carry from{-1, -1};
+            for (size_t k = 0; k < old_lists[b].size(); k++) {
+                const dabphy_subchannel& o = old_lists[b][k];
+                if (taken[k] || o.subch_id != sc.subch_id || o.start_cu != sc.start_cu || o.size_cu != sc.size_cu || memcmp(&o.prot, &sc.prot, sizeof(dabphy_protection))) continue;
+                taken[k] = 1;
+                const dabphy_handle::PairRef w = old_where[b][k];
+                from = Carry{w.cls, w.pair};
+                p.cif0 = old[w.cls].pairs[w.pair].cif0;
+                break;
+            }
+            h->where[b][i] = dabphy_handle::PairRef{ci, (int)c.pairs.size()};
+            c.pairs.push_back(p); c.subch_id.push_back(sc.subch_id); c.start_cu.push_back(sc.start_cu);
+            carry[ci].push_back(from);
         }
-        if ((r = ensure(h, c.tiles, tl.size() * sizeof(int32_t)))) return r;
-        HIPCHK(h, hipMemcpy(c.tiles.p, tl.data(), tl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        // fused decode: what every trellis step reads, in terms of the wave's window ring, for each build of the kernel (dabphy_fused.hip)
-        if ((r = fused_class_tables(h, c.prot, false, c.steps, c.n_windows))) return r;
     }
+    for (size_t ci = 0; ci < h->classes.size(); ci++) {
+        auto& c = h->classes[ci];
+        // the per-profile tables: taken over from the old class of the same profile when there is one
+        dabphy_handle::MscClass* prev = nullptr;
+        for (auto& o : old) if (o.map.p && !memcmp(&o.prot, &c.prot, sizeof(dabphy_protection))) { prev = &o; break; }
+        if (prev) {
+            std::swap(c.map, prev->map); std::swap(c.tiles, prev->tiles);
+            for (int v = 0; v < FUSED_VARIANTS; v++) { std::swap(c.steps[v], prev->steps[v]); c.n_windows[v] = prev->n_windows[v]; }
+        } else {
+            const std::vector<int16_t> m = depuncture_map(&c.prot);
+            if ((r = ensure(h, c.map, m.size() * sizeof(int16_t)))) return fail(r);
+            if (hipMemcpy(c.map.p, m.data(), m.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy(depuncturing map) failed"; return fail(DABPHY_ERR_HIP); }
+            // step tiles of the MSC gather kernel (56 trellis steps each): source byte range of every tile
+            std::vector<int32_t> tl;
+            const int nsteps = c.prot.nbits + 6;
+            for (int s0 = 0; s0 < nsteps; s0 += 56) {
+                const int s1 = std::min(nsteps, s0 + 56);
+                int lo = -1, hi = -1;
+                for (int v = 4 * s0; v < 4 * s1; v++) if (m[v] >= 0) { if (lo < 0) lo = m[v]; hi = m[v]; }
+                if (lo < 0) { tl.push_back(0); tl.push_back(0); continue; }
+                const int lo_al = lo & ~3;
+                tl.push_back(lo_al); tl.push_back((hi - lo_al) / 4 + 1);
+            }
+            if ((r = ensure(h, c.tiles, tl.size() * sizeof(int32_t)))) return fail(r);
+            if (hipMemcpy(c.tiles.p, tl.data(), tl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy(gather tiles) failed"; return fail(DABPHY_ERR_HIP); }
+            // fused decode: what every trellis step reads, in terms of the wave's window ring, for each build of the kernel (dabphy_fused.hip)
+            if ((r = fused_class_tables(h, c.prot, false, c.steps, c.n_windows))) return fail(r);
+        }
+        if ((r = upload_pairs(h, c))) return fail(r);
+        if (c.dabplus_rate()) {
+            // SuperframeFilter windows: empty for new pairs, moved for those that stay (runs of neighbours in one copy)
+            const size_t stride = c.sf_stride(), n = c.pairs.size();
+            if ((r = ensure(h, c.sf_state, stride * n))) return fail(r);
+            if (hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream) != hipSuccess) { h->err = "hipMemsetAsync(superframe windows) failed"; return fail(DABPHY_ERR_HIP); }
+            for (size_t p = 0; p < n;) {
+                const Carry f = carry[ci][p];
+                if (f.old_cls < 0 || !old[f.old_cls].sf_state.p) { p++; continue; }
+                size_t e = p + 1;
+                while (e < n && carry[ci][e].old_cls == f.old_cls && carry[ci][e].old_pair == f.old_pair + (int)(e - p)) e++;
+                if (hipMemcpyAsync(c.sf_state.as<uint8_t>() + p * stride, old[f.old_cls].sf_state.as<uint8_t>() + (size_t)f.old_pair * stride, (e - p) * stride,
+                                   hipMemcpyDeviceToDevice, h->stream) != hipSuccess) { h->err = "hipMemcpyAsync(superframe windows) failed"; return fail(DABPHY_ERR_HIP); }
+                p = e;
+            }
+        }
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed (sub-channel change)"; return fail(DABPHY_ERR_HIP); }
+    for (auto& c : old) free_class(c);
     return DABPHY_OK;
 }
 

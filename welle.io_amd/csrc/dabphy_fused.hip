@@ -92,10 +92,16 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     const int v = R >= FUSED_MIN_CIFS[0] ? 0 : R >= FUSED_MIN_CIFS[1] ? 1 : 2;
     const size_t ens_stride = soft_ens_stride(h);
     // A wave's sources are addressed with 32-bit offsets from the ring slice of its first ensemble.  Its code words span at most
-    // nseg (ensemble, sub-channel) pairs (64 + 15 nseg <= rows), i.e. ceil(nseg / members) + 1 ensembles; the FIC's 64 code words
-    // = 16 frames, ceil(16 / F) + 1 ensembles.  A class whose span leaves the 4 GiB takes the two-kernel path (64-bit addresses).
+    // nseg consecutive (ensemble, sub-channel) pairs of the class's table (64 + 15 nseg <= rows) -- from the first pair's ensemble to the
+    // last one's, however many ensembles without a sub-channel of this class lie between; the FIC's 64 code words = 16 frames,
+    // ceil(16 / F) + 1 ensembles.  A class whose span leaves the 4 GiB takes the two-kernel path (64-bit addresses).
     const int nseg = (FUSED_ROWS[v] - 64) / 15;
     auto reach_ok = [&](int n_ens_spanned) { return (uint64_t)n_ens_spanned * ens_stride <= 0xffffffffull; };
+    auto ens_span = [&](const std::vector<MscPair>& pr) {
+        int span = 1;
+        for (size_t p = 0; p < pr.size(); p++) { const size_t q = std::min(pr.size() - 1, p + (size_t)nseg - 1); span = std::max(span, pr[q].ens - pr[p].ens + 1); }
+        return span;
+    };
     std::vector<FusedClass> cls; std::vector<int> idx;
     struct Item { int nsteps, ci, n_groups; };
     std::vector<Item> items;
@@ -104,16 +110,16 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     // (k_viterbi_sp.hip), every class and the FIC, whatever their window schedules and spans (it addresses with 64-bit pointers).
     uint64_t total_cw = (uint64_t)B * F * 4 * (want_fic && h->fused_fic ? 1 : 0);
     bool sp_ok = h->fused_msc && h->cfg.decode_shape != 1 && (h->sp_max_codewords > 0 || h->cfg.decode_shape == 2);
-    for (auto& c : h->classes) { total_cw += (uint64_t)B * 4 * F * c.members.size(); sp_ok = sp_ok && (c.prot.nbits + 6) % 6 == 0 && c.prot.nbits + 6 <= SP_MAXSTEPS[SP_VARIANTS - 1]; }
+    for (auto& c : h->classes) { total_cw += (uint64_t)4 * F * c.pairs.size(); sp_ok = sp_ok && (c.prot.nbits + 6) % 6 == 0 && c.prot.nbits + 6 <= SP_MAXSTEPS[SP_VARIANTS - 1]; }
     const bool use_sp = sp_ok && (h->cfg.decode_shape == 2 || total_cw <= h->sp_max_codewords);
     for (size_t i = 0; i < h->classes.size(); i++) {
         auto& c = h->classes[i];
-        const int M = (int)c.members.size();
-        if (!h->fused_msc || (!use_sp && (c.n_windows[v] <= 0 || !reach_ok((nseg + M - 1) / M + 1)))) continue;
+        const int P = (int)c.pairs.size();
+        if (!h->fused_msc || (!use_sp && (c.n_windows[v] <= 0 || !reach_ok(ens_span(c.pairs))))) continue;
         FusedClass fc{};
-        fc.steps = c.steps[v].as<MscStep>(); fc.start_bit = c.start_bits.as<int32_t>(); fc.map = c.map.as<int16_t>(); fc.out = c.out.as<uint8_t>();
-        fc.nbits = c.prot.nbits; fc.nsteps = fc.nbits + 6; fc.n_windows = c.n_windows[v]; fc.n_cw = (int32_t)(B * 4 * F * M);
-        fc.n_members = M; fc.kind = 0; fc.dedisperse = 1;
+        fc.steps = c.steps[v].as<MscStep>(); fc.pairs = c.pair_tab.as<MscPair>(); fc.map = c.map.as<int16_t>(); fc.out = c.out.as<uint8_t>();
+        fc.nbits = c.prot.nbits; fc.nsteps = fc.nbits + 6; fc.n_windows = c.n_windows[v]; fc.n_cw = (int32_t)(4 * F * (uint32_t)P);
+        fc.n_pairs = P; fc.kind = 0; fc.dedisperse = 1;
         items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
         cls.push_back(fc); idx.push_back((int)i);
         max_steps = std::max(max_steps, (size_t)fc.nsteps);
@@ -121,9 +127,9 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     bool fic_in = false;
     if (want_fic && h->fused_fic && (use_sp || (h->fic_windows[v] > 0 && reach_ok((16 + (int)F - 1) / (int)F + 1)))) {
         FusedClass fc{};
-        fc.steps = h->fic_steps[v].as<MscStep>(); fc.start_bit = nullptr; fc.map = h->d_fic_map; fc.out = h->s_fib.as<uint8_t>();
+        fc.steps = h->fic_steps[v].as<MscStep>(); fc.pairs = nullptr; fc.map = h->d_fic_map; fc.out = h->s_fib.as<uint8_t>();
         fc.nbits = 768; fc.nsteps = 774; fc.n_windows = h->fic_windows[v]; fc.n_cw = (int32_t)(B * F * 4);
-        fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1;
+        fc.n_pairs = 1; fc.kind = 1; fc.dedisperse = 1;
         items.push_back({fc.nsteps, (int)cls.size(), (fc.n_cw + 63) / 64});
         cls.push_back(fc);
         max_steps = std::max(max_steps, (size_t)fc.nsteps);

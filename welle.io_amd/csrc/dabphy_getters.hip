@@ -157,37 +157,57 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
     return DABPHY_OK;
 }
 
+namespace {
+// rows of one (ensemble, sub-channel) pair from its class's output [pair][4F][nbits / 8]; first_valid / n_rows as documented in include/dabphy.h
+int msc_rows_of(dabphy_handle* h, uint32_t b, dabphy_handle::PairRef w, uint8_t* out, int32_t* first_valid, int32_t* n_rows)
+{
+    const uint32_t F = h->last_frames;
+    const auto& cls = h->classes[w.cls];
+    const size_t bytes = cls.prot.nbits / 8, Rn = (size_t)4 * F;
+    HIPCHK(h, hipMemcpyAsync(out, cls.out.as<uint8_t>() + (size_t)w.pair * Rn * bytes, Rn * bytes, hipMemcpyDeviceToHost, h->stream));
+    if (first_valid) {
+        // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149): counted from the CIF at which this
+        // sub-channel was selected (0 for one that was there from the start of the stream)
+        const int64_t fed = 4 * h->h_desc[(size_t)b * F].frame_no - cls.pairs[w.pair].cif0;
+        *first_valid = fed >= 16 ? 0 : (int32_t)(16 - fed);
+    }
+    if (n_rows) {
+        int nv = 0;
+        for (uint32_t f = 0; f < F; f++) nv += h->h_desc[(size_t)b * F + f].valid == 1 ? 1 : 0;
+        *n_rows = 4 * nv;
+    }
+    return DABPHY_OK;
+}
+}
+
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows)
 {
     DeviceBind dev_(h);
-    if (!h || !out || subch_index >= h->subch.size() || !h->last_frames) return DABPHY_ERR_INVALID;
-    if (out_capacity < (size_t)h->cfg.n_ensembles * 4 * h->last_frames * (h->subch[subch_index].prot.nbits / 8)) { h->err = "dabphy_get_msc: output buffer too small"; return DABPHY_ERR_INVALID; }
+    if (!h || !out || !h->last_frames) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
-    for (auto& cls : h->classes) {
-        for (size_t m = 0; m < cls.members.size(); m++) {
-            if (cls.members[m] != (int)subch_index) continue;
-            const size_t bytes = cls.prot.nbits / 8, nm = cls.members.size();
-            std::vector<uint8_t> all((size_t)B * 4 * F * nm * bytes);
-            HIPCHK(h, hipMemcpyAsync(all.data(), cls.out.p, all.size(), hipMemcpyDeviceToHost, h->stream));
-            int r = sync(h); if (r) return r;
-            const size_t Rn = (size_t)4 * F;
-            for (size_t b = 0; b < B; b++) memcpy(out + b * Rn * bytes, all.data() + ((b * nm + m) * Rn) * bytes, Rn * bytes);
-            if (first_valid)
-                for (uint32_t b = 0; b < B; b++) {
-                    // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149)
-                    const int64_t c0 = 4 * h->h_desc[(size_t)b * F].frame_no;
-                    first_valid[b] = c0 >= 16 ? 0 : (int32_t)(16 - c0);
-                }
-            if (n_rows)
-                for (uint32_t b = 0; b < B; b++) {
-                    int nv = 0;
-                    for (uint32_t f = 0; f < F; f++) nv += h->h_desc[(size_t)b * F + f].valid == 1 ? 1 : 0;
-                    n_rows[b] = 4 * nv;
-                }
-            return DABPHY_OK;
-        }
+    size_t bytes = 0;
+    for (uint32_t b = 0; b < B; b++) {
+        if (subch_index >= h->where[b].size()) { h->err = "ensemble " + std::to_string(b) + " has no sub-channel " + std::to_string(subch_index); return DABPHY_ERR_INVALID; }
+        const size_t mine = h->classes[h->where[b][subch_index].cls].prot.nbits / 8;
+        if (bytes && bytes != mine) { h->err = "the ensembles' sub-channels at this position differ in bit rate: use dabphy_get_msc_ensemble"; return DABPHY_ERR_INVALID; }
+        bytes = mine;
     }
-    return DABPHY_ERR_INVALID;
+    if (out_capacity < (size_t)B * 4 * F * bytes) { h->err = "dabphy_get_msc: output buffer too small"; return DABPHY_ERR_INVALID; }
+    for (uint32_t b = 0; b < B; b++) {
+        int r = msc_rows_of(h, b, h->where[b][subch_index], out + (size_t)b * 4 * F * bytes, first_valid ? first_valid + b : nullptr, n_rows ? n_rows + b : nullptr);
+        if (r) return r;
+    }
+    return sync(h);
+}
+
+int dabphy_get_msc_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows)
+{
+    DeviceBind dev_(h);
+    if (!h || !out || !h->last_frames || ensemble >= h->cfg.n_ensembles || subch_index >= h->where[ensemble].size()) return DABPHY_ERR_INVALID;
+    const dabphy_handle::PairRef w = h->where[ensemble][subch_index];
+    if (out_capacity < (size_t)4 * h->last_frames * (h->classes[w.cls].prot.nbits / 8)) { h->err = "dabphy_get_msc_ensemble: output buffer too small"; return DABPHY_ERR_INVALID; }
+    int r = msc_rows_of(h, ensemble, w, out, first_valid, n_rows);
+    return r ? r : sync(h);
 }
 
 int dabphy_get_impulse_response(dabphy_handle* h, float* out)

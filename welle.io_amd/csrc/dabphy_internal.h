@@ -64,20 +64,33 @@ struct dabphy_handle {
     std::vector<void*> owned;
 
     // ---- streaming receiver (dabphy_stream_* / dabphy_process)
+    // One protection class of the batch: the (ensemble, sub-channel) pairs of ALL ensembles that share a protection profile -- every
+    // ensemble selects its own sub-channels (msc-handler.cpp:61-103) --, ordered by ensemble, then by position in the ensemble's list.
     struct MscClass {
         dabphy_protection prot{};
-        std::vector<int> members;     // indices into subch
-        DevBuf map, start_bits, tiles, out;  // depuncture map, startAddr*64 per member, gather tiles, decoded bytes [B][members][4F][nbits/8]
+        std::vector<MscPair> pairs;          // host mirror of pair_tab
+        std::vector<int32_t> subch_id, start_cu;   // per pair: Subchannel::subChId / startAddr (what identifies a running service when the lists change)
+        bool cif0_pending = false;           // some pair's cif0 is still -1 on the device: the next decode resolves it (k_pair_cif0), then the mirror follows
+        DevBuf map, pair_tab, tiles, out;    // depuncture map, the pair table, gather tiles, decoded bytes [pair][4F][nbits/8]
         DevBuf steps[FUSED_VARIANTS]; int n_windows[FUSED_VARIANTS] = {0, 0, 0};   // fused decode (k_viterbi_fused): per-step window-ring descriptors for each row-count build (0 windows: not decodable that way)
-        DevBuf sf_state;                     // SuperframeFilter window of every (ensemble, member)
+        DevBuf sf_state;                     // SuperframeFilter window of every pair
         DevBuf sf_snap;                      // ... as it was in front of the current batch (exact batch mode)
+        bool dabplus_rate() const { return (prot.nbits / 24) % 8 == 0 && prot.nbits / 8 >= 10; }
+        size_t sf_stride() const { return ((size_t)16 + 5 * (size_t)(prot.nbits / 8) + 15) & ~(size_t)15; }
     };
+    struct PairRef { int cls = -1, pair = -1; };
     const cf32* s_iq = nullptr;       // DEVICE pointer to [B][stride] samples (caller's or s_iq_own)
     DevBuf s_iq_own;
     uint64_t s_stride = 0, s_ring = 0, s_valid = 0; int s_loop = 0;
     bool s_bounded = false;           // every sample the stream ever held came through k_ingest from u8 / s8 / s16: |re|, |im| <= 1
-    std::vector<dabphy_subchannel> subch;
+    // sub-channel selection: per ensemble.  `subch_e` + `classes` + `where` = what the kernels decode with; `subch_next` = what the caller
+    // has asked for (dabphy_set_subchannels / _ensemble); apply_subchannels rebuilds the former from the latter (carrying the state of
+    // every service that stays) before the next batch is decoded.
+    std::vector<std::vector<dabphy_subchannel>> subch_e, subch_next;     // [n_ensembles]
+    std::vector<std::vector<PairRef>> where;                             // [n_ensembles][position in the list] -> class, pair
+    bool subch_dirty = false;
     std::vector<MscClass> classes;
+    DevBuf sf_run;                                                       // pair selections of one-sub-channel superframe filter launches
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
     DevBuf s_raw2[2]; hipStream_t copy_stream = nullptr; hipEvent_t ev_ingest[2] = {nullptr, nullptr}; int raw_sel = 0;   // dabphy_stream_write_raw_async
     uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
@@ -219,7 +232,10 @@ DABPHY_INTERNAL void launch_serial_chain(dabphy_handle* h, SyncArgs sa);
 DABPHY_INTERNAL int queue_chain(dabphy_handle* h, int sel, uint32_t F);
 DABPHY_INTERNAL int resolve_chain(dabphy_handle* h, int sel);
 DABPHY_INTERNAL int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F);       // dabphy_superframes.hip
-DABPHY_INTERNAL int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st = nullptr, int ens0 = 0, int ens_count = 0);
+DABPHY_INTERNAL int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, const int32_t* d_run, int n_run, int32_t* stats, hipStream_t st = nullptr);   // d_run = nullptr: every pair
+DABPHY_INTERNAL int apply_subchannels(dabphy_handle* h);                                          // dabphy_api.hip
+DABPHY_INTERNAL int upload_pairs(dabphy_handle* h, dabphy_handle::MscClass& cls);
+DABPHY_INTERNAL void free_class(dabphy_handle::MscClass& c);
 DABPHY_INTERNAL int launch_superframe_stats(dabphy_handle* h);
 DABPHY_INTERNAL int fused_class_tables(dabphy_handle* h, const dabphy_protection& prot, bool fic, DevBuf (&steps)[FUSED_VARIANTS], int (&n_windows)[FUSED_VARIANTS]);   // dabphy_fused.hip
 DABPHY_INTERNAL int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic);

@@ -131,15 +131,31 @@ struct FicGatherArgs {
     int frame_sel;          // 0: every frame of the batch, codeword (b F + f) 4 + q; f + 1: frame f only, codeword 4 b + q (c.n_cw = 4 B)
 };
 
+// One (ensemble, sub-channel) PAIR of an MSC protection class.  Every ensemble of a batch selects its own sub-channels
+// (MscHandler::addSubchannel, msc-handler.cpp:61-103, is per receiver): a class is the list of the pairs of the whole batch that share
+// one protection profile, ordered by ensemble, then by position in that ensemble's list.  Code word of a class: cw = pair * R + r
+// (CIF r of this batch, R = 4 * n_frames).
+struct MscPair {
+    int32_t ens;            // ensemble of the batch
+    int32_t start_bit;      // Subchannel::startAddr * 64: first soft bit of the sub-channel inside a CIF
+    int64_t cif0;           // CIF count of the ensemble (4 * frame_no) from which this sub-channel's time de-interleaver has been fed: a
+                            // sub-channel added in mid-stream emits its first logical frame 16 CIFs later (dab-audio.cpp:146-149).
+                            // -1: not known yet -- k_pair_cif0 sets it from the first batch decoded with the pair
+    int32_t idx;            // position in its ensemble's sub-channel list (the subch_index of the getters)
+    int32_t pad_;
+};
+static_assert(sizeof(MscPair) == 24, "MscPair layout");
+void launch_pair_cif0(MscPair* pairs, int n_pairs, const FrameDesc* desc, int n_frames, hipStream_t s);
+
 // Gather for one MSC sub-channel class: time de-interleave (dab-audio.cpp:138-143) + depuncture
 // (eep-protection.cpp:127-148) fused into one indexed read of the soft-bit ring.
 struct MscGatherArgs {
     const int8_t* soft; int soft_ring; const RxState* state; int n_ens, n_frames;
     size_t soft_ens_stride;   // bytes between ensembles (0: soft_ring * SOFT_PER_FRAME)
     const int16_t* map;     // [4*nbits+24] -> index into the sub-channel's length*64 soft bits, -1 = erasure
-    const int32_t* start_bit; // [n_subch_in_class] startAddr*64 per member sub-channel
+    const MscPair* pairs;     // [n_pairs] the (ensemble, sub-channel) pairs of the class
     const int32_t* tiles;     // [ceil(nsteps/56)][2]: first source byte (4-aligned) and dwords per row of each step tile
-    int n_members;            // sub-channels in the class (per ensemble)
+    int n_pairs;
     const FrameDesc* desc;    // [B][n_frames]; desc[b][0].frame_no is the first frame of this batch
     VitClass c;
 };
@@ -161,16 +177,16 @@ constexpr int FUSED_ROWS[FUSED_VARIANTS] = {96, 144, 324};      // >= 64 + 15 * 
 constexpr int FUSED_MIN_CIFS[FUSED_VARIANTS] = {64, 16, 4};
 constexpr uint32_t MSC_FIRST_USE = 1u << 15, MSC_LOAD_NEXT = 1u << 31, MSC_OFF_MASK = 0x7fffu;
 // One class of a fused launch (read through the constant address space).  kind 0 = an MSC protection class: code word
-// cw = (b * n_members + m) * R + r (ensemble b, member sub-channel m, CIF r of this batch, R = 4 * n_frames); kind 1 = the FIC:
+// cw = pair * R + r ((ensemble, sub-channel) pair of the class's table, CIF r of this batch, R = 4 * n_frames); kind 1 = the FIC:
 // code word (b * n_frames + f) * 4 + q -- or, k_viterbi_sp only, 4 b + q of frame FusedArgs::fic_frame_sel - 1 alone (the replay of exact
 // batch mode); kind 2 (k_viterbi_sp only) = code words that lie one after the other in a plain array (the Viterbi::deconvolve /
 // Protection::deconvolve seams): FusedArgs::lin_in + cw * lin_stride, depunctured through `map` when there is one.
 struct FusedClass {
     const MscStep* steps;     // [nsteps + 6] for the launch's row-count variant
-    const int32_t* start_bit; // MSC: [n_members] startAddr * 64
+    const MscPair* pairs;     // MSC: [n_pairs] (ensemble, start bit) of every pair, ensembles ascending
     const int16_t* map;       // [4 * nsteps] mother-code index -> index into the class's punctured bit stream, -1 = erasure (k_viterbi_sp gathers by it)
     uint8_t* out;             // [n_cw][nbits / 8]
-    int32_t nsteps, nbits, n_windows, n_cw, n_members, kind, dedisperse, reserved_;
+    int32_t nsteps, nbits, n_windows, n_cw, n_pairs, kind, dedisperse, reserved_;
 };
 static_assert(sizeof(FusedClass) == 64, "FusedClass layout");
 struct FusedArgs {
@@ -253,28 +269,29 @@ struct RsArgs {            // contiguous superframes [n_sf][sf_stride], s = bitr
     uint8_t* data; size_t sf_stride; int n_sf, s;
     int* corr; int* uncorr;                       // [n_sf]
 };
-struct RsMscArgs {         // superframes inside a class's MSC output [B][n_members][n_cif][frame_bytes]
-    uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s, n_sf_per_ens;
-    int member_only;                              // -1: every member, else only this member
-    const int* first_cif;                         // [B] logical-frame slot (in this batch) where the first superframe starts
-    int* result;                                  // [B][n_sf_per_ens][n_members][2] = corrected symbols, uncorrectable flag
+struct RsMscArgs {         // superframes inside a class's MSC output [n_pairs][n_cif][frame_bytes]
+    uint8_t* out; int n_cif, n_pairs, frame_bytes, s, n_sf_per_pair;
+    const MscPair* pairs;
+    int idx_only;                                 // -1: every pair, else only the pairs at this position of their ensemble's list
+    const int* first_cif;                         // [B] logical-frame slot (in this batch) where the ensemble's first superframe starts
+    int* result;                                  // [n_pairs][n_sf_per_pair][2] = corrected symbols, uncorrectable flag
 };
 // DAB+ superframe filter (k_rs.hip: k_superframe): SuperframeFilter::Feed over the logical frames of one batch
 struct SfEvent {           // = dabphy_sf_event (include/dabphy.h)
     int32_t cif, corrected, uncorrectable, sync, format, num_aus, au_start[7], au_crc_ok, sf_slot;
 };
 struct SfArgs {
-    const uint8_t* out; int n_ens, n_cif, n_members, frame_bytes, s;    // class output [B][members][n_cif][frame_bytes]
-    int member;                                   // >= 0: only this member (grid (1, B)); -1: every member (grid (members, B))
+    const uint8_t* out; int n_cif, n_pairs, frame_bytes, s;    // class output [n_pairs][n_cif][frame_bytes]
+    const MscPair* pairs;                         // [n_pairs]
+    const int32_t* run; int n_run;                // the pairs this launch walks: run[0 .. n_run) (nullptr: every pair of the class, n_run = n_pairs)
     const FrameDesc* desc; int n_frames;
-    uint8_t* state; size_t state_stride;          // [B][members] records: int32 frame_count (+12 pad), raw[5 * frame_bytes]
-    SfEvent* events; int32_t* n_events;           // [B][members][n_cif], [B][members]
-    uint8_t* sf; int n_slots;                     // [B][members][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
+    uint8_t* state; size_t state_stride;          // [n_pairs] records: int32 frame_count (+12 pad), raw[5 * frame_bytes]
+    SfEvent* events; int32_t* n_events;           // [n_pairs][n_cif], [n_pairs]
+    uint8_t* sf; int n_slots;                     // [n_pairs][n_slots][5 * frame_bytes] corrected superframes of the synced attempts
     int32_t* stats;                               // optional [B][4]: synchronised superframes, corrected symbols, uncorrectable attempts, AUs failing their CRC
-    int ens0, ens_count;                          // this launch walks ensembles [ens0, ens0 + ens_count); ens_count = 0: all of them
     const uint8_t* gf;                            // alpha_to[256], index_of[256] of GF(256) / 0x11D (init_rs.h:48-60)
-    int32_t* accepted;                            // [B][members]: set by the wide pass for what it settled (nullptr: serial walk only)
-    unsigned long long* wide_stats;               // [2]: (ensemble, member) batches the wide pass settled / was tried on
+    int32_t* accepted;                            // [n_pairs]: set by the wide pass for what it settled (nullptr: serial walk only)
+    unsigned long long* wide_stats;               // [2]: pair batches the wide pass settled / was tried on
 };
 void launch_superframe(const SfArgs& a, hipStream_t s);
 void launch_rs_superframes(const RsArgs& a, hipStream_t s);

@@ -21,6 +21,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     const uint32_t B = h->cfg.n_ensembles, F = n_frames;
     const int ring_frames = (int)h->cfg.max_frames + 5;
     int r;
+    if ((r = apply_subchannels(h))) return r;                // per-ensemble sub-channel changes since the last batch (dabphy_set_subchannels_ensemble)
     for (int k = 0; k < dabphy_handle::N_DESC; k++) {
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
         if ((r = ensure(h, h->s_redo[k], (size_t)B * sizeof(int32_t)))) return r;
@@ -55,7 +56,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if ((r = ensure(h, h->tii_nev, (size_t)B * sizeof(int32_t)))) return r;
         }
         for (auto& cls : h->classes) {
-            const size_t n_groups = ((size_t)B * 4 * F * cls.members.size() + 63) / 64;
+            const size_t n_groups = ((size_t)4 * F * cls.pairs.size() + 63) / 64;
             if ((r = ensure(h, cls.out, n_groups * 64 * (cls.prot.nbits / 8)))) return r;
             if (h->sf_auto && (r = prepare_superframes(h, cls, F))) return r;
         }
@@ -71,7 +72,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
                 ci++;
                 if (fused) continue;
                 VitClass c{};
-                if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * cls.members.size()), 1))) return r;
+                if ((r = prepare_class(h, c, cls.prot.nbits, (int)(4 * F * cls.pairs.size()), 1))) return r;
             }
             const size_t fic_groups = h->fplan.fic_in ? ((size_t)B * 4 + 63) / 64 : (size_t)fic_c.n_groups;
             if (!h->fplan.fic_in || h->exact_batch) {
@@ -158,7 +159,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         const bool fic_sp = sp_single_ok(h, (uint64_t)B * 4, c.nsteps);
         FusedArgs spa{};
         if (fic_sp) {
-            FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = c.n_cw; fc.n_members = 1; fc.kind = 1; fc.dedisperse = 1;
+            FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = c.n_cw; fc.n_pairs = 1; fc.kind = 1; fc.dedisperse = 1;
             spa.soft = da.soft; spa.ens_stride = ens_stride; spa.soft_ring = ring_frames; spa.n_ens = (int)B; spa.n_frames = (int)F; spa.desc = d_desc;
             if ((r = sp_single_prepare(h, fc, spa, h->stream))) return r;
         }
@@ -229,6 +230,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipMemcpyAsync(h->h_desc, d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
     }
+    // pairs selected since the last batch learn the CIF count they start at (their time de-interleaver fills from here, dab-audio.cpp:146-149)
+    for (auto& cls : h->classes) if (cls.cif0_pending) launch_pair_cif0(cls.pair_tab.as<MscPair>(), (int)cls.pairs.size(), d_desc, (int)F, h->stream);
     // MSC (+ FIC): every class the plan holds in ONE launch; the stage events bracket all of it
     h->last_frames = F;
     h->sf_stats_ready = false; h->h_sf_stats_valid = false;
@@ -264,11 +267,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             if (fused) continue;
             if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: class %zu (%d bits) through k_msc_gather + k_viterbi\n", ci - 1, cls.prot.nbits);
             VitClass c{};
-            const int M = (int)cls.members.size();
-            if ((r = prepare_class(h, c, cls.prot.nbits, (int)(B * 4 * F * M), 1))) return r;
+            const int P = (int)cls.pairs.size();
+            if ((r = prepare_class(h, c, cls.prot.nbits, (int)(4 * F * (uint32_t)P), 1))) return r;
             c.out = cls.out.as<uint8_t>();
             MscGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.soft_ens_stride = ens_stride; g.state = h->d_state; g.n_ens = (int)B; g.n_frames = (int)F;
-            g.map = cls.map.as<int16_t>(); g.start_bit = cls.start_bits.as<int32_t>(); g.tiles = cls.tiles.as<int32_t>(); g.n_members = M; g.desc = d_desc; g.c = c;
+            g.map = cls.map.as<int16_t>(); g.pairs = cls.pair_tab.as<MscPair>(); g.tiles = cls.tiles.as<int32_t>(); g.n_pairs = P; g.desc = d_desc; g.c = c;
             if (first_two) mark(dabphy_handle::ST_MSC_GATHER, false);
             launch_msc_gather(g, h->stream);
             VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
@@ -324,6 +327,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // FIC ratio: the main stream has just been drained.)
         for (int i = 1; i <= depth; i++) if ((r = queue_chain(h, (cur + i) % ND, F))) return r;
         h->n_replayed_batches++;
+    }
+    // the host's mirror of the pair tables follows what k_pair_cif0 wrote (same rule, from the host's copy of the descriptors)
+    for (auto& cls : h->classes) if (cls.cif0_pending) {
+        for (MscPair& p : cls.pairs) if (p.cif0 < 0) p.cif0 = 4 * h->h_desc[(size_t)p.ens * F].frame_no;
+        cls.cif0_pending = false;
     }
     if (g_tl_on) { for (int i = 0; i < 5; i++) g_tl.acc[i] += tl[i]; g_tl.n++; if (g_tl.n % 8 == 0) fprintf(stderr, "dabphy timing [us]: before resolve %.1f, resolved %.1f, demod launched %.1f, all launched %.1f, synced %.1f (n=%ld)\n", g_tl.acc[0] / g_tl.n, g_tl.acc[1] / g_tl.n, g_tl.acc[2] / g_tl.n, g_tl.acc[3] / g_tl.n, g_tl.acc[4] / g_tl.n, g_tl.n); }
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }

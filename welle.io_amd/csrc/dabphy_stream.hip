@@ -126,6 +126,8 @@ int dabphy_reset(dabphy_handle* h)
     HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
     for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
+    // ... and the frame count starts over: every selected sub-channel's time de-interleaver fills again from the first CIF decoded
+    for (auto& c : h->classes) { for (MscPair& p : c.pairs) p.cif0 = -1; int r2 = upload_pairs(h, c); if (r2) return r2; }
     if (h->tii_state.p) HIPCHK(h, hipMemsetAsync(h->tii_state.p, 0, h->tii_state.cap, h->stream));      // a new OFDMProcessor owns a new TIIDecoder
     h->tii_ran = false;
     return sync(h);

@@ -4,23 +4,23 @@
 
 extern "C" {
 
-// device buffers of the superframe filter for one class and F frames per batch (the window state is zeroed when it is (re)allocated)
+// device buffers of the superframe filter for one class and F frames per batch (the window state of a class is created with the class,
+// apply_subchannels, which also carries the windows of the services that stay)
 int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F)
 {
-    const uint32_t B = h->cfg.n_ensembles;
-    const int fb = cls.prot.nbits / 8, M = (int)cls.members.size();
-    if ((cls.prot.nbits / 24) % 8 || fb < 10) return 0;                  // not a DAB+ rate: the filter never runs on this class
+    const int fb = cls.prot.nbits / 8;
+    const size_t P = cls.pairs.size();
+    if (!cls.dabplus_rate()) return 0;                                   // not a DAB+ rate: the filter never runs on this class
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
-    const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
     int r;
-    if (cls.sf_state.cap < stride * B * M) {
-        if ((r = ensure(h, cls.sf_state, stride * B * M))) return r;
+    if (cls.sf_state.cap < cls.sf_stride() * P) {
+        if ((r = ensure(h, cls.sf_state, cls.sf_stride() * P))) return r;
         HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
     }
-    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * B * M * n_cif))) return r;
-    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * B * M))) return r;
-    if ((r = ensure(h, h->sf_bytes, (size_t)B * M * n_slots * 5 * fb))) return r;
-    if ((r = ensure(h, h->sf_accept, sizeof(int32_t) * B * M))) return r;
+    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * P * n_cif))) return r;
+    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * P))) return r;
+    if ((r = ensure(h, h->sf_bytes, P * n_slots * 5 * fb))) return r;
+    if ((r = ensure(h, h->sf_accept, sizeof(int32_t) * P))) return r;
     if (!h->sf_gf.p) {
         // GF(256) of RS(120,110), generator polynomial 0x11D (init_rs.h:48-60): alpha_to[256], index_of[256]  (built once, thread-safely:
         // the node receiver creates its handles from several host threads)
@@ -57,7 +57,7 @@ int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint
 int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* first_cif, int32_t* corrected, int32_t* uncorrectable)
 {
     DeviceBind dev_(h);
-    if (!h || !first_cif || !h->last_frames || subch_index >= (int32_t)h->subch.size()) return DABPHY_ERR_INVALID;
+    if (!h || !first_cif || !h->last_frames) return DABPHY_ERR_INVALID;
     const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
     const int n_cif = (int)(4 * F), n_sf = n_cif / 5 + 1;
     int r;
@@ -65,20 +65,21 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
     HIPCHK(h, hipMemcpyAsync(h->rs_first.p, first_cif, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     if (corrected) memset(corrected, 0, sizeof(int32_t) * B);
     if (uncorrectable) memset(uncorrectable, 0, sizeof(int32_t) * B);
-    bool first_launch = true;
+    bool first_launch = true, any = subch_index < 0;
     for (auto& cls : h->classes) {
-        int member = -1;
         if (subch_index >= 0) {
-            for (size_t m = 0; m < cls.members.size(); m++) if (cls.members[m] == subch_index) member = (int)m;
-            if (member < 0) continue;
+            bool here = false;
+            for (const MscPair& p : cls.pairs) if (p.idx == subch_index) { here = true; break; }
+            if (!here) continue;
+            any = true;
         }
         const int bitrate = cls.prot.nbits / 24;
         if (bitrate % 8) continue;
-        const size_t nres = (size_t)B * n_sf * cls.members.size() * 2;
+        const size_t P = cls.pairs.size(), nres = P * n_sf * 2;
         if ((r = ensure(h, h->rs_result, nres * sizeof(int)))) return r;
         HIPCHK(h, hipMemsetAsync(h->rs_result.p, 0, nres * sizeof(int), h->stream));
-        RsMscArgs a{}; a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = (int)cls.members.size();
-        a.frame_bytes = cls.prot.nbits / 8; a.s = bitrate / 8; a.n_sf_per_ens = n_sf; a.member_only = member;
+        RsMscArgs a{}; a.out = cls.out.as<uint8_t>(); a.n_cif = n_cif; a.n_pairs = (int)P; a.pairs = cls.pair_tab.as<MscPair>();
+        a.frame_bytes = cls.prot.nbits / 8; a.s = bitrate / 8; a.n_sf_per_pair = n_sf; a.idx_only = subch_index;
         a.first_cif = h->rs_first.as<int>(); a.result = h->rs_result.as<int>();
         if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
         launch_rs_msc(a, h->stream);
@@ -88,60 +89,95 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
             std::vector<int> res(nres);
             HIPCHK(h, hipMemcpyAsync(res.data(), h->rs_result.p, nres * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             if ((r = sync(h))) return r;
-            for (uint32_t b = 0; b < B; b++)
-                for (size_t k = 0; k < (size_t)n_sf * cls.members.size(); k++) {
-                    const size_t o = ((size_t)b * n_sf * cls.members.size() + k) * 2;   // [b][superframe][member]
-                    if (corrected) corrected[b] += res[o];
-                    if (uncorrectable) uncorrectable[b] += res[o + 1];
+            for (size_t p = 0; p < P; p++)
+                for (int q = 0; q < n_sf; q++) {
+                    const size_t o = (p * n_sf + q) * 2;                            // [pair][superframe]
+                    if (corrected) corrected[cls.pairs[p].ens] += res[o];
+                    if (uncorrectable) uncorrectable[cls.pairs[p].ens] += res[o + 1];
                 }
         }
     }
+    if (!any) return DABPHY_ERR_INVALID;                             // no ensemble has a sub-channel at that position
     return sync(h);
 }
 
-// launches k_superframe for one class: member >= 0 -> that member only, -1 -> all members
-int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, int member, int32_t* stats, hipStream_t st, int ens0, int ens_count)
+// launches k_superframe for one class over the pairs d_run[0 .. n_run) (DEVICE pointer), or over every pair of the class (nullptr)
+int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, const int32_t* d_run, int n_run, int32_t* stats, hipStream_t st)
 {
-    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
-    const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
+    const uint32_t F = h->last_frames;
+    const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
-    const size_t stride = ((size_t)16 + 5 * fb + 15) & ~(size_t)15;
     int r;
     if ((r = prepare_superframes(h, cls, F))) return r;
     SfArgs a{};
-    a.out = cls.out.as<uint8_t>(); a.n_ens = (int)B; a.n_cif = n_cif; a.n_members = M; a.frame_bytes = fb;
-    a.s = bitrate / 8; a.member = member; a.desc = h->last_desc; a.n_frames = (int)F;
-    a.state = cls.sf_state.as<uint8_t>(); a.state_stride = stride; a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
-    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats; a.ens0 = ens0; a.ens_count = ens_count;
+    a.out = cls.out.as<uint8_t>(); a.n_cif = n_cif; a.n_pairs = (int)cls.pairs.size(); a.pairs = cls.pair_tab.as<MscPair>(); a.frame_bytes = fb;
+    a.run = d_run; a.n_run = d_run ? n_run : a.n_pairs;
+    a.s = bitrate / 8; a.desc = h->last_desc; a.n_frames = (int)F;
+    a.state = cls.sf_state.as<uint8_t>(); a.state_stride = cls.sf_stride(); a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
+    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats;
     a.gf = h->sf_gf.as<uint8_t>(); a.accepted = h->sf_accept.as<int32_t>();
     a.wide_stats = reinterpret_cast<unsigned long long*>(h->sf_gf.as<uint8_t>() + 512);
     launch_superframe(a, st ? st : h->stream);
     return 0;
 }
 
+namespace {
+// The filter over a selection of pairs (class, pair) given per output row: rows of one class go in one launch; events / counts /
+// superframes of row i land at events + i * n_cif, n_events + i, sf + i * n_slots * 5 * fb.  Every selected pair must have frames of fb bytes.
+int superframes_of(dabphy_handle* h, const std::vector<dabphy_handle::PairRef>& rows, int fb, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
+{
+    const uint32_t F = h->last_frames;
+    const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+    int r;
+    std::vector<int32_t> run(rows.size());
+    if ((r = ensure(h, h->sf_run, rows.size() * sizeof(int32_t)))) return r;
+    for (size_t ci = 0; ci < h->classes.size(); ci++) {
+        auto& cls = h->classes[ci];
+        std::vector<size_t> mine;
+        for (size_t i = 0; i < rows.size(); i++) if (rows[i].cls == (int)ci) mine.push_back(i);
+        if (mine.empty()) continue;
+        for (size_t k = 0; k < mine.size(); k++) run[k] = rows[mine[k]].pair;
+        HIPCHK(h, hipMemcpyAsync(h->sf_run.p, run.data(), mine.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        if ((r = run_superframes(h, cls, h->sf_run.as<int32_t>(), (int)mine.size(), nullptr))) return r;
+        for (size_t k = 0; k < mine.size(); k++) {
+            const size_t i = mine[k], bm = (size_t)rows[i].pair;
+            HIPCHK(h, hipMemcpyAsync(events + i * n_cif, h->sf_events.as<SfEvent>() + bm * n_cif, sizeof(SfEvent) * n_cif, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(n_events + i, h->sf_count.as<int32_t>() + bm, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            if (sf) HIPCHK(h, hipMemcpyAsync(sf + i * n_slots * 5 * fb, h->sf_bytes.as<uint8_t>() + bm * n_slots * 5 * fb, (size_t)n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
+        }
+        if ((r = sync(h))) return r;             // (the selection and the shared event buffers are reused by the next class)
+    }
+    return DABPHY_OK;
+}
+}
+
 int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
 {
     DeviceBind dev_(h);
     static_assert(sizeof(dabphy_sf_event) == sizeof(SfEvent), "event layouts must match");
-    if (!h || !events || !n_events || subch_index >= h->subch.size() || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
-    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
-    for (auto& cls : h->classes)
-        for (size_t m = 0; m < cls.members.size(); m++) {
-            if (cls.members[m] != (int)subch_index) continue;
-            const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, M = (int)cls.members.size();
-            if (bitrate % 8 || fb < 10) { h->err = "sub-channel bit rate is not a DAB+ rate"; return DABPHY_ERR_INVALID; }
-            const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
-            int r;
-            if ((r = run_superframes(h, cls, (int)m, nullptr))) return r;
-            for (uint32_t b = 0; b < B; b++) {          // rows of member m
-                const size_t bm = (size_t)b * M + m;
-                HIPCHK(h, hipMemcpyAsync(events + (size_t)b * n_cif, h->sf_events.as<SfEvent>() + bm * n_cif, sizeof(SfEvent) * n_cif, hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(h, hipMemcpyAsync(n_events + b, h->sf_count.as<int32_t>() + bm, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                if (sf) HIPCHK(h, hipMemcpyAsync(sf + (size_t)b * n_slots * 5 * fb, h->sf_bytes.as<uint8_t>() + bm * n_slots * 5 * fb, (size_t)n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
-            }
-            return sync(h);
-        }
-    return DABPHY_ERR_INVALID;
+    if (!h || !events || !n_events || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles;
+    std::vector<dabphy_handle::PairRef> rows(B);
+    int fb = 0;
+    for (uint32_t b = 0; b < B; b++) {
+        if (subch_index >= h->where[b].size()) { h->err = "ensemble " + std::to_string(b) + " has no sub-channel " + std::to_string(subch_index); return DABPHY_ERR_INVALID; }
+        rows[b] = h->where[b][subch_index];
+        const auto& cls = h->classes[rows[b].cls];
+        if (!cls.dabplus_rate()) { h->err = "sub-channel bit rate is not a DAB+ rate"; return DABPHY_ERR_INVALID; }
+        if (fb && fb != cls.prot.nbits / 8) { h->err = "the ensembles' sub-channels at this position differ in bit rate: use dabphy_superframes_ensemble"; return DABPHY_ERR_INVALID; }
+        fb = cls.prot.nbits / 8;
+    }
+    return superframes_of(h, rows, fb, events, n_events, sf);
+}
+
+int dabphy_superframes_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
+{
+    DeviceBind dev_(h);
+    if (!h || !events || !n_events || !h->last_frames || !h->last_desc || ensemble >= h->cfg.n_ensembles || subch_index >= h->where[ensemble].size()) return DABPHY_ERR_INVALID;
+    const std::vector<dabphy_handle::PairRef> rows(1, h->where[ensemble][subch_index]);
+    const auto& cls = h->classes[rows[0].cls];
+    if (!cls.dabplus_rate()) { h->err = "sub-channel bit rate is not a DAB+ rate"; return DABPHY_ERR_INVALID; }
+    return superframes_of(h, rows, cls.prot.nbits / 8, events, n_events, sf);
 }
 
 // SuperframeFilter over every DAB+ sub-channel of every ensemble: one launch per protection class on the main stream, totals into sf_stats
@@ -153,10 +189,9 @@ int launch_superframe_stats(dabphy_handle* h)
     HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));
     bool first_launch = true;
     for (auto& cls : h->classes) {
-        const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
-        if (bitrate % 8 || fb < 10) continue;
+        if (!cls.dabplus_rate()) continue;
         if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
-        if ((r = run_superframes(h, cls, -1, h->sf_stats.as<int32_t>()))) return r;
+        if ((r = run_superframes(h, cls, nullptr, 0, h->sf_stats.as<int32_t>()))) return r;
         if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
         first_launch = false;
     }

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_rs_superframes(RsArgs A)
 }
 
 // Superframes inside the MSC output of one protection class: byte k of the superframe that starts at logical
-// frame r0 of (ensemble b, member m) lives in frame r0 + k / frame_bytes at offset k % frame_bytes.
+// frame r0 of a pair lives in frame r0 + k / frame_bytes at offset k % frame_bytes.
 struct RsMscIo {
     uint8_t* frames; size_t frame_stride; int frame_bytes, s, i;
     __device__ __forceinline__ uint8_t* at(int pos) const { const int k = pos * s + i; return frames + (size_t)(k / frame_bytes) * frame_stride + (k % frame_bytes); }
@@ -217,19 +217,19 @@ __global__ void __launch_bounds__(256) k_rs_msc(RsMscArgs A)
     __shared__ uint8_t ws[256 * RS_WS_BYTES];
     rs_tables(alpha_to, index_of, threadIdx.x, blockDim.x);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_ens = A.n_sf_per_ens * A.n_members * A.s;
-    if (idx >= A.n_ens * per_ens) return;
-    const int b = idx / per_ens; int rem = idx % per_ens;
-    const int q = rem / (A.n_members * A.s); rem %= (A.n_members * A.s);
-    const int m = rem / A.s, i = rem % A.s;
-    if (A.member_only >= 0 && m != A.member_only) return;
-    const int r0 = A.first_cif[b] + 5 * q;                       // first logical frame of superframe q
+    const int per_pair = A.n_sf_per_pair * A.s;
+    if (idx >= A.n_pairs * per_pair) return;
+    const int pair = idx / per_pair; const int rem = idx % per_pair;
+    const int q = rem / A.s, i = rem % A.s;
+    const MscPair pp = A.pairs[pair];
+    if (A.idx_only >= 0 && pp.idx != A.idx_only) return;
+    const int r0 = A.first_cif[pp.ens] + 5 * q;                  // first logical frame of superframe q
     if (r0 < 0 || r0 + 5 > A.n_cif) return;
     RsMscIo io;
     io.frame_bytes = A.frame_bytes; io.s = A.s; io.i = i; io.frame_stride = (size_t)A.frame_bytes;
-    io.frames = A.out + (((size_t)b * A.n_members + m) * A.n_cif + r0) * A.frame_bytes;
+    io.frames = A.out + ((size_t)pair * A.n_cif + r0) * A.frame_bytes;
     const int c = rs_decode120(io, alpha_to, index_of, ws + threadIdx.x * RS_WS_BYTES);
-    int* cnt = A.result + 2 * (((size_t)b * A.n_sf_per_ens + q) * A.n_members + m);
+    int* cnt = A.result + 2 * ((size_t)pair * A.n_sf_per_pair + q);
     if (c < 0) atomicOr(cnt + 1, 1);
     else if (c > 0) atomicAdd(cnt, c);
 }
@@ -273,14 +273,15 @@ __device__ __forceinline__ void sf_tables(const SfArgs& A, uint8_t* alpha_to, ui
         }
 }
 
-// What the batch holds for one (ensemble, member): fc frames carried in, of which the window machine still uses the last cu (a full
+// What the batch holds for one (ensemble, sub-channel) pair: fc frames carried in, of which the window machine still uses the last cu (a full
 // window that failed drops its oldest frame with the next one, dabplus_decoder.cpp:78-81); rows [r_first, n_rows) of the class output
 // are the frames it will be fed (rows are packed: k_msc_gather lays the logical frames of an ensemble out in CIF order from the first
 // frame number of the batch, whatever slots the demodulated frames occupied; frames before the 16-CIF fill of the time de-interleaver,
-// dab-audio.cpp:146-149, are never emitted).  If every attempt synchronises, attempts happen at frames 5q + 4 of that sequence: nq of them.
+// dab-audio.cpp:146-149, counted from the CIF at which the pair was selected (MscPair::cif0), are never emitted).  If every attempt synchronises, attempts happen at frames 5q + 4 of that sequence: nq of them.
 struct SfPlan { int fc, cu, n_rows, r_first, avail, nq; };
-__device__ __forceinline__ SfPlan sf_plan(const SfArgs& A, int b, const uint8_t* st)
+__device__ __forceinline__ SfPlan sf_plan(const SfArgs& A, const MscPair& pp, const uint8_t* st)
 {
+    const int b = pp.ens;
     SfPlan p;
     p.fc = *reinterpret_cast<const int32_t*>(st);
     p.cu = p.fc == 5 ? 4 : p.fc;
@@ -289,7 +290,7 @@ __device__ __forceinline__ SfPlan sf_plan(const SfArgs& A, int b, const uint8_t*
     const long long c0 = 4 * A.desc[(size_t)b * A.n_frames].frame_no;
     p.n_rows = 4 * nv;
     p.r_first = 0;
-    while (p.r_first < p.n_rows && c0 + p.r_first < 16) p.r_first++;
+    while (p.r_first < p.n_rows && c0 + p.r_first - pp.cif0 < 16) p.r_first++;
     p.avail = p.n_rows - p.r_first;
     p.nq = p.avail > 0 ? (p.cu + p.avail) / 5 : 0;
     return p;
@@ -365,7 +366,7 @@ __device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const u
     __syncthreads();
 }
 
-// :122-131 AU CRC-16-CCITT of the first ne events of one (ensemble, member), one lane per access unit.  The verdicts do not steer the
+// :122-131 AU CRC-16-CCITT of the first ne events of one (ensemble, sub-channel) pair, one lane per access unit.  The verdicts do not steer the
 // state machine.  (Events and superframes were written by earlier kernels or, behind a barrier, by this work-group.)  Returns nothing:
 // failures are counted into *aubad (LDS).
 __device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t)
@@ -382,9 +383,9 @@ __device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t 
 }
 
 // ---- The wide pass.  A receiver in lock finds a superframe every five frames: all attempts of the batch are made at once, one
-// work-group per (member, ensemble, attempt q), each on the window the serial machine WOULD see if every earlier attempt of the batch
-// synchronises (sf_plan).  k_superframe_settle then accepts an (ensemble, member) iff all its attempts did -- in that case the serial
-// walk makes exactly these attempts on exactly these windows -- and does what the walk does at its end; every other (ensemble, member)
+// work-group per (pair, attempt q), each on the window the serial machine WOULD see if every earlier attempt of the batch
+// synchronises (sf_plan).  k_superframe_settle then accepts an (ensemble, sub-channel) pair iff all its attempts did -- in that case the serial
+// walk makes exactly these attempts on exactly these windows -- and does what the walk does at its end; every other (ensemble, sub-channel) pair
 // is walked by k_superframe from the untouched state, as before.  The state machine's 26 dependent attempts per batch were this
 // stage's whole time: 0.8 ms of a mostly idle device per step.
 template <int SF_MAX>
@@ -394,11 +395,11 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
     __shared__ __attribute__((aligned(16))) uint8_t alpha_to[256], index_of[256];
     __shared__ SfShared sh;
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];
-    const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x, q = (int)blockIdx.z;
+    const int t = threadIdx.x, q = (int)blockIdx.y;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
-    const size_t bm = (size_t)b * A.n_members + m;
+    const size_t bm = A.run ? (size_t)A.run[blockIdx.x] : (size_t)blockIdx.x;      // the pair
     const uint8_t* st = A.state + bm * A.state_stride;
-    const SfPlan p = sf_plan(A, b, st);
+    const SfPlan p = sf_plan(A, A.pairs[bm], st);
     if (q >= p.nq) return;
     sf_tables(A, alpha_to, index_of, nullptr, t);
     for (int k = 0; k < 5; k++) {
@@ -423,11 +424,12 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
 {
     __shared__ uint16_t s_crctab[256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
-    const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
+    const int t = threadIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
-    const size_t bm = (size_t)b * A.n_members + m;
+    const size_t bm = A.run ? (size_t)A.run[blockIdx.x] : (size_t)blockIdx.x;      // the pair
+    const int b = A.pairs[bm].ens;
     uint8_t* st = A.state + bm * A.state_stride;
-    const SfPlan p = sf_plan(A, b, st);
+    const SfPlan p = sf_plan(A, A.pairs[bm], st);
     SfEvent* ev = A.events + bm * A.n_cif;
     for (int v = t; v < 256; v += 64) {
         uint16_t c = (uint16_t)(v << 8);
@@ -471,8 +473,9 @@ __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2
     __shared__ int s_aubad;
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];                   // error-path workspaces of the eight code words decoded at a time
     __shared__ uint16_t s_crctab[256];                          // CRC-16-CCITT (0x1021), one byte per step: the AU checks
-    const int t = threadIdx.x, b = A.ens0 + (int)blockIdx.y, m = A.member >= 0 ? A.member : (int)blockIdx.x;
-    const size_t bm = (size_t)b * A.n_members + m;
+    const int t = threadIdx.x;
+    const size_t bm = A.run ? (size_t)A.run[blockIdx.x] : (size_t)blockIdx.x;      // the pair
+    const int b = A.pairs[bm].ens;
     if (A.accepted && A.accepted[bm]) return;                  // settled by the wide pass
     sf_tables(A, alpha_to, index_of, s_crctab, t);
     if (t == 0) s_aubad = 0;
@@ -480,7 +483,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2
     uint8_t* const s_raw = s_dyn;
     uint8_t* const s_sf = s_dyn + SF_MAX;
     uint8_t* st = A.state + bm * A.state_stride;
-    const SfPlan p = sf_plan(A, b, st);
+    const SfPlan p = sf_plan(A, A.pairs[bm], st);
     int frame_count = p.fc;
     __syncthreads();
     for (int i = t; i < frame_count * fb; i += 64) s_raw[i] = st[16 + i];     // carried frames, oldest first
@@ -553,11 +556,12 @@ __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2
 
 void launch_superframe(const SfArgs& a, hipStream_t s)
 {
-    const dim3 grid(a.member >= 0 ? 1 : a.n_members, a.ens_count > 0 ? a.ens_count : a.n_ens - a.ens0);
+    if (a.n_run <= 0) return;
+    const dim3 grid(a.n_run);
     const int sf_len = 5 * a.frame_bytes;
     if (a.accepted) {
-        // the wide pass: every attempt a locked receiver makes in this batch at once, then the verdict per (ensemble, member)
-        const dim3 wide(grid.x, grid.y, (a.n_cif + 4) / 5);
+        // the wide pass: every attempt a locked receiver makes in this batch at once, then the verdict per (ensemble, sub-channel) pair
+        const dim3 wide(grid.x, (a.n_cif + 4) / 5);
         if (sf_len <= 960) hipLaunchKernelGGL(k_superframe_wide<960>, wide, dim3(64), 0, s, a);
         else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe_wide<2880>, wide, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(k_superframe_wide<5760>, wide, dim3(64), 0, s, a);
@@ -575,7 +579,8 @@ void launch_rs_superframes(const RsArgs& a, hipStream_t s)
 }
 void launch_rs_msc(const RsMscArgs& a, hipStream_t s)
 {
-    const int total = a.n_ens * a.n_sf_per_ens * a.n_members * a.s;
+    const int total = a.n_pairs * a.n_sf_per_pair * a.s;
+    if (total <= 0) return;
     hipLaunchKernelGGL(k_rs_msc, dim3((total + 255) / 256), dim3(256), 0, s, a);
 }
 

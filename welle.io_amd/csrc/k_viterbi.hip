@@ -161,9 +161,9 @@ __global__ void __launch_bounds__(256) k_fic_gather(FicGatherArgs A)
 }
 
 // ------------------------------------------------------------------------------------------ MSC gather
-// Codeword order of an MSC class: cw = (b * n_members + m) * R + r  (ensemble b, member sub-channel m, CIF r of this
-// batch, R = 4 * n_frames), so the 64 lanes of a Viterbi wave are consecutive CIFs of one sub-channel (at most a
-// few (b, m) pairs per group).  Soft bit u of the logical frame emitted at CIF c comes from CIF
+// Codeword order of an MSC class: cw = pair * R + r  ((ensemble, sub-channel) pair of the class's table -- every ensemble
+// selects its own sub-channels, msc-handler.cpp:61-103 --, CIF r of this batch, R = 4 * n_frames), so the 64 lanes of a
+// Viterbi wave are consecutive CIFs of one sub-channel (at most a few pairs per group).  Soft bit u of the logical frame emitted at CIF c comes from CIF
 // c - 16 + map16[u & 15] (dab-audio.cpp:113,138-143: tempX[i] = hist[(idx + map[i & 15]) & 15][i], read BEFORE the
 // current CIF is stored): the time de-interleaver is an address computation on the soft-bit ring, never a copy.
 //
@@ -190,17 +190,18 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
     const int nsteps = A.c.nsteps, R = 4 * A.n_frames;
     const bool live = cw < A.c.n_cw;
     const int pair = live ? cw / R : -1, r = live ? cw % R : 0;
-    const int b = live ? pair / A.n_members : 0, m = live ? pair % A.n_members : 0;
+    const MscPair mine = A.pairs[live ? pair : 0];
+    const int b = mine.ens;
     const long long c_glob = 4 * A.desc[(size_t)b * A.n_frames].frame_no + r;   // CIF whose arrival emits this logical frame
     const size_t ens_stride = A.soft_ens_stride ? A.soft_ens_stride : (size_t)A.soft_ring * SOFT_PER_FRAME;
-    const size_t ens_base = (size_t)b * ens_stride + A.start_bit[m];
+    const size_t ens_base = (size_t)b * ens_stride + (size_t)mine.start_bit;
     const int map16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
     uint32_t* __restrict__ dst = A.c.sym + (size_t)g * nsteps * 64 + lane;
 
     if (wave == 0) { s_pair[lane] = pair; s_c[lane] = c_glob; }
     __syncthreads();
     if (t == 0) {
-        // segments = runs of lanes with the same (b, m) and consecutive CIFs; a segment [c_a .. c_b] needs the rows
+        // segments = runs of lanes with the same pair and consecutive CIFs; a segment [c_a .. c_b] needs the rows
         // of CIFs c_a - 16 .. c_b - 1
         int nrows = 0;
         for (int l = 0; l < 64;) {
@@ -209,8 +210,8 @@ __global__ void __launch_bounds__(256) k_msc_gather(MscGatherArgs A)
             const int need = (e - l) + 16;
             if (s_pair[l] < 0) { for (int k = l; k <= e; k++) s_rowbase[k] = -1; l = e + 1; continue; }
             if (nrows + need > GT_MAXROWS) { nrows = -1; break; }
-            const int pb = s_pair[l] / A.n_members, pm = s_pair[l] % A.n_members;
-            const long long pbase = (long long)pb * (long long)ens_stride + A.start_bit[pm];
+            const MscPair pp = A.pairs[s_pair[l]];
+            const long long pbase = (long long)pp.ens * (long long)ens_stride + pp.start_bit;
             for (int k = 0; k < need; k++) {
                 const long long c_src = s_c[l] - 16 + k;
                 long long src = -1;
@@ -370,18 +371,17 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
     // ---- which rows this wave needs, and where they lie
     int rb, nrows, pb0;
     if (C.kind == 0) {
-        // segments = runs of lanes with the same (b, m) pair: pair0, pair0 + 1, ...; the first one starts at CIF r0 of its pair, the
-        // others at CIF 0.  Segment j >= 1 begins at lane n0 + (j - 1) R and at row n0 + 15 + (j - 1) (R + 15).
-        const int M = C.n_members;
+        // segments = runs of lanes with the same (ensemble, sub-channel) pair: pair0, pair0 + 1, ... of the class's table; the first one
+        // starts at CIF r0 of its pair, the others at CIF 0.  Segment j >= 1 begins at lane n0 + (j - 1) R and at row n0 + 15 + (j - 1) (R + 15).
+        const MscPair* __restrict__ pairs = C.pairs;
         const int pair0 = (int)(cw0 / R), r0 = (int)(cw0 - (long long)pair0 * R);
         const int n0 = R - r0;
         const long long cw_last = cw0 + 63 < n_cw ? cw0 + 63 : (long long)n_cw - 1;
         const int nseg = (int)(cw_last / R) - pair0 + 1;
         nrows = 64 + 15 * nseg;
-        pb0 = pair0 / M;
+        pb0 = pairs[pair0].ens;                                                          // (ensembles ascend along the table: the wave's lowest)
         int seg = cw / R - pair0; if (seg > nseg - 1) seg = nseg - 1;                    // (dead lanes ride in the last segment: their output is dropped)
         rb = lane + 15 * seg;                                                            // row of CIF c_glob - 16
-        const int32_t* __restrict__ start_bit = C.start_bit;
         for (int row = lane; row < ROWS; row += 64) {
             uint32_t src = zero16;                     // no such CIF yet (start of a stream) / row not used by this wave
             if (row < nrows) {
@@ -389,10 +389,11 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
                 if (row >= n0 + 15) { const int q = row - (n0 + 15); j = 1 + q / (R + 15); idx = q - (j - 1) * (R + 15); }
                 const int pr = pair0 + j;
                 if (j == 0 || (long long)pr * R < n_cw) {
-                    const int pb = pr / M, pm = pr - pb * M;
+                    const MscPair pp = pairs[pr];
+                    const int pb = pp.ens;
                     const long long c_src = 4 * A.desc[(size_t)pb * F].frame_no + (j == 0 ? r0 : 0) - 16 + idx;
                     if (c_src >= 0)
-                        src = (uint32_t)(((size_t)(pb - pb0) * A.ens_stride + (size_t)start_bit[pm] +
+                        src = (uint32_t)(((size_t)(pb - pb0) * A.ens_stride + (size_t)pp.start_bit +
                                           ((size_t)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM) >> 4);     // (start_bit is a multiple of 64)
                 }
             }
@@ -552,6 +553,20 @@ void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStrea
     if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0]>), dim3(n_slots), dim3(64), 0, s, a);
     else if (variant == 1) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[1], FUSED_OCC[1]>), dim3(n_slots), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[2], FUSED_OCC[2]>), dim3(n_slots), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------ new pairs
+// A sub-channel selected in mid-stream (MscHandler::addSubchannel while the receiver runs) starts with an empty time de-interleaver:
+// its first logical frame leaves 16 CIFs later (dab-audio.cpp:146-149).  The CIF count at which a new pair joined is only known on the
+// device (the synchroniser runs ahead of the host): the first batch decoded with the pair writes it into the table.
+__global__ void k_pair_cif0(MscPair* pairs, int n_pairs, const FrameDesc* desc, int n_frames)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pairs && pairs[p].cif0 < 0) pairs[p].cif0 = 4 * desc[(size_t)pairs[p].ens * n_frames].frame_no;
+}
+void launch_pair_cif0(MscPair* pairs, int n_pairs, const FrameDesc* desc, int n_frames, hipStream_t s)
+{
+    if (n_pairs > 0) hipLaunchKernelGGL(k_pair_cif0, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pairs, n_pairs, desc, n_frames);
 }
 
 // ------------------------------------------------------------------------------------------ linear gather

@@ -66,9 +66,10 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
     // ---- where this code word's soft bits lie: 16 row offsets (one per column u & 15 of the time de-interleaver), -1 = no such CIF
     const int8_t* base;
     if (C.kind == 0) {
-        const int M = C.n_members;
-        const int pair = cw / R, r = cw - pair * R, b = pair / M, m = pair - b * M;
-        base = A.soft + (size_t)b * A.ens_stride + (size_t)C.start_bit[m];
+        const int pair = cw / R, r = cw - pair * R;
+        const MscPair pp = C.pairs[pair];                                   // every ensemble selects its own sub-channels (msc-handler.cpp:61-103)
+        const int b = pp.ens;
+        base = A.soft + (size_t)b * A.ens_stride + (size_t)pp.start_bit;
         if (lane < 16) {
             const long long c_src = 4 * A.desc[(size_t)b * F].frame_no + r - 16 + sp::brev4(lane);      // dab-audio.cpp:113,138-143
             s_rowoff[lane] = c_src >= 0 ? ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM : -1;
