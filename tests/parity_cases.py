@@ -743,6 +743,146 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
     return logs
 
 
+def check_mixed_layouts(capi_mod, lib_path, B, F, check_ens, n_steps=3, pipeline_sync=1, device="cuda", decode_shape=0, rec_frames=None):
+    """A batch of INDEPENDENT ensembles (what every receiver of the reference is: its own MscHandler, msc-handler.cpp:61-127): ensemble b
+    receives multiplex b % 5 of workload.mixed_layouts -- canonical, heterogeneous, two random ones, canonical again -- and selects ITS
+    sub-channels (all; all; all; every other one; none) through dabphy_set_subchannels_ensemble.  FIBs, CRC flags, correctors, every
+    selected sub-channel's bytes and the superframe totals of the ensembles in check_ens against the oracle on the very same samples."""
+    from welle_io_amd import workload
+    lib = capi_mod.load_library(lib_path)
+    tx_lists, sel_lists = workload.mixed_layouts(lib)
+    nd = len(tx_lists)
+    base = workload.make_base_streams(nd, rec_frames or workload.rec_frames_for(F), seed0=70, subchs=tx_lists)
+    iq, cfo, base_np, txs = workload.make_batch(B, device=device, base=base)
+    sel = [sel_lists[b % nd] for b in range(B)]
+    d = workload.open_receiver(capi_mod, lib_path, iq, F, sel, pipeline_sync=pipeline_sync, profiling=False, decode_shape=decode_shape)
+    logs = {b: dict(fib=[], ok=[], corr=[], msc=[[] for _ in sel[b]], sf=np.zeros(4, np.int64), n_logical=0) for b in check_ens}
+    try:
+        for step in range(n_steps):
+            d.process(F)
+            info = d.frame_info(); fb, ok = d.fibs(); sf = d.superframes_stats()
+            for b in check_ens:
+                L = logs[b]
+                valid = [f for f in range(F) if info[b, f]["valid"] == 1]
+                for f in valid:
+                    L["fib"].append(fb[b, f]); L["ok"].append(ok[b, f]); L["corr"].append((int(info[b, f]["fine"]), int(info[b, f]["coarse"])))
+                for k in range(len(sel[b])):
+                    m, fv, nr = d.msc_ensemble(b, k)
+                    assert nr == 4 * len(valid)
+                    L["msc"][k].append(m[fv:nr].tobytes())
+                    if k == 0:
+                        L["n_logical"] += max(0, nr - fv)      # (all of an ensemble's sub-channels were selected at the start of the stream: one first_valid)
+                L["sf"] += sf[b]
+            for b in range(B):
+                if not sel[b]:
+                    assert not sf[b].any(), "ensemble %d selects nothing but reports superframes %s" % (b, sf[b])
+    finally:
+        d.close()
+    loops = (n_steps * F + 3) // (iq.shape[1] // 196608) + 2
+    for b in check_ens:
+        L = logs[b]
+        row = iq[b].cpu().numpy()
+        o = R.orc_receiver_run(np.tile(row, loops), subchs=sel[b])
+        n = len(L["fib"])
+        assert n >= n_steps * F - 2 and n <= o["n_frames"], (b, n, o["n_frames"])
+        ofib = o["fib"][:12 * n].reshape(n, 12, 33)
+        assert np.array_equal(np.array(L["ok"]), ofib[:, :, 0]), "ensemble %d: CRC flags differ" % b
+        assert np.array_equal(np.array(L["fib"]), ofib[:, :, 1:]), "ensemble %d: FIB bytes differ" % b
+        assert L["corr"] == [tuple(int(v) for v in c) for c in o["corr"][:n]], "ensemble %d: correctors differ" % b
+        want = np.zeros(4, np.int64)
+        for k, sc in enumerate(sel[b]):
+            got = b"".join(L["msc"][k])
+            assert len(got) == L["n_logical"] * sc.frame_bytes and len(got) > 0, (b, k, len(got), L["n_logical"])
+            assert got == o["msc"][k][:len(got)], "ensemble %d: MSC bytes of its sub-channel %d (%d kbit/s) differ" % (b, k, sc.bitrate)
+            fr = np.frombuffer(o["msc"][k], np.uint8)[:L["n_logical"] * sc.frame_bytes].reshape(-1, sc.frame_bytes)
+            ev, _ = R.orc_superframe_run(fr)
+            for e in ev:
+                want += (e[3], e[1], e[2], (e[5] - bin(e[7]).count("1")) if e[3] else 0)
+        assert tuple(L["sf"]) == tuple(want), "ensemble %d: superframe totals %s, oracle %s" % (b, tuple(L["sf"]), tuple(want))
+        assert not sel[b] or want[0] > 0, "ensemble %d: no superframe synchronised" % b
+    return logs
+
+
+def check_service_changes_in_mid_stream(d_factory, F=2, nf=26, snr_db=5.5, add_step=4, remove_step=8):
+    """MscHandler::addSubchannel / removeSubchannel (msc-handler.cpp:61-127) while a batch of two receivers runs: ensemble 0 plays
+    services A and B, adds D before step add_step and drops A before step remove_step; ensemble 1 plays C throughout.  The services
+    that keep playing (B, C) must not notice: their bytes and their SuperframeFilter events (dabplus_decoder.cpp:50-213: a window that
+    lives across batches) equal the uninterrupted oracle's, through both changes and the re-indexing they cause.  The new service D
+    starts like a fresh DabAudio (dab-audio.cpp:146-149): first logical frame on the 17th CIF after the add, then the oracle's frames
+    and the events of a SuperframeFilter that starts there."""
+    xs, txs = [], []
+    for e in range(2):
+        x, tx = synth.make_stream(nf, eid=0x4000 + e, snr_db=snr_db, cfo_hz=(35, -60)[e], delay=(40, 700)[e], return_tx=True, seed=90 + e,
+                                  payload_fn=synth.dabplus_payload_fn(80, 5 + e), noise_seed=78)   # (a noise sequence on which the reference's coarse corrector settles at this level)
+        xs.append(x); txs.append(tx)
+    n = min(len(x) for x in xs)
+    xs = [x[:n] for x in xs]
+    A, Bc, D = txs[0].subchs[2], txs[0].subchs[7], txs[0].subchs[12]
+    Cc = txs[1].subchs[4]
+    o0 = R.orc_receiver_run(xs[0], subchs=[A, Bc, D]); o1 = R.orc_receiver_run(xs[1], subchs=[Cc])
+    want = {"A": o0["msc"][0], "B": o0["msc"][1], "D": o0["msc"][2], "C": o1["msc"][0]}
+    d = d_factory(n_ensembles=2, max_frames=F, want_constellation=False)
+    sub = lambda s: (s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s))
+    got = {k: dict(rows=[], cifs=[], ev=[], sf=[]) for k in "ABCD"}
+    try:
+        d.stream_upload(np.stack(xs))
+        lists = [[("A", A), ("B", Bc)], [("C", Cc)]]
+        d.set_subchannels_ensemble(0, [sub(s) for _, s in lists[0]]); d.set_subchannels_ensemble(1, [sub(s) for _, s in lists[1]])
+        for step in range((nf + F - 1) // F):
+            if step == add_step:
+                lists[0] = [("A", A), ("B", Bc), ("D", D)]; d.set_subchannels_ensemble(0, [sub(s) for _, s in lists[0]])
+            if step == remove_step:
+                lists[0] = [("B", Bc), ("D", D)]; d.set_subchannels_ensemble(0, [sub(s) for _, s in lists[0]])
+            d.process(F)
+            info = d.frame_info()
+            if not (info["valid"] == 1).any():
+                break
+            for b in range(2):
+                c0 = 4 * int(info[b, 0]["frame_no"])
+                for idx, (name, sc) in enumerate(lists[b]):
+                    m, fv, nr = d.msc_ensemble(b, idx)
+                    G = got[name]
+                    base_row = len(G["rows"])
+                    for r in range(fv, nr):
+                        G["rows"].append(m[r].tobytes()); G["cifs"].append(c0 + r)
+                    ev, ne, sf = d.superframes_ensemble(b, idx, sc.bitrate)
+                    for k in range(ne):
+                        e = ev[k]
+                        # (event.cif = row of this batch; in terms of the service's own frame sequence: rows before first_valid do not count)
+                        G["ev"].append((base_row + int(e["cif"]) - fv, int(e["corrected"]), int(e["uncorrectable"]), int(e["sync"]), int(e["format"]) if e["sync"] else 0, int(e["num_aus"]) if e["sync"] else 0,
+                                        tuple(int(v) for v in e["au_start"][:e["num_aus"] + 1]) if e["sync"] else (), int(e["au_crc_ok"]) if e["sync"] else 0))
+                        if e["sync"]:
+                            G["sf"].append(sf[e["sf_slot"]].copy())
+            if step == add_step:
+                add_cif = 4 * int(info[0, 0]["frame_no"])
+    finally:
+        d.close()
+    fb = 3 * Bc.bitrate
+
+    def frames_of(buf, first=0):
+        f = np.frombuffer(bytes(buf), np.uint8)
+        return f[:len(f) // fb * fb].reshape(-1, fb)[first:]
+    for name in "BCA":
+        G = got[name]
+        rows = b"".join(G["rows"])
+        assert len(G["rows"]) >= (4 * (nf - 8) - 16 if name != "A" else 4 * F * (remove_step - 2) - 16), (name, len(G["rows"]))
+        assert rows == bytes(want[name])[:len(rows)], "service %s: bytes differ from the uninterrupted reference stream" % name
+        assert G["cifs"] == list(range(G["cifs"][0], G["cifs"][0] + len(G["cifs"]))) and G["cifs"][0] == 16, "service %s: a CIF is missing or repeated" % name
+        eo, so = R.orc_superframe_run(frames_of(want[name])[:len(G["rows"])])
+        assert G["ev"] == eo[:len(G["ev"])] and len(G["ev"]) >= len(eo) - 1 and len(eo) >= 3, "service %s: superframe events differ" % name
+        assert all(np.array_equal(G["sf"][k], so[k]) for k in range(len(G["sf"]))) and len(G["sf"]) >= 2
+    assert any(e[1] > 0 for e in got["B"]["ev"] + got["C"]["ev"]), "no byte error reached Reed-Solomon: raise the noise"
+    G = got["D"]
+    assert G["cifs"] and G["cifs"][0] == add_cif + 16, "the added service's first frame: CIF %s, expected %d" % (G["cifs"][:1], add_cif + 16)
+    assert G["cifs"] == list(range(G["cifs"][0], G["cifs"][0] + len(G["cifs"])))
+    fr = frames_of(want["D"], G["cifs"][0] - 16)
+    rows = b"".join(G["rows"])
+    assert len(G["rows"]) >= 4 * (nf - 4 - F * add_step) - 24 and rows == fr.tobytes()[:len(rows)], "added service: bytes differ"
+    eo, so = R.orc_superframe_run(fr[:len(G["rows"])])
+    assert G["ev"] == eo[:len(G["ev"])] and len(G["ev"]) >= len(eo) - 1 and len(eo) >= 2, "added service: superframe events differ"
+    return got
+
+
 def check_demod_chunks(d_factory, chunks=(1, 3, 7, 25, 38, 75), snr_db=13, seed=2, early=150):
     """explicit dabphy_config.demod_chunk values (work-groups of 7 / 25 / 75 data symbols; create() picks 25 for B x F >= 1024, the
     benchmark's case, and 15 otherwise): all 230 400 soft bits and the constellation taps equal the oracle's"""

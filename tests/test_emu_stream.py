@@ -283,3 +283,16 @@ def test_live_ring_shorter_than_the_lock(emu):
 def test_exact_batch_mode_with_different_ensembles(emu, pipeline):
     """one ensemble of three makes a batch be decoded twice: all three must still equal their own oracle runs"""
     P.check_exact_batch_mixed(factory, pipeline_sync=pipeline)
+
+
+def test_independent_ensembles_in_one_batch(emu):
+    """five ensembles, five different multiplexes, each with its own sub-channel selection (dabphy_set_subchannels_ensemble): every
+    selected sub-channel of every ensemble, FIBs and superframe totals against the oracle (the device twin runs 256 x 32)"""
+    from conftest import EMU_LIB as lib
+    P.check_mixed_layouts(capi, lib, 5, 4, check_ens=[0, 1, 2, 3, 4], n_steps=3, device="cpu", decode_shape=1, rec_frames=20)
+
+
+def test_service_added_and_removed_in_mid_stream(emu):
+    """dabphy_set_subchannels_ensemble between batches: the services that keep playing (in the changed ensemble and in the other one)
+    deliver the uninterrupted stream's bytes and superframe events; the added one starts like a fresh DabAudio"""
+    P.check_service_changes_in_mid_stream(factory)

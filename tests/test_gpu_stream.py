@@ -286,3 +286,23 @@ def test_live_ring_shorter_than_the_lock(gpu):
 def test_exact_batch_mode_with_different_ensembles(gpu, pipeline):
     """one ensemble of three makes a batch be decoded twice: all three must still equal their own oracle runs"""
     P.check_exact_batch_mixed(factory, pipeline_sync=pipeline)
+
+
+@pytest.mark.parametrize("shape", ["default", "lane", "state"])
+def test_service_added_and_removed_in_mid_stream(gpu, shape):
+    """dabphy_set_subchannels_ensemble between batches (MscHandler::addSubchannel / removeSubchannel on running receivers,
+    msc-handler.cpp:61-127): the services that keep playing -- in the changed ensemble and in the other one -- deliver the uninterrupted
+    stream's bytes and SuperframeFilter events; the added one starts like a fresh DabAudio (first frame on the 17th CIF)"""
+    P.check_service_changes_in_mid_stream({"default": factory, "lane": factory_lane_per_codeword, "state": factory_state_parallel}[shape])
+
+
+def test_service_changes_with_deep_batches(gpu):
+    """the same with eight frames per call (the 144-row build of the fused kernel; the superframe filter's wide pass)"""
+    P.check_service_changes_in_mid_stream(factory_lane_per_codeword, F=8, nf=58, add_step=2, remove_step=4)
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+def test_independent_ensembles_in_one_batch(gpu, shape):
+    """ten ensembles, five multiplexes, five selections (all / all / all / every other service / none), four frames per call, with
+    either Viterbi kernel: every selected sub-channel of every ensemble, FIBs and superframe totals against the oracle"""
+    P.check_mixed_layouts(capi, GPU_LIB, 10, 4, check_ens=list(range(10)), n_steps=3, decode_shape=shape, rec_frames=20)

@@ -68,10 +68,51 @@ def dev_protection(dev, s):
     return dev.protection_uep(s.bitrate, s.level) if s.uep is not None else dev.protection_eep(s.bitrate, s.profile_b, s.level)
 
 
+def random_layout(lib, rng, n_min=3, n_max=14, dabplus=True):
+    """a random multiplex as tools/sweep_multiplex.py draws them: n_min .. n_max sub-channels, EEP profile A at 8 .. 192 kbit/s,
+    profile B at 32 .. 192 kbit/s (levels 1-4) and rows of the UEP table, packed from CU 0"""
+    import ctypes as C
+    uep_rows = []
+    for idx in range(64):
+        size = C.c_int(0); lvl = C.c_int(0); br = C.c_int(0)
+        if lib.dabphy_uep_table_entry(idx, C.byref(size), C.byref(lvl), C.byref(br)) == 0 and 0 < br.value <= 192 and (not dabplus or br.value % 8 == 0):
+            uep_rows.append((br.value, lvl.value))
+    subchs = []; cu = 0
+    want = int(rng.randint(n_min, n_max + 1))
+    for sid in range(1, want + 1):
+        for _ in range(8):                                 # a few draws until one fits the 864 capacity units
+            kind = rng.rand()
+            if kind < 0.2:
+                br, lvl = uep_rows[int(rng.randint(len(uep_rows)))]
+                sc = uep_subchannel(lib, sid, cu, br, lvl, dabplus=dabplus)
+            elif kind < 0.45:
+                sc = synth.SubchannelCfg(sid, cu, int(rng.choice([32, 64, 96, 128, 192])), True, int(rng.randint(1, 5)), dabplus=dabplus)
+            else:
+                sc = synth.SubchannelCfg(sid, cu, int(rng.choice([8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 160, 192])), False, int(rng.randint(1, 5)), dabplus=dabplus)
+            if cu + sc.size_cu <= 864:
+                subchs.append(sc); cu += sc.size_cu
+                break
+    return subchs
+
+
+def mixed_layouts(lib, seed=2024):
+    """The multiplexes of the `mixed_layouts` workload (bench.py extras, tests): a batch of INDEPENDENT ensembles -- every receiver of
+    the reference selects its own services (msc-handler.cpp:61-127) --: the canonical one (18 x 64 kbit/s), the heterogeneous one
+    (HETERO_LAYOUT), two random ones -- of the second the receiver selects every other service --, and the canonical signal again from
+    which the receiver selects nothing (FIC only).
+    -> (transmitted sub-channels per recording, selected sub-channels per recording)"""
+    rng = np.random.RandomState(seed)
+    tx = [synth.default_subchannels(), hetero_subchannels(lib), random_layout(lib, rng), random_layout(lib, rng), synth.default_subchannels()]
+    sel = [list(tx[0]), list(tx[1]), list(tx[2]), list(tx[3][::2]), []]
+    return tx, sel
+
+
 def make_base_streams(n_distinct, n_frames=REC_FRAMES, seed0=0, subchs=None):
+    """subchs: one sub-channel list for every recording, or a list of n_distinct lists (a different multiplex per recording)"""
     out, txs = [], []
+    per_stream = subchs is not None and len(subchs) > 0 and isinstance(subchs[0], (list, tuple))
     for e in range(n_distinct):
-        tx = synth.EnsembleTx(eid=0x1000 + seed0 + e, subchs=subchs, seed=seed0 + e, payload_fn=synth.dabplus_payload_fn(4 * n_frames, seed0 + e))
+        tx = synth.EnsembleTx(eid=0x1000 + seed0 + e, subchs=subchs[e] if per_stream else subchs, seed=seed0 + e, payload_fn=synth.dabplus_payload_fn(4 * n_frames, seed0 + e))
         for _ in range(n_frames):
             tx.next_frame()
         frames = [tx.next_frame() for _ in range(n_frames)]
@@ -110,7 +151,13 @@ def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demo
         dev.stream_bind_device(iq.data_ptr(), N, N, N, loop=loop)
     else:
         dev.stream_upload(iq.numpy(), loop=loop)
-    dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_protection(dev, s)) for s in subchs])
+    if len(subchs) > 0 and isinstance(subchs[0], (list, tuple)):
+        # a batch of independent ensembles: subchs[b] = the selection of ensemble b (dabphy_set_subchannels_ensemble)
+        assert len(subchs) == B
+        for b in range(B):
+            dev.set_subchannels_ensemble(b, [(s.subch_id, s.start_cu, s.size_cu, dev_protection(dev, s)) for s in subchs[b]])
+    else:
+        dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_protection(dev, s)) for s in subchs])
     if profiling:
         dev.set_profiling(True)
     dev.set_auto_superframes(True)
