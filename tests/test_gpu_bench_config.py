@@ -69,7 +69,7 @@ def test_heterogeneous_multiplex_at_the_benchmarked_geometry(gpu):
 def test_independent_ensembles_at_the_benchmarked_geometry(gpu):
     """bench.py's `mixed_layouts` leg: 256 ensembles x 32 frames, ensemble b on multiplex b % 5 (canonical, heterogeneous, two random
     ones, canonical) with ITS OWN selection (all / all / all / every other service / none) -- what a batch of real receivers is
-    (msc-handler.cpp:61-127).  19 protection classes whose pair tables skip ensembles, code word groups that straddle pairs of
+    (msc-handler.cpp:61-127).  20 protection classes whose pair tables skip ensembles, code word groups that straddle pairs of
     different ensembles; every selected sub-channel's bytes, FIBs, correctors and superframe totals of ten ensembles spread over the
     batch (each layout at least once, first and last) against the oracle"""
     P.check_mixed_layouts(capi, GPU_LIB, 256, 32, check_ens=[0, 1, 2, 3, 4, 127, 128, 129, 253, 255], n_steps=2)
