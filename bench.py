@@ -229,6 +229,74 @@ def hetero_leg(capi, workload, torch, lib_path, B, F, steps, local, sched):
     return out
 
 
+def mixed_layouts_leg(capi, workload, torch, lib_path, B, F, steps, local, sched):
+    """A batch of INDEPENDENT ensembles, what a rack of receivers is (every receiver of the reference selects its own services,
+    msc-handler.cpp:61-127): ensemble b receives multiplex b % 5 of workload.mixed_layouts (canonical, heterogeneous, two random ones,
+    canonical) and selects ITS sub-channels (all / all / all / every other service / none) through dabphy_set_subchannels_ensemble.
+    B x F, timed after the headline; never `value`.  Parity of this very run: FIBs and the MSC bytes of EVERY selected sub-channel of one
+    ensemble per layout and of the last ensemble against the oracle on the same rows."""
+    import tempfile
+    lib = capi.load_library(lib_path)
+    tx_lists, sel_lists = workload.mixed_layouts(lib)
+    nd = len(tx_lists)
+    rec_frames = workload.rec_frames_for(F)
+    base = workload.make_base_streams(nd, rec_frames, seed0=70, subchs=tx_lists)
+    iq, cfo_hz, base_np, txs = workload.make_batch(B, rank=9, device="cuda", base=base, rec_frames=rec_frames)
+    sel = [sel_lists[b % nd] for b in range(B)]
+    dev = workload.open_receiver(capi, lib_path, iq, F, sel, device=local, pipeline_sync=sched)
+    classes = {(s.bitrate, s.profile_b, s.level, s.uep is not None) for l in sel for s in l}
+    out = {"workload": "%d ensembles x %d frames, ensemble b on multiplex b %% %d with its own selection: %s sub-channels selected (of %s transmitted), %d protection classes over the batch"
+                       % (B, F, nd, "/".join(str(len(l)) for l in sel_lists), "/".join(str(len(l)) for l in tx_lists), len(classes)),
+           "selected_subchannels": sum(len(l) for l in sel)}
+    try:
+        check = sorted(set(range(min(nd, B))) | {B - 1})
+        logs = {e: dict(fib=[], ok=[], msc=[[] for _ in sel[e]]) for e in check}
+        for W in range(3):
+            dev.process(F); sf = dev.superframes_stats()
+            if W * F < 64:
+                info = dev.frame_info(); fib, ok = dev.fibs()
+                for e in check:
+                    valid = [f for f in range(F) if info[e, f]["valid"] == 1]
+                    for f in valid:
+                        logs[e]["fib"].append(np.array(fib[e, f])); logs[e]["ok"].append(np.array(ok[e, f]))
+                    for k in range(len(sel[e])):
+                        m, fv, nr = dev.msc_ensemble(e, k)
+                        logs[e]["msc"][k].append(m[fv:nr].tobytes())
+        torch.cuda.synchronize(); t0 = time.perf_counter(); acc = {}
+        for _ in range(steps):
+            dev.process(F); sf = dev.superframes_stats(); fib, ok = dev.fibs_host()
+            for k, v in dev.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        assert np.asarray(ok).all(), "FIB CRC failures in the mixed-layout signal"
+        want_sf = np.array([len(l) * (4 * F // 5) for l in sel])
+        assert (sf[:, 2] == 0).all() and (sf[:, 3] == 0).all() and (sf[:, 0] >= want_sf).all() and (sf[want_sf == 0, 0] == 0).all(), "superframe filter: %s" % sf[:5]
+        n_cw_steps = 4 * F * sum(24 * s.bitrate + 6 for l in sel for s in l)
+        out.update(value=B * F * FRAME_S / dt, unit="x real-time", ms_per_step=dt * 1e3, stages_ms={k: v / steps for k, v in acc.items()},
+                   msc_viterbi_ms=acc.get("msc_viterbi", 0.0) / steps, demod_ms=acc.get("demod", 0.0) / steps,
+                   codeword_steps_per_s=n_cw_steps / (acc.get("msc_viterbi", 0.0) / steps * 1e-3) if acc.get("msc_viterbi") else None,
+                   launches="one fused launch for all classes of all ensembles and the FIC (dabphy_fused.hip: classes = lists of (ensemble, sub-channel) pairs)")
+        n = 0
+        for e in check:
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "rec.npy"); np.save(path, iq[e].cpu().numpy())
+                layout = os.path.join(td, "layout.json"); json.dump(workload.subchannels_to_json(sel[e]), open(layout, "w"))
+                env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+                _run_receivers([path], 1, max(2, -(-80 // rec_frames)), "port", env, td, layout=layout)
+                if sel[e]:
+                    n, m = _compare_with_receivers(td, "port", [e], logs, subch_idx=list(range(len(sel[e]))))
+                else:
+                    z = np.load(os.path.join(td, "port_0.npz")); g = logs[e]
+                    k = min(len(g["fib"]), len(z["fib"]) // 12); zf = z["fib"][:12 * k].reshape(k, 12, 33)
+                    assert k > 0 and np.array_equal(np.array(g["ok"][:k]), zf[:, :, 0]) and np.array_equal(np.array(g["fib"][:k]), zf[:, :, 1:]), "parity: FIBs of ensemble %d differ from the oracle's" % e
+        out.update(parity=True, parity_detail="FIBs + CRC flags of %d frames and the MSC bytes of every selected sub-channel of ensembles %s (one per layout, and the last) equal the oracle's (C restatement, same rows, same selection)" % (n, check))
+    except AssertionError as ex:
+        out.update(parity=False, parity_error=str(ex))
+    finally:
+        dev.close()
+    return out
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -580,6 +648,12 @@ def main():
                 line["extras"] = {"hetero": hetero_leg(capi, workload, torch, lib_path, B, F, args.steps, local, sched)}
             except Exception as ex:
                 line["extras"] = {"hetero": {"error": "%s: %s" % (type(ex).__name__, ex)}}
+            torch.cuda.empty_cache()
+            # a batch of independent ensembles: five multiplexes, five selections, interleaved over the batch
+            try:
+                line["extras"]["mixed_layouts"] = mixed_layouts_leg(capi, workload, torch, lib_path, B, F, args.steps, local, sched)
+            except Exception as ex:
+                line["extras"]["mixed_layouts"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             torch.cuda.empty_cache()
             # the latency regime: ONE ensemble, 1 / 4 / 8 / 16 frames per call, both Viterbi kernels (the default picks the state-parallel one here)
             line["extras"]["short_batches"] = _extra([os.path.join(ROOT, "tools", "sweep_decode_shape.py"), "--json"], {}, 300)
