@@ -128,10 +128,11 @@ def test_shallow_batch_above_the_state_parallel_limit(gpu):
 
 
 def test_two_kernel_decode_beyond_the_fused_kernels_reach(gpu):
-    """a handle with ring slices of 4102 frames (945 MB) per ensemble, 4 frames per call: the 5 + 1 ensembles a wave of a one-member
-    class could span lie 5.7 GB apart -- beyond the 32-bit offsets of the fused kernel's buffer resource -- so every class and the FIC
-    go through k_msc_gather / k_fic_gather + k_viterbi (64-bit addresses), and decode the same bytes"""
-    P.check_mixed_ensemble(factory_lane_per_codeword, F=4, nf=11, max_frames=4096, expect_fused=False)
+    """a handle with ring slices of 4102 frames (945 MB) per ensemble, 4 frames per call, six ensembles: the five consecutive pairs
+    a wave of a one-sub-channel-per-ensemble class spans lie in five ensembles, 4.7 GB apart -- beyond the 32-bit offsets of the fused
+    kernel's buffer resource -- so every class and the FIC go through k_msc_gather / k_fic_gather + k_viterbi (64-bit addresses), and
+    decode the same bytes"""
+    P.check_mixed_ensemble(factory_lane_per_codeword, F=4, nf=11, B=6, max_frames=4096, expect_fused=False, check_ens=(0, 3, 5))
 
 
 def test_fused_decode_of_ensembles_beyond_4_gib(gpu):

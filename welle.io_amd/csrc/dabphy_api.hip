@@ -153,13 +153,14 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->ev_fused_done) e = hipEventDestroy(h->ev_fused_done);
     { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2], &h->sp1_cls, &h->sp1_work}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
     if (h->h_sp1) e = hipHostFree(h->h_sp1);
+    if (h->h_sf_batch) e = hipHostFree(h->h_sf_batch);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
     if (h->stream) { e = hipStreamSynchronize(h->stream); e = hipStreamDestroy(h->stream); }
     for (void* p : h->owned) e = hipFree(p);
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++) { if (h->ev_beg[i]) e = hipEventDestroy(h->ev_beg[i]); if (h->ev_end[i]) e = hipEventDestroy(h->ev_end[i]); }
     DevBuf* more[] = {&h->s_raw, &h->s_raw2[0], &h->s_raw2[1], &h->s_null, &h->s_iq_own, &h->s_desc2[0], &h->s_desc2[1], &h->s_desc2[2], &h->s_soft, &h->s_cir2[0], &h->s_cir2[1], &h->s_cir2[2], &h->s_con, &h->s_mag, &h->s_snr, &h->s_fib, &h->s_ok, &h->rs_first, &h->rs_result};
     for (DevBuf* b : more) if (b->p) e = hipFree(b->p);
-    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats, &h->sf_gf, &h->sf_accept, &h->sf_run}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* sfb[] = {&h->sf_events, &h->sf_count, &h->sf_bytes, &h->sf_stats, &h->sf_gf, &h->sf_accept, &h->sf_run, &h->sf_batch}; for (DevBuf* b : sfb) if (b->p) e = hipFree(b->p); }
     { DevBuf* tb[] = {&h->s_hist, &h->tii_rot, &h->tii_rank, &h->tii_pat, &h->tii_err, &h->tii_likely, &h->tii_state, &h->tii_events, &h->tii_nev, &h->tii_ovf}; for (DevBuf* b : tb) if (b->p) e = hipFree(b->p); }
     for (auto& c : h->classes) free_class(c);
     DevBuf* bufs[] = {&h->iq, &h->soft, &h->con, &h->prs_mag, &h->snr, &h->desc, &h->in8, &h->map, &h->vsym, &h->vdec, &h->vout, &h->ok, &h->fsym, &h->fdec};

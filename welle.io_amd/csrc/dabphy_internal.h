@@ -43,6 +43,10 @@ struct DevBuf {
 
 
 constexpr int HIST_CAP = 64;     // window searches remembered per ensemble for the sLevel replay
+// superframe filter launches (dabphy_superframes.hip): a class to walk and which of its pairs (DEVICE list; nullptr: all of them)
+struct SfSel { int cls; const int32_t* d_run; int n_run; };
+constexpr int SF_BATCH_CLASSES = 256;                                                        // classes per bucket (a handle has at most 255)
+constexpr size_t SF_BATCH_BYTES = 3 * (SF_BATCH_CLASSES * sizeof(SfArgs) + (SF_BATCH_CLASSES + 1) * sizeof(int32_t) + 12);
 } // namespace dabphy
 using namespace dabphy;          // (internal header: the handle below names the kernels' argument blocks)
 
@@ -74,6 +78,7 @@ struct dabphy_handle {
         DevBuf map, pair_tab, tiles, out;    // depuncture map, the pair table, gather tiles, decoded bytes [pair][4F][nbits/8]
         DevBuf steps[FUSED_VARIANTS]; int n_windows[FUSED_VARIANTS] = {0, 0, 0};   // fused decode (k_viterbi_fused): per-step window-ring descriptors for each row-count build (0 windows: not decodable that way)
         DevBuf sf_state;                     // SuperframeFilter window of every pair
+        size_t sf_pair0 = 0, sf_bytes0 = 0;  // this class's region of the filter's shared event / count / verdict buffers (in pairs) and of its superframe buffer (in bytes): prepare_superframes
         DevBuf sf_snap;                      // ... as it was in front of the current batch (exact batch mode)
         bool dabplus_rate() const { return (prot.nbits / 24) % 8 == 0 && prot.nbits / 8 >= 10; }
         size_t sf_stride() const { return ((size_t)16 + 5 * (size_t)(prot.nbits / 8) + 15) & ~(size_t)15; }
@@ -90,6 +95,7 @@ struct dabphy_handle {
     std::vector<std::vector<PairRef>> where;                             // [n_ensembles][position in the list] -> class, pair
     bool subch_dirty = false;
     std::vector<MscClass> classes;
+    DevBuf sf_batch; void* h_sf_batch = nullptr;                         // argument blocks of the filter's per-bucket launches (device, page-locked staging)
     DevBuf sf_run;                                                       // pair selections of one-sub-channel superframe filter launches
     DevBuf s_raw;                           // staging of raw-format samples (dabphy_stream_write_raw)
     DevBuf s_raw2[2]; hipStream_t copy_stream = nullptr; hipEvent_t ev_ingest[2] = {nullptr, nullptr}; int raw_sel = 0;   // dabphy_stream_write_raw_async
@@ -231,8 +237,8 @@ DABPHY_INTERNAL SyncArgs sync_args(dabphy_handle* h, int sel, uint32_t F, uint64
 DABPHY_INTERNAL void launch_serial_chain(dabphy_handle* h, SyncArgs sa);
 DABPHY_INTERNAL int queue_chain(dabphy_handle* h, int sel, uint32_t F);
 DABPHY_INTERNAL int resolve_chain(dabphy_handle* h, int sel);
-DABPHY_INTERNAL int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F);       // dabphy_superframes.hip
-DABPHY_INTERNAL int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, const int32_t* d_run, int n_run, int32_t* stats, hipStream_t st = nullptr);   // d_run = nullptr: every pair
+DABPHY_INTERNAL int prepare_superframes(dabphy_handle* h, uint32_t F);       // dabphy_superframes.hip
+DABPHY_INTERNAL int run_superframes(dabphy_handle* h, const std::vector<dabphy::SfSel>& sel, int32_t* stats, hipStream_t st = nullptr);
 DABPHY_INTERNAL int apply_subchannels(dabphy_handle* h);                                          // dabphy_api.hip
 DABPHY_INTERNAL int upload_pairs(dabphy_handle* h, dabphy_handle::MscClass& cls);
 DABPHY_INTERNAL void free_class(dabphy_handle::MscClass& c);

@@ -293,7 +293,10 @@ struct SfArgs {
     int32_t* accepted;                            // [n_pairs]: set by the wide pass for what it settled (nullptr: serial walk only)
     unsigned long long* wide_stats;               // [2]: pair batches the wide pass settled / was tried on
 };
-void launch_superframe(const SfArgs& a, hipStream_t s);
+// the classes of one launch (k_rs.hip): cls = DEVICE array of n_cls argument blocks, first = DEVICE array [n_cls + 1] of first blocks
+struct SfBatch { const SfArgs* cls; const int32_t* first; int n_cls; };
+inline int sf_bucket(int frame_bytes) { const int sf_len = 5 * frame_bytes; return sf_len <= 960 ? 0 : sf_len <= 2880 ? 1 : 2; }
+void launch_superframe_bucket(const SfBatch& Bt, int bucket, int total_blocks, int n_cif, bool wide_pass, hipStream_t s);
 void launch_rs_superframes(const RsArgs& a, hipStream_t s);
 void launch_rs_msc(const RsMscArgs& a, hipStream_t s);
 

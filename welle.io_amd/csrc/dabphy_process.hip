@@ -58,8 +58,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         for (auto& cls : h->classes) {
             const size_t n_groups = ((size_t)4 * F * cls.pairs.size() + 63) / 64;
             if ((r = ensure(h, cls.out, n_groups * 64 * (cls.prot.nbits / 8)))) return r;
-            if (h->sf_auto && (r = prepare_superframes(h, cls, F))) return r;
         }
+        if (h->sf_auto && (r = prepare_superframes(h, F))) return r;
         // (the replay of exact batch mode decodes one frame's FIC at a time, state-parallel when 4 B code words are few: its buffers now)
         if (h->exact_batch && F > 1 && sp_single_ok(h, (uint64_t)B * 4, fic_c.nsteps) && (r = sp_single_reserve(h, (uint64_t)B * 4, fic_c.nsteps))) return r;
         // the fused decode of this batch depth: which classes (and whether the FIC) ride in the one launch; its decision scratch

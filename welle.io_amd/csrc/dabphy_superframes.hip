@@ -4,23 +4,35 @@
 
 extern "C" {
 
-// device buffers of the superframe filter for one class and F frames per batch (the window state of a class is created with the class,
-// apply_subchannels, which also carries the windows of the services that stay)
-int prepare_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, uint32_t F)
+// Device buffers of the superframe filter for F frames per batch: every DAB+-rate class gets its own region of the event / count /
+// superframe / verdict buffers (all classes of a bucket run in one launch); the window state of a class is created with the class
+// (apply_subchannels, which also carries the windows of the services that stay).
+int prepare_superframes(dabphy_handle* h, uint32_t F)
 {
-    const int fb = cls.prot.nbits / 8;
-    const size_t P = cls.pairs.size();
-    if (!cls.dabplus_rate()) return 0;                                   // not a DAB+ rate: the filter never runs on this class
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
+    size_t pairs = 0, bytes = 0;
     int r;
-    if (cls.sf_state.cap < cls.sf_stride() * P) {
-        if ((r = ensure(h, cls.sf_state, cls.sf_stride() * P))) return r;
-        HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
+    for (auto& cls : h->classes) {
+        if (!cls.dabplus_rate()) continue;
+        const size_t P = cls.pairs.size();
+        cls.sf_pair0 = pairs; cls.sf_bytes0 = bytes;
+        pairs += P; bytes += P * n_slots * 5 * (size_t)(cls.prot.nbits / 8);
+        if (cls.sf_state.cap < cls.sf_stride() * P) {
+            if ((r = ensure(h, cls.sf_state, cls.sf_stride() * P))) return r;
+            HIPCHK(h, hipMemsetAsync(cls.sf_state.p, 0, cls.sf_state.cap, h->stream));      // frame_count = 0: nothing collected yet
+        }
     }
-    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * P * n_cif))) return r;
-    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * P))) return r;
-    if ((r = ensure(h, h->sf_bytes, P * n_slots * 5 * fb))) return r;
-    if ((r = ensure(h, h->sf_accept, sizeof(int32_t) * P))) return r;
+    if (!pairs) return 0;
+    if ((r = ensure(h, h->sf_events, sizeof(SfEvent) * pairs * n_cif))) return r;
+    if ((r = ensure(h, h->sf_count, sizeof(int32_t) * pairs))) return r;
+    if ((r = ensure(h, h->sf_bytes, bytes))) return r;
+    if ((r = ensure(h, h->sf_accept, sizeof(int32_t) * pairs))) return r;
+    if ((r = ensure(h, h->sf_batch, SF_BATCH_BYTES))) return r;
+    if (!h->h_sf_batch) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, SF_BATCH_BYTES, hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc failed (superframe filter staging)"; return DABPHY_ERR_NOMEM; }
+        h->h_sf_batch = p;
+    }
     if (!h->sf_gf.p) {
         // GF(256) of RS(120,110), generator polynomial 0x11D (init_rs.h:48-60): alpha_to[256], index_of[256]  (built once, thread-safely:
         // the node receiver creates its handles from several host threads)
@@ -101,53 +113,88 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
     return sync(h);
 }
 
-// launches k_superframe for one class over the pairs d_run[0 .. n_run) (DEVICE pointer), or over every pair of the class (nullptr)
-int run_superframes(dabphy_handle* h, dabphy_handle::MscClass& cls, const int32_t* d_run, int n_run, int32_t* stats, hipStream_t st)
+// The filter over a selection of classes: sel[i] = (class, DEVICE list of its pairs to walk or nullptr for all of them, how many).  The
+// classes of a bucket (kernel LDS size) go in ONE launch each of the wide pass, the verdict and the serial walk; their argument blocks
+// travel through a page-locked staging area that the caller must not reuse before the stream has been synchronised (every caller
+// synchronises before it returns, dabphy_process at its end).
+int run_superframes(dabphy_handle* h, const std::vector<SfSel>& sel, int32_t* stats, hipStream_t st)
 {
     const uint32_t F = h->last_frames;
-    const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8;
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
     int r;
-    if ((r = prepare_superframes(h, cls, F))) return r;
-    SfArgs a{};
-    a.out = cls.out.as<uint8_t>(); a.n_cif = n_cif; a.n_pairs = (int)cls.pairs.size(); a.pairs = cls.pair_tab.as<MscPair>(); a.frame_bytes = fb;
-    a.run = d_run; a.n_run = d_run ? n_run : a.n_pairs;
-    a.s = bitrate / 8; a.desc = h->last_desc; a.n_frames = (int)F;
-    a.state = cls.sf_state.as<uint8_t>(); a.state_stride = cls.sf_stride(); a.events = h->sf_events.as<SfEvent>(); a.n_events = h->sf_count.as<int32_t>();
-    a.sf = h->sf_bytes.as<uint8_t>(); a.n_slots = n_slots; a.stats = stats;
-    a.gf = h->sf_gf.as<uint8_t>(); a.accepted = h->sf_accept.as<int32_t>();
-    a.wide_stats = reinterpret_cast<unsigned long long*>(h->sf_gf.as<uint8_t>() + 512);
-    launch_superframe(a, st ? st : h->stream);
+    if ((r = prepare_superframes(h, F))) return r;
+    if (!h->sf_batch.p) return 0;                                        // no DAB+-rate class at all
+    if (!st) st = h->stream;
+    // staging layout per bucket: [SF_BATCH_CLASSES argument blocks][SF_BATCH_CLASSES + 1 first blocks]
+    uint8_t* const hs = reinterpret_cast<uint8_t*>(h->h_sf_batch);
+    uint8_t* const ds = h->sf_batch.as<uint8_t>();
+    constexpr size_t BUCKET = SF_BATCH_BYTES / 3, FIRST0 = SF_BATCH_CLASSES * sizeof(SfArgs);
+    int n_in[3] = {0, 0, 0}, blocks[3] = {0, 0, 0};
+    for (const SfSel& e : sel) {
+        auto& cls = h->classes[e.cls];
+        if (!cls.dabplus_rate() || cls.pairs.empty()) continue;
+        const int bitrate = cls.prot.nbits / 24, fb = cls.prot.nbits / 8, bk = sf_bucket(fb);
+        SfArgs a{};
+        a.out = cls.out.as<uint8_t>(); a.n_cif = n_cif; a.n_pairs = (int)cls.pairs.size(); a.pairs = cls.pair_tab.as<MscPair>(); a.frame_bytes = fb;
+        a.run = e.d_run; a.n_run = e.d_run ? e.n_run : a.n_pairs;
+        if (a.n_run <= 0) continue;
+        a.s = bitrate / 8; a.desc = h->last_desc; a.n_frames = (int)F;
+        a.state = cls.sf_state.as<uint8_t>(); a.state_stride = cls.sf_stride();
+        a.events = h->sf_events.as<SfEvent>() + cls.sf_pair0 * n_cif; a.n_events = h->sf_count.as<int32_t>() + cls.sf_pair0;
+        a.sf = h->sf_bytes.as<uint8_t>() + cls.sf_bytes0; a.n_slots = n_slots; a.stats = stats;
+        a.gf = h->sf_gf.as<uint8_t>(); a.accepted = h->sf_accept.as<int32_t>() + cls.sf_pair0;
+        a.wide_stats = reinterpret_cast<unsigned long long*>(h->sf_gf.as<uint8_t>() + 512);
+        reinterpret_cast<SfArgs*>(hs + bk * BUCKET)[n_in[bk]] = a;
+        reinterpret_cast<int32_t*>(hs + bk * BUCKET + FIRST0)[n_in[bk]] = blocks[bk];
+        n_in[bk]++; blocks[bk] += a.n_run;
+    }
+    for (int bk = 0; bk < 3; bk++) {
+        if (!n_in[bk]) continue;
+        reinterpret_cast<int32_t*>(hs + bk * BUCKET + FIRST0)[n_in[bk]] = blocks[bk];
+        HIPCHK(h, hipMemcpyAsync(ds + bk * BUCKET, hs + bk * BUCKET, n_in[bk] * sizeof(SfArgs), hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(ds + bk * BUCKET + FIRST0, hs + bk * BUCKET + FIRST0, (n_in[bk] + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    for (int bk = 0; bk < 3; bk++) {
+        if (!n_in[bk]) continue;
+        SfBatch bt{}; bt.cls = reinterpret_cast<const SfArgs*>(ds + bk * BUCKET); bt.first = reinterpret_cast<const int32_t*>(ds + bk * BUCKET + FIRST0); bt.n_cls = n_in[bk];
+        launch_superframe_bucket(bt, bk, blocks[bk], n_cif, true, st);
+    }
     return 0;
 }
 
 namespace {
-// The filter over a selection of pairs (class, pair) given per output row: rows of one class go in one launch; events / counts /
-// superframes of row i land at events + i * n_cif, n_events + i, sf + i * n_slots * 5 * fb.  Every selected pair must have frames of fb bytes.
+// The filter over a selection of pairs (class, pair) given per output row; events / counts / superframes of row i land at
+// events + i * n_cif, n_events + i, sf + i * n_slots * 5 * fb.  Every selected pair must have frames of fb bytes.
 int superframes_of(dabphy_handle* h, const std::vector<dabphy_handle::PairRef>& rows, int fb, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf)
 {
     const uint32_t F = h->last_frames;
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
     int r;
+    if ((r = prepare_superframes(h, F))) return r;
     std::vector<int32_t> run(rows.size());
     if ((r = ensure(h, h->sf_run, rows.size() * sizeof(int32_t)))) return r;
+    std::vector<SfSel> sel; std::vector<std::vector<size_t>> mine_of;
+    size_t used = 0;
     for (size_t ci = 0; ci < h->classes.size(); ci++) {
-        auto& cls = h->classes[ci];
         std::vector<size_t> mine;
         for (size_t i = 0; i < rows.size(); i++) if (rows[i].cls == (int)ci) mine.push_back(i);
         if (mine.empty()) continue;
-        for (size_t k = 0; k < mine.size(); k++) run[k] = rows[mine[k]].pair;
-        HIPCHK(h, hipMemcpyAsync(h->sf_run.p, run.data(), mine.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        if ((r = run_superframes(h, cls, h->sf_run.as<int32_t>(), (int)mine.size(), nullptr))) return r;
-        for (size_t k = 0; k < mine.size(); k++) {
-            const size_t i = mine[k], bm = (size_t)rows[i].pair;
-            HIPCHK(h, hipMemcpyAsync(events + i * n_cif, h->sf_events.as<SfEvent>() + bm * n_cif, sizeof(SfEvent) * n_cif, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(n_events + i, h->sf_count.as<int32_t>() + bm, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            if (sf) HIPCHK(h, hipMemcpyAsync(sf + i * n_slots * 5 * fb, h->sf_bytes.as<uint8_t>() + bm * n_slots * 5 * fb, (size_t)n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
-        }
-        if ((r = sync(h))) return r;             // (the selection and the shared event buffers are reused by the next class)
+        for (size_t k = 0; k < mine.size(); k++) run[used + k] = rows[mine[k]].pair;
+        sel.push_back(SfSel{(int)ci, h->sf_run.as<int32_t>() + used, (int)mine.size()});
+        used += mine.size(); mine_of.push_back(std::move(mine));
     }
-    return DABPHY_OK;
+    HIPCHK(h, hipMemcpyAsync(h->sf_run.p, run.data(), used * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if ((r = run_superframes(h, sel, nullptr, h->stream))) return r;
+    for (size_t s = 0; s < sel.size(); s++) {
+        const auto& cls = h->classes[sel[s].cls];
+        for (size_t i : mine_of[s]) {
+            const size_t bm = (size_t)rows[i].pair;
+            HIPCHK(h, hipMemcpyAsync(events + i * n_cif, h->sf_events.as<SfEvent>() + (cls.sf_pair0 + bm) * n_cif, sizeof(SfEvent) * n_cif, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(n_events + i, h->sf_count.as<int32_t>() + cls.sf_pair0 + bm, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            if (sf) HIPCHK(h, hipMemcpyAsync(sf + i * n_slots * 5 * fb, h->sf_bytes.as<uint8_t>() + cls.sf_bytes0 + bm * n_slots * 5 * fb, (size_t)n_slots * 5 * fb, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    return sync(h);                  // (`run` and the staging area are free again)
 }
 }
 
@@ -180,21 +227,19 @@ int dabphy_superframes_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t su
     return superframes_of(h, rows, cls.prot.nbits / 8, events, n_events, sf);
 }
 
-// SuperframeFilter over every DAB+ sub-channel of every ensemble: one launch per protection class on the main stream, totals into sf_stats
+// SuperframeFilter over every DAB+ sub-channel of every ensemble: the classes of a bucket in one launch each on the main stream, totals into sf_stats
 int launch_superframe_stats(dabphy_handle* h)
 {
     const uint32_t B = h->cfg.n_ensembles;
     int r;
     if ((r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
     HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));
-    bool first_launch = true;
-    for (auto& cls : h->classes) {
-        if (!cls.dabplus_rate()) continue;
-        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
-        if ((r = run_superframes(h, cls, nullptr, 0, h->sf_stats.as<int32_t>()))) return r;
-        if (h->profiling && first_launch) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
-        first_launch = false;
-    }
+    std::vector<SfSel> sel;
+    for (size_t ci = 0; ci < h->classes.size(); ci++) if (h->classes[ci].dabplus_rate()) sel.push_back(SfSel{(int)ci, nullptr, 0});
+    if (sel.empty()) return 0;
+    if (h->profiling) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
+    if ((r = run_superframes(h, sel, h->sf_stats.as<int32_t>(), h->stream))) return r;
+    if (h->profiling) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
     return 0;
 }
 

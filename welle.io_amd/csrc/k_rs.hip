@@ -388,16 +388,29 @@ __device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t 
 // walk makes exactly these attempts on exactly these windows -- and does what the walk does at its end; every other (ensemble, sub-channel) pair
 // is walked by k_superframe from the untouched state, as before.  The state machine's 26 dependent attempts per batch were this
 // stage's whole time: 0.8 ms of a mostly idle device per step.
-template <int SF_MAX>
-__global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
+// Every class of a bucket (same LDS size) in ONE launch: block -> (class, its block) through the bucket's table of first blocks; the class's
+// argument block comes from HBM.  A real multiplex has a handful of protection classes, a batch of independent ensembles a few dozen:
+// one launch per class and kernel was 60 dependent launches of a few work-groups each at the end of every step.
+__device__ __forceinline__ SfArgs sf_args_of(const SfBatch& Bt, uint32_t& bx)
 {
+    int c = 0;
+    while (c + 1 < Bt.n_cls && bx >= (uint32_t)Bt.first[c + 1]) c++;
+    bx -= (uint32_t)Bt.first[c];
+    return Bt.cls[c];
+}
+
+template <int SF_MAX>
+__global__ void __launch_bounds__(64) k_superframe_wide(SfBatch Bt)
+{
+    uint32_t bx = blockIdx.x;
+    const SfArgs A = sf_args_of(Bt, bx);
     __shared__ __attribute__((aligned(16))) uint8_t s_sf[SF_MAX];
     __shared__ __attribute__((aligned(16))) uint8_t alpha_to[256], index_of[256];
     __shared__ SfShared sh;
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];
     const int t = threadIdx.x, q = (int)blockIdx.y;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
-    const size_t bm = A.run ? (size_t)A.run[blockIdx.x] : (size_t)blockIdx.x;      // the pair
+    const size_t bm = A.run ? (size_t)A.run[bx] : (size_t)bx;      // the pair
     const uint8_t* st = A.state + bm * A.state_stride;
     const SfPlan p = sf_plan(A, A.pairs[bm], st);
     if (q >= p.nq) return;
@@ -420,13 +433,15 @@ __global__ void __launch_bounds__(64) k_superframe_wide(SfArgs A)
     }
 }
 
-__global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
+__global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
 {
+    uint32_t bx = blockIdx.x;
+    const SfArgs A = sf_args_of(Bt, bx);
     __shared__ uint16_t s_crctab[256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
     const int t = threadIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
-    const size_t bm = A.run ? (size_t)A.run[blockIdx.x] : (size_t)blockIdx.x;      // the pair
+    const size_t bm = A.run ? (size_t)A.run[bx] : (size_t)bx;      // the pair
     const int b = A.pairs[bm].ens;
     uint8_t* st = A.state + bm * A.state_stride;
     const SfPlan p = sf_plan(A, A.pairs[bm], st);
@@ -464,8 +479,10 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfArgs A)
 // frame with the reference's state machine -- 5-frame sliding window, Reed-Solomon on a copy, Fire-code / AU-table check, AU CRCs, and
 // after a hit a fresh window -- carrying frame_count + the raw window to the next batch.  Runs for what the wide pass did not settle.
 template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
-__global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2) k_superframe(SfArgs A)
+__global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2) k_superframe(SfBatch Bt)
 {
+    uint32_t bx = blockIdx.x;
+    const SfArgs A = sf_args_of(Bt, bx);
     // LDS: the raw 5-frame window (a ring: `head` = oldest frame, nothing is ever shifted) and the working copy
     __shared__ __attribute__((aligned(16))) uint8_t s_dyn[2 * SF_MAX];
     __shared__ __attribute__((aligned(16))) uint8_t alpha_to[256], index_of[256];
@@ -474,7 +491,7 @@ __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2
     __shared__ uint8_t s_ws[8 * RS_WS_BYTES];                   // error-path workspaces of the eight code words decoded at a time
     __shared__ uint16_t s_crctab[256];                          // CRC-16-CCITT (0x1021), one byte per step: the AU checks
     const int t = threadIdx.x;
-    const size_t bm = A.run ? (size_t)A.run[blockIdx.x] : (size_t)blockIdx.x;      // the pair
+    const size_t bm = A.run ? (size_t)A.run[bx] : (size_t)bx;      // the pair
     const int b = A.pairs[bm].ens;
     if (A.accepted && A.accepted[bm]) return;                  // settled by the wide pass
     sf_tables(A, alpha_to, index_of, s_crctab, t);
@@ -554,22 +571,23 @@ __global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2
     }
 }
 
-void launch_superframe(const SfArgs& a, hipStream_t s)
+// bucket = index of the kernels' LDS size (superframes of <= 960 / <= 2880 / <= 5760 bytes: <= 64 / 192 / 384 kbit/s); Bt.cls are the
+// classes of that bucket (DEVICE array), total_blocks = Bt.first[n_cls] (known to the host), n_cif = CIFs per batch, wide = run the wide pass
+void launch_superframe_bucket(const SfBatch& Bt, int bucket, int total_blocks, int n_cif, bool wide_pass, hipStream_t s)
 {
-    if (a.n_run <= 0) return;
-    const dim3 grid(a.n_run);
-    const int sf_len = 5 * a.frame_bytes;
-    if (a.accepted) {
+    if (total_blocks <= 0) return;
+    const dim3 grid(total_blocks);
+    if (wide_pass) {
         // the wide pass: every attempt a locked receiver makes in this batch at once, then the verdict per (ensemble, sub-channel) pair
-        const dim3 wide(grid.x, (a.n_cif + 4) / 5);
-        if (sf_len <= 960) hipLaunchKernelGGL(k_superframe_wide<960>, wide, dim3(64), 0, s, a);
-        else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe_wide<2880>, wide, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(k_superframe_wide<5760>, wide, dim3(64), 0, s, a);
-        hipLaunchKernelGGL(k_superframe_settle, grid, dim3(64), 0, s, a);
+        const dim3 wide(grid.x, (n_cif + 4) / 5);
+        if (bucket == 0) hipLaunchKernelGGL(k_superframe_wide<960>, wide, dim3(64), 0, s, Bt);
+        else if (bucket == 1) hipLaunchKernelGGL(k_superframe_wide<2880>, wide, dim3(64), 0, s, Bt);
+        else hipLaunchKernelGGL(k_superframe_wide<5760>, wide, dim3(64), 0, s, Bt);
+        hipLaunchKernelGGL(k_superframe_settle, grid, dim3(64), 0, s, Bt);
     }
-    if (sf_len <= 960) hipLaunchKernelGGL(k_superframe<960>, grid, dim3(64), 0, s, a);            // <= 64 kbit/s
-    else if (sf_len <= 2880) hipLaunchKernelGGL(k_superframe<2880>, grid, dim3(64), 0, s, a);     // <= 192 kbit/s
-    else hipLaunchKernelGGL(k_superframe<5760>, grid, dim3(64), 0, s, a);                         // <= 384 kbit/s
+    if (bucket == 0) hipLaunchKernelGGL(k_superframe<960>, grid, dim3(64), 0, s, Bt);            // <= 64 kbit/s
+    else if (bucket == 1) hipLaunchKernelGGL(k_superframe<2880>, grid, dim3(64), 0, s, Bt);     // <= 192 kbit/s
+    else hipLaunchKernelGGL(k_superframe<5760>, grid, dim3(64), 0, s, Bt);                       // <= 384 kbit/s
 }
 
 void launch_rs_superframes(const RsArgs& a, hipStream_t s)
