@@ -66,6 +66,21 @@ def check_fic(d, n_frames, snr_db, seed):
     return int(ok.sum())
 
 
+def check_fic_arbitrary_int8(d, n_frames=3, seed=17):
+    """dabphy_fic_decode takes the caller's soft bits: any int8, -128 included -- which the reference's symbol mapping clamps like -127
+    (viterbi.cpp:233-236).  Random bytes (no FIB passes its CRC: the decoded BYTES are the check), either Viterbi kernel"""
+    rng = np.random.RandomState(seed)
+    s = rng.randint(-128, 128, (n_frames, 9216)).astype(np.int8)
+    s[:, ::7] = -128
+    fib, ok, ratio = d.fic_decode(s)
+    r = 0
+    for f in range(n_frames):
+        b, k, r10 = R.orc_fic_decode(s[f], r)
+        r = r10 // 10
+        assert np.array_equal(ok[f], k)
+        assert np.array_equal(fib[f], np.packbits(b, axis=1)), "frame %d: FIB bytes of arbitrary int8 input differ" % f
+
+
 def check_demod(d, n_frames, snr_db, seed, early=100):
     x = synth.make_stream(n_frames + 1, snr_db=snr_db, seed=seed)
     frames = cut_frames(x, n_frames, early)

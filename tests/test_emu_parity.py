@@ -20,6 +20,10 @@ def test_fic(emu):
     assert P.check_fic(emu, 3, snr_db=9, seed=4) > 0
 
 
+def test_fic_arbitrary_int8(emu):
+    P.check_fic_arbitrary_int8(emu)
+
+
 def test_demod(emu):
     P.check_demod(emu, 2, snr_db=14, seed=2)
 
@@ -51,6 +55,7 @@ def test_seams_state_parallel(emu):
         P.check_msc_deconvolve(d, "eep", 32, 1, 1, 4, seed=10)
         P.check_msc_deconvolve(d, "uep", 80, 1, 0, 3, seed=11)
         assert P.check_fic(d, 3, 14, seed=12) > 0
+        P.check_fic_arbitrary_int8(d)                                     # -128 through kind 1 (round 4 clamped only kind 2: ADVICE)
     finally:
         d.close()
 

@@ -104,6 +104,7 @@ def test_seams_with_either_decoder(gpu, shape):
         P.check_msc_deconvolve(d, "eep", 64, 0, 3, 40, seed=9)
         P.check_msc_deconvolve(d, "uep", 80, 1, 0, 30, seed=11)
         assert P.check_fic(d, 5, 14, seed=12) > 0
+        P.check_fic_arbitrary_int8(d, n_frames=7)                         # -128 through the FIC seam, whichever kernel takes it
     finally:
         d.close()
 

@@ -151,7 +151,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     if (h->ev_fused_done) e = hipEventDestroy(h->ev_fused_done);
-    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2], &h->sp1_cls, &h->sp1_work}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fused_dec_off, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2], &h->sp1_cls, &h->sp1_work}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
     if (h->h_sp1) e = hipHostFree(h->h_sp1);
     if (h->h_sf_batch) e = hipHostFree(h->h_sf_batch);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }

@@ -138,18 +138,25 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     if (cls.size() > 255) { h->err = "more than 255 protection classes"; return DABPHY_ERR_INVALID; }
     // longest code words first: the waves that pull the long groups start them while every slot is still busy, the short ones fill the end
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.nsteps > b.nsteps; });
-    std::vector<uint32_t> work;
+    std::vector<uint32_t> work, item_off;
+    uint64_t item_rows = 0;                          // decision rows ([64 lanes] cells) of all groups together
     for (const Item& it : items) {
         if (it.n_groups > 0xffffff) { h->err = "class too large for the fused decode's work list"; return DABPHY_ERR_INVALID; }
-        for (int g = 0; g < it.n_groups; g++) work.push_back(((uint32_t)it.ci << 24) | (uint32_t)g);
+        for (int g = 0; g < it.n_groups; g++) { work.push_back(((uint32_t)it.ci << 24) | (uint32_t)g); item_off.push_back((uint32_t)item_rows); item_rows += (uint64_t)it.nsteps; }
     }
     const int slots = fused_wave_slots(v);
     // (state-parallel: one work-group per code word slot of every listed group, each with its own decision scratch)
     const int n_slots = use_sp ? (int)work.size() * 64 : (int)std::min<size_t>(work.size(), (size_t)slots);
     const int sp_variant = sp_variant_for((int)max_steps);
+    // Decision scratch of the lane-per-code-word kernel: one region per WORK-GROUP sized for the longest code word of the launch (reused by
+    // every group the wave pulls: the headline's shape) -- unless a few very long code words ride among many short ones (one 384 kbit/s
+    // service in a multiplex of small ones: 9222 steps x 5120 waves = 24 GB): then one region per GROUP, each of its own length.
+    const bool dec_by_item = !use_sp && item_rows < (uint64_t)n_slots * max_steps && item_rows < 0xffffffffull;
     int r;
     if (!work.empty()) {
-        if ((r = ensure(h, h->vdec, (size_t)n_slots * (use_sp ? (max_steps / 30 + 1) * 32 : max_steps * 64) * sizeof(uint2)))) return r;
+        const size_t dec_cells = use_sp ? (size_t)n_slots * (max_steps / 30 + 1) * 32 : dec_by_item ? (size_t)item_rows * 64 : (size_t)n_slots * max_steps * 64;
+        if ((r = ensure(h, h->vdec, dec_cells * sizeof(uint2)))) return r;
+        if (dec_by_item && (r = ensure(h, h->fused_dec_off, item_off.size() * sizeof(uint32_t)))) return r;
         if ((r = ensure(h, h->fused_cls, cls.size() * sizeof(FusedClass)))) return r;
         if ((r = ensure(h, h->fused_work, work.size() * sizeof(uint32_t)))) return r;
         if (!h->d_fused_next) {
@@ -160,7 +167,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     }
     const bool same_cls = P.valid && P.buf_gen == h->buf_gen && P.host_cls.size() == cls.size() &&
                           (cls.empty() || !memcmp(P.host_cls.data(), cls.data(), cls.size() * sizeof(FusedClass)));
-    const bool same_work = P.valid && P.buf_gen == h->buf_gen && P.host_work == work;
+    const bool same_work = P.valid && P.buf_gen == h->buf_gen && P.host_work == work && P.dec_by_item == dec_by_item;
     // (an earlier upload may still be reading the plan's host vectors -- a pageable source is not always staged before the call returns --:
     // nothing is replaced under it.  The stream is idle here except inside a call that plans twice.)
     if (P.valid && (!same_cls || !same_work)) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -169,12 +176,13 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         if (!cls.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_cls.p, P.host_cls.data(), cls.size() * sizeof(FusedClass), hipMemcpyHostToDevice, h->stream));
     }
     if (!same_work) {
-        P.host_work = work;
+        P.host_work = work; P.host_dec_off = item_off;
         if (!work.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_work.p, P.host_work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        if (!work.empty() && dec_by_item) HIPCHK(h, hipMemcpyAsync(h->fused_dec_off.p, P.host_dec_off.data(), item_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     }
-    if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: decode plan for %u frames per call: %s, %zu of %zu classes%s, %zu groups, %d work-groups\n", F, use_sp ? "state-parallel" : "lane-per-code-word", idx.size(), h->classes.size(), fic_in ? " + FIC" : "", work.size(), n_slots);
+    if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: decode plan for %u frames per call: %s, %zu of %zu classes%s, %zu groups, %d work-groups, decision scratch %s\n", F, use_sp ? "state-parallel" : "lane-per-code-word", idx.size(), h->classes.size(), fic_in ? " + FIC" : "", work.size(), n_slots, dec_by_item ? "per group" : "per work-group");
     P.valid = true; P.F = F; P.want_fic = want_fic; P.fic_in = fic_in; P.variant = v; P.n_slots = n_slots;
-    P.use_sp = use_sp; P.sp_variant = sp_variant;
+    P.use_sp = use_sp; P.sp_variant = sp_variant; P.dec_by_item = dec_by_item;
     P.dec_slot_cells = use_sp ? (max_steps / 30 + 1) * 32 : max_steps * 64;      // (state-parallel: one 256-byte row of history words per 30 steps)
     P.class_idx = idx; P.buf_gen = h->buf_gen;
     FusedArgs a{};
@@ -182,6 +190,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     a.desc = nullptr;                                  // (set per batch: the descriptor buffers rotate)
     a.cls = h->fused_cls.as<FusedClass>(); a.work = h->fused_work.as<uint32_t>(); a.n_work = (uint32_t)work.size(); a.next = h->d_fused_next;
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = P.dec_slot_cells; a.prbs_words = h->d_prbs_words;
+    a.dec_off = dec_by_item ? h->fused_dec_off.as<uint32_t>() : nullptr;
     P.args = a;
     return DABPHY_OK;
 }
@@ -191,6 +200,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
 bool sp_single_ok(const dabphy_handle* h, uint64_t n_cw, int nsteps)
 {
     if (!h->fused_msc || h->cfg.decode_shape == 1 || nsteps % 6 != 0 || nsteps > SP_MAXSTEPS[SP_VARIANTS - 1]) return false;
+    if (n_cw > (uint64_t)SP_SINGLE_MAX_GROUPS * 64) return false;        // beyond the one-class launch's work list: the two-kernel path decodes it
     return h->cfg.decode_shape == 2 || (h->sp_max_codewords > 0 && n_cw <= h->sp_max_codewords);
 }
 
@@ -203,15 +213,15 @@ int sp_single_reserve(dabphy_handle* h, uint64_t n_cw, int nsteps)
 {
     const uint64_t n_groups = (n_cw + 63) / 64;
     int r;
-    if (n_groups > 4096) { h->err = "one-class state-parallel launch: too many groups"; return DABPHY_ERR_INVALID; }
+    if (n_groups > (uint64_t)SP_SINGLE_MAX_GROUPS) { h->err = "one-class state-parallel launch: too many groups"; return DABPHY_ERR_INVALID; }
     if (!h->h_sp1) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, sizeof(FusedClass) + 4096 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc failed (one-class staging)"; return DABPHY_ERR_NOMEM; }
+        if (hipHostMalloc(&p, sizeof(FusedClass) + SP_SINGLE_MAX_GROUPS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc failed (one-class staging)"; return DABPHY_ERR_NOMEM; }
         h->h_sp1 = p;
     }
     const size_t cells = ((size_t)nsteps / 30 + 1) * 32;
     if ((r = ensure(h, h->sp1_cls, sizeof(FusedClass)))) return r;
-    if ((r = ensure(h, h->sp1_work, 4096 * sizeof(uint32_t)))) return r;
+    if ((r = ensure(h, h->sp1_work, SP_SINGLE_MAX_GROUPS * sizeof(uint32_t)))) return r;
     return ensure(h, h->vdec, (size_t)n_groups * 64 * cells * sizeof(uint2));
 }
 int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipStream_t st)

@@ -45,6 +45,7 @@ struct DevBuf {
 constexpr int HIST_CAP = 64;     // window searches remembered per ensemble for the sLevel replay
 // superframe filter launches (dabphy_superframes.hip): a class to walk and which of its pairs (DEVICE list; nullptr: all of them)
 struct SfSel { int cls; const int32_t* d_run; int n_run; };
+constexpr int SP_SINGLE_MAX_GROUPS = 4096;   // groups of 64 code words a one-class state-parallel launch takes (sp_single_*: the seams, the replay's FIC)
 constexpr int SF_BATCH_CLASSES = 256;                                                        // classes per bucket (a handle has at most 255)
 constexpr size_t SF_BATCH_BYTES = 3 * (SF_BATCH_CLASSES * sizeof(SfArgs) + (SF_BATCH_CLASSES + 1) * sizeof(int32_t) + 12);
 } // namespace dabphy
@@ -113,11 +114,12 @@ struct dabphy_handle {
         int variant = 0, n_slots = 0; size_t dec_slot_cells = 0;
         bool use_sp = false; int sp_variant = 0;         // the batch is small: one wavefront per code word (k_viterbi_sp) instead of 64 code words per wavefront
         std::vector<int> class_idx;                      // classes decoded by the fused launch (the others take k_msc_gather + k_viterbi)
-        std::vector<FusedClass> host_cls; std::vector<uint32_t> host_work;
+        std::vector<FusedClass> host_cls; std::vector<uint32_t> host_work, host_dec_off;
+        bool dec_by_item = false;                        // decision scratch per group of 64 code words instead of per work-group (dabphy_fused.hip)
         FusedArgs args{}; uint64_t buf_gen = 0;          // the launch as it was last queued (dabphy_time_fused_msc re-runs it alone while buf_gen is current)
         bool launched = false;
     } fplan;
-    DevBuf fused_cls, fused_work; uint32_t* d_fused_next = nullptr;
+    DevBuf fused_cls, fused_work, fused_dec_off; uint32_t* d_fused_next = nullptr;
     DevBuf sp1_cls, sp1_work; void* h_sp1 = nullptr;     // one-class state-parallel launches (the seams, the replay's one-frame FIC): descriptor + work list, page-locked staging
     DevBuf fic_steps[FUSED_VARIANTS]; int fic_windows[FUSED_VARIANTS] = {0, 0, 0};
     hipEvent_t ev_fused_done = nullptr;

@@ -196,6 +196,7 @@ struct FusedArgs {
     const uint32_t* work; uint32_t n_work;     // work list: class << 24 | group of 64 code words, longest code words first
     uint32_t* next;                            // its dynamic cursor (zeroed by the launcher)
     uint2* dec; size_t dec_slot_cells;         // decision scratch of work-group i: dec + i * dec_slot_cells ([step][64 lanes] cells)
+    const uint32_t* dec_off;                   // k_viterbi_fused: nullptr, or the scratch goes by work ITEM: item i at dec + dec_off[i] * 64 cells
     const uint32_t* prbs_words;
     // k_viterbi_sp's one-class launches (dabphy_fused.hip: sp_single): the replay's one-frame FIC, the linear seams
     int fic_frame_sel;                         // kind 1: 0 = every frame of the batch; f + 1 = frame f only (n_cw = 4 B)

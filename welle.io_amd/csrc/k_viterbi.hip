@@ -346,9 +346,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
   const int lane = threadIdx.x;
   const int F = A.n_frames, R = 4 * F;
   const uint32_t lane8 = (uint32_t)lane * 8u;                       // byte offset of this lane in a decision row
-  // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
-  uint2* const dec_g = A.dec + (size_t)blockIdx.x * A.dec_slot_cells;
-  const BufRsrc dec_rs = buf_rsrc(dec_g);
+  const DABPHY_CONST_AS uint32_t* const dec_off = as_constant(A.dec_off);
   const DABPHY_CONST_AS FusedClass* const classes = as_constant(A.cls);
   const DABPHY_CONST_AS uint32_t* const work = as_constant(A.work);
   uint32_t* const rowptr = reinterpret_cast<uint32_t*>(lds + G::ROWPTR);
@@ -359,6 +357,10 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
     item = (uint32_t)uniform_i32(__shfl((int)item, 0));
     if (item >= A.n_work) break;
     const uint32_t wk = work[item];
+    // decision scratch: this work-group's own (every group it pulls reuses it), or -- when the launch holds a few very long code words
+    // among many short ones, so that a scratch of the longest per work-group would be many times what all groups need -- this group's own
+    // (wave-uniform base + a 32-bit lane/step offset: the stores take the scalar-base addressing mode, one VGPR instead of a 64-bit pointer)
+    const BufRsrc dec_rs = buf_rsrc(A.dec + (A.dec_off ? (size_t)dec_off[item] * 64 : (size_t)blockIdx.x * A.dec_slot_cells));
     const DABPHY_CONST_AS FusedClass& C = classes[wk >> 24];
     const int g = (int)(wk & 0xffffffu);
     const int nsteps = C.nsteps, nbits = C.nbits, n_cw = C.n_cw, n_windows = C.n_windows;

@@ -88,7 +88,6 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
     __syncthreads();
     {
         const int16_t* __restrict__ map = C.map;
-        const bool clamp = C.kind == 2;                                     // the seams take any int8: -128 maps to symbol 0 like -127 (viterbi.cpp:233-236)
         for (int s = lane; s < nsteps; s += 64) {
             uint2 mm = make_uint2(0, 0);
             if (map) mm = *reinterpret_cast<const uint2*>(map + 4 * s);                    // four map entries
@@ -99,7 +98,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp(FusedArgs A)
                 long long off = -1;
                 if (u >= 0) off = s_rowoff[u & 15];
                 v[j] = off >= 0 ? (int)base[off + u] : 0;
-                if (clamp && v[j] < -127) v[j] = -127;
+                if (v[j] < -127) v[j] = -127;                               // -128 maps to symbol 0 like -127 (viterbi.cpp:233-236): the demapper never produces it, a seam's caller may
             }
             // the three branch-metric inputs of the step, doubled and biased as the trellis takes them (viterbi.cpp:233-238 puts the symbol
             // levels at v + 127: bm(p) = 510 + e0 (x0 - 1) + e1 (v1 - 1/2) + e2 (v2 - 1/2), x0 = v0 + v3): 12 + 10 + 10 signed bits
