@@ -32,37 +32,10 @@ typedef enum {
     DABPHY_ERR_STATE = -5           /* call sequence error (e.g. process before bind) */
 } dabphy_status;
 
-/* Limits of the batch geometry (dabphy_create returns DABPHY_ERR_INVALID beyond them).  The reference has none -- any number of
- * receivers decode correctly, msc-handler.cpp:129-158 -- and neither has the batch below them: no offset on the decode path is
- * narrower than the range it has to cover.  (Round 3 addressed the soft-bit ring of the fused MSC decode with 32-bit offsets from
- * the START of the ring: n_ensembles * (max_frames + 5) > 18 641 wrapped silently.  The offsets are now relative to the ring slice
- * of the first ensemble a wavefront decodes, a span of a few ensembles that dabphy_process checks against 4 GiB per class -- a
- * class that would exceed it is decoded through the two-kernel path with 64-bit addresses -- see DESIGN.md 4.2.) */
-#define DABPHY_MAX_FRAMES 4096u                   /* max_frames: frames per call and ensemble */
-#define DABPHY_MAX_ENSEMBLE_FRAMES (1u << 22)     /* n_ensembles * max_frames: code word counts stay inside 31 bits with 64 sub-channels */
-
-/* ---- ABI versioning.  Structures cross this boundary by layout, and the library and its callers are built separately:
- *   dabphy_config            is SIZED: its first member is the sizeof() the caller was compiled with.  Fields are only ever appended;
- *                            dabphy_create reads the fields the caller's header knew and takes the documented default (0) for the rest,
- *                            and refuses a structure LARGER than its own (fields it does not know: DABPHY_ERR_INVALID).
- *   every other structure    (dabphy_frame_info, dabphy_sf_event, dabphy_subchannel, dabphy_protection, dabphy_tii_measurement) is pinned
- *                            by DABPHY_ABI_VERSION: a change of any of them bumps it.  A caller checks once, e.g. in its constructor:
- *                                dabphy_abi_version() == DABPHY_ABI_VERSION   (dabphy_struct_size(which) tells the library's sizeof for a
- *                                finer diagnosis).
- *   objects built against the headers of rounds 1-3 call the exported symbols `dabphy_create` / `dabphy_get_config` with the UNSIZED
- *   48-byte configuration of those rounds: those entry points stay, frozen to that layout (new fields at their defaults); this header's
- *   dabphy_create / dabphy_get_config are the _v2 symbols (the sized form). */
-#define DABPHY_ABI_VERSION 5u
-uint32_t dabphy_abi_version(void);
-typedef enum { DABPHY_STRUCT_CONFIG = 0, DABPHY_STRUCT_FRAME_INFO = 1, DABPHY_STRUCT_SF_EVENT = 2, DABPHY_STRUCT_SUBCHANNEL = 3,
-               DABPHY_STRUCT_PROTECTION = 4, DABPHY_STRUCT_TII_MEASUREMENT = 5 } dabphy_struct_id;
-size_t dabphy_struct_size(int32_t which);      /* 0 for an unknown id */
-
 /* RadioReceiverOptions (src/backend/radio-receiver-options.h:66-84) + batch geometry */
 typedef struct {
-    uint32_t struct_size;           /* sizeof(dabphy_config) as the CALLER was compiled: DABPHY_CONFIG_INIT sets it */
-    uint32_t n_ensembles;           /* independent ensembles (streams) decoded in lock step; >= 1, n_ensembles * max_frames <= DABPHY_MAX_ENSEMBLE_FRAMES */
-    uint32_t max_frames;            /* transmission frames per dabphy_process call and ensemble; 1 .. DABPHY_MAX_FRAMES */
+    uint32_t n_ensembles;           /* independent ensembles (streams) decoded in lock step; >= 1 */
+    uint32_t max_frames;            /* transmission frames per dabphy_process call and ensemble; >= 1 */
     int32_t device;                 /* HIP device ordinal */
     int32_t fft_placement;          /* FFTPlacementMethod: 2 = ThresholdBeforePeak (default), 1 = EarliestPeakWithBinning, 0 = StrongestPeak */
     int32_t disable_coarse;         /* RadioReceiverOptions::disableCoarseCorrector */
@@ -88,13 +61,7 @@ typedef struct {
                                        n + 1 as in OFDMProcessor::run (ofdm-processor.cpp:397).  Costs a copy of the carried state per batch
                                        (a few MB, device to device) and, in such a batch, about three times its normal time.
                                        1: report only (round 1's behaviour) */
-    int32_t decode_shape;           /* which Viterbi kernel decodes the FIC and the sub-channels.  0 (default): by batch size -- small batches (at
-                                       most 16 384 code words per call: e.g. one ensemble of 18 sub-channels, any batch depth; 16 ensembles x 8 frames) one WAVEFRONT per
-                                       code word, lanes = the 64 trellis states (k_viterbi_sp: four times the instructions per code word, a
-                                       hundredth of the latency); larger ones one LANE per code word (k_viterbi_fused: the throughput shape).
-                                       1: always lane-per-code-word; 2: always state-parallel.  Same bytes either way. */
 } dabphy_config;
-#define DABPHY_CONFIG_INIT { (uint32_t)sizeof(dabphy_config) }      /* dabphy_config cfg = DABPHY_CONFIG_INIT;  -- sized, every option at its default */
 
 /* Depuncturing description of one convolutional codeword class: up to four (L_i blocks of 128 bits, PI_i)
  * tuples followed by the 24-bit tail (PI_X).  Replaces the constructor tables of EEPProtection
@@ -114,19 +81,13 @@ typedef struct {
     dabphy_protection prot;
 } dabphy_subchannel;
 
-int dabphy_create_v2(const dabphy_config* cfg, dabphy_handle** out);   /* RadioReceiver::RadioReceiver, radio-receiver.cpp:66-80 */
-#ifndef DABPHY_BUILDING_LIBRARY
-static inline int dabphy_create(const dabphy_config* cfg, dabphy_handle** out) { return dabphy_create_v2(cfg, out); }
-#endif
+int dabphy_create(const dabphy_config* cfg, dabphy_handle** out);      /* RadioReceiver::RadioReceiver, radio-receiver.cpp:66-80 */
 void dabphy_destroy(dabphy_handle* h);
 const char* dabphy_last_error(const dabphy_handle* h);
 const char* dabphy_device_name(const dabphy_handle* h);
 /* the configuration in effect (defaults resolved: e.g. demod_chunk = 25 when n_ensembles * max_frames >= 1024, else 15; the
  * synchroniser options as last set by dabphy_set_options) */
-int dabphy_get_config_v2(const dabphy_handle* h, dabphy_config* out);  /* out->struct_size = the caller's sizeof(dabphy_config) on entry (at most that much is written) */
-#ifndef DABPHY_BUILDING_LIBRARY
-static inline int dabphy_get_config(const dabphy_handle* h, dabphy_config* out) { return dabphy_get_config_v2(h, out); }
-#endif
+int dabphy_get_config(const dabphy_handle* h, dabphy_config* out);
 /* RadioReceiver::setReceiverOptions -> OFDMProcessor::setReceiverOptions (ofdm-processor.cpp:518-529) at run time: the FFT placement
  * and frequency-sync methods apply from the next frame on (the reference calls phaseRef.selectFFTWindowPlacement and reads
  * freqsyncMethod per frame, :399); a CHANGE of disable_coarse restarts the receiver exactly like the reference does (:523-528
@@ -139,9 +100,6 @@ int dabphy_protection_fic(dabphy_protection* p);
 int dabphy_protection_eep(dabphy_protection* p, int bitrate, int profile_b, int level);     /* eep-protection.cpp:32-113 */
 int dabphy_protection_uep(dabphy_protection* p, int bitrate, int level);                    /* uep-protection.cpp:120-167 */
 int dabphy_protection_input_bits(const dabphy_protection* p);                               /* punctured soft bits consumed */
-/* row `table_index` (0 .. 63, the 6-bit index a short-form FIG 0/1 carries) of the UEP table: sub-channel size in CUs, protection level
- * 1 .. 5, bit rate (fib-processor.cpp:496-503 reads the same triple from ProtLevel, dab-constants.cpp:75-142) */
-int dabphy_uep_table_entry(int table_index, int* size_cu, int* level, int* bitrate);
 
 /* ---- seam 1: OfdmDecoder::pushAllSymbols (ofdm-decoder.cpp:132-139) -> processPRS + 75 x decodeDataSymbol --------
  * frames: n_frames x (2048 + 75*2552) complex floats, [PRS useful part][75 symbols incl. cyclic prefix], already
@@ -224,21 +182,10 @@ void dabphy_host_free(void* p);
 /* OFDMProcessor::restart (ofdm-processor.cpp:115-132): correctors, phase, sync state, FIC counter, SNR filter cleared */
 int dabphy_reset(dabphy_handle* h);
 
-/* Sub-channel selection.  Every receiver of the reference selects its own services (radio-receiver.cpp:120-137 -> MscHandler::
- * addSubchannel / removeSubchannel / stopProcessing, msc-handler.cpp:61-127), so every ensemble of a batch has its OWN list:
- *   dabphy_set_subchannels_ensemble   the list of ONE ensemble (at most 64 entries; n = 0: none).  Takes effect with the next
- *                                     dabphy_process; the results of the last batch stay readable until then.
- *   dabphy_set_subchannels            the same list for every ensemble of the handle (applied at once).
- * A list REPLACES the ensemble's previous one.  A sub-channel that is in both (same subch_id, start_cu, size_cu and protection) is a
- * service that keeps playing: its time de-interleaver and its DAB+ superframe window (dabphy_superframes*) are not disturbed, whatever
- * else is added or removed, in its own or in any other ensemble -- as in the reference, where addSubchannel touches no other stream.
- * A sub-channel that is new starts with an empty time de-interleaver: like DabAudio (dab-audio.cpp:146-149) it emits its first
- * logical frame on the 17th CIF after it was selected (first_valid of dabphy_get_msc).
- * subch_index in the getters below = position in the ensemble's list. */
+/* MscHandler::addSubchannel (msc-handler.cpp:61-103) for every ensemble of the handle; n = 0 clears the list
+ * (MscHandler::stopProcessing).  Must be called before the first dabphy_process of a stream for the time
+ * de-interleaver to see all CIFs, exactly as in the reference. */
 int dabphy_set_subchannels(dabphy_handle* h, const dabphy_subchannel* list, uint32_t n);
-int dabphy_set_subchannels_ensemble(dabphy_handle* h, uint32_t ensemble, const dabphy_subchannel* list, uint32_t n);
-/* entries of the ensemble's list as last set */
-int dabphy_get_subchannel_count(dabphy_handle* h, uint32_t ensemble, uint32_t* n);
 
 /* Decode the next n_frames (<= max_frames) transmission frames of every ensemble: acquisition (null-symbol
  * search) where an ensemble is not synchronised, PRS time sync, coarse/fine frequency tracking, demodulation,
@@ -297,8 +244,7 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
 /* the wide pass of the DAB+ superframe filter since dabphy_create (either pointer may be NULL): (ensemble, sub-channel) batches whose
  * superframe attempts were all made at once and accepted -- the rest were walked frame by frame as SuperframeFilter::Feed does
- * (dabplus_decoder.cpp:50-158); results are identical either way -- and batches it was tried on (those with at least one full
- * five-frame window).  Counts passes, not batches: the second pass of a batch that exact batch mode decodes twice counts again. */
+ * (dabplus_decoder.cpp:50-158); results are identical either way -- and batches it was tried on */
 int dabphy_get_wide_superframe_stats(dabphy_handle* h, uint64_t* settled, uint64_t* tried);
 /* batches decoded a second time (see dabphy_config.no_batch_replay) since dabphy_reset / dabphy_create */
 int dabphy_get_replayed_batches(dabphy_handle* h, uint64_t* batches);
@@ -316,17 +262,14 @@ int dabphy_get_scan_stats(dabphy_handle* h, int32_t* attempts, int32_t* attempts
  * after every frame instead (about 3 ms of one GPU lane per frame and ensemble): always exact, meant for the real-time
  * single-ensemble receiver whose ring holds only a few frames. */
 int dabphy_set_track_slevel(dabphy_handle* h, int32_t on);
-/* decoded logical frames of sub-channel `subch_index` (position in the list) of EVERY ensemble -- all of them must have a sub-channel
- * of the same bit rate there (DABPHY_ERR_INVALID otherwise: read such batches per ensemble, dabphy_get_msc_ensemble):
+/* decoded logical frames of sub-channel `subch_index` (order of dabphy_set_subchannels):
  * out [n_ensembles][4*n_frames][nbits/8] = the bytes DecoderAdapter::addtoFrame writes to its dump file (out_capacity = size of
  * `out` in bytes; DABPHY_ERR_INVALID when it is too small).  Row layout: the logical frames of an ensemble are packed in CIF order
  * from row 0 on, whatever slots of the batch its demodulated frames occupied (a slot that failed its window search leaves no gap):
  * rows [first_valid[b], n_rows[b]) are this batch's frames, n_rows[b] = 4 x (frames of ensemble b with valid == 1), rows beyond it
  * are undefined.  first_valid[b] = number of leading rows that carry no frame yet (the de-interleaver emits its first frame on the
- * 17th CIF after the sub-channel was selected, dab-audio.cpp:146-149).  first_valid / n_rows may be NULL. */
+ * 17th CIF, dab-audio.cpp:146-149).  first_valid / n_rows may be NULL. */
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
-/* ... of ONE ensemble: out [4*n_frames][nbits/8], first_valid / n_rows single values */
-int dabphy_get_msc_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
 int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_frames][2048] */);      /* onNewImpulseResponse */
 /* onNewNullSymbol (ofdm-processor.cpp:462-469): the 2656 oscillator-corrected samples of the null symbol that follows each
  * demodulated frame of the last batch, out[n_ensembles][n_frames][2656][2] (zeros where valid != 1).  Computed on request. */
@@ -339,8 +282,7 @@ int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, in
  * corrected symbols in superframe i (total_corr_count), uncorrectable[i] != 0 when any of its codewords failed. */
 int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint32_t n_sf, int32_t* corrected,
                           int32_t* uncorrectable);
-/* The same on the MSC output of the last dabphy_process, in HBM.  subch_index < 0: every sub-channel; >= 0: the sub-channel at that
- * position of every ensemble that has one.
+/* The same on the MSC output of the last dabphy_process, in HBM.  subch_index < 0: every sub-channel.
  * first_cif[b]: CIF slot of this batch (0..4*n_frames-1, may be negative) where ensemble b's first superframe
  * starts -- the alignment SuperframeFilter::CheckSync (dabplus_decoder.cpp:171-215) finds on the host.  Only
  * superframes lying entirely inside the batch are decoded.  corrected / uncorrectable (may be NULL): per ensemble sums. */
@@ -368,9 +310,6 @@ typedef struct {
     int32_t sf_slot;                     /* index into sf, -1 when not synchronised */
 } dabphy_sf_event;
 int dabphy_superframes(dabphy_handle* h, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf);
-/* ... for sub-channel subch_index of ONE ensemble (its own list position): events [4 * n_frames], n_events [1], sf [n_slots][120 * bitrate/8].
- * dabphy_superframes needs the same bit rate at that position in every ensemble. */
-int dabphy_superframes_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, dabphy_sf_event* events, int32_t* n_events, uint8_t* sf);
 /* The same filter over EVERY DAB+ sub-channel of every ensemble in one launch per protection class (instead of, not in
  * addition to, dabphy_superframes for this batch); nothing but totals leaves the device:
  * stats [n_ensembles][4] = synchronised superframes, corrected symbols, uncorrectable attempts, access units failing their CRC */
@@ -401,7 +340,26 @@ int dabphy_get_tii(dabphy_handle* h, dabphy_tii_measurement* out, int32_t* n, ui
 int dabphy_set_profiling(dabphy_handle* h, int32_t on);
 int dabphy_get_stage_times(dabphy_handle* h, float* ms /* [7] */);
 
-/* (Timing drivers and device self-tests used by tests/ and tools/ are declared in include/dabphy_test.h: not part of the receiver API.) */
+/* ---- diagnostics: time one stage on device-resident data (HIP events on the handle's stream) ------------------
+ * dabphy_time_demod: tiles `n_src` host frames (layout of dabphy_demod_frames) over n_ens x n_frames frame slots in
+ *   HBM and runs the demod kernel `iters` times; *ms = mean kernel time.  mix/f_hz exercise the NCO path.
+ * dabphy_time_viterbi: decodes n_codewords random-content codewords of nbits `iters` times; *ms_gather / *ms_decode.
+ * dabphy_time_fused_msc: re-runs the fused MSC decode of the last dabphy_process batch (first protection class) `iters` times
+ *   with nothing else on the device; *ms = mean kernel time.  DABPHY_ERR_STATE before the first such batch. */
+int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uint32_t n_ens, uint32_t n_frames,
+                      int32_t mix, int32_t f_hz, uint32_t iters, float* ms);
+int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
+                        float* ms_decode);
+int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
+
+/* Device self-test of the reciprocal-based 127/x the demapper uses in place of the IEEE division sequence
+ * (ofdm-decoder.cpp:208 computes 127.0f / l1_norm): every float x in [2^-100, 2^100] is divided both ways on the device.
+ * counts[0] = mismatches of the 4-instruction variant, counts[1] = of the 6-instruction variant, counts[2] = values tried. */
+int dabphy_selftest_div127(dabphy_handle* h, uint64_t* counts);
+/* Device self-test of the one-instruction product by the unit twiddle tw[0] = (1, +-0) in the first two passes of the demod kernel's
+ * FFT (kiss_fft.c:21-90 multiplies by it like by any other twiddle): 2^33 operand pairs -- every exponent, zeros, denormals, infinities
+ * and NaNs included -- through both forms.  counts[0] = results that differ in a bit (two NaNs count as equal), counts[1] = pairs tried. */
+int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
 
 #ifdef __cplusplus
 }

@@ -12,10 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libdabphy_hip.so")
 
 T_U, T_S, FRAME_SYMS_LEN = 2048, 2552, 2048 + 75 * 2552
+ABI_VERSION = 5            # DABPHY_ABI_VERSION of the include/dabphy.h these structures mirror
 
 
 class Config(C.Structure):
-    _fields_ = [("n_ensembles", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("n_ensembles", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
                 ("fft_placement", C.c_int32), ("disable_coarse", C.c_int32), ("want_constellation", C.c_int32),
                 ("want_impulse_response", C.c_int32), ("demod_chunk", C.c_int32), ("freqsync_method", C.c_int32), ("pipeline_sync", C.c_int32), ("serial_sync", C.c_int32), ("no_batch_replay", C.c_int32), ("decode_shape", C.c_int32)]
 
@@ -55,11 +56,13 @@ class DabPhy:
     def __init__(self, n_ensembles=1, max_frames=1, device=0, lib_path=None, fft_placement=2, disable_coarse=False,
                  want_constellation=True, want_impulse_response=True, demod_chunk=0, pipeline_sync=False, freqsync_method=2, serial_sync=False, exact_batch=True, decode_shape=0):
         self.lib = load_library(lib_path)
-        cfg = Config(n_ensembles, max_frames, device, fft_placement, int(disable_coarse), int(want_constellation),
+        cfg = Config(C.sizeof(Config), n_ensembles, max_frames, device, fft_placement, int(disable_coarse), int(want_constellation),
                      int(want_impulse_response), demod_chunk, freqsync_method, int(pipeline_sync), int(serial_sync), int(not exact_batch), int(decode_shape))   # pipeline_sync: False/True/2
         self.cfg = cfg
         self.h = C.c_void_p()
-        r = self.lib.dabphy_create(C.byref(cfg), C.byref(self.h))
+        if self.lib.dabphy_abi_version() != ABI_VERSION:
+            raise DabPhyError("library ABI version %d, this binding was written for %d" % (self.lib.dabphy_abi_version(), ABI_VERSION))
+        r = self.lib.dabphy_create_v2(C.byref(cfg), C.byref(self.h))
         if r != 0:
             raise DabPhyError("dabphy_create failed with status %d (no gfx950 device?)" % r)
 
@@ -362,7 +365,7 @@ class DabPhy:
         return out, fv
 
     def config(self):
-        c = Config(); self._chk(self.lib.dabphy_get_config(self.h, C.byref(c))); return c
+        c = Config(C.sizeof(Config)); self._chk(self.lib.dabphy_get_config_v2(self.h, C.byref(c))); return c
 
     def demod_chunk(self):
         return self.config().demod_chunk

@@ -1,12 +1,53 @@
 // welle.io_amd/csrc/dabphy_api.hip -- C ABI of libdabphy_hip.so (include/dabphy.h): handle, device tables,
 // buffer management and kernel sequencing.  No arithmetic of the hot path happens on the host.
 #include "dabphy_internal.h"
+#include <cstddef>
 
 extern "C" {
 
-int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
+uint32_t dabphy_abi_version(void) { return DABPHY_ABI_VERSION; }
+size_t dabphy_struct_size(int32_t which)
 {
-    if (!cfg || !out || cfg->n_ensembles < 1 || cfg->max_frames < 1) return DABPHY_ERR_INVALID;
+    switch (which) {
+        case DABPHY_STRUCT_CONFIG: return sizeof(dabphy_config);
+        case DABPHY_STRUCT_FRAME_INFO: return sizeof(dabphy_frame_info);
+        case DABPHY_STRUCT_SF_EVENT: return sizeof(dabphy_sf_event);
+        case DABPHY_STRUCT_SUBCHANNEL: return sizeof(dabphy_subchannel);
+        case DABPHY_STRUCT_PROTECTION: return sizeof(dabphy_protection);
+        case DABPHY_STRUCT_TII_MEASUREMENT: return sizeof(dabphy_tii_measurement);
+    }
+    return 0;
+}
+
+// The configuration as the callers of rounds 1-3 were compiled with it: no size member, twelve 32-bit fields.  Their objects call the
+// exported symbol `dabphy_create`, which stays and means exactly this layout; everything added since takes its default.
+struct dabphy_config_r3 {
+    uint32_t n_ensembles, max_frames; int32_t device, fft_placement, disable_coarse, want_constellation, want_impulse_response, demod_chunk,
+             freqsync_method, pipeline_sync, serial_sync, no_batch_replay;
+};
+static_assert(sizeof(dabphy_config_r3) == 48 && offsetof(dabphy_config, n_ensembles) == 4 && sizeof(dabphy_config) == 4 + sizeof(dabphy_config_r3) + 4, "dabphy_config: fields are appended only");
+int dabphy_create(const dabphy_config_r3* old, dabphy_handle** out)
+{
+    if (!old || !out) return DABPHY_ERR_INVALID;
+    dabphy_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (uint32_t)(sizeof(uint32_t) + sizeof *old);                  // the sized form of what that caller knew
+    memcpy(&cfg.n_ensembles, old, sizeof *old);
+    return dabphy_create_v2(&cfg, out);
+}
+
+int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
+{
+    // the caller's structure may be older (shorter: the missing tail = defaults) but not newer than this library's
+    if (!cfg_in || !out || cfg_in->struct_size < offsetof(dabphy_config, fft_placement) || cfg_in->struct_size > sizeof(dabphy_config) || cfg_in->struct_size % 4) return DABPHY_ERR_INVALID;
+    dabphy_config cfg_full;
+    memset(&cfg_full, 0, sizeof cfg_full);
+    memcpy(&cfg_full, cfg_in, cfg_in->struct_size);
+    if (cfg_in->struct_size <= offsetof(dabphy_config, fft_placement)) cfg_full.fft_placement = 2;      // (a caller that knows no synchroniser options gets the reference's defaults,
+    if (cfg_in->struct_size <= offsetof(dabphy_config, freqsync_method)) cfg_full.freqsync_method = 2;  //  radio-receiver-options.h:66-84: ThresholdBeforePeak, PatternOfZeros)
+    cfg_full.struct_size = (uint32_t)sizeof(dabphy_config);
+    const dabphy_config* const cfg = &cfg_full;
+    if (cfg->n_ensembles < 1 || cfg->max_frames < 1) return DABPHY_ERR_INVALID;
     // include/dabphy.h "limits": frame and code word counts are 32-bit quantities in the kernels' argument blocks
     if (cfg->max_frames > DABPHY_MAX_FRAMES || (uint64_t)cfg->n_ensembles * cfg->max_frames > DABPHY_MAX_ENSEMBLE_FRAMES) return DABPHY_ERR_INVALID;
     *out = nullptr;
@@ -61,6 +102,8 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->fic_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (hipEventCreateWithFlags(&h->ev_aux_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_ingest[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_chain_gate, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_demod_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fic_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
@@ -113,6 +156,10 @@ int dabphy_create(const dabphy_config* cfg, dabphy_handle** out)
 #endif
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
+#ifdef DABPHY_WRONG_RESULTS_BUILD
+    fprintf(stderr, "dabphy: THIS LIBRARY WAS BUILT WITH AN FM_EXP_* TIMING SWITCH: its decoder output is wrong by construction\n");
+    strncat(h->devname, " [timing-experiment build: wrong results]", sizeof h->devname - strlen(h->devname) - 1);
+#endif
     *out = h;
     return DABPHY_OK;
 }
@@ -135,6 +182,8 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
     if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
     if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }
+    if (h->fic_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
+    if (h->ev_aux_done) e = hipEventDestroy(h->ev_aux_done);
     for (int i = 0; i < 2; i++) if (h->ev_ingest[i]) e = hipEventDestroy(h->ev_ingest[i]);
     if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);
     if (h->ev_chain_gate) e = hipEventDestroy(h->ev_chain_gate);
@@ -172,11 +221,20 @@ void dabphy_destroy(dabphy_handle* h)
 const char* dabphy_last_error(const dabphy_handle* h) { return h ? h->err.c_str() : "null handle"; }
 const char* dabphy_device_name(const dabphy_handle* h) { return h ? h->devname : ""; }
 
-int dabphy_get_config(const dabphy_handle* h, dabphy_config* out)
+int dabphy_get_config(const dabphy_handle* h, dabphy_config_r3* out)       // (objects of rounds 1-3: the unsized layout)
+{
+    if (!h || !out) return DABPHY_ERR_INVALID;
+    memcpy(out, &h->cfg.n_ensembles, sizeof *out);
+    return DABPHY_OK;
+}
+
+int dabphy_get_config_v2(const dabphy_handle* h, dabphy_config* out)
 {
     DeviceBind dev_(h);
-    if (!h || !out) return DABPHY_ERR_INVALID;
-    *out = h->cfg;
+    if (!h || !out || out->struct_size < sizeof(uint32_t) || out->struct_size % 4) return DABPHY_ERR_INVALID;
+    const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(dabphy_config));
+    memcpy(out, &h->cfg, n);
+    out->struct_size = n;
     return DABPHY_OK;
 }
 

@@ -7,6 +7,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-experiment switches (FM_EXP_* in k_viterbi.hip: variants of the fused decoder that skip a stage and decode GARBAGE;
+// DEMOD_FORCE_CHECKED in k_demod.hip: one oscillator conversion compiled in) exist for A/B timing on the device only.  They compile only
+// into a build that says so (-DDABPHY_EXPERIMENTS, as tools/ use), never into a product library through a stray EXTRA= flag -- and such
+// a build announces itself from dabphy_create (DABPHY_WRONG_RESULTS_BUILD).
+#if defined(FM_EXP_BROADCAST) || defined(FM_EXP_NOLDS) || defined(FM_EXP_NODMA) || defined(FM_EXP_NOSTORE) || defined(FM_EXP_NOWAIT) || defined(FM_EXP_NOTRACE)
+#ifndef DABPHY_EXPERIMENTS
+#error "FM_EXP_* switches are timing experiments that decode wrong results: build them with -DDABPHY_EXPERIMENTS"
+#endif
+#define DABPHY_WRONG_RESULTS_BUILD 1
+#endif
+#if defined(DEMOD_FORCE_CHECKED) && !defined(DABPHY_EXPERIMENTS)
+#error "DEMOD_FORCE_CHECKED is a timing experiment: build it with -DDABPHY_EXPERIMENTS"
+#endif
+
 namespace dabphy {
 
 constexpr int T_U = 2048, T_S = 2552, T_G = 504, T_NULL = 2656, T_F = 196608, L_SYM = 76, K_CARR = 1536;

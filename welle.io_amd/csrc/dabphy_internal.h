@@ -7,6 +7,7 @@
 //   dabphy_superframes.hip  Reed-Solomon seams and the DAB+ superframe filter
 //   dabphy_getters.hip      everything a caller reads back after a batch, profiling, TII
 #pragma once
+#define DABPHY_BUILDING_LIBRARY          // (the exported symbol `dabphy_create` is the frozen round-3 entry point here, not the header's inline)
 #include "../../include/dabphy.h"
 #include "../../include/dabphy_test.h"
 #include "dabphy_kernels.h"
@@ -107,6 +108,7 @@ struct dabphy_handle {
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;
+    hipStream_t fic_stream = nullptr; hipEvent_t ev_aux_done = nullptr;     // FIB CRC + FIC ratio behind a fused launch; end of the auxiliary stream's work of a batch
     // fused decode (k_viterbi_fused): every class of the batch (and the FIC) in one launch.  The plan = which build, which classes, the
     // work list; rebuilt when the batch depth, the class set or a buffer address changes (dabphy_fused.hip)
     struct FusedPlan {

@@ -229,6 +229,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // the host's copies of the descriptors and SNR reports leave here, beside the decoder, instead of behind the step's last kernel
         HIPCHK(h, hipMemcpyAsync(h->h_desc, d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
+        HIPCHK(h, hipEventRecord(h->ev_aux_done, fs));
     }
     // pairs selected since the last batch learn the CIF count they start at (their time de-interleaver fills from here, dab-audio.cpp:146-149)
     for (auto& cls : h->classes) if (cls.cif0_pending) launch_pair_cif0(cls.pair_tab.as<MscPair>(), (int)cls.pairs.size(), d_desc, (int)F, h->stream);
@@ -245,8 +246,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (fic_fused) HIPCHK(h, hipEventRecord(h->ev_fused_done, h->stream));
     }
     {
-        // FIB CRCs, the FIC success ratio (and with it the verdict of exact batch mode), the host's copies of both
-        if (fic_fused) { HIPCHK(h, hipStreamWaitEvent(fs, h->ev_fused_done, 0)); mark(dabphy_handle::ST_FIC, false, fs); }
+        // FIB CRCs, the FIC success ratio (and with it the verdict of exact batch mode), the host's copies of both.  With the FIC in the
+        // fused launch they wait for nothing but that launch, on a stream of their own: the SNR sums (2048 short waves that feed nothing
+        // on the device and find no slot while the persistent decoder waves hold them all) must not stand in front of the FIC verdict
+        if (fic_fused) { fs = h->fic_stream; HIPCHK(h, hipStreamWaitEvent(fs, h->ev_fused_done, 0)); mark(dabphy_handle::ST_FIC, false, fs); }
         CrcArgs k{}; k.fib = ficc.out; k.ok = h->s_ok.as<uint8_t>(); k.state = h->d_dec; k.desc = d_desc; k.n_ens = (int)B; k.n_frames = (int)F; k.disable_coarse = h->cfg.disable_coarse;
         launch_fib_crc(k, fs);
         k.any_effective = h->d_any_eff;
@@ -303,6 +306,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     h->desc_sel = (cur + 1) % ND; h->ahead--;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_aux_done, 0));
     h->last_frames = F;
     tick(3);
     if ((r = sync(h))) return r;
@@ -314,6 +318,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // feedback the reference has; the chains that ran ahead on the wrong state are queued again behind it.
         HIPCHK(h, hipStreamSynchronize(h->sync_stream));
         HIPCHK(h, hipStreamSynchronize(h->aux_stream));
+        HIPCHK(h, hipStreamSynchronize(h->fic_stream));
         for (int i = 0; i < ND; i++) h->wide_pending[i] = false;
         HIPCHK(h, hipMemcpyAsync(h->d_state, h->snap_state[cur].p, sizeof(RxState) * B, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_dec, h->snap_dec.p, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
@@ -322,6 +327,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipMemsetAsync(h->d_any_eff, 0, sizeof(int32_t), h->stream));
         if ((r = decode(true))) return r;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_aux_done, 0));
         if ((r = sync(h))) return r;
         // the batches synchronised ahead started from the state the first pass left: again, from the right one.  (The chain reads the
         // FIC ratio: the main stream has just been drained.)

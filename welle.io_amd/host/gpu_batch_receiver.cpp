@@ -17,8 +17,8 @@ GpuBatchReceiver::GpuBatchReceiver(const std::vector<RadioControllerInterface*>&
         dabphy_signal_clock::Scope at(t0);                 // FIBProcessor's constructor reads the clock (fib-processor.cpp:1271)
         for (auto* c : rci) fib.emplace_back(new FIBProcessor(*c));
     }
-    dabphy_config cfg;
-    memset(&cfg, 0, sizeof cfg);
+    if (dabphy_abi_version() != DABPHY_ABI_VERSION) throw std::runtime_error("libdabphy_hip.so was built from another include/dabphy.h (ABI version)");
+    dabphy_config cfg = DABPHY_CONFIG_INIT;
     cfg.n_ensembles = (uint32_t)rci.size(); cfg.max_frames = max_frames; cfg.device = device;
     cfg.fft_placement = rro.fftPlacementMethod == FFTPlacementMethod::StrongestPeak ? 0
                       : rro.fftPlacementMethod == FFTPlacementMethod::EarliestPeakWithBinning ? 1 : 2;

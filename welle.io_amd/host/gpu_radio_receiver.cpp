@@ -115,8 +115,8 @@ GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterfac
     fibProcessor(rci_), params(transmission_mode), rci(rci_), input(input_), options(rro)
 {
     if (transmission_mode != 1) throw std::logic_error("GpuRadioReceiver: only transmission mode I is implemented");
-    dabphy_config cfg;
-    memset(&cfg, 0, sizeof cfg);
+    if (dabphy_abi_version() != DABPHY_ABI_VERSION) throw std::runtime_error("libdabphy_hip.so was built from another include/dabphy.h (ABI version)");
+    dabphy_config cfg = DABPHY_CONFIG_INIT;
     cfg.n_ensembles = 1; cfg.max_frames = 1; cfg.device = 0;
     cfg.fft_placement = placement_code(rro.fftPlacementMethod);
     cfg.freqsync_method = (int32_t)rro.freqsyncMethod;                  // GetMiddle = 0, CorrelatePRS = 1, PatternOfZeros = 2
