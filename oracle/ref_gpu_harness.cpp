@@ -211,6 +211,49 @@ int gpu_node_run(const float* iq, int64_t n_samples, int n_ens, const int32_t* d
     }
     return 0;
 }
+// ---- batch mode with services: every ensemble selects its own sub-channels (GpuBatchReceiver::addSubchannel / removeSubchannel =
+// MscHandler's, per ensemble), possibly in mid-stream: sub i joins ensemble subs[i].ens before step add_step (0: from the start) and
+// leaves before step remove_step (< 0: never).  Each has its own ProgrammeHandler (Reed-Solomon statistics of the reference's own
+// SuperframeFilter behind DecoderAdapter) and dump file.
+struct gpu_batch_sub { int32_t ens, add_step, remove_step; gpu_subch sub; };
+int gpu_batch_msc_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, const gpu_batch_sub* subs, int n_subs,
+                      int32_t* rs_calls, int32_t* rs_uncorr, int32_t* rs_corr, int32_t* n_fib_ok)
+{
+    std::vector<std::unique_ptr<Rec>> recs;
+    std::vector<RadioControllerInterface*> ctl;
+    std::vector<int> fib_ok(n_ens, 0);
+    struct CountRec : Rec { int* ok; void onFIBDecodeSuccess(bool good, const uint8_t* bits) override { if (good) (*ok)++; Rec::onFIBDecodeSuccess(good, bits); } };
+    for (int e = 0; e < n_ens; e++) { auto r = std::unique_ptr<CountRec>(new CountRec); r->ok = &fib_ok[e]; ctl.push_back(r.get()); recs.push_back(std::move(r)); }
+    std::vector<NullProgrammeHandler> handlers(n_subs > 0 ? n_subs : 1);
+    try {
+        RadioReceiverOptions rro; rro.decodeTII = false;
+        GpuBatchReceiver rx(ctl, (uint32_t)frames_per_step, rro);
+        if (dabphy_stream_upload(rx.phy(), iq, (uint64_t)n_samples, 0) != DABPHY_OK) return -2;
+        for (int k = 0; k < n_steps; k++) {
+            for (int i = 0; i < n_subs; i++) {
+                const gpu_subch& s = subs[i].sub;
+                if (subs[i].add_step == k) {
+                    Subchannel sub;
+                    sub.subChId = s.subChId; sub.startAddr = s.startAddr; sub.length = s.length;
+                    sub.protectionSettings.shortForm = s.shortForm != 0; sub.protectionSettings.uepTableIndex = s.uepTableIndex; sub.protectionSettings.uepLevel = s.uepLevel;
+                    sub.protectionSettings.eepProfile = s.eepProfileB ? EEPProtectionProfile::EEP_B : EEPProtectionProfile::EEP_A;
+                    sub.protectionSettings.eepLevel = (EEPProtectionLevel)s.eepLevel;
+                    if (!rx.addSubchannel((size_t)subs[i].ens, handlers[i], s.dabplus ? AudioServiceComponentType::DABPlus : AudioServiceComponentType::DAB, std::string(s.dump_path), sub)) return -3;
+                }
+                if (subs[i].remove_step == k && !rx.removeSubchannel((size_t)subs[i].ens, s.subChId)) return -4;
+            }
+            rx.process((uint32_t)frames_per_step);
+        }
+        for (int e = 0; e < n_ens; e++) n_fib_ok[e] = fib_ok[e];
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "gpu_batch_msc_run: %s\n", ex.what());
+        return -1;
+    }
+    // (the receiver is gone: every service's decoder thread has delivered its last frame and closed its dump)
+    for (int i = 0; i < n_subs; i++) { rs_calls[i] = handlers[i].rs_calls; rs_uncorr[i] = handlers[i].rs_uncorr; rs_corr[i] = handlers[i].rs_corr; }
+    return 0;
+}
+
 int gpu_batch_run(const float* iq, int64_t n_samples, int n_ens, int frames_per_step, int n_steps, int32_t* eid, int32_t* n_listed, int32_t* n_fib_ok, int32_t* n_detected, int32_t* n_tii)
 {
     return gpu_batch_run2(iq, n_samples, n_ens, frames_per_step, n_steps, 1, eid, n_listed, n_fib_ok, n_detected, n_tii);

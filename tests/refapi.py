@@ -555,3 +555,40 @@ def gpu_batch_run(iq, frames_per_step, n_steps, lib=GPU_EMU_SO):
     r = L.gpu_batch_run(_p(iq), n, B, frames_per_step, n_steps, _p(eid), _p(nl), _p(ok), _p(nd), _p(nt))
     assert r == 0, "gpu_batch_run failed (%d)" % r
     return eid, nl, ok, nd, nt
+
+
+class GpuBatchSub(C.Structure):
+    _fields_ = [("ens", C.c_int32), ("add_step", C.c_int32), ("remove_step", C.c_int32), ("sub", RefSubch)]
+
+
+def _fill_subch(r, s, path):
+    r.subChId = s.subch_id; r.startAddr = s.start_cu; r.length = s.size_cu
+    r.shortForm = 0; r.eepProfileB = int(s.profile_b); r.eepLevel = s.level
+    if getattr(s, "uep", None) is not None:
+        r.shortForm = 1; r.uepTableIndex = s.uep[0]; r.uepLevel = s.level
+    r.dabplus = int(s.dabplus); r.dump_path = path.encode()
+
+
+def gpu_batch_msc_run(iq, frames_per_step, n_steps, subs, lib=GPU_EMU_SO, dump_dir="/tmp"):
+    """GpuBatchReceiver over [n_ens][n_samples] cf32 where every ensemble selects its own services: subs = [(ensemble, synth.SubchannelCfg,
+    add_step, remove_step)] (add_step 0 = from the start, remove_step -1 = never) -> per entry (dump bytes of its DecoderAdapter,
+    onRsErrors calls, uncorrectable ones, corrected symbols), FIBs ok per ensemble"""
+    L = C.CDLL(lib)
+    iq = np.ascontiguousarray(iq, np.complex64); B, n = iq.shape
+    arr = (GpuBatchSub * max(1, len(subs)))(); paths = []
+    for i, (e, s, a, r) in enumerate(subs):
+        path = os.path.join(dump_dir, "gpubatch_%d_%d_%d.msc" % (os.getpid(), e, i))
+        if os.path.exists(path):
+            os.remove(path)
+        arr[i].ens = e; arr[i].add_step = a; arr[i].remove_step = r
+        _fill_subch(arr[i].sub, s, path); paths.append(path)
+    calls = np.zeros(max(1, len(subs)), np.int32); unc = np.zeros_like(calls); corr = np.zeros_like(calls); ok = np.zeros(B, np.int32)
+    L.gpu_batch_msc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = L.gpu_batch_msc_run(_p(iq), n, B, frames_per_step, n_steps, arr, len(subs), _p(calls), _p(unc), _p(corr), _p(ok))
+    assert r == 0, "gpu_batch_msc_run failed (%d)" % r
+    out = []
+    for i, pth in enumerate(paths):
+        out.append((open(pth, "rb").read() if os.path.exists(pth) else b"", int(calls[i]), int(unc[i]), int(corr[i])))
+        if os.path.exists(pth):
+            os.remove(pth)
+    return out, ok

@@ -93,3 +93,12 @@ def test_worker_failure_becomes_input_failure(gpu):
     """an exception on the facade's worker thread surfaces as onInputFailure() (ofdm-processor.cpp:492-499), on the device build too"""
     x = synth.make_stream(6, snr_db=20, seed=2)
     assert R.gpu_failing_input_run(x, 3 * 196608, lib=R.GPU_HIP_SO) == 1
+
+
+def test_batch_receiver_decodes_each_ensembles_own_services(gpu):
+    """GpuBatchReceiver on the device: three different multiplexes in one batch, every ensemble selecting (and re-selecting in
+    mid-stream) its own services, each into its own reference DecoderAdapter: dumps and Reed-Solomon statistics = three reference
+    RadioReceivers'"""
+    from conftest import GPU_LIB
+    from test_host_mirror import check_batch_receiver_services
+    check_batch_receiver_services(GPU_LIB, R.GPU_HIP_SO)

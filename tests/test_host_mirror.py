@@ -95,6 +95,57 @@ def test_batch_receiver_feeds_one_fibprocessor_per_ensemble(emu):
         assert ok[e] >= 12 * 4 and ok[e] % 12 == 0      # every FIB of every demodulated frame passed its CRC
 
 
+def check_batch_receiver_services(lib, hostlib):
+    """GpuBatchReceiver with services: three DIFFERENT multiplexes in one batch, every ensemble selecting its own sub-channels -- and
+    changing the selection in mid-stream -- each selected service decoded into its own reference DecoderAdapter; against three
+    reference RadioReceivers, one per stream (src/tests/backend_tests.cpp's pattern): the dumps are the reference's byte for byte and
+    the reference's own SuperframeFilter behind the adapter reports the same Reed-Solomon statistics.
+    lib = the C-ABI library (pure host helpers for the UEP rows), hostlib = the host mirror linked against it"""
+    from welle_io_amd import capi, workload
+    F, n_steps = 3, 6
+    nf = F * n_steps + 1
+    L = capi.load_library(lib)
+    layouts = [synth.default_subchannels(), workload.hetero_subchannels(L), P.mixed_subchannels()]
+    xs = []
+    for e, (eid, cfo) in enumerate([(0x10A1, 0), (0x20B2, 120), (0x30C3, -80)]):
+        xs.append(synth.make_stream(nf, eid=eid, subchs=layouts[e], snr_db=(9, 20, 20)[e], cfo_hz=cfo, seed=40 + e, payload_fn=synth.dabplus_payload_fn(80, 7 + e)))
+    # (ensemble, sub-channel, joins before step, leaves before step)
+    subs = [(0, layouts[0][2], 0, -1), (0, layouts[0][11], 0, 4), (0, layouts[0][15], 2, -1),
+            (1, layouts[1][0], 0, -1), (1, layouts[1][11], 0, -1), (1, layouts[1][13], 0, -1),
+            (2, layouts[2][1], 0, -1), (2, layouts[2][5], 3, -1), (2, layouts[2][8], 0, -1)]
+    got, fib_ok = R.gpu_batch_msc_run(np.stack(xs), F, n_steps, subs, lib=hostlib)
+    assert (fib_ok >= 12 * F * (n_steps - 1)).all(), fib_ok              # (the first batch spends a slot on the acquisition)
+    for e in range(3):
+        mine = [i for i in range(len(subs)) if subs[i][0] == e]
+        ref = R.receiver_run(xs[e], subchs=[subs[i][1] for i in mine])
+        for k, i in enumerate(mine):
+            _, sc, add, rem = subs[i]
+            fb = sc.frame_bytes
+            dump, calls, unc, corr = got[i]
+            want = ref["msc"][k]
+            assert len(dump) % fb == 0 and len(dump) >= 16 * fb, (e, i, len(dump))
+            # the dump is a run of the reference receiver's logical frames: from its first one for a service selected at the start; for
+            # one that joins before step `add`, from the 17th CIF it is fed (dab-audio.cpp:146-149) = logical frame 4 x (frames decoded
+            # before that step) of the stream; one that leaves before step `rem` ends with the frames decoded before that step
+            first = want.find(dump[:fb]) // fb
+            assert first >= 0 and want[first * fb:first * fb + len(dump)] == dump, "ensemble %d service %d: dump differs from the reference receiver's" % (e, sc.subch_id)
+            assert (first == 0) if add == 0 else (4 * (F * add - 1) <= first <= 4 * F * add), (e, sc.subch_id, first)
+            n_end = first + len(dump) // fb
+            assert (4 * (F * rem - 1) - 16 <= n_end <= 4 * F * rem - 16) if rem >= 0 else (n_end >= 4 * (F * n_steps - 1) - 16), (e, sc.subch_id, n_end)
+            if sc.dabplus and add == 0 and rem < 0:
+                # the reference's own SuperframeFilter / RSDecoder behind the adapter saw the same frames (it also decodes the last, cut-off
+                # frame of the finite stream: up to one transmission frame = 4 logical frames more)
+                assert ref["rs_calls"][k] >= 8 and 0 <= ref["rs_calls"][k] - calls <= 4, (ref["rs_calls"][k], calls)
+                assert 0 <= ref["rs_uncorr"][k] - unc <= 4 and abs(ref["rs_corr"][k] - corr) <= max(4, ref["rs_corr"][k] // 4), (e, sc.subch_id, ref["rs_uncorr"][k], unc, ref["rs_corr"][k], corr)
+    return got
+
+
+def test_batch_receiver_decodes_each_ensembles_own_services(emu):
+    from conftest import EMU_LIB
+    got = check_batch_receiver_services(EMU_LIB, R.GPU_EMU_SO)
+    assert sum(g[1] for g in got) >= 40 and sum(g[3] for g in got) > 0   # the reference's SuperframeFilter ran behind the adapters (and Reed-Solomon had something to correct)
+
+
 def test_node_receiver_shards_ensembles_over_devices(emu):
     """GpuNodeReceiver (SURVEY 8e in-process: shard by ensemble, one GpuBatchReceiver = one handle = one device per shard, the shards
     decoded concurrently by one host thread each, no collective): five different ensembles over two shards (3 + 2) give what one

@@ -9,7 +9,7 @@
 #include "signal_clock.h"
 
 GpuBatchReceiver::GpuBatchReceiver(const std::vector<RadioControllerInterface*>& controllers, uint32_t max_frames_, RadioReceiverOptions rro, int device) :
-    rci(controllers), synced(controllers.size(), 0), max_frames(max_frames_)
+    rci(controllers), synced(controllers.size(), 0), max_frames(max_frames_), streams(controllers.size()), active(controllers.size()), dirty(controllers.size(), 0)
 {
     if (controllers.empty() || max_frames == 0) throw std::logic_error("GpuBatchReceiver: needs at least one ensemble and one frame");
     t0 = std::chrono::steady_clock::now();
@@ -29,13 +29,105 @@ GpuBatchReceiver::GpuBatchReceiver(const std::vector<RadioControllerInterface*>&
     if (decode_tii && dabphy_set_tii(handle, 1) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
 }
 
-GpuBatchReceiver::~GpuBatchReceiver() { dabphy_destroy(handle); }
+GpuBatchReceiver::~GpuBatchReceiver()
+{
+    alive = false;
+    active.clear(); streams.clear();                    // the services' decoder threads end (after the frames already queued)
+    dabphy_destroy(handle);
+}
+
+// ---- services: RadioReceiver's methods (radio-receiver.cpp:120-185), per ensemble
+bool GpuBatchReceiver::playSingleProgramme(size_t e, ProgrammeHandlerInterface& handler, const std::string& dumpFileName, const Service& s)
+{
+    return playProgramme(e, handler, s, dumpFileName, true);
+}
+
+bool GpuBatchReceiver::addServiceToDecode(size_t e, ProgrammeHandlerInterface& handler, const std::string& dumpFileName, const Service& s)
+{
+    return playProgramme(e, handler, s, dumpFileName, false);
+}
+
+bool GpuBatchReceiver::playProgramme(size_t e, ProgrammeHandlerInterface& handler, const Service& s, const std::string& dumpFileName, bool unique)
+{
+    // radio-receiver.cpp:146-174
+    for (const auto& sc : fib.at(e)->getComponents(s)) {
+        if (sc.transportMode() != TransportMode::Audio) continue;
+        const auto subch = fib[e]->getSubchannel(sc);
+        if (!subch.valid()) continue;
+        if (unique) clearSubchannels(e);
+        if (sc.audioType() == AudioServiceComponentType::DAB || sc.audioType() == AudioServiceComponentType::DABPlus)
+            return addSubchannel(e, handler, sc.audioType(), dumpFileName, subch);
+    }
+    return false;
+}
+
+bool GpuBatchReceiver::removeServiceToDecode(size_t e, const Service& s)
+{
+    // radio-receiver.cpp:130-144
+    for (const auto& sc : fib.at(e)->getComponents(s)) {
+        if (sc.transportMode() != TransportMode::Audio) continue;
+        const auto subch = fib[e]->getSubchannel(sc);
+        if (!subch.valid()) continue;
+        return removeSubchannel(e, subch.subChId);
+    }
+    return false;
+}
+
+bool GpuBatchReceiver::addSubchannel(size_t e, ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& sub)
+{
+    for (const auto& st : streams.at(e)) if (st->sub.subChId == sub.subChId) return true;       // msc-handler.cpp:69-74
+    dabphy_subchannel d;
+    if (!SubchannelStream::describe(sub, &d)) return false;           // no such protection profile: nothing the channel decoder could do with it
+    streams[e].push_back(std::make_shared<SubchannelStream>(handler, ascty, dumpFileName, sub));   // may throw like DecoderAdapter does (unknown component type)
+    dirty[e] = 1;
+    return true;
+}
+
+bool GpuBatchReceiver::removeSubchannel(size_t e, int subChId)
+{
+    for (auto it = streams.at(e).begin(); it != streams[e].end(); ++it)
+        if ((*it)->sub.subChId == subChId) {
+            // the library keeps decoding the sub-channel until the next batch is set up, nobody reads it any more; the stream's own
+            // thread ends here (MscHandler::removeSubchannel joins DabAudio, msc-handler.cpp:105-122)
+            for (auto& a : active[e]) if (a == *it) a.reset();
+            streams[e].erase(it);
+            dirty[e] = 1;
+            return true;
+        }
+    return false;
+}
+
+void GpuBatchReceiver::clearSubchannels(size_t e)
+{
+    if (streams.at(e).empty()) return;
+    for (auto& a : active[e]) a.reset();
+    streams[e].clear();
+    dirty[e] = 1;
+}
 
 size_t GpuBatchReceiver::process(uint32_t n_frames)
 {
     if (n_frames == 0 || n_frames > max_frames) throw std::out_of_range("GpuBatchReceiver::process: n_frames");
-    if (dabphy_process(handle, n_frames) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
     const size_t B = rci.size();
+    // the ensembles whose selection changed tell the library their new list: it decodes this batch with it, services that stay keep
+    // their time de-interleaver and superframe state (include/dabphy.h: dabphy_set_subchannels_ensemble)
+    for (size_t e = 0; e < B; e++) {
+        if (!dirty[e]) continue;
+        std::vector<dabphy_subchannel> list; std::vector<std::shared_ptr<SubchannelStream>> now;
+        for (const auto& st : streams[e]) {
+            dabphy_subchannel d;
+            if (!SubchannelStream::describe(st->sub, &d)) continue;
+            list.push_back(d); now.push_back(st);
+        }
+        if (dabphy_set_subchannels_ensemble(handle, (uint32_t)e, list.data(), (uint32_t)list.size()) != DABPHY_OK) {
+            // (a sub-channel the library refuses, e.g. one that runs past the CIF: decode none of this ensemble rather than the wrong ones)
+            dabphy_set_subchannels_ensemble(handle, (uint32_t)e, nullptr, 0);
+            now.clear();
+        }
+        active[e].swap(now);
+        dirty[e] = 0;
+    }
+    if (dabphy_process(handle, n_frames) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
     std::vector<dabphy_frame_info> info(B * n_frames);
     std::vector<uint8_t> fibs(B * n_frames * 12 * 32), ok(B * n_frames * 12);
     dabphy_get_frame_info(handle, info.data());
@@ -70,6 +162,15 @@ size_t GpuBatchReceiver::process(uint32_t n_frames)
                 tii_measurement_t t; t.comb = m.comb; t.pattern = m.pattern; t.delay_samples = m.delay_samples; t.error = m.error;
                 rci[e]->onTIIMeasurement(std::move(t));
             }
+        }
+        // thread C of every selected service: its decoded logical frames of this batch, in CIF order (dab-audio.cpp:151-160)
+        for (size_t idx = 0; idx < active[e].size(); idx++) {
+            if (!active[e][idx]) continue;                  // removed since the batch was set up
+            SubchannelStream& st = *active[e][idx];
+            std::vector<uint8_t> out(4 * (size_t)n_frames * st.frame_bytes);
+            int32_t first_valid = 0, n_rows = 0;
+            if (dabphy_get_msc_ensemble(handle, (uint32_t)e, (uint32_t)idx, out.data(), out.size(), &first_valid, &n_rows) != DABPHY_OK) continue;
+            for (int c = first_valid; c < n_rows; c++) st.push(out.data() + (size_t)c * st.frame_bytes, alive);
         }
     }
     return decoded;

@@ -14,8 +14,16 @@
 // every ensemble gets a SIGNAL clock instead: while its FIBs are processed, `steady_clock` inside fib-processor.cpp reads
 // t0 + (samples of that ensemble consumed so far) / 2.048 MHz (signal_clock.h; fib-processor.cpp is compiled with that header
 // force-included, unmodified).  The counters then age exactly as they do in a receiver running in real time, at any decode speed.
+//
+// Services (SURVEY 8a-11 ... 8a-16 for a batch): every ensemble selects ITS OWN, as every RadioReceiver of the reference does
+// (radio-receiver.cpp:120-185 -> MscHandler::addSubchannel / removeSubchannel, msc-handler.cpp:61-127): addServiceToDecode(e, ...) /
+// removeServiceToDecode(e, ...) mirror the facade's methods per ensemble, the selection reaches the library through
+// dabphy_set_subchannels_ensemble before the next batch, and process() hands every selected sub-channel's logical frames to a
+// DecoderAdapter of its own (subchannel_stream.h: one decoder thread per service, as DabAudio::run is).
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <list>
 #include <memory>
 #include <vector>
 
@@ -23,8 +31,7 @@
 #include "radio-receiver-options.h"
 #include "dab-constants.h"
 #include "fib-processor.h"
-
-struct dabphy_handle;
+#include "subchannel_stream.h"
 
 class GpuBatchReceiver {
     public:
@@ -48,12 +55,29 @@ class GpuBatchReceiver {
         std::list<ServiceComponent> getComponents(size_t e, const Service& s) const { return fib[e]->getComponents(s); }
         Subchannel getSubchannel(size_t e, const ServiceComponent& sc) const { return fib[e]->getSubchannel(sc); }
 
+        // RadioReceiver::playSingleProgramme / addServiceToDecode / removeServiceToDecode (radio-receiver.cpp:120-185) of ensemble e.
+        // Call them between process() calls, from the thread that calls process() (the handle is not thread-safe); the selection applies
+        // from the next batch on.  A removed service's handler may be destroyed when removeServiceToDecode returns (its decoder thread
+        // has ended, the frames already decoded have been delivered).
+        bool playSingleProgramme(size_t e, ProgrammeHandlerInterface& handler, const std::string& dumpFileName, const Service& s);
+        bool addServiceToDecode(size_t e, ProgrammeHandlerInterface& handler, const std::string& dumpFileName, const Service& s);
+        bool removeServiceToDecode(size_t e, const Service& s);
+        // MscHandler::addSubchannel / removeSubchannel (msc-handler.cpp:61-122) of ensemble e
+        bool addSubchannel(size_t e, ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& sub);
+        bool removeSubchannel(size_t e, int subChId);
+        void clearSubchannels(size_t e);
+
     private:
         std::vector<RadioControllerInterface*> rci;
         std::vector<std::unique_ptr<FIBProcessor>> fib;
         std::vector<char> synced;
         dabphy_handle* handle = nullptr;
         uint32_t max_frames;
+        bool playProgramme(size_t e, ProgrammeHandlerInterface& handler, const Service& s, const std::string& dumpFileName, bool unique);
+        std::vector<std::list<std::shared_ptr<SubchannelStream>>> streams;    // [ensemble]: the services selected, in the order they were added
+        std::vector<std::vector<std::shared_ptr<SubchannelStream>>> active;   // [ensemble]: the list the library decodes the current batch with, in its order
+        std::vector<char> dirty;                                              // [ensemble]: `streams` changed since the library was told
+        std::atomic<bool> alive{true};
         bool decode_tii = false;
         std::chrono::steady_clock::time_point t0;         // signal time 0 of every ensemble (construction time)
         bool use_signal_clock = true;

@@ -22,15 +22,13 @@ namespace {
 constexpr uint64_t kRing = 80ull * 196608;
 constexpr uint64_t kAhead = 8ull * 196608;
 constexpr int kPull = 65536;                         // samples per InputInterface::getSamples call
-constexpr size_t kMaxQueued = 64;                    // logical frames a sub-channel's decoder thread may lag behind the channel decoder
 
 bool protection_of(const Subchannel& sub, dabphy_protection* p)
 {
-    memset(p, 0, sizeof *p);
-    const auto& ps = sub.protectionSettings;
-    const int r = ps.shortForm ? dabphy_protection_uep(p, sub.bitrate(), ps.uepLevel)
-                               : dabphy_protection_eep(p, sub.bitrate(), ps.eepProfile == EEPProtectionProfile::EEP_B, (int)ps.eepLevel);
-    return r == DABPHY_OK;
+    dabphy_subchannel d;
+    const bool ok = SubchannelStream::describe(sub, &d);
+    *p = d.prot;
+    return ok;
 }
 
 int placement_code(FFTPlacementMethod m)
@@ -60,55 +58,6 @@ const char* freqSyncMethodToString(FreqsyncMethod method)
     throw std::logic_error("Unhandled freqsyncMethod placement");
 }
 #endif
-
-// ------------------------------------------------------------------------------------------------ one selected sub-channel
-GpuRadioReceiver::Stream::Stream(ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& s) :
-    sub(s), frame_bytes(3 * s.bitrate()), adapter(handler, (int16_t)s.bitrate(), ascty, dumpFileName)
-{
-    thread = std::thread(&Stream::run, this);
-}
-
-GpuRadioReceiver::Stream::~Stream()
-{
-    {
-        std::lock_guard<std::mutex> lock(m);
-        closing = true;
-    }
-    cv.notify_all();
-    if (thread.joinable()) thread.join();           // frames already queued are still delivered (a file ends with its last frames decoded)
-}
-
-void GpuRadioReceiver::Stream::push(const uint8_t* p, const std::atomic<bool>& receiver_running)
-{
-    {
-        // a full queue holds the channel decoder back (an unthrottled file input would otherwise run arbitrarily far ahead of the audio
-        // decoder): DabAudio::process waits the same way on its ring buffer (dab-audio.cpp:99-106).  The wait is bounded: a receiver
-        // that is being stopped must not sit behind a stalled audio decoder (the frame is then dropped with the receiver)
-        std::unique_lock<std::mutex> lock(m);
-        while (!cv_space.wait_for(lock, std::chrono::milliseconds(50), [&] { return closing || q.size() < kMaxQueued; }))
-            if (!receiver_running) return;
-        if (closing) return;
-        q.emplace_back(p, p + frame_bytes);
-    }
-    cv.notify_one();
-}
-
-void GpuRadioReceiver::Stream::run()
-{
-    std::vector<uint8_t> bits(8 * (size_t)frame_bytes);
-    for (;;) {
-        std::vector<uint8_t> f;
-        {
-            std::unique_lock<std::mutex> lock(m);
-            cv.wait(lock, [&] { return closing || !q.empty(); });
-            if (q.empty()) return;
-            f = std::move(q.front()); q.pop_front();
-        }
-        cv_space.notify_one();
-        for (int i = 0; i < 8 * frame_bytes; i++) bits[i] = (f[i >> 3] >> (7 - (i & 7))) & 1;     // DabAudio hands over one bit per byte
-        adapter.addtoFrame(bits.data());                                                          // dab-audio.cpp:157
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ facade
 GpuRadioReceiver::GpuRadioReceiver(RadioControllerInterface& rci_, InputInterface& input_, RadioReceiverOptions rro, int transmission_mode) :

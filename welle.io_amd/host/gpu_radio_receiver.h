@@ -36,8 +36,8 @@
 #include "dab-constants.h"
 #include "fib-processor.h"
 #include "decoder_adapter.h"
+#include "subchannel_stream.h"
 
-struct dabphy_handle;
 
 #ifndef DABPHY_HAVE_RECEIVER_STATS                  // radio-receiver.h:48-50 (the drop-in header replaces that file)
 #define DABPHY_HAVE_RECEIVER_STATS
@@ -85,22 +85,7 @@ class GpuRadioReceiver {
         FIBProcessor fibProcessor;      // public like FicHandler::fibProcessor (fic-handler.h:47)
 
     private:
-        // one selected sub-channel: DabAudio's role after the channel decoder (dab-audio.cpp:151-160), on its own thread
-        struct Stream {
-            Stream(ProgrammeHandlerInterface& handler, AudioServiceComponentType ascty, const std::string& dumpFileName, const Subchannel& sub);
-            ~Stream();
-            void push(const uint8_t* frame_bytes_msb_first, const std::atomic<bool>& receiver_running);   // one logical frame (3 * bitrate bytes)
-            Subchannel sub;
-            int frame_bytes;
-          private:
-            void run();
-            DecoderAdapter adapter;
-            std::mutex m; std::condition_variable cv, cv_space;
-            std::deque<std::vector<uint8_t>> q;                         // at most kMaxQueued logical frames: push blocks beyond that, as
-                                                                        // DabAudio::process does on a full mscBuffer (dab-audio.cpp:99-106)
-            bool closing = false;
-            std::thread thread;
-        };
+        using Stream = SubchannelStream;     // one selected sub-channel: DabAudio's role after the channel decoder, on its own thread (subchannel_stream.h)
         bool playProgramme(ProgrammeHandlerInterface& handler, const Service& s, const std::string& dumpFileName, bool unique);
         void run();
         bool decode_one_frame();
