@@ -59,8 +59,14 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, freqsync=2, max_frames=None):
-    """Run the real reference RadioReceiver over a cf32 stream.  subchs: list of synth.SubchannelCfg."""
+def level2_lib(variant, backend):
+    """oracle/_ref/libwelle_l2{a,b}_{emu,hip}.so: the reference backend with ONE source replaced by a seam binding (INTEGRATION.md level 2)"""
+    return os.path.join(ROOT, "oracle", "_ref", "libwelle_l2%s_%s.so" % (variant, backend))
+
+
+def receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_placement=2, freqsync=2, max_frames=None, lib=None):
+    """Run the real reference RadioReceiver over a cf32 stream.  subchs: list of synth.SubchannelCfg.
+    lib: another build of the same sources behind the same harness (level2_lib: one file replaced by a seam binding)"""
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     nf = max_frames or (len(iq) // 196608 + 2)
     io = RefRunIO()
@@ -86,7 +92,7 @@ def receiver_run(iq, subchs=(), dump_dir="/tmp", disable_coarse=False, fft_place
     nul = np.zeros((nf, 2656), np.complex64); io.nul = _p(nul); io.nul_cap = nf
     snr = np.zeros(nf, np.float32); io.snr = _p(snr); io.snr_cap = nf
     corr = np.zeros((nf, 2), np.int32); io.corr = _p(corr); io.corr_cap = nf
-    ref().ref_receiver_run(C.byref(io))
+    (C.CDLL(lib) if lib else ref()).ref_receiver_run(C.byref(io))
     msc = []
     for pth in paths:
         msc.append(open(pth, "rb").read() if os.path.exists(pth) else b"")

@@ -1,0 +1,83 @@
+// welle.io_amd/host/seams/ofdm_decoder_seam.cpp -- INTEGRATION.md level 2, BASELINE config 2 ("2048-pt FFT + DQPSK HIP path, Viterbi
+// still on CPU"): this file REPLACES src/backend/ofdm-decoder.cpp in a build of the reference; every other source, and the class's own
+// header ofdm-decoder.h, stay as they are.  The seam is OfdmDecoder::pushAllSymbols (ofdm-decoder.cpp:132-139): the 76 symbols of one
+// transmission frame go to dabphy_demod_frames -- processPRS + 75 x decodeDataSymbol on the device -- and the unchanged consumers get
+// what they always got, in the reference's order: onSNR (:155-158), processFicBlock x 3, processMscBlock x 72 (:221-228),
+// onConstellationPoints (:119-121).  oracle/Makefile builds it (welle-cli-l2a-*, libwelle_l2a_*); tests/test_level2_seams.py compares
+// every callback and dump with the reference build's.
+#include "ofdm-decoder.h"
+#include "../../../include/dabphy.h"
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+
+namespace {   // the class declaration is the reference's own: the device handle of each decoder lives beside it
+std::mutex g_m; std::map<const OfdmDecoder*, dabphy_handle*> g_h;
+dabphy_handle* handle_of(const OfdmDecoder* d) { std::lock_guard<std::mutex> l(g_m); return g_h.at(d); }
+}
+
+OfdmDecoder::OfdmDecoder(const DABParams& p, RadioControllerInterface& mr, FicHandler& fic, MscHandler& msc) :
+    params(p), radioInterface(mr), ficHandler(fic), mscHandler(msc), pending_symbols(p.L), phaseReference(0), fft_handler(p.T_u), interleaver(p), ibits(0)
+{
+    dabphy_config cfg = DABPHY_CONFIG_INIT;
+    cfg.n_ensembles = 1; cfg.max_frames = 1; cfg.fft_placement = 2; cfg.freqsync_method = 2; cfg.want_constellation = 1;
+    dabphy_handle* h = nullptr;
+    if (p.L != 76 || dabphy_create(&cfg, &h) != DABPHY_OK) throw std::runtime_error("OfdmDecoder (GPU seam): Mode I and a gfx950 device are required");
+    { std::lock_guard<std::mutex> l(g_m); g_h[this] = h; }
+    thread = std::thread(&OfdmDecoder::workerthread, this);
+}
+
+OfdmDecoder::~OfdmDecoder()
+{
+    running = false; pending_symbols_cv.notify_all();
+    if (thread.joinable()) thread.join();
+    dabphy_handle* h = handle_of(this);
+    { std::lock_guard<std::mutex> l(g_m); g_h.erase(this); }
+    dabphy_destroy(h);
+}
+
+void OfdmDecoder::reset()
+{
+    running = false; pending_symbols_cv.notify_all();
+    if (thread.joinable()) thread.join();
+    thread = std::thread(&OfdmDecoder::workerthread, this);
+}
+
+void OfdmDecoder::pushAllSymbols(std::vector<std::vector<DSPCOMPLEX> >&& syms)      // ofdm-decoder.cpp:132-139, unchanged
+{
+    std::unique_lock<std::mutex> lock(mutex);
+    pending_symbols = std::move(syms);
+    num_pending_symbols = pending_symbols.size();
+    pending_symbols_cv.notify_one();
+}
+
+void OfdmDecoder::workerthread()
+{
+    dabphy_handle* const h = handle_of(this);
+    const size_t T_u = params.T_u, T_s = params.T_s, K = params.K;
+    std::vector<float> flat(2 * (T_u + 75 * T_s));
+    std::vector<softbit_t> soft(75 * 2 * K);
+    running = true;
+    while (running) {
+        std::unique_lock<std::mutex> lock(mutex);
+        pending_symbols_cv.wait_for(lock, std::chrono::milliseconds(100));
+        if (num_pending_symbols != params.L || !running) continue;
+        memcpy(flat.data(), pending_symbols[0].data(), T_u * sizeof(DSPCOMPLEX));
+        for (int s = 1; s < params.L; s++) memcpy(flat.data() + 2 * (T_u + (s - 1) * T_s), pending_symbols[s].data(), T_s * sizeof(DSPCOMPLEX));
+        constellationPoints.resize((params.L - 1) * K / constellationDecimation);
+        float snr_report = NAN;
+        if (dabphy_demod_frames(h, flat.data(), 1, soft.data(), reinterpret_cast<float*>(constellationPoints.data()), &snr_report) != DABPHY_OK)
+            throw std::runtime_error(dabphy_last_error(h));
+        if (!std::isnan(snr_report)) radioInterface.onSNR(snr_report);
+        for (int s = 1; s < params.L; s++) {
+            if (s < 4) ficHandler.processFicBlock(soft.data() + (size_t)(s - 1) * 2 * K, s);
+            else mscHandler.processMscBlock(soft.data() + (size_t)(s - 1) * 2 * K, s);
+        }
+        num_pending_symbols = 0;
+        radioInterface.onConstellationPoints(std::move(constellationPoints));
+        constellationPoints.clear();
+    }
+    std::clog << "OFDM-decoder (GPU seam):" << "closing down now" << std::endl;
+}
