@@ -90,3 +90,11 @@ def test_sized_configuration(emu):
     for bad in (C.sizeof(capi.Config) + 4, 8, 0, 18):
         p.cfg.struct_size = bad; h = C.c_void_p()
         assert lib.dabphy_create_v2(C.byref(p), C.byref(h)) == -2 and not h.value, bad
+
+
+def test_integration_md_shows_the_seam_files():
+    """INTEGRATION.md level 2 shows welle.io_amd/host/seams/*.cpp VERBATIM (the files oracle/Makefile builds and tests/test_level2_seams.py
+    tests), not a restatement that can drift"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sync_integration.py"), "--check"])
+    assert r.returncode == 0, "INTEGRATION.md is out of date: run python tools/sync_integration.py"
