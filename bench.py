@@ -504,8 +504,15 @@ def main():
                 for e in check:
                     path = os.path.join(td, "rec%d.npy" % e); np.save(path, iq[e].cpu().numpy()); recs.append(path)
                 env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-                _run_receivers(recs, len(recs), max(2, -(-80 // rec_frames)), "port", env, td)
-                _compare_with_receivers(td, "port", check, logs)
+                # every rank's leg runs on the same host: each takes its share of the cores (at least one receiver at a time), so that
+                # N ranks never start more receivers together than the host has cores
+                cores_ = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+                share = max(1, min(len(recs), cores_ // world))
+                for i0 in range(0, len(recs), share):
+                    part = list(range(i0, min(len(recs), i0 + share)))
+                    tdp = os.path.join(td, "part%d" % i0); os.makedirs(tdp)
+                    _run_receivers([recs[i] for i in part], len(part), max(2, -(-80 // rec_frames)), "port", env, tdp)
+                    _compare_with_receivers(tdp, "port", [check[i] for i in part], logs)
             flag = 1
         except Exception as ex:
             rank_err = "rank %d: %s: %s" % (rank, type(ex).__name__, ex)
@@ -514,6 +521,20 @@ def main():
         dist.all_reduce(tf, op=dist.ReduceOp.SUM)
         ranks_ok = int(tf.item())
 
+    # Rank 0 measures the CPU baseline on the host's cores after the timed region.  The other ranks must not spin in an RCCL barrier on
+    # those cores meanwhile: they sleep on a file rank 0 writes when its line is out (bounded: the watchdog below), and only then does
+    # everybody meet in the final barrier.
+    park = os.path.join(os.environ.get("TMPDIR", "/tmp"), "dabphy_bench_%s_%s.done" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))) if world > 1 else None
+    if park and rank == 0 and os.path.exists(park):
+        os.remove(park)
+    if dist is not None:
+        dist.barrier()                                     # (the stale file of an earlier run is gone before anybody looks for it)
+    if park and rank != 0:
+        t_park = time.time()
+        while not os.path.exists(park):
+            if time.time() - t_park > 1500:
+                sys.stderr.write("bench.py rank %d/%d: rank 0 did not finish its CPU baseline within 1500 s -- giving up\n" % (rank, world)); sys.stderr.flush(); os._exit(5)
+            time.sleep(0.25)
     if rank == 0:
         n_simd = 4 * torch.cuda.get_device_properties(local).multi_processor_count
         ms_step = dt / args.steps * 1e3
@@ -660,11 +681,15 @@ def main():
             line["facade"] = _extra([os.path.join(ROOT, "tools", "bench_facade.py"), "--json"], {}, 420)
             line["host_u8"] = _extra([os.path.join(ROOT, "tools", "bench_host_u8.py")], {"HOSTU8_B": str(B), "HOSTU8_F": str(F), "HOSTU8_STEPS": "3"}, 300)
         print(json.dumps(line), flush=True)
+        if park:
+            open(park, "w").write("done\n")
     if dev is not None:
         dev.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if park and rank == 0 and os.path.exists(park):
+        os.remove(park)
 
 
 if __name__ == "__main__":

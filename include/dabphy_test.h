@@ -41,6 +41,11 @@ int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
  * GPU-less execution model of tests/hipemu stands in for.  counts[0] = mismatches, counts[1] = values checked. */
 int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts);
 
+/* Which Viterbi kernel decoded the last dabphy_process batch (dabphy_config.decode_shape = 0 leaves the choice to the library):
+ * *shape = 1 lane per code word (k_viterbi_fused), 2 state-parallel (k_viterbi_sp), 0 nothing decoded yet; *fused_classes = protection
+ * classes (not counting the FIC) that rode in that launch -- the others took the two-kernel path.  Either pointer may be NULL. */
+int dabphy_last_decode_plan(dabphy_handle* h, int32_t* shape, int32_t* fused_classes);
+
 #ifdef __cplusplus
 }
 #endif

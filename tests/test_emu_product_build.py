@@ -39,3 +39,40 @@ def test_benchmark_handle_configuration_small(emu_product):
     from welle_io_amd import workload
     P.check_bench_config(capi, LIB, 3, 3, 1, check_ens=[0, 2], n_steps=4, demod_chunk=25, device="cpu", subs_idx=(0, 17),
                          base=workload.make_base_streams(2, workload.REC_FRAMES, seed0=0), expect_chunk=25, decode_shape=1)
+
+
+def test_default_choice_of_the_viterbi_kernel(emu_product, monkeypatch):
+    """dabphy_config.decode_shape = 0 on the product build (no environment override exists in it): one ensemble, one frame per call --
+    the live receiver's shape -- is decoded state-parallel (76 code words), and so are the per-frame seams; a batch beyond 16 384 code
+    words takes the lane-per-code-word kernel.  Bytes against the oracle either way."""
+    monkeypatch.delenv("DABPHY_SP_MAX_CW", raising=False)
+    from welle_io_amd import synth
+    import refapi as R
+    import numpy as np
+    x, tx = synth.make_stream(4, snr_db=15, cfo_hz=30, delay=77, return_tx=True, seed=9)
+    subs = [tx.subchs[3], tx.subchs[10]]
+    o = R.orc_receiver_run(x, subchs=subs)
+    d = factory(n_ensembles=1, max_frames=1, want_constellation=False)
+    try:
+        assert d.last_decode_plan() == (0, 0)
+        d.stream_upload(x)
+        d.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, P.dev_prot(d, s)) for s in subs])
+        fibs = []
+        for _ in range(3):
+            d.process(1)
+            assert d.last_decode_plan() == (2, 1), d.last_decode_plan()        # state-parallel, the one MSC class in the launch
+            if d.frame_info()[0, 0]["valid"] == 1:
+                fibs.append(d.fibs()[0][0, 0])
+        assert len(fibs) >= 2 and np.array_equal(np.array(fibs), o["fib"][:12 * len(fibs)].reshape(len(fibs), 12, 33)[:, :, 1:])
+        P.check_viterbi(d, 768, 3, seed=5, kind="uniform")                      # a seam call of three code words: one wavefront each
+        P.check_fic_arbitrary_int8(d, n_frames=1)
+    finally:
+        d.close()
+    big = factory(n_ensembles=58, max_frames=4, want_constellation=False)       # 58 x 4 frames x (4 FIC + 72 MSC) = 17 632 code words with 18 sub-channels
+    try:
+        big.stream_upload(np.tile(x, (58, 1)))
+        big.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, P.dev_prot(big, s)) for s in tx.subchs])
+        big.process(4)
+        assert big.last_decode_plan() == (1, 1), big.last_decode_plan()
+    finally:
+        big.close()

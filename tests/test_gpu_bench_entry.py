@@ -40,6 +40,12 @@ def test_single_gpu_line_and_parity_leg(gpu):
     # the heterogeneous multiplex behind the headline: its own throughput, Viterbi stage time and parity leg (every sub-channel)
     het = j["extras"]["hetero"]
     assert het.get("parity") is True and het["value"] > 0 and het["msc_viterbi_ms"] > 0, het
+    # ... and the batch of independent ensembles (five multiplexes, five selections): throughput, Viterbi stage time, its own parity leg
+    mix = j["extras"]["mixed_layouts"]
+    assert mix.get("parity") is True and mix["value"] > 0 and mix["msc_viterbi_ms"] > 0, mix
+    # INTEGRATION level 2 as a build: the reference backend with one file replaced by a seam binding, next to the unmodified build
+    l2 = j["facade"].get("level2", {})
+    assert all(l2.get(k, {}).get("x_realtime", 0) > 0 for k in ("reference", "l2a", "l2b")), l2
     assert j["roofline"]["measured_copy_GBps"] > 1000 and 0 < j["roofline"]["frac_of_achievable"] < 1.2
     assert j["profile_build"]["src_sha256"] and j["profile_build"]["lib_sha256"]
 
@@ -65,3 +71,11 @@ def test_gpus_2_starts_its_ranks(gpu):
     assert j["cpu_baseline"]["kind"] in ("reference", "port") and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
     # every rank proved its own shard against the oracle outside the timed region
     assert j["parity_check"]["ranks_ok"] == 2 and j["parity_check"]["fib_equal"] and j["parity_check"]["msc_equal"], j["parity_check"]
+    # rank 0 measured the CPU baseline while the other rank slept on a file (not in a spinning barrier) and each rank's parity leg took
+    # its share of the cores: the figure is the one a single-rank run of the same configuration measures
+    j1 = run_bench(["--gpus", "1", "--steps", "1", "--ensembles", "4", "--frames", "10", "--no-alt-schedule", "--no-extras"])
+    a2, a1 = j["cpu_baseline"], j1["cpu_baseline"]
+    v2 = a2["oracle_port"]["value"] if a2["kind"] == "reference" else a2["value"]
+    v1 = a1["oracle_port"]["value"] if a1["kind"] == "reference" else a1["value"]
+    print("cpu_baseline (oracle receivers on all cores): %.2f x with 2 ranks, %.2f x with 1" % (v2, v1))
+    assert abs(v2 / v1 - 1) < 0.10, (v2, v1)

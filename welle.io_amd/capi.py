@@ -225,6 +225,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_time_copy(self.h, C.c_uint64(nbytes), blocks_per_cu, iters, C.byref(a)))
         return a.value
 
+    def last_decode_plan(self):
+        """(1 = lane per code word / 2 = state-parallel / 0 = nothing decoded yet, protection classes in the fused launch) of the last process()"""
+        a = C.c_int32(0); b = C.c_int32(0)
+        self._chk(self.lib.dabphy_last_decode_plan(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def time_fused_msc(self, iters=3):
         a = C.c_float(0)
         self._chk(self.lib.dabphy_time_fused_msc(self.h, iters, C.byref(a)))

@@ -251,6 +251,16 @@ int dabphy_get_soft_bits(dabphy_handle* h, uint32_t ensemble, uint32_t frame, in
     return sync(h);
 }
 
+int dabphy_last_decode_plan(dabphy_handle* h, int32_t* shape, int32_t* fused_classes)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    const auto& P = h->fplan;
+    const bool ran = P.valid && P.launched && h->last_frames;
+    if (shape) *shape = !ran ? 0 : P.use_sp ? 2 : 1;
+    if (fused_classes) *fused_classes = ran ? (int32_t)P.class_idx.size() : 0;
+    return DABPHY_OK;
+}
+
 int dabphy_set_profiling(dabphy_handle* h, int32_t on)
 {
     DeviceBind dev_(h);

@@ -369,15 +369,33 @@ __device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const u
 // :122-131 AU CRC-16-CCITT of the first ne events of one (ensemble, sub-channel) pair, one lane per access unit.  The verdicts do not steer the
 // state machine.  (Events and superframes were written by earlier kernels or, behind a barrier, by this work-group.)  Returns nothing:
 // failures are counted into *aubad (LDS).
-__device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t)
+// `stage` (LDS, stage_bytes; nullptr: none): the corrected superframes are brought in with coalesced loads, as many events at a time as
+// fit, and the CRCs walk LDS bytes -- a lane that reads its access unit byte by byte from HBM spends ~300 dependent memory round trips per
+// unit (round 4: this was all of k_superframe_settle's 0.4 ms, half of the filter's time in the headline step).
+__device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t,
+                                           uint8_t* stage = nullptr, int stage_bytes = 0)
 {
-    for (int base = 0; base < ne * 6; base += 64) {
-        const int k = base + t, e_i = k / 6, au_i = k % 6;
-        if (e_i < ne && ev[e_i].sync && au_i < ev[e_i].num_aus) {
-            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
-            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
-            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
-            else atomicAdd(aubad, 1);
+    const int per = (stage && stage_bytes >= sf_len) ? stage_bytes / sf_len : 0;       // events per staged chunk (0: read from HBM)
+    for (int e0 = 0; e0 < ne; e0 += per ? per : ne) {
+        const int n = per ? (ne - e0 < per ? ne - e0 : per) : ne;
+        if (per) {
+            __syncthreads();                                                            // (the previous chunk has been read)
+            for (int e = 0; e < n; e++) {
+                if (!ev[e0 + e].sync) continue;
+                const uint2* src = reinterpret_cast<const uint2*>(A.sf + (bm * A.n_slots + ev[e0 + e].sf_slot) * sf_len);     // (superframes are 120 s bytes: multiples of 8, 8-aligned)
+                uint2* dst = reinterpret_cast<uint2*>(stage + (size_t)e * sf_len);
+                for (int i = t; i < sf_len / 8; i += 64) dst[i] = src[i];
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < n * 6; base += 64) {
+            const int k = base + t, e_i = e0 + k / 6, au_i = k % 6;
+            if (k < n * 6 && ev[e_i].sync && au_i < ev[e_i].num_aus) {
+                const uint8_t* au = (per ? stage + (size_t)(e_i - e0) * sf_len : A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len) + ev[e_i].au_start[au_i];
+                const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
+                if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
+                else atomicAdd(aubad, 1);
+            }
         }
     }
 }
@@ -439,6 +457,8 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
     const SfArgs A = sf_args_of(Bt, bx);
     __shared__ uint16_t s_crctab[256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
+    constexpr int SF_STAGE = 24576;                                                     // 25 superframes of a 64 kbit/s service (a 32-frame batch), 4 of a 384 kbit/s one
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[SF_STAGE];
     const int t = threadIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
     const size_t bm = A.run ? (size_t)A.run[bx] : (size_t)bx;      // the pair
@@ -461,7 +481,7 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
     const int ok = s_ok;
     if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats && p.nq >= 1) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }   // (a batch without a full window has nothing the wide pass could settle: not counted as tried)
     if (!ok) return;
-    sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t);
+    sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t, s_stage, SF_STAGE);
     // the frames behind the last attempt are the next batch's carried window (a hit empties it, dabplus_decoder.cpp:156)
     const int n_left = p.cu + p.avail - 5 * p.nq;
     for (int k = 0; k < n_left; k++) {

@@ -544,6 +544,8 @@ int fused_wave_slots(int variant)
     int occ = FUSED_OCC[variant];
 #ifdef DABPHY_EXPERIMENTS
     { const char* e = getenv("DABPHY_VITM_SLOTS"); if (e && atoi(e) > 0) occ = atoi(e); }
+    // (round 5 experiment: leave a few per cent of the wave slots to the next batch's synchroniser, profiles/r05_sync_tail.txt)
+    { const char* e = getenv("DABPHY_VITM_SLOTS_PCT"); if (e && atoi(e) > 0 && atoi(e) <= 100) return (int)((long long)occ * device_simds() * atoi(e) / 100); }
 #endif
     return occ * device_simds();
 }
