@@ -39,7 +39,7 @@ int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
 /* Device self-test of the lane exchanges of the state-parallel Viterbi kernel (k_viterbi_sp.hip: v_permlane32_swap, v_permlane16_swap,
  * bank-masked row DPP moves, quad_perm DPP reads, v_readlane) against plain shuffles: the forms the
  * GPU-less execution model of tests/hipemu stands in for.  counts[0] = mismatches, counts[1] = values checked. */
-int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts);
+int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts);   /* (also swap16 / partner of k_viterbi_sp2.hip) */
 
 /* Which Viterbi kernel decoded the last dabphy_process batch (dabphy_config.decode_shape = 0 leaves the choice to the library):
  * *shape = 1 lane per code word (k_viterbi_fused), 2 state-parallel (k_viterbi_sp), 0 nothing decoded yet; *fused_classes = protection

@@ -57,6 +57,16 @@ template <int B> static inline void pair_values(uint32_t m, uint32_t& x, uint32_
     x = hipemu_wave_exchange(m, lane & ~(1 << B), true);
     y = hipemu_wave_exchange(m, lane | (1 << B), true);
 }
+static inline int mad_i24_vv(int x, int m, int acc) { return (int)((uint32_t)x * (uint32_t)m + (uint32_t)acc); }
+static inline uint32_t sub_borrow(uint32_t y, uint32_t x, unsigned long long mask) { return y - x - (uint32_t)((mask >> hipemu_lane()) & 1ull); }
+// two code words per wavefront: pairs along lane bit B inside each half of 32 lanes (see the product header)
+static inline void swap16(uint32_t r0, uint32_t r1, uint32_t& a, uint32_t& b)
+{
+    const int lane = hipemu_lane(); const bool set = (lane >> 4) & 1;
+    const uint32_t p0 = hipemu_wave_exchange(r0, lane ^ 16, true), p1 = hipemu_wave_exchange(r1, lane ^ 16, true);
+    a = set ? p1 : r0; b = set ? r1 : p0;
+}
+template <int B> static inline uint32_t partner(uint32_t g) { return hipemu_wave_exchange(g, hipemu_lane() ^ (1 << B), true); }
 static inline uint32_t lane_get(uint32_t v, uint32_t idx) { return hipemu_wave_exchange(v, (int)(idx & 63), true); }
 static inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
 

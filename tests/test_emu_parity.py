@@ -45,7 +45,14 @@ def test_seams_state_parallel(emu):
     arbitrary int8 input incl. -128 (the clamp of viterbi.cpp:233-236), every EEP / UEP profile kind, the FIC"""
     from welle_io_amd import capi
     import conftest
-    d = capi.DabPhy(lib_path=conftest.EMU_LIB, decode_shape=2)
+    d = capi.DabPhy(lib_path=conftest.EMU_LIB, decode_shape=3)              # round 4's kernel (one code word per wavefront) stays selectable
+    try:
+        P.check_viterbi(d, 192, 7, seed=6, kind="extreme")
+        P.check_msc_deconvolve(d, "uep", 80, 1, 0, 3, seed=11)
+        P.check_fic_arbitrary_int8(d, n_frames=1)
+    finally:
+        d.close()
+    d = capi.DabPhy(lib_path=conftest.EMU_LIB, decode_shape=2)              # k_viterbi_sp2: two code words per wavefront, odd counts included
     try:
         P.check_viterbi(d, 768, 9, seed=5, kind="uniform")
         P.check_viterbi(d, 192, 70, seed=6, kind="extreme")

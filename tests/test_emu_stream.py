@@ -18,7 +18,7 @@ def factory_lane_per_codeword(**kw):
 
 
 def factory_state_parallel(**kw):
-    """dabphy_config.decode_shape = 2: one wavefront per code word (k_viterbi_sp) whatever the batch size"""
+    """dabphy_config.decode_shape = 2: the state-parallel kernel (k_viterbi_sp2: two code words per wavefront) whatever the batch size"""
     return capi.DabPhy(lib_path=EMU_LIB, decode_shape=2, **kw)
 
 

@@ -89,7 +89,7 @@ def test_demod_then_fic_roundtrip_full_batch(gpu):
     assert np.array_equal(fib, sent)
 
 
-@pytest.mark.parametrize("shape", [1, 2])
+@pytest.mark.parametrize("shape", [1, 2, 3])
 def test_seams_with_either_decoder(gpu, shape):
     """the seams of INTEGRATION.md level 2 with both Viterbi kernels forced (the default decodes these small calls state-parallel: every
     other seam test of this file): arbitrary int8 input incl. -128, EEP / UEP profiles, the FIC"""

@@ -20,8 +20,13 @@ def factory_lane_per_codeword(**kw):
 
 
 def factory_state_parallel(**kw):
-    """dabphy_config.decode_shape = 2: one wavefront per code word (k_viterbi_sp) whatever the batch size"""
+    """dabphy_config.decode_shape = 2: the state-parallel kernel (k_viterbi_sp2: two code words per wavefront) whatever the batch size"""
     return capi.DabPhy(lib_path=GPU_LIB, decode_shape=2, **kw)
+
+
+def factory_state_parallel_r4(**kw):
+    """dabphy_config.decode_shape = 3: round 4's state-parallel kernel (k_viterbi_sp: one code word per wavefront)"""
+    return capi.DabPhy(lib_path=GPU_LIB, decode_shape=3, **kw)
 
 
 @pytest.mark.parametrize("snr,cfo,delay,nf,lockstep", [(25, 0, 0, 22, False), (None, 0, 0, 9, False), (13, 137, 1000, 14, True), (20, 2300, 0, 12, True),
@@ -118,7 +123,8 @@ def test_lane_exchanges_of_the_state_parallel_kernel(gpu):
     """v_permlane32_swap / v_permlane16_swap / bank-masked row DPP / quad_perm DPP / v_readlane as k_viterbi_sp uses them, against plain
     shuffles on the device (the GPU-less execution model stands in for exactly these forms)"""
     bad, n = gpu.selftest_pair_exchange()
-    assert bad == 0 and n == 8 * 64 * 16 * 13, (bad, n)
+    # (13 checks per lane and round of k_viterbi_sp's forms, 6 of k_viterbi_sp2's swap16 / partner<3..0>)
+    assert bad == 0 and n == 8 * 64 * 16 * (13 + 6), (bad, n)
 
 
 def test_shallow_batch_above_the_state_parallel_limit(gpu):
@@ -307,3 +313,10 @@ def test_independent_ensembles_in_one_batch(gpu, shape):
     """ten ensembles, five multiplexes, five selections (all / all / all / every other service / none), four frames per call, with
     either Viterbi kernel: every selected sub-channel of every ensemble, FIBs and superframe totals against the oracle"""
     P.check_mixed_layouts(capi, GPU_LIB, 10, 4, check_ens=list(range(10)), n_steps=3, decode_shape=shape, rec_frames=20)
+
+
+def test_round_4_state_parallel_kernel_is_still_there(gpu):
+    """dabphy_config.decode_shape = 3 (k_viterbi_sp, one code word per wavefront): the mixed ensemble incl. its 9216-bit code words and a
+    stream with services changing in mid-stream, against the oracle"""
+    P.check_mixed_ensemble(factory_state_parallel_r4, F=4, nf=11, expect_fused=True)
+    P.check_service_changes_in_mid_stream(factory_state_parallel_r4)

@@ -67,7 +67,7 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
-    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 2) return fail(DABPHY_ERR_INVALID);
+    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 3) return fail(DABPHY_ERR_INVALID);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
@@ -312,7 +312,7 @@ static int run_lin_decode(dabphy_handle* h, const int8_t* in, size_t in_stride, 
         FusedClass fc{}; fc.map = d_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = nbits; fc.n_cw = (int32_t)n_cw; fc.n_pairs = 1; fc.kind = 2; fc.dedisperse = dedisperse;
         FusedArgs a{}; a.n_ens = 1; a.n_frames = 1; a.lin_in = h->in8.as<int8_t>(); a.lin_stride = in_stride;
         if ((r = sp_single_prepare(h, fc, a, h->stream))) return r;
-        launch_viterbi_sp(a, sp_variant_for(c.nsteps), h->stream);
+        launch_sp(a, h->sp1_two, sp_variant_for(c.nsteps), h->stream);
         HIPCHK(h, hipMemcpyAsync(out, c.out, (size_t)n_cw * (nbits / 8), hipMemcpyDeviceToHost, h->stream));
         return sync(h);
     }
@@ -364,7 +364,7 @@ int dabphy_fic_decode(dabphy_handle* h, const int8_t* soft, uint32_t n_frames, u
         FusedClass fc{}; fc.map = h->d_fic_map; fc.out = c.out; fc.nsteps = c.nsteps; fc.nbits = 768; fc.n_cw = (int32_t)(n_frames * 4); fc.n_pairs = 1; fc.kind = 1; fc.dedisperse = 1;
         FusedArgs a{}; a.soft = g.soft; a.ens_stride = (size_t)n_frames * 9216; a.soft_ring = (int)n_frames; a.n_ens = 1; a.n_frames = (int)n_frames; a.desc = g.desc; a.fic_frame_stride = 9216;
         if ((r = sp_single_prepare(h, fc, a, h->stream))) return r;
-        launch_viterbi_sp(a, sp_variant_for(c.nsteps), h->stream);
+        launch_sp(a, h->sp1_two, sp_variant_for(c.nsteps), h->stream);
     } else {
         launch_fic_gather(g, h->stream);
         VitArgs v{}; v.c = c; v.prbs_words = h->d_prbs_words;
@@ -567,6 +567,7 @@ int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts)
     HIPCHK(h, hipMalloc((void**)&d, 2 * sizeof *d));
     HIPCHK(h, hipMemsetAsync(d, 0, 2 * sizeof *d, h->stream));
     launch_selftest_pair_exchange(d, h->stream);
+    launch_selftest_half_exchange(d, h->stream);                 // ... and the forms of the two-code-words-per-wavefront kernel (same counters)
     unsigned host[2];
     HIPCHK(h, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
     const int r = sync(h);
@@ -711,7 +712,7 @@ int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(h, hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); h->err = "hipEventCreate failed"; return DABPHY_ERR_HIP; }
-    auto again = [&]() { if (P.use_sp) launch_viterbi_sp(P.args, P.sp_variant, h->stream); else launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream); };
+    auto again = [&]() { if (P.use_sp) launch_sp(P.args, P.sp_two, P.sp_variant, h->stream); else launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream); };
     again();                                                                  // (same inputs, same outputs: the launch is idempotent)
     hipError_t e = hipEventRecord(e0, h->stream);
     for (uint32_t i = 0; i < iters; i++) again();

@@ -109,9 +109,9 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     // A small batch -- fewer code words than the device has lanes to give them -- is decoded STATE-PARALLEL: one wavefront per code word
     // (k_viterbi_sp.hip), every class and the FIC, whatever their window schedules and spans (it addresses with 64-bit pointers).
     uint64_t total_cw = (uint64_t)B * F * 4 * (want_fic && h->fused_fic ? 1 : 0);
-    bool sp_ok = h->fused_msc && h->cfg.decode_shape != 1 && (h->sp_max_codewords > 0 || h->cfg.decode_shape == 2);
+    bool sp_ok = h->fused_msc && h->cfg.decode_shape != 1 && (h->sp_max_codewords > 0 || h->cfg.decode_shape >= 2);
     for (auto& c : h->classes) { total_cw += (uint64_t)4 * F * c.pairs.size(); sp_ok = sp_ok && (c.prot.nbits + 6) % 6 == 0 && c.prot.nbits + 6 <= SP_MAXSTEPS[SP_VARIANTS - 1]; }
-    const bool use_sp = sp_ok && (h->cfg.decode_shape == 2 || total_cw <= h->sp_max_codewords);
+    const bool use_sp = sp_ok && (h->cfg.decode_shape >= 2 || total_cw <= h->sp_max_codewords);
     for (size_t i = 0; i < h->classes.size(); i++) {
         auto& c = h->classes[i];
         const int P = (int)c.pairs.size();
@@ -144,17 +144,19 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         if (it.n_groups > 0xffffff) { h->err = "class too large for the fused decode's work list"; return DABPHY_ERR_INVALID; }
         for (int g = 0; g < it.n_groups; g++) { work.push_back(((uint32_t)it.ci << 24) | (uint32_t)g); item_off.push_back((uint32_t)item_rows); item_rows += (uint64_t)it.nsteps; }
     }
-    const int slots = fused_wave_slots(v);
-    // (state-parallel: one work-group per code word slot of every listed group, each with its own decision scratch)
-    const int n_slots = use_sp ? (int)work.size() * 64 : (int)std::min<size_t>(work.size(), (size_t)slots);
     const int sp_variant = sp_variant_for((int)max_steps);
+    const bool sp_two = use_sp && sp_two_for(h, (int)max_steps);
+    const int slots = fused_wave_slots(v);
+    // (state-parallel: one work-group per code word slot -- or pair of slots -- of every listed group, each with its own decision scratch)
+    const int n_slots = use_sp ? (int)work.size() * (sp_two ? 32 : 64) : (int)std::min<size_t>(work.size(), (size_t)slots);
+    const size_t sp_cells = (max_steps / 30 + 1) * (sp_two ? 64 : 32);                 // one 256-byte row of history words per 30 steps and code word
     // Decision scratch of the lane-per-code-word kernel: one region per WORK-GROUP sized for the longest code word of the launch (reused by
     // every group the wave pulls: the headline's shape) -- unless a few very long code words ride among many short ones (one 384 kbit/s
     // service in a multiplex of small ones: 9222 steps x 5120 waves = 24 GB): then one region per GROUP, each of its own length.
     const bool dec_by_item = !use_sp && item_rows < (uint64_t)n_slots * max_steps && item_rows < 0xffffffffull;
     int r;
     if (!work.empty()) {
-        const size_t dec_cells = use_sp ? (size_t)n_slots * (max_steps / 30 + 1) * 32 : dec_by_item ? (size_t)item_rows * 64 : (size_t)n_slots * max_steps * 64;
+        const size_t dec_cells = use_sp ? (size_t)n_slots * sp_cells : dec_by_item ? (size_t)item_rows * 64 : (size_t)n_slots * max_steps * 64;
         if ((r = ensure(h, h->vdec, dec_cells * sizeof(uint2)))) return r;
         if (dec_by_item && (r = ensure(h, h->fused_dec_off, item_off.size() * sizeof(uint32_t)))) return r;
         if ((r = ensure(h, h->fused_cls, cls.size() * sizeof(FusedClass)))) return r;
@@ -180,10 +182,10 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         if (!work.empty()) HIPCHK(h, hipMemcpyAsync(h->fused_work.p, P.host_work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         if (!work.empty() && dec_by_item) HIPCHK(h, hipMemcpyAsync(h->fused_dec_off.p, P.host_dec_off.data(), item_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     }
-    if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: decode plan for %u frames per call: %s, %zu of %zu classes%s, %zu groups, %d work-groups, decision scratch %s\n", F, use_sp ? "state-parallel" : "lane-per-code-word", idx.size(), h->classes.size(), fic_in ? " + FIC" : "", work.size(), n_slots, dec_by_item ? "per group" : "per work-group");
+    if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: decode plan for %u frames per call: %s, %zu of %zu classes%s, %zu groups, %d work-groups, decision scratch %s\n", F, use_sp ? (sp_two ? "state-parallel, two code words per wavefront" : "state-parallel") : "lane-per-code-word", idx.size(), h->classes.size(), fic_in ? " + FIC" : "", work.size(), n_slots, dec_by_item ? "per group" : "per work-group");
     P.valid = true; P.F = F; P.want_fic = want_fic; P.fic_in = fic_in; P.variant = v; P.n_slots = n_slots;
-    P.use_sp = use_sp; P.sp_variant = sp_variant; P.dec_by_item = dec_by_item;
-    P.dec_slot_cells = use_sp ? (max_steps / 30 + 1) * 32 : max_steps * 64;      // (state-parallel: one 256-byte row of history words per 30 steps)
+    P.use_sp = use_sp; P.sp_variant = sp_variant; P.sp_two = sp_two; P.dec_by_item = dec_by_item;
+    P.dec_slot_cells = use_sp ? sp_cells : max_steps * 64;
     P.class_idx = idx; P.buf_gen = h->buf_gen;
     FusedArgs a{};
     a.soft = h->s_soft.as<int8_t>(); a.ens_stride = ens_stride; a.soft_ring = (int)h->cfg.max_frames + 5; a.n_ens = (int)B; a.n_frames = (int)F;
@@ -201,7 +203,7 @@ bool sp_single_ok(const dabphy_handle* h, uint64_t n_cw, int nsteps)
 {
     if (!h->fused_msc || h->cfg.decode_shape == 1 || nsteps % 6 != 0 || nsteps > SP_MAXSTEPS[SP_VARIANTS - 1]) return false;
     if (n_cw > (uint64_t)SP_SINGLE_MAX_GROUPS * 64) return false;        // beyond the one-class launch's work list: the two-kernel path decodes it
-    return h->cfg.decode_shape == 2 || (h->sp_max_codewords > 0 && n_cw <= h->sp_max_codewords);
+    return h->cfg.decode_shape >= 2 || (h->sp_max_codewords > 0 && n_cw <= h->sp_max_codewords);
 }
 
 // One class through k_viterbi_sp on stream st: descriptor and work list go up through a small page-locked staging area (the copies are
@@ -219,7 +221,7 @@ int sp_single_reserve(dabphy_handle* h, uint64_t n_cw, int nsteps)
         if (hipHostMalloc(&p, sizeof(FusedClass) + SP_SINGLE_MAX_GROUPS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc failed (one-class staging)"; return DABPHY_ERR_NOMEM; }
         h->h_sp1 = p;
     }
-    const size_t cells = ((size_t)nsteps / 30 + 1) * 32;
+    const size_t cells = ((size_t)nsteps / 30 + 1) * 32;                 // (per code word: the same for either kernel)
     if ((r = ensure(h, h->sp1_cls, sizeof(FusedClass)))) return r;
     if ((r = ensure(h, h->sp1_work, SP_SINGLE_MAX_GROUPS * sizeof(uint32_t)))) return r;
     return ensure(h, h->vdec, (size_t)n_groups * 64 * cells * sizeof(uint2));
@@ -229,7 +231,8 @@ int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipS
     const uint32_t n_groups = (uint32_t)((fc.n_cw + 63) / 64);
     int r;
     if ((r = sp_single_reserve(h, (uint64_t)fc.n_cw, fc.nsteps))) return r;
-    const size_t cells = ((size_t)fc.nsteps / 30 + 1) * 32;
+    h->sp1_two = sp_two_for(h, fc.nsteps);
+    const size_t cells = ((size_t)fc.nsteps / 30 + 1) * (h->sp1_two ? 64 : 32);
     FusedClass* hc = reinterpret_cast<FusedClass*>(h->h_sp1);
     uint32_t* hw = reinterpret_cast<uint32_t*>(hc + 1);
     *hc = fc;
@@ -239,6 +242,15 @@ int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipS
     a.cls = h->sp1_cls.as<FusedClass>(); a.work = h->sp1_work.as<uint32_t>(); a.n_work = n_groups; a.next = nullptr;
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = cells; a.prbs_words = h->d_prbs_words;
     return DABPHY_OK;
+}
+bool sp_two_for(const dabphy_handle* h, int max_steps)
+{
+    (void)max_steps;                                     // (k_viterbi_sp2 takes code words of any length: its table holds them chunk by chunk)
+    return h->cfg.decode_shape != 3;
+}
+void launch_sp(const FusedArgs& a, bool two, int lds_variant, hipStream_t s)
+{
+    if (two) launch_viterbi_sp2(a, lds_variant < SP2_VARIANTS ? lds_variant : SP2_VARIANTS - 1, s); else launch_viterbi_sp(a, lds_variant, s);
 }
 int sp_variant_for(int nsteps)
 {

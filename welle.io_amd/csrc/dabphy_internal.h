@@ -114,7 +114,7 @@ struct dabphy_handle {
     struct FusedPlan {
         bool valid = false; uint32_t F = 0; bool want_fic = false; bool fic_in = false;
         int variant = 0, n_slots = 0; size_t dec_slot_cells = 0;
-        bool use_sp = false; int sp_variant = 0;         // the batch is small: one wavefront per code word (k_viterbi_sp) instead of 64 code words per wavefront
+        bool use_sp = false; int sp_variant = 0; bool sp_two = false;   // ... two code words per wavefront (k_viterbi_sp2)         // the batch is small: one wavefront per code word (k_viterbi_sp) instead of 64 code words per wavefront
         std::vector<int> class_idx;                      // classes decoded by the fused launch (the others take k_msc_gather + k_viterbi)
         std::vector<FusedClass> host_cls; std::vector<uint32_t> host_work, host_dec_off;
         bool dec_by_item = false;                        // decision scratch per group of 64 code words instead of per work-group (dabphy_fused.hip)
@@ -122,6 +122,7 @@ struct dabphy_handle {
         bool launched = false;
     } fplan;
     DevBuf fused_cls, fused_work, fused_dec_off; uint32_t* d_fused_next = nullptr;
+    bool sp1_two = false;                                // the last one-class launch prepared goes to k_viterbi_sp2
     DevBuf sp1_cls, sp1_work; void* h_sp1 = nullptr;     // one-class state-parallel launches (the seams, the replay's one-frame FIC): descriptor + work list, page-locked staging
     DevBuf fic_steps[FUSED_VARIANTS]; int fic_windows[FUSED_VARIANTS] = {0, 0, 0};
     hipEvent_t ev_fused_done = nullptr;
@@ -253,5 +254,9 @@ DABPHY_INTERNAL bool sp_single_ok(const dabphy_handle* h, uint64_t n_cw, int nst
 DABPHY_INTERNAL int sp_single_reserve(dabphy_handle* h, uint64_t n_cw, int nsteps);
 DABPHY_INTERNAL int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipStream_t st);
 DABPHY_INTERNAL int sp_variant_for(int nsteps);
+// the state-parallel launch of `a`: two code words per wavefront (k_viterbi_sp2) or one (k_viterbi_sp), as sp_two_for decided when the
+// decision scratch was laid out
+DABPHY_INTERNAL bool sp_two_for(const dabphy_handle* h, int max_steps);
+DABPHY_INTERNAL void launch_sp(const FusedArgs& a, bool two, int lds_variant, hipStream_t s);
 DABPHY_INTERNAL size_t soft_ens_stride(const dabphy_handle* h);                                   // bytes between the soft-bit ring slices of two ensembles
 }

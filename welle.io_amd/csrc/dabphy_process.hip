@@ -171,7 +171,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             d1.chunk_count = (3 + da.chunk_len - 1) / da.chunk_len;          // the chunks that hold the FIC symbols 1..3 (demod_chunk may be 1 or 2)
             launch_demod(d1, (int)B, h->stream);
             g.frame_sel = (int)f + 1; k.frame_sel = (int)f + 1;
-            if (fic_sp) { spa.fic_frame_sel = (int)f + 1; launch_viterbi_sp(spa, sp_variant_for(c.nsteps), h->stream); }
+            if (fic_sp) { spa.fic_frame_sel = (int)f + 1; launch_sp(spa, h->sp1_two, sp_variant_for(c.nsteps), h->stream); }
             else { launch_fic_gather(g, h->stream); launch_viterbi(v, h->stream); }
             launch_fib_crc(k, h->stream);
             CrcArgs kf = k; kf.frame_sel = 0; kf.frame_first = (int)f; kf.frame_count = 1;
@@ -240,7 +240,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         FusedArgs fa = h->fplan.args; fa.desc = d_desc;
         h->fplan.args = fa; h->fplan.launched = true;
         mark(dabphy_handle::ST_MSC_VITERBI, false);
-        if (h->fplan.use_sp) launch_viterbi_sp(fa, h->fplan.sp_variant, h->stream);
+        if (h->fplan.use_sp) launch_sp(fa, h->fplan.sp_two, h->fplan.sp_variant, h->stream);
         else launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream);
         mark(dabphy_handle::ST_MSC_VITERBI, true);
         if (fic_fused) HIPCHK(h, hipEventRecord(h->ev_fused_done, h->stream));

@@ -147,6 +147,36 @@ template <int B> __device__ __forceinline__ void pair_values(uint32_t m, uint32_
     else if constexpr (B == 1) { x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x44, 0xf, 0xf, false); y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xEE, 0xf, 0xf, false); }
     else { x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xA0, 0xf, 0xf, false); y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xF5, 0xf, 0xf, false); }
 }
+// x * m + acc for |x|, |m| < 2^23, all per lane (v_mad_i32_i24)
+__device__ __forceinline__ int mad_i24_vv(int x, int m, int acc) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(x), "v"(acc)); return r; }
+// y - x - (bit `lane` of the wave-uniform mask): one v_subb_co_u32 with the mask as its borrow-in (the borrow-out is discarded)
+__device__ __forceinline__ uint32_t sub_borrow(uint32_t y, uint32_t x, unsigned long long mask)
+{
+    uint32_t r; unsigned long long bout;
+    asm("v_subb_co_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(bout) : "v"(y), "v"(x), "s"(mask));
+    return r;
+}
+// ---- two code words per wavefront (k_viterbi_sp2.hip): each half of 32 lanes is one code word, every lane holds TWO path metrics and
+// the lanes of a half pair up along lane bit B = 4 .. 0.
+// B = 4: swap16(r0, r1, a, b): a = the lane's own r0 where its bit 4 is clear, its partner's r1 where it is set; b = its partner's r0 where
+//        the bit is clear, its own r1 where it is set (ONE v_permlane16_swap_b32).
+// B < 4: partner<B>(g) = the value of g held by the lane's partner: row_ror:8 (B = 3), two bank-masked row moves (B = 2), a quad_perm read
+//        (B = 1, 0).
+__device__ __forceinline__ void swap16(uint32_t r0, uint32_t r1, uint32_t& a, uint32_t& b)
+{
+    const pair_u32x2 r = __builtin_amdgcn_permlane16_swap(r0, r1, false, false); a = r[0]; b = r[1];
+}
+template <int B> __device__ __forceinline__ uint32_t partner(uint32_t g)
+{
+    static_assert(B >= 0 && B <= 3, "lane bit");
+    if constexpr (B == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x128, 0xf, 0xf, false);                 // row_ror:8
+    else if constexpr (B == 2) {
+        const int up = __builtin_amdgcn_update_dpp((int)g, (int)g, 0x114, 0xf, 0xA, false);                                 // lanes with the bit set read lane - 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(up, (int)g, 0x104, 0xf, 0x5, false);                                   // ... the others lane + 4
+    }
+    else if constexpr (B == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x4E, 0xf, 0xf, false);            // quad_perm [2,3,0,1]
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0xB1, 0xf, 0xf, false);                                    // quad_perm [1,0,3,2]
+}
 // the value lane `idx` (wave-uniform) holds, as a wave-uniform value (v_readlane_b32)
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
 

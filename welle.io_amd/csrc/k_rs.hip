@@ -369,9 +369,10 @@ __device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const u
 // :122-131 AU CRC-16-CCITT of the first ne events of one (ensemble, sub-channel) pair, one lane per access unit.  The verdicts do not steer the
 // state machine.  (Events and superframes were written by earlier kernels or, behind a barrier, by this work-group.)  Returns nothing:
 // failures are counted into *aubad (LDS).
-// `stage` (LDS, stage_bytes; nullptr: none): the corrected superframes are brought in with coalesced loads, as many events at a time as
-// fit, and the CRCs walk LDS bytes -- a lane that reads its access unit byte by byte from HBM spends ~300 dependent memory round trips per
-// unit (round 4: this was all of k_superframe_settle's 0.4 ms, half of the filter's time in the headline step).
+// `stage` (LDS, stage_bytes; nullptr: none): the wide pass' verdict.  There every event e of the pair synchronised and its corrected
+// superframe lies in slot e: one contiguous run of HBM, brought into LDS with coalesced 8-byte loads, as many superframes at a time as
+// fit, and the CRCs walk LDS bytes -- a lane that reads its access unit byte by byte from HBM spends ~300 dependent memory round trips
+// per unit (round 4: that was k_superframe_settle's 0.4 ms, half of the filter's time in the headline step).
 __device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t,
                                            uint8_t* stage = nullptr, int stage_bytes = 0)
 {
@@ -380,19 +381,16 @@ __device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t 
         const int n = per ? (ne - e0 < per ? ne - e0 : per) : ne;
         if (per) {
             __syncthreads();                                                            // (the previous chunk has been read)
-            for (int e = 0; e < n; e++) {
-                if (!ev[e0 + e].sync) continue;
-                const uint2* src = reinterpret_cast<const uint2*>(A.sf + (bm * A.n_slots + ev[e0 + e].sf_slot) * sf_len);     // (superframes are 120 s bytes: multiples of 8, 8-aligned)
-                uint2* dst = reinterpret_cast<uint2*>(stage + (size_t)e * sf_len);
-                for (int i = t; i < sf_len / 8; i += 64) dst[i] = src[i];
-            }
+            const uint2* src = reinterpret_cast<const uint2*>(A.sf + (bm * A.n_slots + e0) * sf_len);     // (superframes are 120 s bytes: multiples of 8, 8-aligned)
+            uint2* dst = reinterpret_cast<uint2*>(stage);
+            for (int i = t; i < n * (sf_len / 8); i += 64) dst[i] = src[i];
             __syncthreads();
         }
         for (int base = 0; base < n * 6; base += 64) {
             const int k = base + t, e_i = e0 + k / 6, au_i = k % 6;
             if (k < n * 6 && ev[e_i].sync && au_i < ev[e_i].num_aus) {
-                const uint8_t* au = (per ? stage + (size_t)(e_i - e0) * sf_len : A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len) + ev[e_i].au_start[au_i];
-                const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
+                const int a0 = ev[e_i].au_start[au_i], au_len = ev[e_i].au_start[au_i + 1] - a0;
+                const uint8_t* au = (per ? stage + (size_t)(e_i - e0) * sf_len : A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len) + a0;
                 if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
                 else atomicAdd(aubad, 1);
             }
@@ -411,10 +409,16 @@ __device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t 
 // one launch per class and kernel was 60 dependent launches of a few work-groups each at the end of every step.
 __device__ __forceinline__ SfArgs sf_args_of(const SfBatch& Bt, uint32_t& bx)
 {
+    // (everything here is wave-uniform and read-only: through the constant address space these are scalar loads, the argument block
+    // lives in scalar registers as a kernel argument would)
+    const DABPHY_CONST_AS int32_t* first = as_constant(Bt.first);
     int c = 0;
-    while (c + 1 < Bt.n_cls && bx >= (uint32_t)Bt.first[c + 1]) c++;
-    bx -= (uint32_t)Bt.first[c];
-    return Bt.cls[c];
+    while (c + 1 < Bt.n_cls && bx >= (uint32_t)first[c + 1]) c++;
+    bx -= (uint32_t)first[c];
+    const DABPHY_CONST_AS SfArgs* cls = as_constant(Bt.cls);
+    SfArgs a;
+    __builtin_memcpy(&a, (const void DABPHY_CONST_AS*)&cls[c], sizeof a);
+    return a;
 }
 
 template <int SF_MAX>
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
     const SfArgs A = sf_args_of(Bt, bx);
     __shared__ uint16_t s_crctab[256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
-    constexpr int SF_STAGE = 24576;                                                     // 25 superframes of a 64 kbit/s service (a 32-frame batch), 4 of a 384 kbit/s one
+    constexpr int SF_STAGE = 11520;                                                     // 12 superframes of a 64 kbit/s service at a time, 2 of a 384 kbit/s one (13 work-groups per CU)
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[SF_STAGE];
     const int t = threadIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;

@@ -1,0 +1,287 @@
+// welle.io_amd/csrc/k_viterbi_sp2.hip -- K = 7 Viterbi decoder, state-parallel, TWO code words per wavefront.
+//
+// Replaces (reference file:line, relative to src/backend) what k_viterbi_sp replaces -- Viterbi::deconvolve / BFLY / chainback_viterbi
+// (viterbi.cpp:227-339), the depuncturing of EEPProtection / UEPProtection::deconvolve (eep-protection.cpp:115-152,
+// uep-protection.cpp:169-239) and FicHandler::processFicInput (fic-handler.cpp:144-204), DabAudio's time de-interleaver
+// (dab-audio.cpp:113-149), energy dispersal and bit packing -- for the batches the lane-per-code-word kernel is the wrong shape for,
+// at half the instructions per code word of round 4's k_viterbi_sp (which stays: dabphy_config.decode_shape = 3).  Code words of any
+// length: the LDS table of branch-metric sums holds 1560 or 3090 trellis steps and is refilled chunk by chunk for longer ones.
+//
+// Layout.  A code word owns HALF a wavefront: 32 lanes, two path metrics per lane.  In round 4's kernel a lane held one state, both
+// lanes of a pair fetched both inputs of their butterfly and each computed one output: twelve instructions per step, half of them the
+// exchange and the branch metric.  Here a lane holds BOTH inputs k and k + 32 of butterfly k and computes BOTH outputs 2k and 2k + 1 --
+// the butterfly is local -- and what crosses lanes is one register per step:
+//   step t runs in layout f = t % 5.  Lane j (5 bits) of a half works butterfly k = rotl5(j, f); its registers (P, Q) hold the metrics
+//   of states k and k + 32, in this order or swapped (s_in, below).  The outputs 2k + y have their new top bit = old state bit 4, which
+//   is lane bit p = 4 - f: the next butterfly pairs the lane with its partner along that bit, same y.  So each lane keeps the output
+//   its own bit selects and takes the partner's other one:
+//     f = 0 (lane bit 4):   (P, Q)' = swap16(out0, out1): ONE v_permlane16_swap_b32 delivers both registers in (k, k + 32) order;
+//     f = 1 .. 4 (bits 3 .. 0):  a lane whose bit is set writes (out1, out0) instead of (out0, out1) -- a sign folded into its
+//                           constants, no instruction -- then (P, Q)' = (reg0, partner's reg1): one DPP move (row_ror:8 / quad_perm;
+//                           two bank-masked row moves for bit 2).  Lanes with the bit set now hold (k + 32, k): s_in = that bit, again
+//                           only a sign and, in the traceback, one XOR on the scalar unit.
+//   After five steps the layout is back where it started.
+// Branch metrics.  b = bm(pattern) - 510 of butterfly k is +-a0 +-a1 +-a2 in the three soft inputs of the step (x0 = v0 + v3, v1, v2:
+// viterbi_acs.h): four values up to sign.  The gather leaves all four per step in LDS (int16 x 4); a lane reads THE ONE its pattern
+// selects with one ds_read_i16 at a per-layout address -- no multiply-add chain -- and its sign rides in the per-lane multiplier of the
+// four v_mad_i32_i24 that form P + b, Q - b, P - b, Q + b.  Per step and wavefront: 4 mad, 2 sub + 2 v_alignbit (decisions into two
+// history words), 2 min, 1-2 exchange = 11-12 vector instructions for TWO code words (round 4: 12 for one).
+// Metrics are int32, doubled, never renormalised (|b| <= 1020 per step, 9222 steps); decisions compare true integers, ties keep the
+// k branch (viterbi.cpp:263-268) -- for a swapped lane "Q < P" is that comparison with the roles exchanged, and the traceback undoes it.
+//
+// Traceback on the scalar unit, both code words of the wave interleaved (two independent chains).  The walk carries PHYSICAL
+// coordinates: lane j of the half and register r.  One step back at step t (layout f): dec = history bit of (j, r); the decoded bit is
+// dec ^ s_in_f(j); the survivor came in through input register q = dec, which the exchange after step t - 1 (layout f - 1, lane bit p')
+// filled from output register r' = bit p' of j of lane j' = j with bit p' := q (f - 1 = 0) or := bit ^ q (else).  State 0 ends in
+// lane 0, register 0.
+#include "dabphy_kernels.h"
+#include <dabphy_wave_ops.h>
+#include "viterbi_acs.h"
+
+namespace dabphy {
+
+constexpr int SP2_HIST = 30;                      // trellis steps per decision history word: a multiple of the five layouts and of the six-step code word granule
+namespace sp2 {
+__device__ __forceinline__ int rotl5(int x, int r) { r %= 5; return r == 0 ? x : (((x << r) | (x >> (5 - r))) & 31); }
+__device__ __forceinline__ int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }   // = map16[i] of dab-audio.cpp:113
+__host__ __device__ constexpr int xbit(int f) { return 4 - f; }                  // lane bit of the exchange after a step in layout f
+__host__ __device__ constexpr int inbit(int f) { return f == 0 ? 0 : f == 1 ? -1 : 5 - f; }   // lane bit that tells whether a lane's inputs are swapped in layout f (-1: never)
+}
+
+template <int MAXSTEPS, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
+{
+    __shared__ __attribute__((aligned(8))) int16_t tab[2][(MAXSTEPS + SP2_HIST) * 4];       // per code word and step: +a0+a1+a2, -a0+a1+a2, +a0-a1+a2, -a0-a1+a2
+    __shared__ long long s_rowoff[2][16];
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const int F = A.n_frames, R = 4 * F;
+    const uint32_t wk = as_constant(A.work)[blockIdx.x >> 5];
+    const DABPHY_CONST_AS FusedClass& C = as_constant(A.cls)[wk >> 24];
+    const int cw_a = (int)(wk & 0xffffffu) * 64 + 2 * (int)(blockIdx.x & 31u);
+    const int nsteps = C.nsteps, nbits = C.nbits;
+    if (cw_a >= C.n_cw) return;
+    constexpr int CHUNK = (MAXSTEPS + SP2_HIST - 1) / SP2_HIST * SP2_HIST;  // trellis steps the table holds: a longer code word comes through it chunk by chunk
+    const bool second = cw_a + 1 < C.n_cw;                                  // (an odd class: the last wave's upper half decodes the same code word again, its output is dropped)
+    const int cw = cw_a + (second ? half : 0);
+
+    // ---- where this half's code word lies: 16 row offsets (one per column u & 15 of the time de-interleaver), -1 = no such CIF
+    const int8_t* base;
+    if (C.kind == 0) {
+        const int pair = cw / R, r = cw - pair * R;
+        const MscPair pp = C.pairs[pair];                                   // every ensemble selects its own sub-channels (msc-handler.cpp:61-103)
+        const int b = pp.ens;
+        base = A.soft + (size_t)b * A.ens_stride + (size_t)pp.start_bit;
+        if (j < 16) {
+            const long long c_src = 4 * A.desc[(size_t)b * F].frame_no + r - 16 + sp2::brev4(j);      // dab-audio.cpp:113,138-143
+            s_rowoff[half][j] = c_src >= 0 ? ((long long)((c_src >> 2) % A.soft_ring) * 75 + 3 + 18 * (int)(c_src & 3)) * SOFT_PER_SYM : -1;
+        }
+    } else if (C.kind == 1) {
+        const int fsel = A.fic_frame_sel;
+        const int bf = fsel ? (cw >> 2) * F + (fsel - 1) : cw >> 2, b = bf / F;
+        const FrameDesc& d = A.desc[bf];
+        const size_t fstride = A.fic_frame_stride ? A.fic_frame_stride : (size_t)SOFT_PER_FRAME;
+        base = A.soft + (size_t)b * A.ens_stride + (size_t)(d.frame_no % A.soft_ring) * fstride + (size_t)2304 * (cw & 3);
+        if (j < 16) s_rowoff[half][j] = d.valid == 1 ? 0 : -1;
+    } else {
+        base = A.lin_in + (size_t)cw * A.lin_stride;                        // a code word of the linear seams: no de-interleaver
+        if (j < 16) s_rowoff[half][j] = 0;
+    }
+    __syncthreads();
+    // the table of steps [c0, c0 + n): entry (s - c0)
+    auto fill = [&](int c0, int n) {
+        const int16_t* __restrict__ map = C.map;
+        for (int s = c0 + j; s < c0 + n; s += 32) {
+            uint2 mm = make_uint2(0, 0);
+            if (map) mm = *reinterpret_cast<const uint2*>(map + 4 * s);                    // four map entries
+            int v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int u = map ? (int)(int16_t)(((q < 2 ? mm.x : mm.y) >> (16 * (q & 1))) & 0xffffu) : 4 * s + q;
+                long long off = -1;
+                if (u >= 0) off = s_rowoff[half][u & 15];
+                v[q] = off >= 0 ? (int)base[off + u] : 0;
+                if (v[q] < -127) v[q] = -127;                               // -128 maps to symbol 0 like -127 (viterbi.cpp:233-236)
+            }
+            // the three branch-metric inputs, doubled and biased as the trellis takes them (viterbi.cpp:233-238 puts the symbol levels at
+            // v + 127: bm(p) = 510 + e0 (x0 - 1) + e1 (v1 - 1/2) + e2 (v2 - 1/2), x0 = v0 + v3), and their four sign combinations
+            const int a0 = 2 * (v[0] + v[3]) - 2, a1 = 2 * v[1] - 1, a2 = 2 * v[2] - 1;
+            const int t0 = a0 + a1 + a2, t1 = -a0 + a1 + a2, t2 = a0 - a1 + a2, t3 = -a0 - a1 + a2;
+            int16_t* e = &tab[half][4 * (s - c0)];
+            e[0] = (int16_t)t0; e[1] = (int16_t)t1; e[2] = (int16_t)t2; e[3] = (int16_t)t3;
+        }
+    };
+
+    // ---- per-lane constants of the five layouts: which of the four sums the lane's butterfly takes (an LDS address), and the sign
+    // it enters P + b with: pattern sign x (the lane writes its outputs swapped) x (the lane's inputs are swapped)
+    const int16_t* tp[5]; int M[5];
+#pragma unroll
+    for (int f = 0; f < 5; f++) {
+        const int k = sp2::rotl5(j, f), p = acs::pat(k);
+        const int idx = p < 4 ? p : 7 - p;
+        int sg = p < 4 ? 1 : -1;
+        if (f != 0 && ((j >> sp2::xbit(f)) & 1)) sg = -sg;                  // o_out
+        if (sp2::inbit(f) >= 0 && ((j >> sp2::inbit(f)) & 1)) sg = -sg;     // s_in
+        M[f] = sg; tp[f] = &tab[half][idx];
+    }
+    int P = j == 0 ? 0 : 126, Q = 126;                                      // init_viterbi (viterbi.cpp:342-354): all 63, start state 0 at 0; doubled.  (Lane 0's inputs are never swapped.)
+    uint32_t* __restrict__ const dec_g = reinterpret_cast<uint32_t*>(A.dec + (size_t)blockIdx.x * A.dec_slot_cells);
+    uint32_t acc0 = 0, acc1 = 0;
+    auto one_step = [&](auto fc, int T) {
+        constexpr int FL = decltype(fc)::value;
+        const int x0 = mad_i24_vv(M[FL], T, P), y0 = mad_i24_vv(-M[FL], T, Q);     // reg0: P + b against Q - b
+        const int x1 = mad_i24_vv(-M[FL], T, P), y1 = mad_i24_vv(M[FL], T, Q);     // reg1: P - b against Q + b
+        // decision = "the Q side wins": strictly smaller where Q is state k + 32 -- ties keep the k branch, viterbi.cpp:263-268 --, smaller
+        // OR EQUAL where the lane's inputs are swapped and Q is state k.  All metrics are even (doubled), so "y <= x" is "y - x - 1 < 0": the
+        // lane's swap bit enters the subtraction as its borrow, and the sign goes into the history word
+        if constexpr (sp2::inbit(FL) >= 0) {
+            constexpr unsigned long long SW = sp2::inbit(FL) == 0 ? 0xAAAAAAAAAAAAAAAAull : sp2::inbit(FL) == 1 ? 0xCCCCCCCCCCCCCCCCull : sp2::inbit(FL) == 2 ? 0xF0F0F0F0F0F0F0F0ull : 0xFF00FF00FF00FF00ull;
+            acc0 = funnel_shr(acc0, sub_borrow((uint32_t)y0, (uint32_t)x0, SW), 31);
+            acc1 = funnel_shr(acc1, sub_borrow((uint32_t)y1, (uint32_t)x1, SW), 31);
+        } else {
+            acc0 = funnel_shr(acc0, (uint32_t)(y0 - x0), 31);
+            acc1 = funnel_shr(acc1, (uint32_t)(y1 - x1), 31);
+        }
+        const uint32_t r0 = (uint32_t)(x0 < y0 ? x0 : y0), r1 = (uint32_t)(x1 < y1 ? x1 : y1);
+        if constexpr (FL == 0) { uint32_t a, b; swap16(r0, r1, a, b); P = (int)a; Q = (int)b; }
+        else { P = (int)r0; Q = (int)partner<sp2::xbit(FL)>(r1); }
+    };
+    // six steps from step index K of a block (K a multiple of six; the block starts at a multiple of 30, so the layout of step K + i is (K + i) % 5)
+    auto six_steps = [&](int e0, auto kc) {                               // e0 = table entry of the block's first step
+        constexpr int K = decltype(kc)::value;
+        int T[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) T[i] = tp[(K + i) % 5][4 * (e0 + K + i)];
+        one_step(std::integral_constant<int, (K + 0) % 5>{}, T[0]); one_step(std::integral_constant<int, (K + 1) % 5>{}, T[1]);
+        one_step(std::integral_constant<int, (K + 2) % 5>{}, T[2]); one_step(std::integral_constant<int, (K + 3) % 5>{}, T[3]);
+        one_step(std::integral_constant<int, (K + 4) % 5>{}, T[4]); one_step(std::integral_constant<int, (K + 5) % 5>{}, T[5]);
+    };
+    const int nfull = nsteps / SP2_HIST;
+    const int rem = nsteps - nfull * SP2_HIST;                               // steps in the last, partial block (a multiple of six)
+    for (int c0 = 0; c0 < nsteps; c0 += CHUNK) {
+        const int n = nsteps - c0 < CHUNK ? nsteps - c0 : CHUNK;
+        if (c0) __syncthreads();                                            // (the previous chunk has been read)
+        fill(c0, n);
+        __syncthreads();
+        for (int blk = c0 / SP2_HIST; blk < (c0 + n) / SP2_HIST; blk++) {
+            const int e0 = blk * SP2_HIST - c0;
+            six_steps(e0, std::integral_constant<int, 0>{}); six_steps(e0, std::integral_constant<int, 6>{}); six_steps(e0, std::integral_constant<int, 12>{});
+            six_steps(e0, std::integral_constant<int, 18>{}); six_steps(e0, std::integral_constant<int, 24>{});
+            dec_g[blk * 128 + lane] = acc0; dec_g[blk * 128 + 64 + lane] = acc1;
+        }
+    }
+    {
+        const int t0 = nfull * SP2_HIST - (nsteps - 1) / CHUNK * CHUNK;     // (the partial block lies in the last chunk)
+        if (rem >= 6) six_steps(t0, std::integral_constant<int, 0>{});
+        if (rem >= 12) six_steps(t0, std::integral_constant<int, 6>{});
+        if (rem >= 18) six_steps(t0, std::integral_constant<int, 12>{});
+        if (rem >= 24) six_steps(t0, std::integral_constant<int, 18>{});
+        if (rem) { dec_g[nfull * 128 + lane] = acc0 << (SP2_HIST - rem); dec_g[nfull * 128 + 64 + lane] = acc1 << (SP2_HIST - rem); }   // its first step in bit SP2_HIST - 1 like the others
+    }
+    __syncthreads();                                                        // (one wave: the wait it implies orders the stores above before the loads below)
+
+    // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339), both code words of the wave side by side on the scalar unit.
+    // The decoded bits are shifted into the top of a 64-bit register, newest first; whenever 32 of them have gathered the oldest 32
+    // leave as one output word (bytes packed MSB first, decoder_adapter.cpp:61-67; the first bit read is data bit nbits - 1).
+    struct Walk { uint32_t jl, r; unsigned long long bits; };
+    Walk W[2] = {{0u, 0u, 0ull}, {32u, 0u, 0ull}};                          // (lane of the wave, register): state 0 ends in lane 0 of its half, register 0
+    int cnt = 0, wi = nbits / 32;
+    uint32_t* __restrict__ const out_a = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_a * (nbits / 32);
+    const uint32_t* __restrict__ prbs = A.prbs_words;
+    const int dedisperse = C.dedisperse;
+    // one step back in layout FL at bit position `pos` of the history words (c0, c1 = the words of register 0 / 1, one per lane)
+    auto back = [&](auto fc, Walk& w, uint32_t c0, uint32_t c1, int pos) {
+        constexpr int FL = decltype(fc)::value;
+        const uint32_t h0 = lane_get(c0, w.jl), h1 = lane_get(c1, w.jl);
+        const uint32_t dec = ((w.r ? h1 : h0) >> pos) & 1u;
+        uint32_t d = dec;
+        if constexpr (sp2::inbit(FL) >= 0) d ^= (w.jl >> sp2::inbit(FL)) & 1u;          // the lane's inputs were swapped: "Q side" was state k
+        w.bits = (w.bits >> 1) | ((unsigned long long)d << 63);
+        // the survivor came in through input register q = dec; the exchange after the previous step (layout FP, lane bit pb) filled it
+        constexpr int FP = (FL + 4) % 5, pb = sp2::xbit(FP);
+        if constexpr (FP == 0) {                         // swap16: outputs in (2k, 2k + 1) order; register = the lane's bit, the lane = this one with the bit set to q
+            w.r = (w.jl >> pb) & 1u;
+            w.jl = (w.jl & ~(1u << pb)) | (dec << pb);
+        } else {                                         // kept / given: input 0 = the lane's own register 0, input 1 = its partner's register 1
+            w.r = dec;
+            w.jl ^= dec << pb;
+        }
+    };
+    auto emit = [&]() {
+        if (cnt >= 32) {
+            wi--; cnt -= 32;
+            const uint32_t wa = acs::back_word((uint32_t)(W[0].bits >> (32 - cnt))), wb = acs::back_word((uint32_t)(W[1].bits >> (32 - cnt)));
+            const uint32_t x = dedisperse ? prbs[wi] : 0u;
+            if (lane == 0) out_a[wi] = wa ^ x;
+            if (lane == 32 && second) out_a[(nbits / 32) + wi] = wb ^ x;
+        }
+    };
+    auto back_n = [&](uint32_t c0, uint32_t c1, auto hi, auto lo) {          // steps hi - 1 down to lo of a block, straight-line
+        constexpr int HI = decltype(hi)::value, LO = decltype(lo)::value;
+        auto go = [&](auto self, auto kc) -> void {
+            constexpr int k = decltype(kc)::value;
+            back(std::integral_constant<int, k % 5>{}, W[0], c0, c1, SP2_HIST - 1 - k);
+            back(std::integral_constant<int, k % 5>{}, W[1], c0, c1, SP2_HIST - 1 - k);
+            if constexpr (k > LO) self(self, std::integral_constant<int, k - 1>{});
+        };
+        if constexpr (HI > LO) go(go, std::integral_constant<int, HI - 1>{});
+    };
+    if (rem) {
+        const uint32_t c0 = dec_g[nfull * 128 + lane], c1 = dec_g[nfull * 128 + 64 + lane];
+        if (rem == 6) back_n(c0, c1, std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+        else if (rem == 12) back_n(c0, c1, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
+        else if (rem == 18) back_n(c0, c1, std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
+        else back_n(c0, c1, std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
+        cnt += rem; emit();
+    }
+    uint32_t c0 = nfull ? dec_g[(nfull - 1) * 128 + lane] : 0u, c1 = nfull ? dec_g[(nfull - 1) * 128 + 64 + lane] : 0u;
+    for (int blk = nfull - 1; blk >= 1; blk--) {                            // whole blocks above the first
+        const uint32_t n0 = dec_g[(blk - 1) * 128 + lane], n1 = dec_g[(blk - 1) * 128 + 64 + lane];   // the block below, in flight while this one is walked
+        back_n(c0, c1, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
+        cnt += SP2_HIST; emit();
+        c0 = n0; c1 = n1;
+    }
+    if (nfull) {                                                            // block 0: its first six steps decide nothing that is kept
+        back_n(c0, c1, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
+        cnt += SP2_HIST - 6; emit();
+    }
+}
+
+// swap16 / partner against plain shuffles, all five lane bits (device self-test of the instruction forms the execution model of
+// tests/hipemu stands in for): out[0] += mismatching lanes, out[1] += lanes checked
+__global__ void __launch_bounds__(64) k_selftest_half_exchange(unsigned* out)
+{
+    const int lane = threadIdx.x;
+    unsigned bad = 0, n = 0;
+    for (unsigned round = 0; round < 16; round++) {
+        const uint32_t r0 = (uint32_t)lane * 2654435761u + round * 40503u + (blockIdx.x << 20), r1 = ~r0 * 2246822519u + round;
+        {
+            uint32_t a, b; swap16(r0, r1, a, b);
+            const bool set = (lane >> 4) & 1;
+            const uint32_t p0 = (uint32_t)__shfl((int)r0, lane ^ 16), p1 = (uint32_t)__shfl((int)r1, lane ^ 16);
+            bad += (a != (set ? p1 : r0)) + (b != (set ? r1 : p0)); n += 2;
+        }
+        auto chk = [&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            bad += partner<B>(r1) != (uint32_t)__shfl((int)r1, lane ^ (1 << B)); n += 1;
+        };
+        chk(std::integral_constant<int, 0>{}); chk(std::integral_constant<int, 1>{}); chk(std::integral_constant<int, 2>{}); chk(std::integral_constant<int, 3>{});
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], n);
+}
+void launch_selftest_half_exchange(unsigned* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_half_exchange, dim3(8), dim3(64), 0, s, out);
+}
+
+void launch_viterbi_sp2(const FusedArgs& a, int lds_variant, hipStream_t s)
+{
+    if (a.n_work == 0) return;
+    const dim3 grid(a.n_work * 32u);
+    // LDS: four 16-bit sums per trellis step, for two code words, 1560 or 3090 steps at a time: 25 / 49 KiB -- 6 / 3 work-groups per compute
+    // unit (a 384 kbit/s code word, 9222 steps, passes through the larger table in three chunks)
+    if (lds_variant == 0) hipLaunchKernelGGL((k_viterbi_sp2<SP_MAXSTEPS[0], 1>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_viterbi_sp2<SP_MAXSTEPS[1], 1>), grid, dim3(64), 0, s, a);
+}
+
+} // namespace dabphy
