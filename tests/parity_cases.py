@@ -622,7 +622,7 @@ def check_error_behaviour(d_factory):
     come back as negative status codes with a message, never as a crash (the reference throws std::logic_error / out_of_range)"""
     from welle_io_amd.capi import DabPhyError
     # the documented limits of the batch geometry and of the configuration (include/dabphy.h): refused at creation, never wrapped silently
-    for kw in (dict(n_ensembles=1, max_frames=4097), dict(n_ensembles=(1 << 22) // 64 + 1, max_frames=64), dict(n_ensembles=1, max_frames=1, decode_shape=3),
+    for kw in (dict(n_ensembles=1, max_frames=4097), dict(n_ensembles=(1 << 22) // 64 + 1, max_frames=64), dict(n_ensembles=1, max_frames=1, decode_shape=4),
                dict(n_ensembles=0, max_frames=1), dict(n_ensembles=1, max_frames=1, pipeline_sync=4)):
         try:
             d_factory(**kw).close()

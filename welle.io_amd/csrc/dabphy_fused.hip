@@ -145,7 +145,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         for (int g = 0; g < it.n_groups; g++) { work.push_back(((uint32_t)it.ci << 24) | (uint32_t)g); item_off.push_back((uint32_t)item_rows); item_rows += (uint64_t)it.nsteps; }
     }
     const int sp_variant = sp_variant_for((int)max_steps);
-    const bool sp_two = use_sp && sp_two_for(h, (int)max_steps);
+    const bool sp_two = use_sp && sp_two_for(h, total_cw);
     const int slots = fused_wave_slots(v);
     // (state-parallel: one work-group per code word slot -- or pair of slots -- of every listed group, each with its own decision scratch)
     const int n_slots = use_sp ? (int)work.size() * (sp_two ? 32 : 64) : (int)std::min<size_t>(work.size(), (size_t)slots);
@@ -231,7 +231,7 @@ int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipS
     const uint32_t n_groups = (uint32_t)((fc.n_cw + 63) / 64);
     int r;
     if ((r = sp_single_reserve(h, (uint64_t)fc.n_cw, fc.nsteps))) return r;
-    h->sp1_two = sp_two_for(h, fc.nsteps);
+    h->sp1_two = sp_two_for(h, (uint64_t)fc.n_cw);
     const size_t cells = ((size_t)fc.nsteps / 30 + 1) * (h->sp1_two ? 64 : 32);
     FusedClass* hc = reinterpret_cast<FusedClass*>(h->h_sp1);
     uint32_t* hw = reinterpret_cast<uint32_t*>(hc + 1);
@@ -243,10 +243,14 @@ int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipS
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = cells; a.prbs_words = h->d_prbs_words;
     return DABPHY_OK;
 }
-bool sp_two_for(const dabphy_handle* h, int max_steps)
+// Two code words per wavefront (k_viterbi_sp2: half the vector instructions per code word) pays once the code words outnumber the SIMDs
+// a few times over; below that the launch runs at the latency of ONE wave, and a wave that gathers and walks back two code words takes
+// longer than one that does it for one (profiles/r05_viterbi_sp2.txt).  decode_shape 2 / 3 force either kernel.
+bool sp_two_for(const dabphy_handle* h, uint64_t n_cw)
 {
-    (void)max_steps;                                     // (k_viterbi_sp2 takes code words of any length: its table holds them chunk by chunk)
-    return h->cfg.decode_shape != 3;
+    if (h->cfg.decode_shape == 3) return false;
+    if (h->cfg.decode_shape == 2) return true;
+    return n_cw > h->sp2_min_codewords;
 }
 void launch_sp(const FusedArgs& a, bool two, int lds_variant, hipStream_t s)
 {

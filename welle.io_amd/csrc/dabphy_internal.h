@@ -129,6 +129,7 @@ struct dabphy_handle {
     uint64_t buf_gen = 1;                                // bumped whenever a device buffer is reallocated or a class is rebuilt
     bool fused_msc = true;                               // MSC classes: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     uint32_t sp_max_codewords = 16384;                   // batches with at most this many code words (all classes + FIC) are decoded state-parallel: measured crossover, profiles/r04_viterbi_state_parallel.txt (DABPHY_SP_MAX_CW; 0: never)
+    uint32_t sp2_min_codewords = 4096;                   // ... of which those above this many take two code words per wavefront (k_viterbi_sp2) (DABPHY_SP2_MIN_CW)
     bool chain_early = false;                            // pipelined schedules: queue the next batch's synchroniser in front of this batch's decoder instead of behind it (DABPHY_CHAIN_EARLY)
     bool fused_fic = true;                               // the FIC rides in the same launch (DABPHY_FUSED_FIC=0: k_fic_gather + k_viterbi on the auxiliary stream)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch
@@ -256,7 +257,7 @@ DABPHY_INTERNAL int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, Fu
 DABPHY_INTERNAL int sp_variant_for(int nsteps);
 // the state-parallel launch of `a`: two code words per wavefront (k_viterbi_sp2) or one (k_viterbi_sp), as sp_two_for decided when the
 // decision scratch was laid out
-DABPHY_INTERNAL bool sp_two_for(const dabphy_handle* h, int max_steps);
+DABPHY_INTERNAL bool sp_two_for(const dabphy_handle* h, uint64_t n_cw);
 DABPHY_INTERNAL void launch_sp(const FusedArgs& a, bool two, int lds_variant, hipStream_t s);
 DABPHY_INTERNAL size_t soft_ens_stride(const dabphy_handle* h);                                   // bytes between the soft-bit ring slices of two ensembles
 }

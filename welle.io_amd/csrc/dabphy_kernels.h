@@ -214,8 +214,8 @@ constexpr int SP_MAXSTEPS[SP_VARIANTS] = {1542, 3078, 9222};     // <= 64, <= 12
 void launch_viterbi_sp(const FusedArgs& a, int lds_variant, hipStream_t s);
 void launch_selftest_pair_exchange(unsigned* out, hipStream_t s);
 // ... two code words per wavefront (k_viterbi_sp2.hip): half the instructions per code word; one work-group per PAIR of code word slots:
-// a.n_work * 32 of them, a.dec_slot_cells = (steps / 30 + 1) * 64 per work-group.  lds_variant < SP2_VARIANTS: its LDS table holds four
-// 16-bit sums per trellis step and code word for 1560 or 3090 steps; longer code words pass through it chunk by chunk
+// a.n_work * 32 of them, a.dec_slot_cells = (steps / 30 + 1) * 64 per work-group.  Its LDS table holds four 16-bit sums per trellis
+// step and code word for 480 steps at a time: code words of any length pass through it chunk by chunk (lds_variant is ignored)
 constexpr int SP2_VARIANTS = 2;
 void launch_viterbi_sp2(const FusedArgs& a, int lds_variant, hipStream_t s);
 void launch_selftest_half_exchange(unsigned* out, hipStream_t s);

@@ -4,8 +4,8 @@
 // (viterbi.cpp:227-339), the depuncturing of EEPProtection / UEPProtection::deconvolve (eep-protection.cpp:115-152,
 // uep-protection.cpp:169-239) and FicHandler::processFicInput (fic-handler.cpp:144-204), DabAudio's time de-interleaver
 // (dab-audio.cpp:113-149), energy dispersal and bit packing -- for the batches the lane-per-code-word kernel is the wrong shape for,
-// at half the instructions per code word of round 4's k_viterbi_sp (which stays: dabphy_config.decode_shape = 3).  Code words of any
-// length: the LDS table of branch-metric sums holds 1560 or 3090 trellis steps and is refilled chunk by chunk for longer ones.
+// at half the instructions per code word of round 4's k_viterbi_sp (which stays for the smallest batches and as
+// dabphy_config.decode_shape = 3).  Code words of any length: the LDS table of branch-metric sums holds 480 trellis steps at a time.
 //
 // Layout.  A code word owns HALF a wavefront: 32 lanes, two path metrics per lane.  In round 4's kernel a lane held one state, both
 // lanes of a pair fetched both inputs of their butterfly and each computed one output: twelve instructions per step, half of them the
@@ -48,10 +48,14 @@ __host__ __device__ constexpr int xbit(int f) { return 4 - f; }                 
 __host__ __device__ constexpr int inbit(int f) { return f == 0 ? 0 : f == 1 ? -1 : 5 - f; }   // lane bit that tells whether a lane's inputs are swapped in layout f (-1: never)
 }
 
-template <int MAXSTEPS, int OCC>
+// CHUNK = trellis steps the LDS table holds (a multiple of 30): the code word passes through it chunk by chunk.  The table is what bounds
+// the waves per SIMD (8 bytes per step and code word): 480 steps = 7.7 KB per work-group, five waves per SIMD -- with the whole 1542-step
+// code word resident (25 KB: 1.5 waves per SIMD) the kernel ran at the latency of its dependent chain, twice as slow as round 4's.
+template <int CHUNK, int OCC>
 __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
 {
-    __shared__ __attribute__((aligned(8))) int16_t tab[2][(MAXSTEPS + SP2_HIST) * 4];       // per code word and step: +a0+a1+a2, -a0+a1+a2, +a0-a1+a2, -a0-a1+a2
+    static_assert(CHUNK % SP2_HIST == 0, "whole history blocks per chunk");
+    __shared__ __attribute__((aligned(8))) int16_t tab[2][CHUNK * 4 + 4];                   // per code word and step: +a0+a1+a2, -a0+a1+a2, +a0-a1+a2, -a0-a1+a2 (+ 8 bytes: the halves' reads fall on different banks)
     __shared__ long long s_rowoff[2][16];
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
     const int F = A.n_frames, R = 4 * F;
@@ -60,7 +64,6 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
     const int cw_a = (int)(wk & 0xffffffu) * 64 + 2 * (int)(blockIdx.x & 31u);
     const int nsteps = C.nsteps, nbits = C.nbits;
     if (cw_a >= C.n_cw) return;
-    constexpr int CHUNK = (MAXSTEPS + SP2_HIST - 1) / SP2_HIST * SP2_HIST;  // trellis steps the table holds: a longer code word comes through it chunk by chunk
     const bool second = cw_a + 1 < C.n_cw;                                  // (an odd class: the last wave's upper half decodes the same code word again, its output is dropped)
     const int cw = cw_a + (second ? half : 0);
 
@@ -278,10 +281,9 @@ void launch_viterbi_sp2(const FusedArgs& a, int lds_variant, hipStream_t s)
 {
     if (a.n_work == 0) return;
     const dim3 grid(a.n_work * 32u);
-    // LDS: four 16-bit sums per trellis step, for two code words, 1560 or 3090 steps at a time: 25 / 49 KiB -- 6 / 3 work-groups per compute
-    // unit (a 384 kbit/s code word, 9222 steps, passes through the larger table in three chunks)
-    if (lds_variant == 0) hipLaunchKernelGGL((k_viterbi_sp2<SP_MAXSTEPS[0], 1>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_viterbi_sp2<SP_MAXSTEPS[1], 1>), grid, dim3(64), 0, s, a);
+    // LDS: four 16-bit sums per trellis step, for two code words, 480 steps at a time: 7.7 KiB, 20 work-groups per compute unit
+    (void)lds_variant;
+    hipLaunchKernelGGL((k_viterbi_sp2<480, 4>), grid, dim3(64), 0, s, a);
 }
 
 } // namespace dabphy
