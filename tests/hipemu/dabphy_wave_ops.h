@@ -66,6 +66,14 @@ static inline void swap16(uint32_t r0, uint32_t r1, uint32_t& a, uint32_t& b)
     const uint32_t p0 = hipemu_wave_exchange(r0, lane ^ 16, true), p1 = hipemu_wave_exchange(r1, lane ^ 16, true);
     a = set ? p1 : r0; b = set ? r1 : p0;
 }
+static inline uint32_t ubfe(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((width >= 32 ? 0u : (1u << width)) - 1u); }
+static inline uint32_t bit_reverse32(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+static inline void swap32(uint32_t r0, uint32_t r1, uint32_t& a, uint32_t& b)
+{
+    const int lane = hipemu_lane(); const bool up = lane >= 32;
+    const uint32_t p0 = hipemu_wave_exchange(r0, lane ^ 32, true), p1 = hipemu_wave_exchange(r1, lane ^ 32, true);
+    a = up ? p1 : r0; b = up ? r1 : p0;
+}
 template <int B> static inline uint32_t partner(uint32_t g) { return hipemu_wave_exchange(g, hipemu_lane() ^ (1 << B), true); }
 static inline uint32_t lane_get(uint32_t v, uint32_t idx) { return hipemu_wave_exchange(v, (int)(idx & 63), true); }
 static inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }

@@ -123,8 +123,8 @@ def test_lane_exchanges_of_the_state_parallel_kernel(gpu):
     """v_permlane32_swap / v_permlane16_swap / bank-masked row DPP / quad_perm DPP / v_readlane as k_viterbi_sp uses them, against plain
     shuffles on the device (the GPU-less execution model stands in for exactly these forms)"""
     bad, n = gpu.selftest_pair_exchange()
-    # (13 checks per lane and round of k_viterbi_sp's forms, 6 of k_viterbi_sp2's swap16 / partner<3..0>)
-    assert bad == 0 and n == 8 * 64 * 16 * (13 + 6), (bad, n)
+    # (13 checks per lane and round of k_viterbi_sp's forms, 8 of k_viterbi_sp2's swap16 / swap32 / partner<3..0>)
+    assert bad == 0 and n == 8 * 64 * 16 * (13 + 8), (bad, n)
 
 
 def test_shallow_batch_above_the_state_parallel_limit(gpu):

@@ -166,6 +166,14 @@ __device__ __forceinline__ void swap16(uint32_t r0, uint32_t r1, uint32_t& a, ui
 {
     const pair_u32x2 r = __builtin_amdgcn_permlane16_swap(r0, r1, false, false); a = r[0]; b = r[1];
 }
+__device__ __forceinline__ uint32_t ubfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }     // bits [off, off + width) of x (s_bfe_u32 / v_bfe_u32)
+__device__ __forceinline__ uint32_t bit_reverse32(uint32_t x) { return __builtin_bitreverse32(x); }     // s_brev_b32 / v_bfrev_b32
+// swap32(r0, r1, a, b): a = r0 of the lower 32 lanes followed by r1 of the LOWER 32 lanes (moved up); b = r0 of the UPPER 32 lanes (moved
+// down) followed by r1 of the upper 32 lanes (one v_permlane32_swap_b32): the two registers of one half-wave side by side in one register
+__device__ __forceinline__ void swap32(uint32_t r0, uint32_t r1, uint32_t& a, uint32_t& b)
+{
+    const pair_u32x2 r = __builtin_amdgcn_permlane32_swap(r0, r1, false, false); a = r[0]; b = r[1];
+}
 template <int B> __device__ __forceinline__ uint32_t partner(uint32_t g)
 {
     static_assert(B >= 0 && B <= 3, "lane bit");

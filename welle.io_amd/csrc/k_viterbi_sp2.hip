@@ -29,11 +29,13 @@
 // Metrics are int32, doubled, never renormalised (|b| <= 1020 per step, 9222 steps); decisions compare true integers, ties keep the
 // k branch (viterbi.cpp:263-268) -- for a swapped lane "Q < P" is that comparison with the roles exchanged, and the traceback undoes it.
 //
-// Traceback on the scalar unit, both code words of the wave interleaved (two independent chains).  The walk carries PHYSICAL
-// coordinates: lane j of the half and register r.  One step back at step t (layout f): dec = history bit of (j, r); the decoded bit is
-// dec ^ s_in_f(j); the survivor came in through input register q = dec, which the exchange after step t - 1 (layout f - 1, lane bit p')
-// filled from output register r' = bit p' of j of lane j' = j with bit p' := q (f - 1 = 0) or := bit ^ q (else).  State 0 ends in
-// lane 0, register 0.
+// Traceback on the scalar unit -- one per compute unit, shared by its four SIMDs: at scale it is what bounds a state-parallel kernel, so
+// a step is eight scalar instructions and one v_readlane per code word --, both code words of the wave interleaved (two independent
+// chains).  The walk carries PHYSICAL coordinates c = (register r, lane j of the half); the history words of a block are stored so that
+// a code word's row holds register 0 in lanes 0 .. 31 and register 1 in lanes 32 .. 63: c is the lane to read.  One step back at step t
+// (layout f): dec = history bit of c; the decoded bit is dec ^ s_in_f(j); the survivor came in through input register q = dec, which
+// the exchange after step t - 1 (layout f - 1, lane bit p') filled from: swap16 -- register = bit p' of j, lane = j with bit p' := q;
+// kept / given -- register q of lane j (q = 0) or of its partner (q = 1).  State 0 ends in lane 0, register 0.
 #include "dabphy_kernels.h"
 #include <dabphy_wave_ops.h>
 #include "viterbi_acs.h"
@@ -158,6 +160,12 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
         one_step(std::integral_constant<int, (K + 2) % 5>{}, T[2]); one_step(std::integral_constant<int, (K + 3) % 5>{}, T[3]);
         one_step(std::integral_constant<int, (K + 4) % 5>{}, T[4]); one_step(std::integral_constant<int, (K + 5) % 5>{}, T[5]);
     };
+    // the history words of a block leave as TWO rows of 64: one per code word, the words of its register 0 in lanes 0 .. 31 and those of
+    // its register 1 in lanes 32 .. 63 (one v_permlane32_swap_b32), so that the traceback reads coordinate (register, lane) with one v_readlane
+    auto store_hist = [&](int blk, uint32_t h0, uint32_t h1) {
+        uint32_t ca, cb; swap32(h0, h1, ca, cb);
+        dec_g[blk * 128 + lane] = ca; dec_g[blk * 128 + 64 + lane] = cb;
+    };
     const int nfull = nsteps / SP2_HIST;
     const int rem = nsteps - nfull * SP2_HIST;                               // steps in the last, partial block (a multiple of six)
     for (int c0 = 0; c0 < nsteps; c0 += CHUNK) {
@@ -169,7 +177,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
             const int e0 = blk * SP2_HIST - c0;
             six_steps(e0, std::integral_constant<int, 0>{}); six_steps(e0, std::integral_constant<int, 6>{}); six_steps(e0, std::integral_constant<int, 12>{});
             six_steps(e0, std::integral_constant<int, 18>{}); six_steps(e0, std::integral_constant<int, 24>{});
-            dec_g[blk * 128 + lane] = acc0; dec_g[blk * 128 + 64 + lane] = acc1;
+            store_hist(blk, acc0, acc1);
         }
     }
     {
@@ -178,78 +186,79 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
         if (rem >= 12) six_steps(t0, std::integral_constant<int, 6>{});
         if (rem >= 18) six_steps(t0, std::integral_constant<int, 12>{});
         if (rem >= 24) six_steps(t0, std::integral_constant<int, 18>{});
-        if (rem) { dec_g[nfull * 128 + lane] = acc0 << (SP2_HIST - rem); dec_g[nfull * 128 + 64 + lane] = acc1 << (SP2_HIST - rem); }   // its first step in bit SP2_HIST - 1 like the others
+        if (rem) store_hist(nfull, acc0 << (SP2_HIST - rem), acc1 << (SP2_HIST - rem));        // its first step in bit SP2_HIST - 1 like the others
     }
     __syncthreads();                                                        // (one wave: the wait it implies orders the stores above before the loads below)
 
     // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339), both code words of the wave side by side on the scalar unit.
     // The decoded bits are shifted into the top of a 64-bit register, newest first; whenever 32 of them have gathered the oldest 32
     // leave as one output word (bytes packed MSB first, decoder_adapter.cpp:61-67; the first bit read is data bit nbits - 1).
-    struct Walk { uint32_t jl, r; unsigned long long bits; };
-    Walk W[2] = {{0u, 0u, 0ull}, {32u, 0u, 0ull}};                          // (lane of the wave, register): state 0 ends in lane 0 of its half, register 0
+    // A walk's coordinate c = register << 5 | lane of the half: the lane of its code word's history row that holds the decision.
+    struct Walk { uint32_t c, blk; unsigned long long bits; };              // blk: the bits of the block being walked, newest in bit 0
+    Walk W[2] = {{0u, 0u, 0ull}, {0u, 0u, 0ull}};                           // state 0 ends in lane 0 of its half, register 0
     int cnt = 0, wi = nbits / 32;
     uint32_t* __restrict__ const out_a = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_a * (nbits / 32);
     const uint32_t* __restrict__ prbs = A.prbs_words;
     const int dedisperse = C.dedisperse;
-    // one step back in layout FL at bit position `pos` of the history words (c0, c1 = the words of register 0 / 1, one per lane)
-    auto back = [&](auto fc, Walk& w, uint32_t c0, uint32_t c1, int pos) {
+    // one step back in layout FL at bit position `pos` of the history words (row = the code word's history row of this block, one word per lane)
+    auto back = [&](auto fc, Walk& w, uint32_t row, int pos) {
         constexpr int FL = decltype(fc)::value;
-        const uint32_t h0 = lane_get(c0, w.jl), h1 = lane_get(c1, w.jl);
-        const uint32_t dec = ((w.r ? h1 : h0) >> pos) & 1u;
+        const uint32_t dec = ubfe(lane_get(row, w.c), pos, 1);
         uint32_t d = dec;
-        if constexpr (sp2::inbit(FL) >= 0) d ^= (w.jl >> sp2::inbit(FL)) & 1u;          // the lane's inputs were swapped: "Q side" was state k
-        w.bits = (w.bits >> 1) | ((unsigned long long)d << 63);
+        if constexpr (sp2::inbit(FL) >= 0) d ^= ubfe(w.c, sp2::inbit(FL), 1);           // the lane's inputs were swapped: "Q side" was state k
+        w.blk = (w.blk << 1) | d;                                                         // (newest in bit 0: reversed when a word leaves)
         // the survivor came in through input register q = dec; the exchange after the previous step (layout FP, lane bit pb) filled it
         constexpr int FP = (FL + 4) % 5, pb = sp2::xbit(FP);
-        if constexpr (FP == 0) {                         // swap16: outputs in (2k, 2k + 1) order; register = the lane's bit, the lane = this one with the bit set to q
-            w.r = (w.jl >> pb) & 1u;
-            w.jl = (w.jl & ~(1u << pb)) | (dec << pb);
-        } else {                                         // kept / given: input 0 = the lane's own register 0, input 1 = its partner's register 1
-            w.r = dec;
-            w.jl ^= dec << pb;
-        }
+        if constexpr (FP == 0)                           // swap16: outputs in (2k, 2k + 1) order; register = the lane's bit, the lane = this one with the bit set to q
+            w.c = (w.c & 15u) | (dec << 4) | ((w.c & 16u) << 1);
+        else                                             // kept / given: input 0 = the lane's own register 0, input 1 = its partner's register 1
+            w.c = (w.c & 31u) ^ (dec ? ((1u << pb) | 32u) : 0u);
     };
     auto emit = [&]() {
         if (cnt >= 32) {
             wi--; cnt -= 32;
-            const uint32_t wa = acs::back_word((uint32_t)(W[0].bits >> (32 - cnt))), wb = acs::back_word((uint32_t)(W[1].bits >> (32 - cnt)));
+            // the 32 oldest of the bits gathered, the first one read in bit 0 (acs::back_word's order): bits [cnt, cnt + 32), reversed
+            const uint32_t wa = acs::back_word(bit_reverse32((uint32_t)(W[0].bits >> cnt))), wb = acs::back_word(bit_reverse32((uint32_t)(W[1].bits >> cnt)));
             const uint32_t x = dedisperse ? prbs[wi] : 0u;
             if (lane == 0) out_a[wi] = wa ^ x;
             if (lane == 32 && second) out_a[(nbits / 32) + wi] = wb ^ x;
         }
     };
-    auto back_n = [&](uint32_t c0, uint32_t c1, auto hi, auto lo) {          // steps hi - 1 down to lo of a block, straight-line
+    auto back_n = [&](uint32_t ca, uint32_t cb, auto hi, auto lo) {          // steps hi - 1 down to lo of a block, straight-line, the two walks side by side
         constexpr int HI = decltype(hi)::value, LO = decltype(lo)::value;
         auto go = [&](auto self, auto kc) -> void {
             constexpr int k = decltype(kc)::value;
-            back(std::integral_constant<int, k % 5>{}, W[0], c0, c1, SP2_HIST - 1 - k);
-            back(std::integral_constant<int, k % 5>{}, W[1], c0, c1, SP2_HIST - 1 - k);
+            back(std::integral_constant<int, k % 5>{}, W[0], ca, SP2_HIST - 1 - k);
+            back(std::integral_constant<int, k % 5>{}, W[1], cb, SP2_HIST - 1 - k);
             if constexpr (k > LO) self(self, std::integral_constant<int, k - 1>{});
         };
         if constexpr (HI > LO) go(go, std::integral_constant<int, HI - 1>{});
     };
     if (rem) {
-        const uint32_t c0 = dec_g[nfull * 128 + lane], c1 = dec_g[nfull * 128 + 64 + lane];
-        if (rem == 6) back_n(c0, c1, std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
-        else if (rem == 12) back_n(c0, c1, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
-        else if (rem == 18) back_n(c0, c1, std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
-        else back_n(c0, c1, std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
+        const uint32_t ca = dec_g[nfull * 128 + lane], cb = dec_g[nfull * 128 + 64 + lane];
+        if (rem == 6) back_n(ca, cb, std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+        else if (rem == 12) back_n(ca, cb, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
+        else if (rem == 18) back_n(ca, cb, std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
+        else back_n(ca, cb, std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
+        W[0].bits = (W[0].bits << rem) | W[0].blk; W[1].bits = (W[1].bits << rem) | W[1].blk; W[0].blk = W[1].blk = 0;
         cnt += rem; emit();
     }
-    uint32_t c0 = nfull ? dec_g[(nfull - 1) * 128 + lane] : 0u, c1 = nfull ? dec_g[(nfull - 1) * 128 + 64 + lane] : 0u;
+    uint32_t ca = nfull ? dec_g[(nfull - 1) * 128 + lane] : 0u, cb = nfull ? dec_g[(nfull - 1) * 128 + 64 + lane] : 0u;
     for (int blk = nfull - 1; blk >= 1; blk--) {                            // whole blocks above the first
-        const uint32_t n0 = dec_g[(blk - 1) * 128 + lane], n1 = dec_g[(blk - 1) * 128 + 64 + lane];   // the block below, in flight while this one is walked
-        back_n(c0, c1, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
+        const uint32_t na = dec_g[(blk - 1) * 128 + lane], nb = dec_g[(blk - 1) * 128 + 64 + lane];   // the block below, in flight while this one is walked
+        back_n(ca, cb, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
+        W[0].bits = (W[0].bits << SP2_HIST) | W[0].blk; W[1].bits = (W[1].bits << SP2_HIST) | W[1].blk; W[0].blk = W[1].blk = 0;
         cnt += SP2_HIST; emit();
-        c0 = n0; c1 = n1;
+        ca = na; cb = nb;
     }
     if (nfull) {                                                            // block 0: its first six steps decide nothing that is kept
-        back_n(c0, c1, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
+        back_n(ca, cb, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
+        W[0].bits = (W[0].bits << (SP2_HIST - 6)) | W[0].blk; W[1].bits = (W[1].bits << (SP2_HIST - 6)) | W[1].blk;
         cnt += SP2_HIST - 6; emit();
     }
 }
 
-// swap16 / partner against plain shuffles, all five lane bits (device self-test of the instruction forms the execution model of
+// swap16 / swap32 / partner against plain shuffles, all five lane bits (device self-test of the instruction forms the execution model of
 // tests/hipemu stands in for): out[0] += mismatching lanes, out[1] += lanes checked
 __global__ void __launch_bounds__(64) k_selftest_half_exchange(unsigned* out)
 {
@@ -262,6 +271,12 @@ __global__ void __launch_bounds__(64) k_selftest_half_exchange(unsigned* out)
             const bool set = (lane >> 4) & 1;
             const uint32_t p0 = (uint32_t)__shfl((int)r0, lane ^ 16), p1 = (uint32_t)__shfl((int)r1, lane ^ 16);
             bad += (a != (set ? p1 : r0)) + (b != (set ? r1 : p0)); n += 2;
+        }
+        {
+            uint32_t a, b; swap32(r0, r1, a, b);
+            const bool up = lane >= 32;
+            const uint32_t p0 = (uint32_t)__shfl((int)r0, lane ^ 32), p1 = (uint32_t)__shfl((int)r1, lane ^ 32);
+            bad += (a != (up ? p1 : r0)) + (b != (up ? r1 : p0)); n += 2;
         }
         auto chk = [&](auto bc) {
             constexpr int B = decltype(bc)::value;
