@@ -369,31 +369,18 @@ __device__ __forceinline__ void sf_attempt(uint8_t* s_sf, int fb, int s, const u
 // :122-131 AU CRC-16-CCITT of the first ne events of one (ensemble, sub-channel) pair, one lane per access unit.  The verdicts do not steer the
 // state machine.  (Events and superframes were written by earlier kernels or, behind a barrier, by this work-group.)  Returns nothing:
 // failures are counted into *aubad (LDS).
-// `stage` (LDS, stage_bytes; nullptr: none): the wide pass' verdict.  There every event e of the pair synchronised and its corrected
-// superframe lies in slot e: one contiguous run of HBM, brought into LDS with coalesced 8-byte loads, as many superframes at a time as
-// fit, and the CRCs walk LDS bytes -- a lane that reads its access unit byte by byte from HBM spends ~300 dependent memory round trips
-// per unit (round 4: that was k_superframe_settle's 0.4 ms, half of the filter's time in the headline step).
-__device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t,
-                                           uint8_t* stage = nullptr, int stage_bytes = 0)
+// (Round 5 tried bringing the superframes into LDS with coalesced loads first and walking LDS bytes: 0.45-0.60 ms for the verdict kernel
+// against 0.40 ms as it is -- the staging's barriers and its 12-24 KB of LDS per work-group cost more occupancy than the byte-wise HBM
+// reads cost latency; with ~16 work-groups per compute unit in flight those round trips overlap.  profiles/r05_summary.md.)
+__device__ __forceinline__ void sf_au_crcs(const SfArgs& A, SfEvent* ev, size_t bm, int ne, int sf_len, const uint16_t* crctab, int* aubad, int t)
 {
-    const int per = (stage && stage_bytes >= sf_len) ? stage_bytes / sf_len : 0;       // events per staged chunk (0: read from HBM)
-    for (int e0 = 0; e0 < ne; e0 += per ? per : ne) {
-        const int n = per ? (ne - e0 < per ? ne - e0 : per) : ne;
-        if (per) {
-            __syncthreads();                                                            // (the previous chunk has been read)
-            const uint2* src = reinterpret_cast<const uint2*>(A.sf + (bm * A.n_slots + e0) * sf_len);     // (superframes are 120 s bytes: multiples of 8, 8-aligned)
-            uint2* dst = reinterpret_cast<uint2*>(stage);
-            for (int i = t; i < n * (sf_len / 8); i += 64) dst[i] = src[i];
-            __syncthreads();
-        }
-        for (int base = 0; base < n * 6; base += 64) {
-            const int k = base + t, e_i = e0 + k / 6, au_i = k % 6;
-            if (k < n * 6 && ev[e_i].sync && au_i < ev[e_i].num_aus) {
-                const int a0 = ev[e_i].au_start[au_i], au_len = ev[e_i].au_start[au_i + 1] - a0;
-                const uint8_t* au = (per ? stage + (size_t)(e_i - e0) * sf_len : A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len) + a0;
-                if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
-                else atomicAdd(aubad, 1);
-            }
+    for (int base = 0; base < ne * 6; base += 64) {
+        const int k = base + t, e_i = k / 6, au_i = k % 6;
+        if (e_i < ne && ev[e_i].sync && au_i < ev[e_i].num_aus) {
+            const uint8_t* au = A.sf + (bm * A.n_slots + ev[e_i].sf_slot) * sf_len + ev[e_i].au_start[au_i];
+            const int au_len = ev[e_i].au_start[au_i + 1] - ev[e_i].au_start[au_i];
+            if (au_len >= 2 && (uint16_t)(au[au_len - 2] << 8 | au[au_len - 1]) == crc16_msb_tab(au, au_len - 2, true, true, crctab)) atomicOr(&ev[e_i].au_crc_ok, 1 << au_i);
+            else atomicAdd(aubad, 1);
         }
     }
 }
@@ -461,8 +448,6 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
     const SfArgs A = sf_args_of(Bt, bx);
     __shared__ uint16_t s_crctab[256];
     __shared__ int s_ok, s_corr, s_unc, s_aubad;
-    constexpr int SF_STAGE = 11520;                                                     // 12 superframes of a 64 kbit/s service at a time, 2 of a 384 kbit/s one (13 work-groups per CU)
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[SF_STAGE];
     const int t = threadIdx.x;
     const int fb = A.frame_bytes, sf_len = 5 * fb, fw = fb >> 3;
     const size_t bm = A.run ? (size_t)A.run[bx] : (size_t)bx;      // the pair
@@ -485,7 +470,7 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
     const int ok = s_ok;
     if (t == 0) { A.accepted[bm] = ok; if (A.wide_stats && p.nq >= 1) { atomicAdd(A.wide_stats + 1, 1ull); if (ok) atomicAdd(A.wide_stats, 1ull); } }   // (a batch without a full window has nothing the wide pass could settle: not counted as tried)
     if (!ok) return;
-    sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t, s_stage, SF_STAGE);
+    sf_au_crcs(A, ev, bm, p.nq, sf_len, s_crctab, &s_aubad, t);
     // the frames behind the last attempt are the next batch's carried window (a hit empties it, dabplus_decoder.cpp:156)
     const int n_left = p.cu + p.avail - 5 * p.nq;
     for (int k = 0; k < n_left; k++) {
