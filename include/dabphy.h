@@ -350,8 +350,15 @@ int dabphy_rs_superframes(dabphy_handle* h, uint8_t* sf, uint32_t s_per_sf, uint
 int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* first_cif, int32_t* corrected,
                          int32_t* uncorrectable);
 
-/* ---- per-stage device time of the last dabphy_process (HIP events on the handle's stream) -------------------
- * ms[0..6] = sync chain, demod kernel, SNR, FIC (gather+Viterbi+CRC), MSC gather, MSC Viterbi, Reed-Solomon */
+/* ---- per-stage device time of the last dabphy_process (HIP events on the stream each stage is queued on; dabphy_get_stage_times) ----
+ * ms[0] sync chain   the synchroniser chain that produced this batch (on its own stream: in pipelined modes it ran beside the previous batch's decode)
+ * ms[1] demod        the demod kernel
+ * ms[2] SNR          the SNR kernels (auxiliary stream; they may wait for wave slots beside the decoder: wall time, not work)
+ * ms[3] FIC          since round 4 the FIC's code words ride in the fused decode launch: this is then ONLY the FIB CRC + FIC-ratio kernels
+ *                    behind it; with the FIC on its own kernels (experiments build, spans beyond 4 GiB) gather + Viterbi + CRC as before
+ * ms[4] MSC gather   classes that take the two-kernel path (0 when every class rides in the fused launch)
+ * ms[5] MSC Viterbi  the fused decode launch: EVERY protection class of every ensemble AND, when fused, the FIC
+ * ms[6] Reed-Solomon the superframe filter pass over all classes (dabphy_set_auto_superframes / dabphy_superframes_stats), or dabphy_rs_decode_msc */
 /* DAB+ superframe filter on the device (SuperframeFilter::Feed / CheckSync, dabplus_decoder.cpp:50-213) for sub-channel
  * subch_index of every ensemble, over the logical frames of the last dabphy_process() batch: 5-frame sliding window,
  * Reed-Solomon, Fire-code synchronisation, access-unit table and AU CRCs.  The window state is carried from batch to

@@ -137,3 +137,71 @@ if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
         json.dump({"cycles_packed": cp, "cycles_plain": cl, "cycles_per_instruction_kernel_mix": (n_packed * cp + n_plain * cl) / (n_packed + n_plain), "at_waves_per_simd": 5, "per_instruction": cyc,
                    "source": "profiles/%s_ubench_valu_rate.txt (tools/ubench/valu_rate.hip on the GPU box, 2.4 GHz assumed)" % TAG, **BUILD},
                   open(os.path.join(DST, "valu_rate.json"), "w"), indent=1)
+
+
+# ---- profiles/<tag>_summary.md: the figures DESIGN.md quotes, derived from the files above and from the bench line of the same session
+# (gpurun_out/prof/bench.json when make_profiles.sh left one), so that no prose number is typed by hand
+def _kernel_stats():
+    out = {}
+    for r in csv.DictReader(open(os.path.join(DST, TAG + "_bench_kernel_stats.csv"))):
+        name = r.get("Name") or r.get("Kernel_Name") or ""
+        if "dabphy" not in name:
+            continue
+        k = name.split("(")[0].replace("dabphy::", "").replace("void ", "")
+        out[k] = dict(calls=int(r["Calls"]), avg_ms=float(r["AverageNs"]) / 1e6, min_ms=float(r["MinNs"]) / 1e6, max_ms=float(r["MaxNs"]) / 1e6, pct=float(r["Percentage"]))
+    return out
+
+
+try:
+    ks = _kernel_stats()
+    dj = json.load(open(os.path.join(DST, "demod_hbm_traffic.json")))
+    vj = json.load(open(os.path.join(DST, "viterbi_counters.json"))) if os.path.exists(os.path.join(DST, "viterbi_counters.json")) else {}
+    lines = ["# %s profile summary (generated by tools/collect_profiles.py -- do not edit)" % TAG, "",
+             "Build: src_sha256 `%s...`, lib_sha256 `%s...`; batch %d ensembles x %d frames; command: `tools/make_profiles.sh` (rocprofv3 --kernel-trace --stats of the default" % (BUILD["src_sha256"][:16], BUILD["lib_sha256"][:16], B, F),
+             "`bench.py` step counts; counters in their own --pmc passes).", "", "## Kernel statistics (`%s_bench_kernel_stats.csv`)" % TAG, "",
+             "| kernel | launches | average ms | minimum ms | maximum ms | % of kernel time |", "|---|---|---|---|---|---|"]
+    for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["pct"]):
+        lines.append("| `%s` | %d | %.4f | %.4f | %.4f | %.2f |" % (k, v["calls"], v["avg_ms"], v["min_ms"], v["max_ms"], v["pct"]))
+    kd = [k for k in ks if k.startswith("k_demod")]
+    if kd:
+        v = ks[kd[0]]; alg = dj["algorithmic_bytes_per_launch"]
+        lines += ["", "## FFT stage (`k_demod`) against the HBM roofline", "",
+                  "* algorithmic bytes per launch: %d (IQ useful parts read once + int8 soft bits written once)" % alg,
+                  "* average launch %.4f ms -> %.0f GB/s = **%.3f of 8 TB/s**; minimum launch %.4f ms -> %.3f" % (v["avg_ms"], alg / v["avg_ms"] / 1e6, alg / v["avg_ms"] / 1e6 / 8000.0, v["min_ms"], alg / v["min_ms"] / 1e6 / 8000.0),
+                  "* HBM traffic from the counters: FETCH_SIZE %.0f KB x 2 (gfx950 correction) + WRITE_SIZE %.0f KB = %d bytes = **%.3f x algorithmic**" % (dj["fetch_size_kb_raw"], dj["write_size_kb_raw"], dj["hbm_bytes_per_launch"], dj["traffic_over_algorithmic"])]
+    kv = [k for k in ks if k.startswith("k_viterbi_fused")]
+    if kv and vj:
+        v = ks[kv[0]]
+        n_simd = 1024
+        lines += ["", "## Viterbi stage (`k_viterbi_fused`, all classes + FIC in one launch)", "",
+                  "* average launch %.4f ms (minimum %.4f)" % (v["avg_ms"], v["min_ms"]),
+                  "* SQ_INSTS_VALU %.4g per launch -> %.4g wave-instructions/s = **%.3f** of one plain instruction per SIMD every two cycles (%d SIMDs x 2.4 GHz / 2)" % (vj["valu_insts_per_launch"], vj["valu_insts_per_launch"] / (v["avg_ms"] * 1e-3), vj["valu_insts_per_launch"] / (v["avg_ms"] * 1e-3) / (n_simd * 2.4e9 / 2), n_simd),
+                  "* HBM: FETCH_SIZE %.0f KB raw, WRITE_SIZE %.0f KB -> %.2f GB with the fetch doubled, %.2f GB with narrow requests tallied in full, against %.2f GB algorithmic (%.1f x / %.1f x); decision array written + read: %.2f GB" % (
+                      vj["fetch_size_kb_raw"], vj["write_size_kb_raw"], vj["hbm_bytes_per_launch"] / 1e9, vj["hbm_bytes_if_narrow_requests_are_tallied_in_full"] / 1e9, vj["algorithmic_bytes_per_launch"] / 1e9,
+                      vj["hbm_bytes_per_launch"] / vj["algorithmic_bytes_per_launch"], vj["hbm_bytes_if_narrow_requests_are_tallied_in_full"] / vj["algorithmic_bytes_per_launch"], vj["decision_bytes_written_plus_read"] / 1e9),
+                  "* LDS bank efficiency 1 - SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.3f" % (1.0 - vj["lds_bank_conflict_cycles"] / vj["lds_idx_active_cycles"] if vj.get("lds_idx_active_cycles") else float("nan"))]
+    bj = os.path.join(SRC, "bench.json")
+    if os.path.exists(bj):
+        try:
+            j = json.loads([l for l in open(bj).read().splitlines() if l.startswith("{")][-1])
+            shutil.copy(bj, os.path.join(DST, TAG + "_bench_default.json"))
+            lines += ["", "## The bench line of the same session (`%s_bench_default.json`)" % TAG, "",
+                      "* value **%.0f x real-time**, %.3f ms per step; stages (HIP events, ms): %s" % (j["value"], j["ms_per_step"], ", ".join("%s %.3f" % kv for kv in j["stages_ms"].items())),
+                      "* roofline.frac %.4f (kernel_ms %.4f); measured float4 copy %.0f GB/s -> %.3f of achievable" % (j["roofline"]["frac"], j["roofline"]["kernel_ms"], j["roofline"].get("measured_copy_GBps", float("nan")), j["roofline"].get("frac_of_achievable", float("nan")))]
+            cb = j.get("cpu_baseline")
+            if cb:
+                lines.append("* cpu_baseline: %.1f x real-time (%s, %d cores); oracle receivers on all cores %.1f x; -O3 build %s" % (cb["value"], cb["kind"], cb["cores"], (cb.get("oracle_port") or {}).get("value", float("nan")), ("%.1f x" % cb["o3"]["value"]) if cb.get("o3") and "value" in cb["o3"] else "-"))
+            ex = j.get("extras", {})
+            for name in ("hetero", "mixed_layouts"):
+                e = ex.get(name)
+                if e and "value" in e:
+                    lines.append("* extras.%s: %.0f x, %.3f ms per step, decoder %.3f ms, superframe filter %.3f ms, parity %s" % (name, e["value"], e["ms_per_step"], e["msc_viterbi_ms"], e["stages_ms"].get("rs", float("nan")), e.get("parity")))
+            fc = j.get("facade")
+            if fc and "ms_per_frame" in fc:
+                lines.append("* facade: %.3f ms per 96 ms frame; level 2 builds (ms per frame): %s" % (fc["ms_per_frame"], ", ".join("%s %.2f" % (k, v["ms_per_frame"]) for k, v in fc.get("level2", {}).items() if "ms_per_frame" in v)))
+        except Exception as ex_:
+            lines.append("(bench line not summarised: %s)" % ex_)
+    open(os.path.join(DST, TAG + "_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+except Exception as ex_:
+    print("summary not written:", ex_)
