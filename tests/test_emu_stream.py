@@ -296,3 +296,11 @@ def test_service_added_and_removed_in_mid_stream(emu):
     """dabphy_set_subchannels_ensemble between batches: the services that keep playing (in the changed ensemble and in the other one)
     deliver the uninterrupted stream's bytes and superframe events; the added one starts like a fresh DabAudio"""
     P.check_service_changes_in_mid_stream(factory)
+
+
+def test_state_parallel_with_the_traceback_as_its_own_pass(emu, monkeypatch):
+    """k_viterbi_sp2 + k_traceback_sp2 (lane = code word): what batches above 8192 code words take on the device, forced here for a small
+    one (DABPHY_SP2_TB_MIN_CW = 0, experiments build): mixed protection classes incl. 9216-bit code words, and services changing in mid-stream"""
+    monkeypatch.setenv("DABPHY_SP2_TB_MIN_CW", "0")
+    P.check_mixed_ensemble(factory_state_parallel, F=3, nf=9, expect_fused=True)
+    P.check_service_changes_in_mid_stream(factory_state_parallel)

@@ -320,3 +320,11 @@ def test_round_4_state_parallel_kernel_is_still_there(gpu):
     stream with services changing in mid-stream, against the oracle"""
     P.check_mixed_ensemble(factory_state_parallel_r4, F=4, nf=11, expect_fused=True)
     P.check_service_changes_in_mid_stream(factory_state_parallel_r4)
+
+
+def test_medium_batch_takes_the_split_state_parallel_path(gpu):
+    """16 ensembles x 8 frames x 76 code words = 9728 per call: the automatic choice is k_viterbi_sp2 with the traceback as its own
+    lane-per-code-word pass (k_traceback_sp2); FIBs, correctors, soft bits and MSC bytes of every ensemble against the oracle"""
+    d = capi.DabPhy(lib_path=GPU_LIB, n_ensembles=16, max_frames=8)
+    d.close()
+    P.check_stream_vs_oracle(factory, 15, 40, 123, 26, False, B=16, F=8, con=False)

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
         if (rem >= 24) six_steps(t0, std::integral_constant<int, 18>{});
         if (rem) store_hist(nfull, acc0 << (SP2_HIST - rem), acc1 << (SP2_HIST - rem));        // its first step in bit SP2_HIST - 1 like the others
     }
+    if (A.sp2_split) return;                                                // the traceback is a pass of its own (k_traceback_sp2, below)
     __syncthreads();                                                        // (one wave: the wait it implies orders the stores above before the loads below)
 
     // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339), both code words of the wave side by side on the scalar unit.
@@ -258,6 +259,90 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
     }
 }
 
+// ---- The traceback as a pass of its own: LANE = code word.  At scale the in-kernel walk above is what bounds a state-parallel kernel --
+// it runs on the scalar unit, one per compute unit, ~10 instructions per code word and step --; here 64 walks run side by side on the
+// vector unit, one work-group per group of 64 code words (= one item of the work list = 32 work-groups of the forward launch).  Per block
+// of 30 steps the 64 history rows of the group (256 bytes each, one per code word: register 0 in words 0 .. 31, register 1 in 32 .. 63)
+// come into LDS with coalesced 16-byte loads; a lane then reads word c of ITS row per step -- c = its walk's coordinate, exactly the lane
+// the scalar walk hands to v_readlane -- and applies the same step (back() above, on vector registers).  8.5 bytes of HBM per code word
+// and step, eleven vector instructions per step for 64 code words.
+constexpr int TB_PITCH = 65;                       // words per row in LDS: consecutive rows start on consecutive banks
+__global__ void __launch_bounds__(64) k_traceback_sp2(FusedArgs A)
+{
+    __shared__ uint32_t rows[64 * TB_PITCH];
+    const int lane = threadIdx.x;
+    const uint32_t wk = as_constant(A.work)[blockIdx.x];
+    const DABPHY_CONST_AS FusedClass& C = as_constant(A.cls)[wk >> 24];
+    const int cw = (int)(wk & 0xffffffu) * 64 + lane;
+    const int nsteps = C.nsteps, nbits = C.nbits;
+    const bool live = cw < C.n_cw;
+    // the forward launch's work-group (32 * item + lane / 2) decoded this code word; its scratch holds two rows of 64 words per block
+    const uint32_t* __restrict__ const dec_w = reinterpret_cast<const uint32_t*>(A.dec) + (size_t)blockIdx.x * 32 * A.dec_slot_cells * 2;
+    const size_t wg_words = A.dec_slot_cells * 2;
+    auto stage = [&](int blk) {
+        __syncthreads();                                                    // (the previous block's rows have been read)
+        for (int i = lane; i < 64 * 16; i += 64) {                          // 16 x 16 bytes per row
+            const int r = i >> 4, q = i & 15;
+            const uint4 v = *reinterpret_cast<const uint4*>(dec_w + (size_t)(r >> 1) * wg_words + (size_t)blk * 128 + (r & 1) * 64 + 4 * q);
+            uint32_t* d = &rows[r * TB_PITCH + 4 * q];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+    };
+    uint32_t c = 0, blkbits = 0; unsigned long long bits = 0;              // state 0 ends in lane 0 of its half, register 0: coordinate 0
+    int cnt = 0, wi = nbits / 32;
+    uint32_t* __restrict__ const out = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw * (nbits / 32);
+    const uint32_t* __restrict__ prbs = A.prbs_words;
+    const int dedisperse = C.dedisperse;
+    const uint32_t* const my = &rows[lane * TB_PITCH];
+    auto back = [&](auto fc, int pos) {
+        constexpr int FL = decltype(fc)::value;
+        const uint32_t dec = (my[c] >> pos) & 1u;
+        uint32_t d = dec;
+        if constexpr (sp2::inbit(FL) >= 0) d ^= (c >> sp2::inbit(FL)) & 1u;
+        blkbits = (blkbits << 1) | d;
+        constexpr int FP = (FL + 4) % 5, pb = sp2::xbit(FP);
+        if constexpr (FP == 0) c = (c & 15u) | (dec << 4) | ((c & 16u) << 1);
+        else c = (c & 31u) ^ (dec * ((1u << pb) | 32u));
+    };
+    auto back_n = [&](auto hi, auto lo) {                                   // steps hi - 1 down to lo of the staged block, straight-line
+        constexpr int HI = decltype(hi)::value, LO = decltype(lo)::value;
+        auto go = [&](auto self, auto kc) -> void {
+            constexpr int k = decltype(kc)::value;
+            back(std::integral_constant<int, k % 5>{}, SP2_HIST - 1 - k);
+            if constexpr (k > LO) self(self, std::integral_constant<int, k - 1>{});
+        };
+        if constexpr (HI > LO) go(go, std::integral_constant<int, HI - 1>{});
+    };
+    auto gathered = [&](int n) {                                            // n more bits: whenever 32 have gathered the oldest 32 leave as one output word
+        bits = (bits << n) | blkbits; blkbits = 0; cnt += n;
+        if (cnt >= 32) {
+            wi--; cnt -= 32;
+            const uint32_t w = acs::back_word(bit_reverse32((uint32_t)(bits >> cnt)));
+            if (live) out[wi] = dedisperse ? w ^ prbs[wi] : w;
+        }
+    };
+    const int nfull = nsteps / SP2_HIST, rem = nsteps - nfull * SP2_HIST;
+    if (rem) {
+        stage(nfull);
+        if (rem == 6) back_n(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+        else if (rem == 12) back_n(std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
+        else if (rem == 18) back_n(std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
+        else back_n(std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
+        gathered(rem);
+    }
+    for (int blk = nfull - 1; blk >= 1; blk--) {
+        stage(blk);
+        back_n(std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
+        gathered(SP2_HIST);
+    }
+    if (nfull) {                                                            // block 0: its first six steps decide nothing that is kept
+        stage(0);
+        back_n(std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
+        gathered(SP2_HIST - 6);
+    }
+}
+
 // swap16 / swap32 / partner against plain shuffles, all five lane bits (device self-test of the instruction forms the execution model of
 // tests/hipemu stands in for): out[0] += mismatching lanes, out[1] += lanes checked
 __global__ void __launch_bounds__(64) k_selftest_half_exchange(unsigned* out)
@@ -299,6 +384,7 @@ void launch_viterbi_sp2(const FusedArgs& a, int lds_variant, hipStream_t s)
     // LDS: four 16-bit sums per trellis step, for two code words, 480 steps at a time: 7.7 KiB, 20 work-groups per compute unit
     (void)lds_variant;
     hipLaunchKernelGGL((k_viterbi_sp2<480, 4>), grid, dim3(64), 0, s, a);
+    if (a.sp2_split) hipLaunchKernelGGL(k_traceback_sp2, dim3(a.n_work), dim3(64), 0, s, a);
 }
 
 } // namespace dabphy
