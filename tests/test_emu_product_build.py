@@ -43,7 +43,7 @@ def test_benchmark_handle_configuration_small(emu_product):
 
 def test_default_choice_of_the_viterbi_kernel(emu_product, monkeypatch):
     """dabphy_config.decode_shape = 0 on the product build (no environment override exists in it): one ensemble, one frame per call --
-    the live receiver's shape -- is decoded state-parallel (76 code words), and so are the per-frame seams; a batch beyond 18 432 code
+    the live receiver's shape -- is decoded state-parallel (76 code words), and so are the per-frame seams; a batch beyond 40 960 code
     words takes the lane-per-code-word kernel.  Bytes against the oracle either way."""
     monkeypatch.delenv("DABPHY_SP_MAX_CW", raising=False)
     from welle_io_amd import synth
@@ -68,9 +68,9 @@ def test_default_choice_of_the_viterbi_kernel(emu_product, monkeypatch):
         P.check_fic_arbitrary_int8(d, n_frames=1)
     finally:
         d.close()
-    big = factory(n_ensembles=61, max_frames=4, want_constellation=False)       # 61 x 4 frames x (4 FIC + 72 MSC) = 18 544 code words with 18 sub-channels
+    big = factory(n_ensembles=135, max_frames=4, want_constellation=False)      # 135 x 4 frames x (4 FIC + 72 MSC) = 41 040 code words with 18 sub-channels
     try:
-        big.stream_upload(np.tile(x, (61, 1)))
+        big.stream_upload(np.tile(x, (135, 1)))
         big.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, P.dev_prot(big, s)) for s in tx.subchs])
         big.process(4)
         assert big.last_decode_plan() == (1, 1), big.last_decode_plan()

@@ -107,8 +107,8 @@ def test_mixed_protection_classes(gpu, F, nf):
 @pytest.mark.parametrize("F,nf", [(4, 11), (16, 36), (1, 7), (7, 17)])
 def test_mixed_protection_classes_state_parallel(gpu, F, nf):
     """the same ensemble (EEP A/B, UEP, 8 .. 384 kbit/s: code words of 192 .. 9216 bits, all three LDS sizes of the kernel) through
-    k_viterbi_sp: one wavefront per code word, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
-    stream test of this file runs small batches too, hence this kernel: the default picks it below 16 384 code words per call.)"""
+    k_viterbi_sp2: two code words per wavefront, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
+    stream test of this file runs small batches too, hence the state-parallel kernels: the default picks them below 40 960 code words per call.)"""
     P.check_mixed_ensemble(factory_state_parallel, F=F, nf=nf, expect_fused=True)
 
 
@@ -128,8 +128,14 @@ def test_lane_exchanges_of_the_state_parallel_kernel(gpu):
 
 
 def test_shallow_batch_above_the_state_parallel_limit(gpu):
-    """128 ensembles x 4 frames of the mixed ensemble = 20 480 code words per call: too many for the state-parallel kernel's default
-    limit, too shallow for the 96-row build: the 144-row build of the fused kernel as the DEFAULT choice"""
+    """288 ensembles x 4 frames of the mixed ensemble = 46 080 code words per call: too many for the state-parallel kernels' default
+    limit (40 960), too shallow for the 96-row build: the 144-row build of the fused kernel as the DEFAULT choice"""
+    P.check_mixed_ensemble(factory, F=4, nf=11, B=288, expect_fused=True, check_ens=(0, 143, 287))
+
+
+def test_shallow_batch_below_the_state_parallel_limit(gpu):
+    """128 ensembles x 4 frames of the mixed ensemble = 20 480 code words per call, code words of 192 .. 9216 bits in nine classes: the
+    DEFAULT choice is k_viterbi_sp2 with its traceback as a pass of its own"""
     P.check_mixed_ensemble(factory, F=4, nf=11, B=128, expect_fused=True, check_ens=(0, 63, 127))
 
 

@@ -128,7 +128,7 @@ struct dabphy_handle {
     hipEvent_t ev_fused_done = nullptr;
     uint64_t buf_gen = 1;                                // bumped whenever a device buffer is reallocated or a class is rebuilt
     bool fused_msc = true;                               // MSC classes: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
-    uint32_t sp_max_codewords = 18432;                   // batches with at most this many code words (all classes + FIC) are decoded state-parallel: measured crossover, profiles/r05_viterbi_sp2.txt (DABPHY_SP_MAX_CW; 0: never)
+    uint32_t sp_max_codewords = 40960;                   // batches with at most this many code words (all classes + FIC) are decoded state-parallel: measured crossover of the whole call, profiles/r05_viterbi_sp2.txt (DABPHY_SP_MAX_CW; 0: never)
     uint32_t sp2_min_codewords = 6144;                   // ... of which those above this many take two code words per wavefront (k_viterbi_sp2) (DABPHY_SP2_MIN_CW)
     uint32_t sp2_tb_min_codewords = 8192;                // ... and above this many k_viterbi_sp2 leaves the traceback to k_traceback_sp2, lane = code word (DABPHY_SP2_TB_MIN_CW)
     bool chain_early = false;                            // pipelined schedules: queue the next batch's synchroniser in front of this batch's decoder instead of behind it (DABPHY_CHAIN_EARLY)
