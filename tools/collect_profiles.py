@@ -201,6 +201,11 @@ try:
                 lines.append("* facade: %.3f ms per 96 ms frame; level 2 builds (ms per frame): %s" % (fc["ms_per_frame"], ", ".join("%s %.2f" % (k, v["ms_per_frame"]) for k, v in fc.get("level2", {}).items() if "ms_per_frame" in v)))
         except Exception as ex_:
             lines.append("(bench line not summarised: %s)" % ex_)
+    # the -m gpu suite of the same device session (GPUTEST_LOG = its pytest output), e.g. gpurun_out/r5g/gputest.log
+    gl = os.environ.get("GPUTEST_LOG")
+    if gl and os.path.exists(gl):
+        res = [l.strip() for l in open(gl).read().splitlines() if " passed" in l or " failed" in l or l.startswith("pytest rc")]
+        lines += ["", "## The `-m gpu` suite of the same session (`%s`)" % gl, "", "* " + "; ".join(res[-2:])]
     open(os.path.join(DST, TAG + "_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 except Exception as ex_:
