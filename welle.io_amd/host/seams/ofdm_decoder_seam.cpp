@@ -29,27 +29,38 @@ OfdmDecoder::OfdmDecoder(const DABParams& p, RadioControllerInterface& mr, FicHa
     thread = std::thread(&OfdmDecoder::workerthread, this);
 }
 
+namespace {
+// end the worker (it wakes at least every 100 ms) and wait for it
+void end_worker(std::atomic<bool>& running, std::condition_variable& cv, std::thread& t)
+{
+    running = false;
+    cv.notify_all();
+    if (t.joinable()) t.join();
+}
+}
+
 OfdmDecoder::~OfdmDecoder()
 {
-    running = false; pending_symbols_cv.notify_all();
-    if (thread.joinable()) thread.join();
+    end_worker(running, pending_symbols_cv, thread);
     dabphy_handle* h = handle_of(this);
     { std::lock_guard<std::mutex> l(g_m); g_h.erase(this); }
     dabphy_destroy(h);
 }
 
-void OfdmDecoder::reset()
+void OfdmDecoder::reset()                                  // ofdm-decoder.cpp:79-88: a new worker, the SNR filter (here: in the handle) lives on
 {
-    running = false; pending_symbols_cv.notify_all();
-    if (thread.joinable()) thread.join();
+    end_worker(running, pending_symbols_cv, thread);
     thread = std::thread(&OfdmDecoder::workerthread, this);
 }
 
-void OfdmDecoder::pushAllSymbols(std::vector<std::vector<DSPCOMPLEX> >&& syms)      // ofdm-decoder.cpp:132-139, unchanged
+// the seam itself (ofdm-decoder.cpp:132-139): the frame's 76 symbol vectors change hands under the mutex, the worker is told
+void OfdmDecoder::pushAllSymbols(std::vector<std::vector<DSPCOMPLEX> >&& syms)
 {
-    std::unique_lock<std::mutex> lock(mutex);
-    pending_symbols = std::move(syms);
-    num_pending_symbols = pending_symbols.size();
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        pending_symbols.swap(syms);
+        num_pending_symbols = (int)pending_symbols.size();
+    }
     pending_symbols_cv.notify_one();
 }
 
