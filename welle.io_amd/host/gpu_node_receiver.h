@@ -42,6 +42,12 @@ class GpuNodeReceiver {
         Subchannel getSubchannel(size_t e, const ServiceComponent& sc) const { return shard[e / per]->getSubchannel(e % per, sc); }
         void setSignalClock(bool on) { for (auto& s : shard) s->setSignalClock(on); }
 
+        // every ensemble selects its own services (RadioReceiver::playSingleProgramme / addServiceToDecode / removeServiceToDecode,
+        // radio-receiver.cpp:120-185), by global ensemble index; call between process() calls from the thread that calls process()
+        bool playSingleProgramme(size_t e, ProgrammeHandlerInterface& handler, const std::string& dumpFileName, const Service& s) { return shard[e / per]->playSingleProgramme(e % per, handler, dumpFileName, s); }
+        bool addServiceToDecode(size_t e, ProgrammeHandlerInterface& handler, const std::string& dumpFileName, const Service& s) { return shard[e / per]->addServiceToDecode(e % per, handler, dumpFileName, s); }
+        bool removeServiceToDecode(size_t e, const Service& s) { return shard[e / per]->removeServiceToDecode(e % per, s); }
+
     private:
         size_t n_ens = 0, per = 1;
         std::vector<std::unique_ptr<GpuBatchReceiver>> shard;
