@@ -818,7 +818,7 @@ def check_mixed_layouts(capi_mod, lib_path, B, F, check_ens, n_steps=3, pipeline
     return logs
 
 
-def check_service_changes_in_mid_stream(d_factory, F=2, nf=26, snr_db=5.5, add_step=4, remove_step=8):
+def check_service_changes_in_mid_stream(d_factory, F=2, nf=26, snr_db=5.5, add_step=4, remove_step=8, pipeline_sync=False):
     """MscHandler::addSubchannel / removeSubchannel (msc-handler.cpp:61-127) while a batch of two receivers runs: ensemble 0 plays
     services A and B, adds D before step add_step and drops A before step remove_step; ensemble 1 plays C throughout.  The services
     that keep playing (B, C) must not notice: their bytes and their SuperframeFilter events (dabplus_decoder.cpp:50-213: a window that
@@ -836,7 +836,7 @@ def check_service_changes_in_mid_stream(d_factory, F=2, nf=26, snr_db=5.5, add_s
     Cc = txs[1].subchs[4]
     o0 = R.orc_receiver_run(xs[0], subchs=[A, Bc, D]); o1 = R.orc_receiver_run(xs[1], subchs=[Cc])
     want = {"A": o0["msc"][0], "B": o0["msc"][1], "D": o0["msc"][2], "C": o1["msc"][0]}
-    d = d_factory(n_ensembles=2, max_frames=F, want_constellation=False)
+    d = d_factory(n_ensembles=2, max_frames=F, want_constellation=False, pipeline_sync=pipeline_sync)
     sub = lambda s: (s.subch_id, s.start_cu, s.size_cu, dev_prot(d, s))
     got = {k: dict(rows=[], cifs=[], ev=[], sf=[]) for k in "ABCD"}
     try:

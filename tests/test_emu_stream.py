@@ -298,6 +298,13 @@ def test_service_added_and_removed_in_mid_stream(emu):
     P.check_service_changes_in_mid_stream(factory)
 
 
+@pytest.mark.parametrize("mode", [1, 3])
+def test_service_changes_while_the_synchroniser_runs_ahead(emu, mode):
+    """the same with the pipelined schedules (the next one or two batches are synchronised while this one is decoded): a selection change
+    between two dabphy_process calls applies to the batch decoded next, whatever has been synchronised ahead"""
+    P.check_service_changes_in_mid_stream(factory, pipeline_sync=mode)
+
+
 def test_state_parallel_with_the_traceback_as_its_own_pass(emu, monkeypatch):
     """k_viterbi_sp2 + k_traceback_sp2 (lane = code word): what batches above 8192 code words take on the device, forced here for a small
     one (DABPHY_SP2_TB_MIN_CW = 0, experiments build): mixed protection classes incl. 9216-bit code words, and services changing in mid-stream"""

@@ -334,3 +334,10 @@ def test_medium_batch_takes_the_split_state_parallel_path(gpu):
     d = capi.DabPhy(lib_path=GPU_LIB, n_ensembles=16, max_frames=8)
     d.close()
     P.check_stream_vs_oracle(factory, 15, 40, 123, 26, False, B=16, F=8, con=False)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_service_changes_while_the_synchroniser_runs_ahead(gpu, mode):
+    """selection changes between dabphy_process calls with the pipelined schedules: they apply to the batch decoded next, whatever has been
+    synchronised ahead; bytes and superframe events of the services that stay = the uninterrupted oracle's"""
+    P.check_service_changes_in_mid_stream(factory, pipeline_sync=mode)
