@@ -10,4 +10,5 @@ idx = [i for i, r in enumerate(rows) if "k_demod" in r["Kernel_Name"]]
 start = idx[-2]; t0 = int(rows[start]["Start_Timestamp"])
 for r in rows[start:idx[-1] + 1]:
     n = r["Kernel_Name"].split("(")[0].replace("dabphy::", "").replace("void ", "")
-    print("%-28s start %8.3f ms  dur %7.3f ms  stream %s" % (n, (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Stream_Id", "?")))
+    print("%-28s start %8.3f ms  dur %7.3f ms  end %8.3f ms  stream %s" % (n, (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
+                                                                       (int(r["End_Timestamp"]) - t0) / 1e6, r.get("Stream_Id", "?")))
