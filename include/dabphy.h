@@ -91,10 +91,10 @@ typedef struct {
     int32_t decode_shape;           /* which Viterbi kernel decodes the FIC and the sub-channels.  0 (default): by batch size -- small batches (at
                                        most 40 960 code words per call: e.g. one ensemble of 18 sub-channels, any batch depth; 32 ensembles x 16
                                        frames) STATE-PARALLEL, the 64 trellis states of a code word in the lanes of a wavefront: one code word
-                                       per wavefront up to 6 144 code words (k_viterbi_sp: four times the instructions per code word of the
+                                       per wavefront up to 1 024 code words (k_viterbi_sp: four times the instructions per code word of the
                                        throughput kernel, a hundredth of its latency), two per wavefront, 32 lanes and two states per lane each,
-                                       above that (k_viterbi_sp2: half the vector instructions; above 8 192 code words its traceback is a
-                                       lane-per-code-word pass of its own, k_traceback_sp2); larger batches one LANE per code word
+                                       above that (k_viterbi_sp2: half the vector instructions; its traceback is a pass of its own,
+                                       k_traceback_sp2: a lane per code word, a wave per stretch of it); larger batches one LANE per code word
                                        (k_viterbi_fused: the throughput shape).  1: always lane-per-code-word; 2: always k_viterbi_sp2;
                                        3: always k_viterbi_sp.  Same bytes whichever runs. */
 } dabphy_config;

@@ -42,7 +42,8 @@ int dabphy_selftest_unit_twiddle(dabphy_handle* h, uint64_t* counts);
 int dabphy_selftest_pair_exchange(dabphy_handle* h, uint64_t* counts);   /* (also swap16 / partner of k_viterbi_sp2.hip) */
 
 /* Which Viterbi kernel decoded the last dabphy_process batch (dabphy_config.decode_shape = 0 leaves the choice to the library):
- * *shape = 1 lane per code word (k_viterbi_fused), 2 state-parallel (k_viterbi_sp), 0 nothing decoded yet; *fused_classes = protection
+ * *shape = numbered like dabphy_config.decode_shape: 1 lane per code word (k_viterbi_fused), 2 state-parallel with two code words per wavefront
+ * (k_viterbi_sp2 + k_traceback_sp2), 3 state-parallel with one (k_viterbi_sp), 0 nothing decoded yet; *fused_classes = protection
  * classes (not counting the FIC) that rode in that launch -- the others took the two-kernel path.  Either pointer may be NULL. */
 int dabphy_last_decode_plan(dabphy_handle* h, int32_t* shape, int32_t* fused_classes);
 

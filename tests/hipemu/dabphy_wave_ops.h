@@ -101,6 +101,7 @@ static inline uint32_t opaque_vgpr(uint32_t x) { return x; }
 #define DABPHY_CONST_AS
 template <typename T> static inline const T* as_constant(const T* p) { return p; }
 static inline uint32_t u32_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+#define DABPHY_WAVES_PER_SIMD(n)
 static inline void wave_converge() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }
 static inline int uniform_i32(int x) { return x; }
 static inline void lds_reads_done() { (void)hipemu_wave_exchange(0u, hipemu_lane(), true); }     // every lane of the wave has read

@@ -43,8 +43,9 @@ def test_benchmark_handle_configuration_small(emu_product):
 
 def test_default_choice_of_the_viterbi_kernel(emu_product, monkeypatch):
     """dabphy_config.decode_shape = 0 on the product build (no environment override exists in it): one ensemble, one frame per call --
-    the live receiver's shape -- is decoded state-parallel (76 code words), and so are the per-frame seams; a batch beyond 40 960 code
-    words takes the lane-per-code-word kernel.  Bytes against the oracle either way."""
+    the live receiver's shape -- is decoded state-parallel, one code word per wavefront (76 code words), and so are the per-frame seams;
+    above 1 024 code words per call two code words share a wavefront and the traceback is a pass of its own; a batch beyond 40 960 code
+    words takes the lane-per-code-word kernel.  Bytes against the oracle where checked."""
     monkeypatch.delenv("DABPHY_SP_MAX_CW", raising=False)
     from welle_io_amd import synth
     import refapi as R
@@ -60,7 +61,7 @@ def test_default_choice_of_the_viterbi_kernel(emu_product, monkeypatch):
         fibs = []
         for _ in range(3):
             d.process(1)
-            assert d.last_decode_plan() == (2, 1), d.last_decode_plan()        # state-parallel, the one MSC class in the launch
+            assert d.last_decode_plan() == (3, 1), d.last_decode_plan()        # k_viterbi_sp, the one MSC class in the launch
             if d.frame_info()[0, 0]["valid"] == 1:
                 fibs.append(d.fibs()[0][0, 0])
         assert len(fibs) >= 2 and np.array_equal(np.array(fibs), o["fib"][:12 * len(fibs)].reshape(len(fibs), 12, 33)[:, :, 1:])
@@ -68,6 +69,19 @@ def test_default_choice_of_the_viterbi_kernel(emu_product, monkeypatch):
         P.check_fic_arbitrary_int8(d, n_frames=1)
     finally:
         d.close()
+    got = []
+    for shape in (0, 1):                                                        # 4 x 4 frames x (4 FIC + 72 MSC) = 1 216 code words: k_viterbi_sp2 + k_traceback_sp2; the lane-per-code-word kernel beside it
+        mid = factory(n_ensembles=4, max_frames=4, want_constellation=False, decode_shape=shape)
+        try:
+            mid.stream_upload(np.tile(x, (4, 1)))
+            mid.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, P.dev_prot(mid, s)) for s in tx.subchs])
+            mid.process(4)
+            assert mid.last_decode_plan() == ((2, 1) if shape == 0 else (1, 1)), mid.last_decode_plan()
+            got.append([mid.fibs()[0].copy()] + [mid.msc(i)[0][:, :8].copy() for i in (0, 7, 17)])     # the rows the batch decoded
+            assert (mid.msc_rows == 8).all()
+        finally:
+            mid.close()
+    assert all(np.array_equal(a, b) for a, b in zip(*got)) and got[0][0].any() and got[0][3].any()
     big = factory(n_ensembles=135, max_frames=4, want_constellation=False)      # 135 x 4 frames x (4 FIC + 72 MSC) = 41 040 code words with 18 sub-channels
     try:
         big.stream_upload(np.tile(x, (135, 1)))

@@ -305,9 +305,21 @@ def test_service_changes_while_the_synchroniser_runs_ahead(emu, mode):
     P.check_service_changes_in_mid_stream(factory, pipeline_sync=mode)
 
 
-def test_state_parallel_with_the_traceback_as_its_own_pass(emu, monkeypatch):
-    """k_viterbi_sp2 + k_traceback_sp2 (lane = code word): what batches above 8192 code words take on the device, forced here for a small
-    one (DABPHY_SP2_TB_MIN_CW = 0, experiments build): mixed protection classes incl. 9216-bit code words, and services changing in mid-stream"""
-    monkeypatch.setenv("DABPHY_SP2_TB_MIN_CW", "0")
+@pytest.mark.parametrize("warm,three", [(0, False), (1, False), (0, True), (4, True)])
+def test_block_parallel_traceback_with_wrong_guesses(emu, monkeypatch, warm, three):
+    """k_traceback_sp2 (lane = code word, wave = a stretch of the code word walked from a guessed state and CHECKED against the exit state of
+    the stretch above).  warm = the blocks of 30 steps a stretch's walk runs in over before its own: the product's 4 (every other
+    state-parallel test: guesses are almost always right), here 1 (some are wrong) and 0 (every guess is wrong: every stretch is walked
+    again from the true state, the rounds cascade down the code word) -- the bytes are the serial walk's in every case.  Mixed
+    protection classes incl. 9216-bit code words (four stretches), 64 kbit/s ones (four) and the FIC (three).  three: the build with three
+    waves per work-group, which launches of more than 512 groups take on the device (DABPHY_SP2_TB_RESIDENT = 0 forces it here)."""
+    monkeypatch.setenv("DABPHY_SP2_TB_WARM", str(warm))
+    if three:
+        monkeypatch.setenv("DABPHY_SP2_TB_RESIDENT", "0")
     P.check_mixed_ensemble(factory_state_parallel, F=3, nf=9, expect_fused=True)
+
+
+def test_service_changes_with_two_code_words_per_wavefront(emu):
+    """services changing in mid-stream through k_viterbi_sp2 + k_traceback_sp2 (decode_shape = 2: what batches of 1 024 .. 40 960 code words
+    take on the device)"""
     P.check_service_changes_in_mid_stream(factory_state_parallel)

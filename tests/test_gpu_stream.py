@@ -107,8 +107,9 @@ def test_mixed_protection_classes(gpu, F, nf):
 @pytest.mark.parametrize("F,nf", [(4, 11), (16, 36), (1, 7), (7, 17)])
 def test_mixed_protection_classes_state_parallel(gpu, F, nf):
     """the same ensemble (EEP A/B, UEP, 8 .. 384 kbit/s: code words of 192 .. 9216 bits, all three LDS sizes of the kernel) through
-    k_viterbi_sp2: two code words per wavefront, lanes = trellis states, decisions as per-lane histories, scalar traceback.  (Every other
-    stream test of this file runs small batches too, hence the state-parallel kernels: the default picks them below 40 960 code words per call.)"""
+    k_viterbi_sp2 + k_traceback_sp2: two code words per wavefront, lanes = trellis states, decisions as history rows, the traceback a pass
+    of its own (lane = code word, wave = a stretch of the code word, guessed entry states checked).  (Every other stream test of this file
+    runs small batches too, hence the state-parallel kernels: the default picks them below 40 960 code words per call.)"""
     P.check_mixed_ensemble(factory_state_parallel, F=F, nf=nf, expect_fused=True)
 
 

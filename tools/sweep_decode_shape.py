@@ -1,7 +1,7 @@
-"""Not a test: the two Viterbi kernels against each other over batch sizes (the canonical ensemble, 18 x 64 kbit/s + FIC = 76 code words per
+"""Not a test: the three Viterbi decoders against each other over batch sizes (the canonical ensemble, 18 x 64 kbit/s + FIC = 76 code words per
 frame): per (ensembles, frames per call) the whole dabphy_process call (host clock, steady state) and the decode launch alone
 (dabphy_time_fused_msc) with dabphy_config.decode_shape = 1 (one LANE per code word, k_viterbi_fused), = 2 (state-parallel, two code words per
-wavefront, k_viterbi_sp2) and = 3 (round 4's state-parallel kernel, one code word per wavefront, k_viterbi_sp).  Where the state-parallel kernel stops winning is what dabphy's default (decode_shape = 0) switches at.
+wavefront, k_viterbi_sp2 + its traceback pass k_traceback_sp2) and = 3 (round 4's state-parallel kernel, one code word per wavefront, k_viterbi_sp).  Where the state-parallel kernel stops winning is what dabphy's default (decode_shape = 0) switches at.
   python tools/sweep_decode_shape.py            table (profiles/r04_viterbi_state_parallel.txt)
   python tools/sweep_decode_shape.py --json     one JSON line with the single-ensemble rows (bench.py's extras.short_batches)"""
 import json
@@ -28,7 +28,7 @@ for B, F in GEOM:
     iq, cfo, base_np, txs = workload.make_batch(B, base=base, device="cuda")
     rec = {"ensembles": B, "frames_per_call": F, "code_words": B * F * 76}
     # (--json, bench.py's extras.short_batches: the lane-per-code-word kernel against what the library picks by itself for these sizes,
-    # decode_shape = 0 -- one ensemble is at most 1216 code words per call: k_viterbi_sp; the table compares all three explicitly)
+    # decode_shape = 0 -- k_viterbi_sp up to 1024 code words per call, k_viterbi_sp2 + k_traceback_sp2 for the 16-frame row; the table compares all three explicitly)
     for shape, name in ((1, "lane_per_codeword"), (0 if as_json else 2, "state_parallel")) + (() if as_json else ((3, "state_parallel_r4"),)):
         dev = workload.open_receiver(capi, lib, iq, F, txs[0].subchs, pipeline_sync=0, profiling=True, decode_shape=shape)
         dev.set_auto_superframes(False)
@@ -48,4 +48,4 @@ for B, F in GEOM:
         print("%4d ensembles x %2d frames (%6d code words): lane-per-code-word %7.3f ms per call, decode alone %7.3f ms | state-parallel (2 code words per wave) %7.3f ms per call, decode alone %7.3f ms | round 4's (1 per wave) %7.3f / %7.3f | %s"
               % (B, F, rec["code_words"], a["ms_per_call"], a["decode_ms_alone"], b["ms_per_call"], b["decode_ms_alone"], c["ms_per_call"], c["decode_ms_alone"], "state-parallel wins" if b["decode_ms_alone"] < a["decode_ms_alone"] else "lane-per-code-word wins"), flush=True)
 if as_json:
-    print(json.dumps({"what": "one ensemble, F frames per dabphy_process call (serial synchroniser, FIBs copied out): per-call latency and x real-time with the lane-per-code-word kernel forced (decode_shape 1) and with the library's own choice (decode_shape 0: state-parallel, k_viterbi_sp at these sizes)", "rows": rows}))
+    print(json.dumps({"what": "one ensemble, F frames per dabphy_process call (serial synchroniser, FIBs copied out): per-call latency and x real-time with the lane-per-code-word kernel forced (decode_shape 1) and with the library's own choice (decode_shape 0: state-parallel -- k_viterbi_sp, above 1024 code words k_viterbi_sp2 + k_traceback_sp2)", "rows": rows}))

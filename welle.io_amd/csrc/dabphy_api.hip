@@ -153,7 +153,8 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     if (const char* e = getenv("DABPHY_FUSED_FIC")) h->fused_fic = atoi(e) != 0;
     if (const char* e = getenv("DABPHY_SP_MAX_CW")) h->sp_max_codewords = (uint32_t)atoll(e);
     if (const char* e = getenv("DABPHY_SP2_MIN_CW")) h->sp2_min_codewords = (uint32_t)atoll(e);
-    if (const char* e = getenv("DABPHY_SP2_TB_MIN_CW")) h->sp2_tb_min_codewords = (uint32_t)atoll(e);
+    if (const char* e = getenv("DABPHY_SP2_TB_WARM")) h->sp2_tb_warm = (uint32_t)atoll(e);
+    if (const char* e = getenv("DABPHY_SP2_TB_RESIDENT")) h->sp2_tb_resident = (uint32_t)atoll(e);
     if (const char* e = getenv("DABPHY_CHAIN_EARLY")) h->chain_early = atoi(e) != 0;
 #endif
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)

@@ -193,7 +193,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     a.cls = h->fused_cls.as<FusedClass>(); a.work = h->fused_work.as<uint32_t>(); a.n_work = (uint32_t)work.size(); a.next = h->d_fused_next;
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = P.dec_slot_cells; a.prbs_words = h->d_prbs_words;
     a.dec_off = dec_by_item ? h->fused_dec_off.as<uint32_t>() : nullptr;
-    a.sp2_split = sp_two && total_cw > h->sp2_tb_min_codewords;            // enough code words for the traceback to be a vector pass of its own (§4.2c)
+    a.sp2_warm = (int)h->sp2_tb_warm; a.sp2_resident = (int)h->sp2_tb_resident;
     P.args = a;
     return DABPHY_OK;
 }
@@ -242,7 +242,7 @@ int sp_single_prepare(dabphy_handle* h, const FusedClass& fc, FusedArgs& a, hipS
     HIPCHK(h, hipMemcpyAsync(h->sp1_work.p, hw, n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     a.cls = h->sp1_cls.as<FusedClass>(); a.work = h->sp1_work.as<uint32_t>(); a.n_work = n_groups; a.next = nullptr;
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = cells; a.prbs_words = h->d_prbs_words;
-    a.sp2_split = h->sp1_two && (uint64_t)fc.n_cw > h->sp2_tb_min_codewords;
+    a.sp2_warm = (int)h->sp2_tb_warm; a.sp2_resident = (int)h->sp2_tb_resident;
     return DABPHY_OK;
 }
 // Two code words per wavefront (k_viterbi_sp2: half the vector instructions per code word) pays once the code words outnumber the SIMDs

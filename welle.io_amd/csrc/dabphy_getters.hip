@@ -256,7 +256,7 @@ int dabphy_last_decode_plan(dabphy_handle* h, int32_t* shape, int32_t* fused_cla
     if (!h) return DABPHY_ERR_INVALID;
     const auto& P = h->fplan;
     const bool ran = P.valid && P.launched && h->last_frames;
-    if (shape) *shape = !ran ? 0 : P.use_sp ? 2 : 1;
+    if (shape) *shape = !ran ? 0 : P.use_sp ? (P.sp_two ? 2 : 3) : 1;         // (numbered like dabphy_config.decode_shape)
     if (fused_classes) *fused_classes = ran ? (int32_t)P.class_idx.size() : 0;
     return DABPHY_OK;
 }

@@ -129,8 +129,9 @@ struct dabphy_handle {
     uint64_t buf_gen = 1;                                // bumped whenever a device buffer is reallocated or a class is rebuilt
     bool fused_msc = true;                               // MSC classes: gather inside the Viterbi kernel (DABPHY_FUSED_MSC=0: two kernels)
     uint32_t sp_max_codewords = 40960;                   // batches with at most this many code words (all classes + FIC) are decoded state-parallel: measured crossover of the whole call, profiles/r05_viterbi_sp2.txt (DABPHY_SP_MAX_CW; 0: never)
-    uint32_t sp2_min_codewords = 6144;                   // ... of which those above this many take two code words per wavefront (k_viterbi_sp2) (DABPHY_SP2_MIN_CW)
-    uint32_t sp2_tb_min_codewords = 8192;                // ... and above this many k_viterbi_sp2 leaves the traceback to k_traceback_sp2, lane = code word (DABPHY_SP2_TB_MIN_CW)
+    uint32_t sp2_min_codewords = 1024;                   // ... of which those above this many take two code words per wavefront and the traceback as a pass of its own (k_viterbi_sp2 + k_traceback_sp2) (DABPHY_SP2_MIN_CW)
+    uint32_t sp2_tb_resident = 512;                      // k_traceback_sp2: work-groups of four waves the device holds at once (two per compute unit: LDS); a launch of more takes three waves each (DABPHY_SP2_TB_RESIDENT)
+    uint32_t sp2_tb_warm = 4;                            // k_traceback_sp2: blocks of 30 steps a stretch's walk runs in over (120 steps ~ 17 constraint lengths; DABPHY_SP2_TB_WARM)
     bool chain_early = false;                            // pipelined schedules: queue the next batch's synchroniser in front of this batch's decoder instead of behind it (DABPHY_CHAIN_EARLY)
     bool fused_fic = true;                               // the FIC rides in the same launch (DABPHY_FUSED_FIC=0: k_fic_gather + k_viterbi on the auxiliary stream)
     hipEvent_t ev_chain_beg[N_DESC]{}, ev_chain_end[N_DESC]{}; float chain_ms = 0.0f;   // duration of the sync chain that produced the current batch

@@ -202,7 +202,8 @@ struct FusedArgs {
     int fic_frame_sel;                         // kind 1: 0 = every frame of the batch; f + 1 = frame f only (n_cw = 4 B)
     size_t fic_frame_stride;                   // kind 1: bytes between frame slots of `soft` (0: SOFT_PER_FRAME, the ring)
     const int8_t* lin_in; size_t lin_stride;   // kind 2
-    int sp2_split;                             // k_viterbi_sp2: 1 = the forward launch only stores its history rows, k_traceback_sp2 (lane = code word) walks them
+    int sp2_warm;                              // k_traceback_sp2: history blocks (30 steps each) a stretch's walk runs in over before its own blocks
+    int sp2_resident;                          // k_traceback_sp2: groups of 64 code words up to which a launch cuts the code word into four stretches (above: three)
 };
 // variant = index into FUSED_ROWS; n_slots = work-groups (one wave each) to launch
 void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s);

@@ -264,6 +264,8 @@ __device__ __forceinline__ uint32_t u32_max(uint32_t a, uint32_t b) { return __b
 
 // The lanes of a wavefront run in lock step: what one lane wrote to LDS before this point is visible to the others after it without
 // any instruction (a scheduling fence for the compiler).  tests/hipemu runs lanes as fibres and switches them here.
+// register budget of a kernel: at least n waves per SIMD
+#define DABPHY_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 __device__ __forceinline__ void wave_converge() { __builtin_amdgcn_wave_barrier(); }
 
 // accumulate into a double in LDS from many threads (order irrelevant to its users)

@@ -29,13 +29,15 @@
 // Metrics are int32, doubled, never renormalised (|b| <= 1020 per step, 9222 steps); decisions compare true integers, ties keep the
 // k branch (viterbi.cpp:263-268) -- for a swapped lane "Q < P" is that comparison with the roles exchanged, and the traceback undoes it.
 //
-// Traceback on the scalar unit -- one per compute unit, shared by its four SIMDs: at scale it is what bounds a state-parallel kernel, so
-// a step is eight scalar instructions and one v_readlane per code word --, both code words of the wave interleaved (two independent
-// chains).  The walk carries PHYSICAL coordinates c = (register r, lane j of the half); the history words of a block are stored so that
-// a code word's row holds register 0 in lanes 0 .. 31 and register 1 in lanes 32 .. 63: c is the lane to read.  One step back at step t
-// (layout f): dec = history bit of c; the decoded bit is dec ^ s_in_f(j); the survivor came in through input register q = dec, which
-// the exchange after step t - 1 (layout f - 1, lane bit p') filled from: swap16 -- register = bit p' of j, lane = j with bit p' := q;
+// Traceback: a second launch, k_traceback_sp2 (below) -- lane = code word, wave = a stretch of the code word.  The forward kernel leaves
+// its decisions as history rows: per block of 30 steps and code word 64 words, register 0 of lanes 0 .. 31 and register 1 in words 32 .. 63.
+// A walk carries PHYSICAL coordinates c = (register r, lane j of the half) = the word of the row that holds its decision.  One step back
+// at step t (layout f): dec = history bit of c; the decoded bit is dec ^ s_in_f(j); the survivor came in through input register q = dec,
+// which the exchange after step t - 1 (layout f - 1, lane bit p') filled from: swap16 -- register = bit p' of j, lane = j with bit p' := q;
 // kept / given -- register q of lane j (q = 0) or of its partner (q = 1).  State 0 ends in lane 0, register 0.
+// (Round 5's first versions walked back inside this kernel, on the scalar unit -- one per compute unit, shared by its four SIMDs: ~10
+// scalar instructions per code word and step bounded the kernel at scale, and one wave's walk bounded it for small batches:
+// profiles/r05_viterbi_sp2.txt has the numbers; the separate pass is faster at every size.)
 #include "dabphy_kernels.h"
 #include <dabphy_wave_ops.h>
 #include "viterbi_acs.h"
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
     const uint32_t wk = as_constant(A.work)[blockIdx.x >> 5];
     const DABPHY_CONST_AS FusedClass& C = as_constant(A.cls)[wk >> 24];
     const int cw_a = (int)(wk & 0xffffffu) * 64 + 2 * (int)(blockIdx.x & 31u);
-    const int nsteps = C.nsteps, nbits = C.nbits;
+    const int nsteps = C.nsteps;
     if (cw_a >= C.n_cw) return;
     const bool second = cw_a + 1 < C.n_cw;                                  // (an odd class: the last wave's upper half decodes the same code word again, its output is dropped)
     const int cw = cw_a + (second ? half : 0);
@@ -188,113 +190,88 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_sp2(FusedArgs A)
         if (rem >= 24) six_steps(t0, std::integral_constant<int, 18>{});
         if (rem) store_hist(nfull, acc0 << (SP2_HIST - rem), acc1 << (SP2_HIST - rem));        // its first step in bit SP2_HIST - 1 like the others
     }
-    if (A.sp2_split) return;                                                // the traceback is a pass of its own (k_traceback_sp2, below)
-    __syncthreads();                                                        // (one wave: the wait it implies orders the stores above before the loads below)
-
-    // ---- traceback from state 0 (chainback_viterbi, viterbi.cpp:313-339), both code words of the wave side by side on the scalar unit.
-    // The decoded bits are shifted into the top of a 64-bit register, newest first; whenever 32 of them have gathered the oldest 32
-    // leave as one output word (bytes packed MSB first, decoder_adapter.cpp:61-67; the first bit read is data bit nbits - 1).
-    // A walk's coordinate c = register << 5 | lane of the half: the lane of its code word's history row that holds the decision.
-    struct Walk { uint32_t c, blk; unsigned long long bits; };              // blk: the bits of the block being walked, newest in bit 0
-    Walk W[2] = {{0u, 0u, 0ull}, {0u, 0u, 0ull}};                           // state 0 ends in lane 0 of its half, register 0
-    int cnt = 0, wi = nbits / 32;
-    uint32_t* __restrict__ const out_a = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_a * (nbits / 32);
-    const uint32_t* __restrict__ prbs = A.prbs_words;
-    const int dedisperse = C.dedisperse;
-    // one step back in layout FL at bit position `pos` of the history words (row = the code word's history row of this block, one word per lane)
-    auto back = [&](auto fc, Walk& w, uint32_t row, int pos) {
-        constexpr int FL = decltype(fc)::value;
-        const uint32_t dec = ubfe(lane_get(row, w.c), pos, 1);
-        uint32_t d = dec;
-        if constexpr (sp2::inbit(FL) >= 0) d ^= ubfe(w.c, sp2::inbit(FL), 1);           // the lane's inputs were swapped: "Q side" was state k
-        w.blk = (w.blk << 1) | d;                                                         // (newest in bit 0: reversed when a word leaves)
-        // the survivor came in through input register q = dec; the exchange after the previous step (layout FP, lane bit pb) filled it
-        constexpr int FP = (FL + 4) % 5, pb = sp2::xbit(FP);
-        if constexpr (FP == 0)                           // swap16: outputs in (2k, 2k + 1) order; register = the lane's bit, the lane = this one with the bit set to q
-            w.c = (w.c & 15u) | (dec << 4) | ((w.c & 16u) << 1);
-        else                                             // kept / given: input 0 = the lane's own register 0, input 1 = its partner's register 1
-            w.c = (w.c & 31u) ^ (dec ? ((1u << pb) | 32u) : 0u);
-    };
-    auto emit = [&]() {
-        if (cnt >= 32) {
-            wi--; cnt -= 32;
-            // the 32 oldest of the bits gathered, the first one read in bit 0 (acs::back_word's order): bits [cnt, cnt + 32), reversed
-            const uint32_t wa = acs::back_word(bit_reverse32((uint32_t)(W[0].bits >> cnt))), wb = acs::back_word(bit_reverse32((uint32_t)(W[1].bits >> cnt)));
-            const uint32_t x = dedisperse ? prbs[wi] : 0u;
-            if (lane == 0) out_a[wi] = wa ^ x;
-            if (lane == 32 && second) out_a[(nbits / 32) + wi] = wb ^ x;
-        }
-    };
-    auto back_n = [&](uint32_t ca, uint32_t cb, auto hi, auto lo) {          // steps hi - 1 down to lo of a block, straight-line, the two walks side by side
-        constexpr int HI = decltype(hi)::value, LO = decltype(lo)::value;
-        auto go = [&](auto self, auto kc) -> void {
-            constexpr int k = decltype(kc)::value;
-            back(std::integral_constant<int, k % 5>{}, W[0], ca, SP2_HIST - 1 - k);
-            back(std::integral_constant<int, k % 5>{}, W[1], cb, SP2_HIST - 1 - k);
-            if constexpr (k > LO) self(self, std::integral_constant<int, k - 1>{});
-        };
-        if constexpr (HI > LO) go(go, std::integral_constant<int, HI - 1>{});
-    };
-    if (rem) {
-        const uint32_t ca = dec_g[nfull * 128 + lane], cb = dec_g[nfull * 128 + 64 + lane];
-        if (rem == 6) back_n(ca, cb, std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
-        else if (rem == 12) back_n(ca, cb, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
-        else if (rem == 18) back_n(ca, cb, std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
-        else back_n(ca, cb, std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
-        W[0].bits = (W[0].bits << rem) | W[0].blk; W[1].bits = (W[1].bits << rem) | W[1].blk; W[0].blk = W[1].blk = 0;
-        cnt += rem; emit();
-    }
-    uint32_t ca = nfull ? dec_g[(nfull - 1) * 128 + lane] : 0u, cb = nfull ? dec_g[(nfull - 1) * 128 + 64 + lane] : 0u;
-    for (int blk = nfull - 1; blk >= 1; blk--) {                            // whole blocks above the first
-        const uint32_t na = dec_g[(blk - 1) * 128 + lane], nb = dec_g[(blk - 1) * 128 + 64 + lane];   // the block below, in flight while this one is walked
-        back_n(ca, cb, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
-        W[0].bits = (W[0].bits << SP2_HIST) | W[0].blk; W[1].bits = (W[1].bits << SP2_HIST) | W[1].blk; W[0].blk = W[1].blk = 0;
-        cnt += SP2_HIST; emit();
-        ca = na; cb = nb;
-    }
-    if (nfull) {                                                            // block 0: its first six steps decide nothing that is kept
-        back_n(ca, cb, std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
-        W[0].bits = (W[0].bits << (SP2_HIST - 6)) | W[0].blk; W[1].bits = (W[1].bits << (SP2_HIST - 6)) | W[1].blk;
-        cnt += SP2_HIST - 6; emit();
-    }
+    // the traceback is a pass of its own (k_traceback_sp2, below)
 }
 
-// ---- The traceback as a pass of its own: LANE = code word.  At scale the in-kernel walk above is what bounds a state-parallel kernel --
-// it runs on the scalar unit, one per compute unit, ~10 instructions per code word and step --; here 64 walks run side by side on the
-// vector unit, one work-group per group of 64 code words (= one item of the work list = 32 work-groups of the forward launch).  Per block
-// of 30 steps the 64 history rows of the group (256 bytes each, one per code word: register 0 in words 0 .. 31, register 1 in 32 .. 63)
-// come into LDS with coalesced 16-byte loads; a lane then reads word c of ITS row per step -- c = its walk's coordinate, exactly the lane
-// the scalar walk hands to v_readlane -- and applies the same step (back() above, on vector registers).  8.5 bytes of HBM per code word
-// and step, eleven vector instructions per step for 64 code words.
+// ---- The traceback as a pass of its own: LANE = code word, WAVE = a stretch of the code word.  At scale the in-kernel walk above is what
+// bounds a state-parallel kernel -- it runs on the scalar unit, one per compute unit, ~10 instructions per code word and step --; here 64
+// walks run side by side on the vector unit, one work-group per group of 64 code words (= one item of the work list = 32 work-groups of
+// the forward launch).  Per block of 30 steps the 64 history rows of the group (256 bytes each, one per code word: register 0 in words
+// 0 .. 31, register 1 in 32 .. 63) come into LDS with coalesced 16-byte loads -- the next block's are in flight while this one is walked --;
+// a lane then reads word c of ITS row per step -- c = its walk's coordinate, exactly the lane the scalar walk hands to v_readlane -- and
+// applies the same step (back() above, on vector registers).
+// A walk is a chain of 1500+ dependent LDS reads, and a medium batch has too few code words to hide it (152 work-groups for 16 ensembles x 8
+// frames): the pass ran at the latency of ONE walk.  So the code word is cut into TB_SEG stretches of whole blocks, one per wave of the
+// work-group, walked AT THE SAME TIME (the block-parallel traceback of the north star):
+//   * the last stretch starts where the trellis ends, in state 0 (viterbi.cpp:313): exact;
+//   * every other stretch does not know the state its walk enters with -- the exit state of the stretch above.  It starts `warm` blocks
+//     higher from an arbitrary state (coordinate 0), walks them without output -- survivor paths merge within a few constraint lengths, so
+//     it almost always arrives in the right state --, then walks its own blocks and writes their output words;
+//   * then the guess is CHECKED, nothing is assumed: each wave compares the state it entered its stretch with against the exit state of
+//     the wave above (LDS); a wave with any lane that differs walks its stretch again from the true state, which can change ITS exit, so
+//     the check repeats until no wave has walked again -- at most TB_SEG - 1 rounds, because the top stretch is exact, after one round
+//     the one below it is, and so on.  The result is the serial walk's, bit for bit, whatever the data (tests force warm = 0, where every
+//     guess is wrong and the rounds cascade);
+//   * stretches are whole blocks, output words are 32 bits: the word that straddles a boundary is put together at the end from the upper
+//     stretch's last bits (LDS) and the lower one's first.
+// 8.5 bytes of HBM per code word and step (+ warm / stretch length), eleven vector instructions per step for 64 code words.
 constexpr int TB_PITCH = 65;                       // words per row in LDS: consecutive rows start on consecutive banks
-__global__ void __launch_bounds__(64) k_traceback_sp2(FusedArgs A)
+// TB_SEG = stretches per code word = waves per work-group.  4 x 16.6 KB of rows: two work-groups per compute unit, 512 on the device --
+// a launch of more groups than that (up to 640 + the classes' remainders within the state-parallel limit) takes 3: three work-groups per
+// compute unit, so that every walk of the launch is resident at once instead of a second round of work-groups waiting for the first
+template <int TB_SEG>
+__global__ void __launch_bounds__(64 * TB_SEG) DABPHY_WAVES_PER_SIMD(TB_SEG == 3 ? 3 : 2) k_traceback_sp2(FusedArgs A)
 {
-    __shared__ uint32_t rows[64 * TB_PITCH];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t s_rows[TB_SEG][64 * TB_PITCH];
+    __shared__ uint32_t s_exit[TB_SEG][64], s_part[TB_SEG][64];             // per stretch and code word: exit coordinate; the bits it holds of the word that straddles its lower boundary
+    __shared__ int s_again[TB_SEG];
+    const int lane = threadIdx.x & 63, seg = uniform_i32((int)(threadIdx.x >> 6));
     const uint32_t wk = as_constant(A.work)[blockIdx.x];
     const DABPHY_CONST_AS FusedClass& C = as_constant(A.cls)[wk >> 24];
     const int cw = (int)(wk & 0xffffffu) * 64 + lane;
     const int nsteps = C.nsteps, nbits = C.nbits;
     const bool live = cw < C.n_cw;
+    if (threadIdx.x < TB_SEG) s_again[threadIdx.x] = 0;
     // the forward launch's work-group (32 * item + lane / 2) decoded this code word; its scratch holds two rows of 64 words per block
     const uint32_t* __restrict__ const dec_w = reinterpret_cast<const uint32_t*>(A.dec) + (size_t)blockIdx.x * 32 * A.dec_slot_cells * 2;
     const size_t wg_words = A.dec_slot_cells * 2;
-    auto stage = [&](int blk) {
-        __syncthreads();                                                    // (the previous block's rows have been read)
-        for (int i = lane; i < 64 * 16; i += 64) {                          // 16 x 16 bytes per row
-            const int r = i >> 4, q = i & 15;
-            const uint4 v = *reinterpret_cast<const uint4*>(dec_w + (size_t)(r >> 1) * wg_words + (size_t)blk * 128 + (r & 1) * 64 + 4 * q);
-            uint32_t* d = &rows[r * TB_PITCH + 4 * q];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    uint32_t* const rows = s_rows[seg];
+    // block `blk` of the group's 64 rows: 16 x 16 bytes per row, 16 loads per lane
+    auto load = [&](int blk, uint4 (&nx)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = lane + 64 * k, r = i >> 4, q = i & 15;
+            nx[k] = *reinterpret_cast<const uint4*>(dec_w + (size_t)(r >> 1) * wg_words + (size_t)blk * 128 + (r & 1) * 64 + 4 * q);
         }
-        __syncthreads();
     };
-    uint32_t c = 0, blkbits = 0; unsigned long long bits = 0;              // state 0 ends in lane 0 of its half, register 0: coordinate 0
-    int cnt = 0, wi = nbits / 32;
+    auto put = [&](const uint4 (&nx)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = lane + 64 * k, r = i >> 4, q = i & 15;
+            uint32_t* d = &rows[r * TB_PITCH + 4 * q];
+            d[0] = nx[k].x; d[1] = nx[k].y; d[2] = nx[k].z; d[3] = nx[k].w;
+        }
+    };
+    // ---- the stretches: whole blocks [lo_b, hi_b); the partial block at the end of the code word (index nfull, `rem` steps) rides with the
+    // last one, which has no warm-up: it gets `warm` blocks more than the others
+    const int nfull = nsteps / SP2_HIST, rem = nsteps - nfull * SP2_HIST;
+    const int warm = A.sp2_warm;
+    const int spread = nfull - warm;                                        // blocks shared out evenly
+    const int n_seg = spread >= 2 * 6 ? (spread / 6 < TB_SEG ? spread / 6 : TB_SEG) : 1;       // (six blocks or more per stretch: a word has at most one boundary in it)
+    const bool active = seg < n_seg, last = seg == n_seg - 1;
+    const int lo_b = active ? spread * seg / n_seg : 0, hi_b = last ? nfull : spread * (seg + 1) / n_seg;
+    const int own_top = last ? (rem ? nfull : nfull - 1) : hi_b - 1;       // the first block of the stretch that is walked
+    const int hi_bit = last ? nbits : SP2_HIST * hi_b - 6;                  // step t decides data bit t - 6: the stretch's bits are [.., hi_bit)
+    const int hpart = hi_bit & 31;                                          // of them in the word that straddles the upper boundary
+
+    uint32_t c = 0, blkbits = 0, used = 0, headw = 0; unsigned long long bits = 0;
+    int cnt = 0, wi = 0; bool head_pending = false;
     uint32_t* __restrict__ const out = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw * (nbits / 32);
     const uint32_t* __restrict__ prbs = A.prbs_words;
     const int dedisperse = C.dedisperse;
     const uint32_t* const my = &rows[lane * TB_PITCH];
+    // bytes packed MSB first (decoder_adapter.cpp:61-67), energy dispersal (a permutation of bit positions, then an XOR: partial words may be OR-ed before it)
+    auto finish_word = [&](uint32_t w, int idx) { const uint32_t v = acs::back_word(bit_reverse32(w)); return dedisperse ? v ^ prbs[idx] : v; };
     auto back = [&](auto fc, int pos) {
         constexpr int FL = decltype(fc)::value;
         const uint32_t dec = (my[c] >> pos) & 1u;
@@ -314,33 +291,71 @@ __global__ void __launch_bounds__(64) k_traceback_sp2(FusedArgs A)
         };
         if constexpr (HI > LO) go(go, std::integral_constant<int, HI - 1>{});
     };
-    auto gathered = [&](int n) {                                            // n more bits: whenever 32 have gathered the oldest 32 leave as one output word
+    // n more bits: whenever 32 have gathered the oldest 32 leave as one output word.  A stretch that does not start on a word boundary
+    // starts as if the bits above it in that word (the upper stretch's) had been gathered as zeros; the first word to leave is then the
+    // straddling one: held back (headw) until the upper stretch's share is known
+    auto gathered = [&](int n) {
         bits = (bits << n) | blkbits; blkbits = 0; cnt += n;
         if (cnt >= 32) {
             wi--; cnt -= 32;
-            const uint32_t w = acs::back_word(bit_reverse32((uint32_t)(bits >> cnt)));
-            if (live) out[wi] = dedisperse ? w ^ prbs[wi] : w;
+            const uint32_t w = (uint32_t)(bits >> cnt);
+            if (head_pending) { headw = w; head_pending = false; }
+            else if (live) out[wi] = finish_word(w, wi);
         }
     };
-    const int nfull = nsteps / SP2_HIST, rem = nsteps - nfull * SP2_HIST;
-    if (rem) {
-        stage(nfull);
-        if (rem == 6) back_n(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
-        else if (rem == 12) back_n(std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
-        else if (rem == 18) back_n(std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
-        else back_n(std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
-        gathered(rem);
+    // blocks top .. lo_b from coordinate c0; blocks above own_top are warm-up: walked, nothing kept but the coordinate
+    auto run = [&](int top, uint32_t c0) {
+        c = c0; blkbits = 0; bits = 0;
+        cnt = hpart ? 32 - hpart : 0; wi = (hi_bit + 31) >> 5; head_pending = hpart != 0; headw = 0;
+        uint4 nx[16];
+        lds_reads_done(); wave_converge();                                  // (whatever this wave read of its rows before)
+        load(top, nx); put(nx);
+        for (int blk = top; blk >= lo_b; blk--) {
+            lds_reads_done(); wave_converge();                              // the rows are in LDS for every lane of the wave
+            if (blk > lo_b) load(blk - 1, nx);                              // the block below, in flight while this one is walked
+            if (blk == own_top) used = c;
+            int n;
+            if (blk == nfull) {                                             // the partial block (a multiple of six steps)
+                if (rem == 6) back_n(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+                else if (rem == 12) back_n(std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
+                else if (rem == 18) back_n(std::integral_constant<int, 18>{}, std::integral_constant<int, 0>{});
+                else back_n(std::integral_constant<int, 24>{}, std::integral_constant<int, 0>{});
+                n = rem;
+            } else if (blk == 0) {                                          // block 0: its first six steps decide nothing that is kept
+                back_n(std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
+                n = SP2_HIST - 6;
+            } else {
+                back_n(std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
+                n = SP2_HIST;
+            }
+            if (blk <= own_top) gathered(n); else blkbits = 0;
+            if (blk > lo_b) { lds_reads_done(); wave_converge(); put(nx); }
+        }
+        s_exit[seg][lane] = c;
+        s_part[seg][lane] = cnt ? (uint32_t)bits << (32 - cnt) : 0u;        // what is left: the top bits of the word that straddles the lower boundary
+    };
+    if (active) {
+        int top = own_top;
+        if (!last) { top = hi_b + warm - 1; if (top > nfull - 1) top = nfull - 1; }
+        run(top, 0u);                                                       // state 0 ends in lane 0 of its half, register 0: coordinate 0
     }
-    for (int blk = nfull - 1; blk >= 1; blk--) {
-        stage(blk);
-        back_n(std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 0>{});
-        gathered(SP2_HIST);
+    __syncthreads();
+    for (int round = 1; round < n_seg; round++) {
+        uint32_t truth = 0; bool redo = false;
+        if (active && !last) {
+            truth = s_exit[seg + 1][lane];
+            redo = __ballot(live && truth != used) != 0;
+        }
+        __syncthreads();                                                    // (every wave has read the exit it checks against before any is written again)
+        if (redo) {
+            run(own_top, truth);                                            // lanes that had guessed right walk the same way again
+            if (lane == 0) s_again[round] = 1;
+        }
+        __syncthreads();
+        if (!s_again[round]) break;
     }
-    if (nfull) {                                                            // block 0: its first six steps decide nothing that is kept
-        stage(0);
-        back_n(std::integral_constant<int, SP2_HIST>{}, std::integral_constant<int, 6>{});
-        gathered(SP2_HIST - 6);
-    }
+    // the words that straddle the boundaries
+    if (active && !last && hpart && live) { const int idx = hi_bit >> 5; out[idx] = finish_word(headw | s_part[seg + 1][lane], idx); }
 }
 
 // swap16 / swap32 / partner against plain shuffles, all five lane bits (device self-test of the instruction forms the execution model of
@@ -384,7 +399,8 @@ void launch_viterbi_sp2(const FusedArgs& a, int lds_variant, hipStream_t s)
     // LDS: four 16-bit sums per trellis step, for two code words, 480 steps at a time: 7.7 KiB, 20 work-groups per compute unit
     (void)lds_variant;
     hipLaunchKernelGGL((k_viterbi_sp2<480, 4>), grid, dim3(64), 0, s, a);
-    if (a.sp2_split) hipLaunchKernelGGL(k_traceback_sp2, dim3(a.n_work), dim3(64), 0, s, a);
+    if ((int)a.n_work <= a.sp2_resident) hipLaunchKernelGGL(k_traceback_sp2<4>, dim3(a.n_work), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_traceback_sp2<3>, dim3(a.n_work), dim3(192), 0, s, a);
 }
 
 } // namespace dabphy
