@@ -617,6 +617,48 @@ def check_dropout_relock(d_factory, F=1):
         assert np.array_equal(g[4], ofib[k, :, 0]) and np.array_equal(g[5], ofib[k, :, 1:])
 
 
+def check_lock_lost_inside_a_replayed_batch(d_factory, F=8, pipeline_sync=0):
+    """exact batch mode decodes a batch a second time, frame by frame, when a coarse-corrector decision was taken with a stale FIC ratio --
+    and inside THAT batch the window search fails and the receiver re-acquires: the sLevel the null-symbol search starts with is replayed
+    from the synchroniser's history ring (what every window search since the last acquisition pulled), which the first pass has already
+    restarted over those entries -- the ring has to go back with the state.  Found by tools/sweep_independent.py (seed 2026, trial 33,
+    ensemble 1: a random multiplex at 13 dB with -212.6 Hz offset, where the reference's coarse corrector runs wild from the ninth frame
+    on; before the ring was put back the re-acquisition ended one sample early and the rest of the batch differed).  Every frame's
+    position, window index, correctors and FIBs against the oracle."""
+    u = [None, None, None, (4, 35, [(3, 24), (5, 17), (13, 12), (3, 17)]), None, (3, 29, [(3, 22), (4, 13), (14, 8), (3, 13)]), (28, 104, [(6, 24), (13, 18), (50, 13), (3, 19)]), None, None]
+    spec = [(112, False, 3), (64, True, 3), (128, True, 1), (32, False, 1), (96, False, 2), (32, False, 2), (96, False, 1), (48, False, 3), (40, False, 3)]
+    layout = []; cu = 0
+    for i, (br, pb, lvl) in enumerate(spec):
+        layout.append(synth.SubchannelCfg(i + 1, cu, br, pb, lvl, dabplus=False, uep=u[i])); cu += layout[-1].size_cu
+    nf = 34
+    x = synth.make_stream(nf, eid=0x5211, subchs=layout, snr_db=13.0, cfo_hz=-212.59620557244568, delay=71, seed=905702647)
+    o = R.orc_receiver_run(x, subchs=[])
+    assert o["n_sync_false"] >= 3 and o["n_frames"] >= 30, (o["n_sync_false"], o["n_frames"])
+    d = d_factory(n_ensembles=1, max_frames=F, want_constellation=False, want_impulse_response=False, pipeline_sync=pipeline_sync)
+    try:
+        d.stream_upload(x[None, :])
+        got = []; failed_in = []
+        for step in range((nf - 2) // F):
+            d.process(F)
+            info = d.frame_info(); fb, ok = d.fibs()
+            failed_in.append(bool((info["valid"] == 3).any()))
+            for f in range(F):
+                if info[0, f]["valid"] == 1:
+                    got.append((int(info[0, f]["pos"]), int(info[0, f]["start_index"]), int(info[0, f]["fine"]), int(info[0, f]["coarse"]), ok[0, f].copy(), fb[0, f].copy()))
+        assert d.replayed_batches() >= 1 and any(failed_in), (d.replayed_batches(), failed_in)     # (the batch of frames 24 .. 31 is the one that is both)
+        lost, ex = d.sync_stats()
+        assert lost[0] >= 2 and d.relock_inexact[0] == 0
+    finally:
+        d.close()
+    ofib = o["fib"].reshape(-1, 12, 33)
+    assert len(got) >= 28
+    for k in range(min(len(got), o["n_frames"])):
+        g = got[k]
+        assert (g[0], g[1]) == (int(o["frame_pos"][k]), int(o["start_index"][k])), "frame %d found at %s, the reference finds it at %s" % (k, g[:2], (o["frame_pos"][k], o["start_index"][k]))
+        assert (g[2], g[3]) == tuple(int(v) for v in o["corr"][k])
+        assert np.array_equal(g[4], ofib[k, :, 0]) and np.array_equal(g[5], ofib[k, :, 1:])
+
+
 def check_error_behaviour(d_factory):
     """signal problems never raise (they surface as valid = 0 / CRC false, like the reference's callbacks); programming errors
     come back as negative status codes with a message, never as a crash (the reference throws std::logic_error / out_of_range)"""

@@ -157,6 +157,10 @@ def test_relock_after_long_lock(emu):
     P.check_relock_after_long_lock(factory)
 
 
+def test_lock_lost_inside_a_replayed_batch(emu):
+    P.check_lock_lost_inside_a_replayed_batch(factory)
+
+
 def test_fine_corrector_on_the_edge(emu):
     P.check_fine_corrector_on_the_edge(factory)
 

@@ -205,6 +205,15 @@ def test_relock_after_long_lock(gpu):
     P.check_relock_after_long_lock(factory)
 
 
+def test_lock_lost_inside_a_replayed_batch(gpu):
+    P.check_lock_lost_inside_a_replayed_batch(factory)
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_lock_lost_inside_a_replayed_batch_pipelined(gpu, mode):
+    P.check_lock_lost_inside_a_replayed_batch(factory, pipeline_sync=mode)
+
+
 def test_fine_corrector_on_the_edge(gpu):
     P.check_fine_corrector_on_the_edge(factory)
 

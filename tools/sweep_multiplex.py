@@ -2,7 +2,7 @@
 stream draws its own sub-channel layout (3 ... 14 sub-channels; EEP profile A at 8 ... 192 kbit/s and B at 32 ... 192 kbit/s, levels 1-4;
 UEP rows of the table; code words of 192 ... 4608 bits in as many protection classes as come up), batch depth (1 ... 20 frames per call: all
 three builds of the fused kernel's window ring), number of ensembles (2 ... 6) and Viterbi kernel (dabphy_config.decode_shape 0 = the default's
-choice, 1 = lane per code word), and compares FIBs, CRC flags and the MSC bytes of EVERY sub-channel of every ensemble with the oracle
+choice, 1 = lane per code word, 2 = k_viterbi_sp2 + k_traceback_sp2, 3 = k_viterbi_sp), and compares FIBs, CRC flags and the MSC bytes of EVERY sub-channel of every ensemble with the oracle
 (tests/parity_cases.check_mixed_ensemble): no tolerance.
 python tools/sweep_multiplex.py [n_streams] [seed]"""
 import ctypes as C
@@ -51,7 +51,7 @@ def random_layout():
 tot_frames = 0
 for it in range(n):
     subchs = random_layout()
-    F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 20])); B = int(rng.choice([2, 3, 6])); shape = int(rng.choice([0, 1]))
+    F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 20])); B = int(rng.choice([2, 3, 6])); shape = int(rng.choice([0, 1, 2, 3]))
     nf = max(7, 2 * F + 6); snr = float(rng.choice([9, 12, 16, 22])); seed = int(rng.randint(1 << 30))
     P.check_mixed_ensemble(lambda **kw: capi.DabPhy(lib_path=lib_path, decode_shape=shape, **kw), F=F, nf=nf, snr_db=snr, seed=seed, B=B, subchs=subchs, expect_fused=True)
     classes = len({(s.bitrate, s.profile_b, s.level, s.uep is not None) for s in subchs})

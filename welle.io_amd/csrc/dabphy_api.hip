@@ -199,6 +199,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->h_sf_stats) e = hipHostFree(h->h_sf_stats);
     if (h->h_any_eff) e = hipHostFree(h->h_any_eff);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (h->snap_state[i].p) e = hipFree(h->snap_state[i].p);
+    for (int i = 0; i < dabphy_handle::N_DESC; i++) if (h->snap_hist[i].p) e = hipFree(h->snap_hist[i].p);
     if (h->snap_dec.p) e = hipFree(h->snap_dec.p);
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);

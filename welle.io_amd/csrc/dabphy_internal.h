@@ -147,7 +147,7 @@ struct dabphy_handle {
     // exact batch mode (cfg.no_batch_replay == 0): state as it was in front of a batch, to replay the batch frame by frame when one of its
     // coarse-corrector decisions was taken with a stale FIC ratio and can have mattered (k_fic_ratio's verdict)
     bool exact_batch = false;
-    DevBuf snap_state[N_DESC], snap_dec, snap_tii;
+    DevBuf snap_state[N_DESC], snap_hist[N_DESC], snap_dec, snap_tii;     // (snap_hist: the synchroniser's history ring goes with its state -- an acquisition inside the first pass restarts the ring over the entries the second pass must replay)
     int32_t* d_any_eff = nullptr; int32_t* h_any_eff = nullptr;
     uint64_t n_replayed_batches = 0;
     int desc_sel = 0;                 // which of s_desc2/s_cir2 holds the batch that dabphy_process decodes next

@@ -26,6 +26,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
         if ((r = ensure(h, h->s_redo[k], (size_t)B * sizeof(int32_t)))) return r;
         if (h->exact_batch && (r = ensure(h, h->snap_state[k], (size_t)B * sizeof(RxState)))) return r;
+        if (h->exact_batch && (r = ensure(h, h->snap_hist[k], (size_t)B * HIST_CAP * sizeof(FrameDesc)))) return r;
         if (h->cfg.want_impulse_response && (r = ensure(h, h->s_cir2[k], (size_t)B * h->cfg.max_frames * T_U * sizeof(float)))) return r;
     }
     const size_t ens_stride = soft_ens_stride(h);
@@ -321,6 +322,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipStreamSynchronize(h->fic_stream));
         for (int i = 0; i < ND; i++) h->wide_pending[i] = false;
         HIPCHK(h, hipMemcpyAsync(h->d_state, h->snap_state[cur].p, sizeof(RxState) * B, hipMemcpyDeviceToDevice, h->stream));
+        if (h->snap_hist[cur].p && h->s_hist.p) HIPCHK(h, hipMemcpyAsync(h->s_hist.p, h->snap_hist[cur].p, (size_t)B * HIST_CAP * sizeof(FrameDesc), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_dec, h->snap_dec.p, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
         if (h->tii_state.p && h->snap_tii.p) HIPCHK(h, hipMemcpyAsync(h->tii_state.p, h->snap_tii.p, h->tii_state.cap, hipMemcpyDeviceToDevice, h->stream));
         for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_state.p, cls.sf_snap.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));

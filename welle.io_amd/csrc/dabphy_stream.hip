@@ -42,7 +42,13 @@ int queue_chain(dabphy_handle* h, int sel, uint32_t F)
     SyncArgs sa = sync_args(h, sel, F, h->s_valid);
     h->chain_valid[sel] = h->s_valid; h->chain_frames[sel] = F;
     if (h->exact_batch && F > 1 && h->snap_state[sel].p)              // (one frame per call is exact by construction: nothing to put back)
+    {
         HIPCHK(h, hipMemcpyAsync(h->snap_state[sel].p, h->d_state, sizeof(RxState) * h->cfg.n_ensembles, hipMemcpyDeviceToDevice, h->sync_stream));
+        // ... and the history ring its hist_head / hist_count index: an acquisition inside the batch restarts the ring at entry 0, over the
+        // window searches the second pass has to replay through the sLevel recurrence when it loses lock at the same frame
+        if (h->snap_hist[sel].p && h->s_hist.p)
+            HIPCHK(h, hipMemcpyAsync(h->snap_hist[sel].p, h->s_hist.p, (size_t)h->cfg.n_ensembles * HIST_CAP * sizeof(FrameDesc), hipMemcpyDeviceToDevice, h->sync_stream));
+    }
     { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
     // one frame per call (the real-time facade) gains nothing from the wide pass; two batches ahead its verdict would come too late
     if (h->wide_sync && F >= 2 && h->cfg.pipeline_sync != 3 && !h->track_slevel) {
