@@ -201,11 +201,18 @@ try:
                 lines.append("* facade: %.3f ms per 96 ms frame; level 2 builds (ms per frame): %s" % (fc["ms_per_frame"], ", ".join("%s %.2f" % (k, v["ms_per_frame"]) for k, v in fc.get("level2", {}).items() if "ms_per_frame" in v)))
         except Exception as ex_:
             lines.append("(bench line not summarised: %s)" % ex_)
-    # the -m gpu suite of the same device session (GPUTEST_LOG = its pytest output), e.g. gpurun_out/r5g/gputest.log
+    # the -m gpu suite of the same device session (GPUTEST_LOG = its pytest output), e.g. gpurun_out/r5g/gputest.log; GPUTEST_NOTE = what to
+    # say about it when the log is not a full suite run of this very session
     gl = os.environ.get("GPUTEST_LOG")
     if gl and os.path.exists(gl):
         res = [l.strip() for l in open(gl).read().splitlines() if " passed" in l or " failed" in l or l.startswith("pytest rc")]
-        lines += ["", "## The `-m gpu` suite of the same session (`%s`)" % gl, "", "* " + "; ".join(res[-2:])]
+        note = os.environ.get("GPUTEST_NOTE")
+        lines += ["", "## The `-m gpu` %s (`%s`)" % ("suite of the same session" if not note else "tests: " + note, gl), "", "* " + "; ".join(res[-2:])]
+    for k in range(2, 4):                               # further logs (GPUTEST_LOG2 / GPUTEST_NOTE2, ...)
+        gl = os.environ.get("GPUTEST_LOG%d" % k)
+        if gl and os.path.exists(gl):
+            res = [l.strip() for l in open(gl).read().splitlines() if " passed" in l or " failed" in l or l.startswith("pytest rc")]
+            lines += ["", "## The `-m gpu` tests: %s (`%s`)" % (os.environ.get("GPUTEST_NOTE%d" % k, ""), gl), "", "* " + "; ".join(res[-2:])]
     open(os.path.join(DST, TAG + "_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 except Exception as ex_:
