@@ -3,12 +3,15 @@ schedule, every stream through tests/parity_cases.check_stream_vs_oracle -- FIBs
 symbols, SNR reports and the MSC bytes of three sub-channels against the oracle, frame by frame; batch mode's documented deviation
 (a coarse-corrector decision taken with a stale FIC ratio) is tolerated only from the frame the library itself reports -- and reports
 how many frames came from the wide synchroniser pass and how many OFDM symbols took the unchecked / checked oscillator conversion.
-python tools/sweep_batch.py [n_streams] [seed] [exact | channels]
+python tools/sweep_batch.py [n_streams] [seed] [exact | channels | wild]
 With `exact` the library's default is swept instead -- exact batch mode, replay armed -- at 2-8 dB, and NO tolerance is given: every frame
 must equal the oracle's; the replayed batches are counted.
 With `channels` (exact batch mode too, 6-20 dB) every stream also passes a random channel: one to three echoes with complex gains and delays
 from -250 to 700 samples (pre-echoes, echoes beyond the guard interval), a sampling-clock offset of up to +-120 ppm, flat fading of
-10-40 % at 2-12 Hz -- each with probability 1/2 --, and a random FFT placement method: the signals that break the wide pass' prediction."""
+10-40 % at 2-12 Hz -- each with probability 1/2 --, and a random FFT placement method: the signals that break the wide pass' prediction.
+With `wild` (exact batch mode, all four schedules) 10-13 dB at 150-300 Hz offset in batches of 8-16 frames: the fine corrector needs ten frames
+to get there, the reference's coarse corrector meanwhile takes false alarms and throws the receiver out of lock -- batches that are decoded
+twice AND lose lock inside (where round 5's sweep of independent ensembles found the history ring not put back: DESIGN.md section 7)."""
 import os
 import sys
 
@@ -25,7 +28,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = os.environ.get("DABPHY_LIB", GPU_LIB)
 chan = len(sys.argv) > 3 and sys.argv[3] == "channels"
-exact = (len(sys.argv) > 3 and sys.argv[3] == "exact") or chan
+wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
+exact = (len(sys.argv) > 3 and sys.argv[3] == "exact") or chan or wild
 
 
 SHAPE = int(os.environ.get("SWEEP_DECODE_SHAPE", "0"))      # dabphy_config.decode_shape: 0 = the default (these small batches: state-parallel kernel), 1 = lane per code word (the fused kernel's 144- / 324-row builds at 2 ... 8 frames per call)
@@ -44,6 +48,9 @@ for it in range(n):
     if exact and rng.rand() < 0.5:
         cfo = float(rng.choice([-2400, -1000, 300, 1500, 2300, 17400]))
     channel = None; placement = 2; desc = ""
+    if wild:
+        snr = float(rng.choice([10, 13])); cfo = float(rng.uniform(150, 300)) * (1 if rng.rand() < 0.5 else -1)
+        F = int(rng.choice([8, 12, 16])); pipe = int(rng.choice([0, 1, 2, 3])); nf = int(rng.choice([34, 42, 50]))
     if chan:
         snr = float(rng.choice([6, 8, 10, 14, 20]))
         channel = {}
