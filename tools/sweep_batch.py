@@ -22,7 +22,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conftest  # noqa: F401,E402
 from conftest import GPU_LIB  # noqa: E402
 import parity_cases as P  # noqa: E402
-from welle_io_amd import capi  # noqa: E402
+from welle_io_amd import capi, synth  # noqa: E402
+import refapi as R  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -39,7 +40,7 @@ def factory(**kw):
     return capi.DabPhy(lib_path=lib, decode_shape=SHAPE, **kw)
 
 
-frames = wide = fast = checked = lagged = effective = replayed = 0
+frames = wide = fast = checked = lagged = effective = replayed = skipped = 0
 for it in range(n):
     snr = float(rng.choice([2, 3, 4, 5, 6, 8])) if exact else float(rng.choice([10, 13, 16, 20, 25, 30]))
     cfo = float(rng.uniform(-60, 60)) if rng.rand() < 0.5 else float(rng.uniform(-450, 450))
@@ -49,8 +50,13 @@ for it in range(n):
         cfo = float(rng.choice([-2400, -1000, 300, 1500, 2300, 17400]))
     channel = None; placement = 2; desc = ""
     if wild:
-        snr = float(rng.choice([10, 13])); cfo = float(rng.uniform(150, 300)) * (1 if rng.rand() < 0.5 else -1)
-        F = int(rng.choice([8, 12, 16])); pipe = int(rng.choice([0, 1, 2, 3])); nf = int(rng.choice([34, 42, 50]))
+        # drawn again until the REFERENCE loses lock in mid-stream (the oracle alone is cheap): only those streams reach the case
+        while True:
+            snr = float(rng.choice([10, 13])); cfo = float(rng.uniform(150, 300)) * (1 if rng.rand() < 0.5 else -1)
+            F = int(rng.choice([8, 12, 16])); pipe = int(rng.choice([0, 1, 2, 3])); nf = int(rng.choice([34, 42, 50])); seed = int(rng.randint(1 << 30))
+            if R.orc_receiver_run(synth.make_stream(nf, snr_db=snr, cfo_hz=cfo, delay=delay, seed=seed))["n_sync_false"] >= 2:
+                break
+            skipped += 1
     if chan:
         snr = float(rng.choice([6, 8, 10, 14, 20]))
         channel = {}
@@ -69,5 +75,7 @@ for it in range(n):
     k = len(L["info"]); frames += k; wide += L["wide"][0]; fast += L["osc"][0]; checked += L["osc"][1]; lagged += int(L["ratio_lag"][0] > 0); effective += int(L["ratio_lag_effect"][0] > 0)
     print("stream %3d  snr %4.0f dB  cfo %7.1f Hz  delay %4d  F %d  schedule %d  frames %2d  from the wide pass %2d  oscillator symbols unchecked/checked %d/%d  ratio lag %s with an effect %s"
           % (it, snr, cfo, delay, F, pipe, k, L["wide"][0], L["osc"][0], L["osc"][1], L["ratio_lag"], L["ratio_lag_effect"]) + desc, flush=True)
+if wild:
+    print("(%d streams drawn in which the reference holds its lock: not run)" % skipped)
 print("decode_shape %d  streams %d  frames %d (x 2 ensembles)  accepted from the wide pass %d  oscillator symbols unchecked %d / checked %d  streams with a reported stale-ratio decision %d (with an effect: %d)  batches decoded twice %d  mismatches 0"
       % (SHAPE, n, frames, wide, fast, checked, lagged, effective, replayed))
