@@ -6,7 +6,7 @@ list.  For every session: the logical frames it delivered are consecutive CIFs s
 and equal the oracle's frames of those CIFs; the superframe events and corrected superframes the library reported for it
 (dabphy_superframes_ensemble, batch by batch, through every re-indexing the other services' changes cause) equal those of ONE
 SuperframeFilter fed with exactly these frames (dabplus_decoder.cpp:50-213).  5.5 ... 9 dB: at the low end byte errors reach Reed-Solomon.
-python tools/sweep_services.py [n_trials] [seed]"""
+python tools/sweep_services.py [n_trials] [seed] [first trial]"""
 import os
 import sys
 
@@ -22,19 +22,31 @@ from welle_io_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+first_trial = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # earlier trials only draw their random numbers (to repeat one trial of a sweep)
 lib_path = os.environ.get("DABPHY_LIB", GPU_LIB)
 tot_sessions = tot_rows = tot_events = tot_changes = tot_corrected = 0
 for it in range(n):
     B = int(rng.randint(2, 5)); F = int(rng.choice([1, 2, 3, 4, 6])); shape = int(rng.randint(0, 4)); pipe = int(rng.choice([0, 0, 1, 3]))
+    if F == 1:
+        pipe = 0            # (one frame per call on a pipelined schedule keeps round 1's reported deviation: exact batch mode's second pass is for batches)
     n_steps = max(5, int(np.ceil(36 / F))); nf = F * n_steps + 3
     snr = float(rng.choice([5.5, 6.0, 7.0, 9.0]))
+    par = [dict(cfo_hz=float(rng.uniform(-80, 80)), delay=int(rng.randint(0, 900)), seed=int(rng.randint(1 << 30)), pseed=int(rng.randint(1000))) for e in range(B)]
+    pool = [sorted(rng.choice(18, int(rng.randint(2, 6)), replace=False).tolist()) for e in range(B)]      # the services an ensemble's listener ever asks for
+    if it < first_trial:
+        for e in range(B):
+            rng.choice(pool[e], int(rng.randint(0, len(pool[e]) + 1)), replace=False)
+        for step in range(1, n_steps):
+            for e in range(B):
+                if rng.rand() < 0.4:
+                    rng.choice(pool[e], int(rng.randint(0, len(pool[e]) + 1)), replace=False)
+        continue
     xs, txs = [], []
     for e in range(B):
-        x, tx = synth.make_stream(nf, eid=0x6000 + 16 * it + e, snr_db=snr, cfo_hz=float(rng.uniform(-80, 80)), delay=int(rng.randint(0, 900)), return_tx=True,
-                                  seed=int(rng.randint(1 << 30)), payload_fn=synth.dabplus_payload_fn(80, int(rng.randint(1000))), noise_seed=78)
+        x, tx = synth.make_stream(nf, eid=0x6000 + 16 * it + e, snr_db=snr, cfo_hz=par[e]["cfo_hz"], delay=par[e]["delay"], return_tx=True,
+                                  seed=par[e]["seed"], payload_fn=synth.dabplus_payload_fn(80, par[e]["pseed"]), noise_seed=78)
         xs.append(x); txs.append(tx)
     nmin = min(len(x) for x in xs); xs = [x[:nmin] for x in xs]
-    pool = [sorted(rng.choice(18, int(rng.randint(2, 6)), replace=False).tolist()) for e in range(B)]      # the services an ensemble's listener ever asks for
     orc = [R.orc_receiver_run(xs[e], subchs=[txs[e].subchs[i] for i in pool[e]]) for e in range(B)]
     want = [{i: np.frombuffer(bytes(orc[e]["msc"][k]), np.uint8).reshape(-1, txs[e].subchs[i].frame_bytes) for k, i in enumerate(pool[e])} for e in range(B)]
 
