@@ -261,6 +261,17 @@ def test_exact_batch_mode(gpu, snr, cfo, F, seed, pipeline, replay):
     P.check_exact_batch(factory, snr, cfo, F, seed, pipeline_sync=pipeline, expect_replay=replay)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_one_frame_per_call_on_a_pipelined_schedule(gpu, mode):
+    """one frame per call with the synchroniser one or two frames ahead (pipeline_sync 1-3): the second pass of exact batch mode is armed
+    for it too (ofdm-processor.cpp:397-409: the coarse corrector consults the FIC ratio of the PREVIOUS frame); equal to the oracle frame
+    for frame, on the stream whose coarse corrector acts on a stale ratio from frame 6 on, and on a second one at another offset"""
+    logs = P.check_exact_batch(factory, 3, -1000, 1, 5, pipeline_sync=mode, nf=21)
+    if mode == 3:
+        assert logs[0]["replayed"] >= 1, logs[0]["replayed"]
+    P.check_exact_batch(factory, 4, 17400, 1, 13, pipeline_sync=mode, nf=17)
+
+
 @pytest.mark.parametrize("chunk", [1, 2])
 def test_exact_batch_mode_with_short_demod_chunks(gpu, chunk):
     """the replay demodulates only the chunks that hold the FIC symbols 1 .. 3 of a frame: with one or two symbols per work-group that

@@ -27,8 +27,6 @@ lib_path = os.environ.get("DABPHY_LIB", GPU_LIB)
 tot_sessions = tot_rows = tot_events = tot_changes = tot_corrected = 0
 for it in range(n):
     B = int(rng.randint(2, 5)); F = int(rng.choice([1, 2, 3, 4, 6])); shape = int(rng.randint(0, 4)); pipe = int(rng.choice([0, 0, 1, 3]))
-    if F == 1:
-        pipe = 0            # (one frame per call on a pipelined schedule keeps round 1's reported deviation: exact batch mode's second pass is for batches)
     n_steps = max(5, int(np.ceil(36 / F))); nf = F * n_steps + 3
     snr = float(rng.choice([5.5, 6.0, 7.0, 9.0]))
     par = [dict(cfo_hz=float(rng.uniform(-80, 80)), delay=int(rng.randint(0, 900)), seed=int(rng.randint(1 << 30)), pseed=int(rng.randint(1000))) for e in range(B)]

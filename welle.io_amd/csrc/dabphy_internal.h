@@ -214,6 +214,11 @@ template <typename T> int upload_const(dabphy_handle* h, T** dst, const std::vec
     return 0;
 }
 
+// Exact batch mode's second pass is armed whenever a coarse-corrector decision can have seen a FIC ratio older than the reference's
+// (ofdm-processor.cpp:397-409: the ratio of the PREVIOUS frame): batches of several frames, and ONE frame per call too when the
+// synchroniser runs ahead of the decoder (pipeline_sync 1-3).  One frame per call on the serial schedule is exact by construction.
+inline bool replay_armed(const dabphy_handle* h, uint32_t F) { return h->exact_batch && (F > 1 || h->cfg.pipeline_sync != 0); }
+
 inline int sync(dabphy_handle* h)
 {
     HIPCHK(h, hipStreamSynchronize(h->stream));

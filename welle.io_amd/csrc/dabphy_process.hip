@@ -62,7 +62,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         }
         if (h->sf_auto && (r = prepare_superframes(h, F))) return r;
         // (the replay of exact batch mode decodes one frame's FIC at a time, state-parallel when 4 B code words are few: its buffers now)
-        if (h->exact_batch && F > 1 && sp_single_ok(h, (uint64_t)B * 4, fic_c.nsteps) && (r = sp_single_reserve(h, (uint64_t)B * 4, fic_c.nsteps))) return r;
+        if (replay_armed(h, F) && sp_single_ok(h, (uint64_t)B * 4, fic_c.nsteps) && (r = sp_single_reserve(h, (uint64_t)B * 4, fic_c.nsteps))) return r;
         // the fused decode of this batch depth: which classes (and whether the FIC) ride in the one launch; its decision scratch
         if ((r = fused_plan(h, F, true))) return r;
         {   // what is left for the two-kernel path: Viterbi scratch of the largest such class; the FIC's own (the replay of exact batch
@@ -292,7 +292,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     return DABPHY_OK;
     };
-    if (h->exact_batch && F > 1) {
+    if (replay_armed(h, F)) {
         // what the decoders carry from batch to batch, as it is in front of this one (the synchroniser's share was saved when this
         // batch's chain was queued: queue_chain)
         HIPCHK(h, hipMemcpyAsync(h->snap_dec.p, h->d_dec, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
@@ -312,7 +312,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     tick(3);
     if ((r = sync(h))) return r;
     tick(4);
-    if (h->exact_batch && F > 1 && *h->h_any_eff) {
+    if (replay_armed(h, F) && *h->h_any_eff) {
         // Exact batch mode: a coarse-corrector decision of this batch was taken with a stale FIC ratio and can have mattered.  Everything
         // the batch changed is put back -- synchroniser state (as saved when its chain was queued), decoder state, superframe windows,
         // TII sums; the soft-bit ring and the outputs are simply written again -- and the batch is decoded a second time with the

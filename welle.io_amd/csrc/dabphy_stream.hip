@@ -41,7 +41,7 @@ int queue_chain(dabphy_handle* h, int sel, uint32_t F)
 {
     SyncArgs sa = sync_args(h, sel, F, h->s_valid);
     h->chain_valid[sel] = h->s_valid; h->chain_frames[sel] = F;
-    if (h->exact_batch && F > 1 && h->snap_state[sel].p)              // (one frame per call is exact by construction: nothing to put back)
+    if (replay_armed(h, F) && h->snap_state[sel].p)              // (one frame per call on the serial schedule is exact by construction: nothing to put back)
     {
         HIPCHK(h, hipMemcpyAsync(h->snap_state[sel].p, h->d_state, sizeof(RxState) * h->cfg.n_ensembles, hipMemcpyDeviceToDevice, h->sync_stream));
         // ... and the history ring its hist_head / hist_count index: an acquisition inside the batch restarts the ring at entry 0, over the
