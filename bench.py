@@ -297,6 +297,83 @@ def mixed_layouts_leg(capi, workload, torch, lib_path, B, F, steps, local, sched
     return out
 
 
+def channel_leg(capi, workload, torch, lib_path, B, F, steps, local, sched, kind, device="cuda"):
+    """The headline's batch geometry on signals as a receiver MEETS them; timed after the headline, never `value`.
+      kind "drift":   every ensemble has its own sampling-clock offset, +-1 ... +-50 ppm (log-uniform), sigma 0.02, a NON-looping stream:
+                      the PRS window index moves from frame to frame (ofdm-processor.cpp:337-350,432-463; phasereference.cpp:73-256),
+                      so the wide synchroniser pass's prediction (window index T_g, correctors unmoved) fails and the frame-by-frame
+                      chain takes over;
+      kind "low_snr": every ensemble has its own SNR, 6 ... 10 dB (looping recordings as in the headline): Reed-Solomon corrects and
+                      sometimes gives up, FIBs fail their CRC, fine correctors move, batches may be decoded twice (exact batch mode).
+    Reports x real-time, the stage times, how the synchroniser's wide pass fared and the batches decoded twice.  Parity of this very run:
+    FIBs + CRC flags and the MSC bytes of three sub-channels of four ensembles against the oracle on the same rows."""
+    import tempfile
+    sync_ = torch.cuda.synchronize if device == "cuda" else (lambda: None)      # (device "cpu": tests/test_workload.py runs the leg on the kernels' CPU execution model)
+    rec_frames = workload.rec_frames_for(F)
+    base = workload.make_base_streams(min(4, B), rec_frames, seed0=300)
+    subchs = base[1][0].subchs
+    n_warm = 3
+    if kind == "drift":
+        steps = max(2, min(steps, 5))
+        n_frames = (n_warm + steps + 2) * F + 4                # the synchroniser runs a batch ahead and wants a whole frame beyond it
+        iq, par, base_np, txs = workload.make_channel_batch(B, n_frames, rank=11, ppm=(1.0, 50.0), device=device, base=base, rec_frames=rec_frames)
+        loop = False
+        what = "sampling-clock offset log-uniform in +-[1, 50] ppm per ensemble (non-looping stream of %d frames, band-limited resampling), sigma 0.02" % n_frames
+    else:
+        iq, par, base_np, txs = workload.make_channel_batch(B, rec_frames, rank=12, snr_db=(6.0, 10.0), device=device, base=base, rec_frames=rec_frames)
+        loop = True
+        what = "SNR uniform in [6, 10] dB per ensemble (looping recordings, noise part of the loop)"
+    dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=sched, loop=loop)
+    out = {"workload": "%d ensembles x %d frames, 18 x 64 kbit/s DAB+ EEP-3A each, %s" % (B, F, what)}
+    try:
+        check = sorted({0, 1, B // 2, B - 1} & set(range(B)))
+        logs = {e: dict(fib=[], ok=[], msc=[[] for _ in PARITY_SUBCH]) for e in check}
+        for W in range(n_warm):
+            dev.process(F); sf = dev.superframes_stats()
+            if W * F < 64:
+                info = dev.frame_info(); fib, ok = dev.fibs(); mscs = [dev.msc(i) for i in PARITY_SUBCH]
+                for e in check:
+                    valid = [f for f in range(F) if info[e, f]["valid"] == 1]
+                    for f in valid:
+                        logs[e]["fib"].append(np.array(fib[e, f])); logs[e]["ok"].append(np.array(ok[e, f]))
+                    for k in range(len(PARITY_SUBCH)):
+                        m, fv = mscs[k]
+                        logs[e]["msc"][k].append(m[e, fv[e]:4 * len(valid)].tobytes())
+        wf0, passes0, fb0 = dev.wide_sync_stats(); rep0 = dev.replayed_batches(); ss0 = dev.sync_stats()
+        sync_(); t0 = time.perf_counter(); acc = {}; n_valid = 0; fib_ok = fibs = 0; sf_acc = np.zeros(4, np.int64)
+        for _ in range(steps):
+            dev.process(F); sf = dev.superframes_stats(); fib, ok = dev.fibs_host()
+            for k, v in dev.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v
+            ok = np.asarray(ok); fib_ok += int(ok.sum()); fibs += ok.size; sf_acc += sf.sum(0)
+            n_valid += int((dev.frame_info()["valid"] == 1).sum())
+        sync_(); dt = (time.perf_counter() - t0) / steps
+        wf1, passes1, fb1 = dev.wide_sync_stats(); rep1 = dev.replayed_batches(); ss1 = dev.sync_stats()
+        assert n_valid >= int(0.98 * steps * B * F), "frames demodulated in the timed steps: %d of %d" % (n_valid, steps * B * F)
+        if kind == "drift":
+            assert fib_ok == fibs, "FIB CRC failures in the drifting signal: %d of %d pass" % (fib_ok, fibs)
+        out.update(value=n_valid / steps * FRAME_S / dt, unit="x real-time", ms_per_step=dt * 1e3, frames_per_step=n_valid / steps,
+                   stages_ms={k: v / steps for k, v in acc.items()}, demod_ms=acc.get("demod", 0.0) / steps, msc_viterbi_ms=acc.get("msc_viterbi", 0.0) / steps,
+                   wide_sync_stats={"frames_accepted_from_the_wide_pass": int((wf1 - wf0).sum()), "frames": n_valid, "passes": int(passes1 - passes0), "passes_that_needed_the_serial_chain": int(fb1 - fb0)},
+                   replayed_batches=int(rep1 - rep0), failed_window_searches=int(ss1[0].sum() - ss0[0].sum()), frames_settled_by_ordered_float_sums=int(ss1[1].sum() - ss0[1].sum()),
+                   fib_crc_ok=[fib_ok, fibs],
+                   superframes={"synchronised": int(sf_acc[0]), "rs_corrected_symbols": int(sf_acc[1]), "rs_uncorrectable": int(sf_acc[2]), "au_crc_failures": int(sf_acc[3])},
+                   per_ensemble={k: [float(np.min(np.abs(v))), float(np.max(np.abs(v)))] for k, v in par.items() if v is not None and k in ("ppm", "snr_db")})
+        with tempfile.TemporaryDirectory() as td:
+            recs = []
+            for e in check:
+                path = os.path.join(td, "rec%d.npy" % e); np.save(path, iq[e, :(n_warm * F + 8) * T_F].cpu().numpy() if not loop else iq[e].cpu().numpy()); recs.append(path)
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            _run_receivers(recs, len(recs), 1 if not loop else max(2, -(-80 // rec_frames)), "port", env, td)
+            n, m = _compare_with_receivers(td, "port", check, logs)
+        out.update(parity=True, parity_detail="FIBs + CRC flags of %d frames and %d MSC bytes of each of sub-channels %s of ensembles %s equal the oracle's (C restatement, same rows)" % (n, m, list(PARITY_SUBCH), check))
+    except AssertionError as ex:
+        out.update(parity=False, parity_error=str(ex))
+    finally:
+        dev.close()
+    return out
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -676,6 +753,13 @@ def main():
             except Exception as ex:
                 line["extras"]["mixed_layouts"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             torch.cuda.empty_cache()
+            # the headline's geometry on signals as a receiver meets them: drifting sample clocks, low SNR (own parity legs)
+            for kind in ("drift", "low_snr"):
+                try:
+                    line["extras"][kind] = channel_leg(capi, workload, torch, lib_path, B, F, args.steps, local, sched, kind)
+                except Exception as ex:
+                    line["extras"][kind] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                torch.cuda.empty_cache()
             # the latency regime: ONE ensemble, 1 / 4 / 8 / 16 frames per call, both Viterbi kernels (the default picks the state-parallel one here)
             line["extras"]["short_batches"] = _extra([os.path.join(ROOT, "tools", "sweep_decode_shape.py"), "--json"], {}, 300)
             line["facade"] = _extra([os.path.join(ROOT, "tools", "bench_facade.py"), "--json"], {}, 420)

@@ -141,6 +141,74 @@ def make_batch(B, rank=0, n_distinct=4, cfo_max_hz=60.0, sigma=0.02, device="cud
     return iq, cfo_hz, base_np, txs
 
 
+def resample_periodic(gx, n_out, ppm, taps=16, chunk=1 << 22):
+    """torch form of synth.resample_ppm for a PERIODIC recording gx (a seamless loop): y[n] = x(n (1 + ppm 1e-6)) for n < n_out, the loop
+    continued as far as needed -- a non-looping stream of any length as a receiver whose sampling clock is `ppm` parts per million fast
+    sees it (band-limited interpolation, Hann-windowed sinc).  The PRS of frame k arrives k * 196608 * ppm * 1e-6 samples early."""
+    import torch
+    N0 = gx.shape[0]
+    y = torch.empty(n_out, dtype=torch.complex64, device=gx.device)
+    half = taps // 2
+    for n0 in range(0, n_out, chunk):
+        n = torch.arange(n0, min(n_out, n0 + chunk), device=gx.device, dtype=torch.float64)
+        t = n * (1.0 + ppm * 1e-6)
+        k0 = torch.floor(t)
+        frac = (t - k0).to(torch.float32)
+        k0 = k0.to(torch.int64)
+        acc = torch.zeros(n.shape[0], dtype=torch.complex64, device=gx.device)
+        for j in range(-half + 1, half + 1):
+            u = frac - j
+            w = torch.sinc(u) * (0.5 + 0.5 * torch.cos(np.pi * u / half))
+            acc += gx[(k0 + j) % N0] * w
+        y[n0:n0 + n.shape[0]] = acc
+    return y
+
+
+def make_channel_batch(B, n_frames, rank=0, n_distinct=4, cfo_max_hz=60.0, sigma=0.02, ppm=None, snr_db=None, device="cuda", base=None, rec_frames=REC_FRAMES,
+                       amplitude=0.25):
+    """The headline's ensembles as a receiver MEETS them (bench.py's `drift` and `low_snr` legs): ensemble b = recording b % n_distinct with
+    its own carrier offset and its own noise, and
+      ppm     = (lo, hi): a sampling-clock offset of its own, magnitude log-uniform in [lo, hi] ppm, random sign -- the window index of
+                every frame moves (ofdm-processor.cpp:337-350), the wide synchroniser pass's prediction of an unmoved window fails;
+                the stream is NOT a loop then: n_frames frames of the continued recording, resampled (resample_periodic);
+      snr_db  = (lo, hi): its own signal-to-noise ratio, uniform in dB (instead of sigma): Reed-Solomon corrects, FIBs fail, the
+                coarse corrector's FIC-ratio feedback acts (ofdm-processor.cpp:397-409).
+    -> (iq [B][n_frames * 196608] on `device`, dict of the per-ensemble parameters, base recordings, their transmitters)"""
+    import torch
+    if base is None:
+        base = make_base_streams(n_distinct, rec_frames, seed0=100 * rank)
+    base_np, txs = base
+    N0 = base_np.shape[1]
+    N = int(n_frames) * 196608
+    gbase = torch.from_numpy(base_np).to(device)
+    gen = torch.Generator(device=device); gen.manual_seed(9234 + rank)
+    rs = np.random.RandomState(7321 + rank)
+    if ppm is None:
+        assert N % N0 == 0 or N <= N0, "a looping stream is a whole number of recordings"
+        cfo_hz = np.round(rs.uniform(-cfo_max_hz, cfo_max_hz, B) * N0 / RATE) * RATE / N0
+        ppm_b = np.zeros(B)
+    else:
+        cfo_hz = rs.uniform(-cfo_max_hz, cfo_max_hz, B)
+        ppm_b = np.exp(rs.uniform(np.log(ppm[0]), np.log(ppm[1]), B)) * rs.choice([-1.0, 1.0], B)
+    snr_b = rs.uniform(snr_db[0], snr_db[1], B) if snr_db is not None else None
+    sig_b = np.sqrt(amplitude ** 2 / (10 ** (snr_b / 10)) / 2) if snr_db is not None else np.full(B, sigma)
+    iq = torch.empty((B, N), dtype=torch.complex64, device=device)
+    n_idx = torch.arange(N, device=device, dtype=torch.float64)
+    for b in range(B):
+        x = gbase[b % base_np.shape[0]]
+        if ppm is not None:
+            x = resample_periodic(x, N, float(ppm_b[b]))
+        elif N > N0:
+            x = x.repeat(N // N0)
+        else:
+            x = x[:N]
+        noise = torch.randn((N, 2), generator=gen, device=device, dtype=torch.float32) * float(sig_b[b])
+        rot = torch.polar(torch.ones_like(n_idx), n_idx * (2.0 * np.pi * cfo_hz[b] / RATE)).to(torch.complex64)
+        iq[b] = x * rot + torch.view_as_complex(noise)
+        del noise, rot, x
+    return iq, dict(cfo_hz=cfo_hz, ppm=ppm_b, snr_db=snr_b, sigma=sig_b), base_np, txs
+
+
 def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demod_chunk=0, profiling=True, loop=True, decode_shape=0):
     """the handle bench.py times: batch geometry B x F, looping HBM-resident ring, coarse corrector enabled, no constellation / CIR
     taps, all sub-channels decoded, superframe filter inside process()"""
