@@ -45,17 +45,17 @@ typedef enum {
  *   dabphy_config            is SIZED: its first member is the sizeof() the caller was compiled with.  Fields are only ever appended;
  *                            dabphy_create reads the fields the caller's header knew and takes the documented default (0) for the rest,
  *                            and refuses a structure LARGER than its own (fields it does not know: DABPHY_ERR_INVALID).
- *   every other structure    (dabphy_frame_info, dabphy_sf_event, dabphy_subchannel, dabphy_protection, dabphy_tii_measurement) is pinned
+ *   every other structure    (dabphy_frame_info, dabphy_sf_event, dabphy_subchannel, dabphy_protection, dabphy_tii_measurement, dabphy_msc_desc) is pinned
  *                            by DABPHY_ABI_VERSION: a change of any of them bumps it.  A caller checks once, e.g. in its constructor:
  *                                dabphy_abi_version() == DABPHY_ABI_VERSION   (dabphy_struct_size(which) tells the library's sizeof for a
  *                                finer diagnosis).
  *   objects built against the headers of rounds 1-3 call the exported symbols `dabphy_create` / `dabphy_get_config` with the UNSIZED
  *   48-byte configuration of those rounds: those entry points stay, frozen to that layout (new fields at their defaults); this header's
  *   dabphy_create / dabphy_get_config are the _v2 symbols (the sized form). */
-#define DABPHY_ABI_VERSION 5u
+#define DABPHY_ABI_VERSION 6u
 uint32_t dabphy_abi_version(void);
 typedef enum { DABPHY_STRUCT_CONFIG = 0, DABPHY_STRUCT_FRAME_INFO = 1, DABPHY_STRUCT_SF_EVENT = 2, DABPHY_STRUCT_SUBCHANNEL = 3,
-               DABPHY_STRUCT_PROTECTION = 4, DABPHY_STRUCT_TII_MEASUREMENT = 5 } dabphy_struct_id;
+               DABPHY_STRUCT_PROTECTION = 4, DABPHY_STRUCT_TII_MEASUREMENT = 5, DABPHY_STRUCT_MSC_DESC = 6 } dabphy_struct_id;
 size_t dabphy_struct_size(int32_t which);      /* 0 for an unknown id */
 
 /* RadioReceiverOptions (src/backend/radio-receiver-options.h:66-84) + batch geometry */
@@ -299,6 +299,11 @@ int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, 
  * ensemble that were accepted from it [n_ensembles]; passes queued; passes after which the frame-by-frame chain had to take over for
  * at least one ensemble */
 int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t* passes, uint64_t* fallbacks);
+/* ... of the frames accepted from the wide pass, those whose window search ran in the FIND CHAIN [n_ensembles]: an ensemble whose window
+ * index moves (a sampling-clock offset: ofdm-processor.cpp:337-350) cannot have its window positions predicted; its searches then run
+ * one after the other on the device, each from the position the previous one really found, and only the cyclic-prefix sums of all
+ * those frames run at once */
+int dabphy_get_find_chain_stats(dabphy_handle* h, int32_t* chain_frames);
 /* the wide pass of the DAB+ superframe filter since dabphy_create (either pointer may be NULL): (ensemble, sub-channel) batches whose
  * superframe attempts were all made at once and accepted -- the rest were walked frame by frame as SuperframeFilter::Feed does
  * (dabplus_decoder.cpp:50-158); results are identical either way -- and batches it was tried on (those with at least one full
@@ -331,6 +336,32 @@ int dabphy_set_track_slevel(dabphy_handle* h, int32_t on);
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
 /* ... of ONE ensemble: out [4*n_frames][nbits/8], first_valid / n_rows single values */
 int dabphy_get_msc_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows);
+/* ... of EVERY selected sub-channel of EVERY ensemble in one pass: the bulk drain (MscHandler hands every selected sub-channel its
+ * logical frames as the CIF completes, msc-handler.cpp:129-158 -> dab-audio.cpp:151-160; a host that drains thousands of services per
+ * batch cannot afford one copy and one stream synchronisation per service).  A protection class's output is ONE contiguous array in
+ * HBM ([pair][4*n_frames][nbits/8], pairs = the (ensemble, sub-channel) pairs of the batch that share the profile), so the drain is one
+ * device-to-host copy per class into `buf` -- at PCIe rate when `buf` is page-locked (dabphy_host_alloc) -- and an index table:
+ *   desc [n]  one record per (ensemble, list position), ordered by ensemble, then by position: where that service's rows lie in `buf`
+ *             (row r of the service = buf + offset + r * row_bytes, 4*n_frames rows reserved), and first_valid / n_rows as dabphy_get_msc
+ *             defines them.
+ *   dabphy_msc_batch_size        bytes `buf` must hold and records `desc` must hold for the last batch (either pointer may be NULL)
+ *   dabphy_get_msc_batch         queue the copies, wait for them, return (n_desc = records written)
+ *   dabphy_msc_drain_begin       queue the copies on a stream of their own and return at once: the NEXT dabphy_process may be called while
+ *                                they are in flight -- its decoder waits on the device for the drain before it overwrites a class output,
+ *                                its synchroniser and FFT stage do not --; `desc` is complete on return, `buf` when
+ *   dabphy_msc_drain_wait        returns (also called by dabphy_destroy / dabphy_reset and before the sub-channel lists are re-applied).
+ * DABPHY_ERR_INVALID when a capacity is too small (nothing is queued then). */
+typedef struct {
+    uint32_t ensemble, subch_index;      /* position in that ensemble's list (dabphy_set_subchannels[_ensemble]) */
+    uint32_t row_bytes;                  /* one logical frame: nbits / 8 = 3 * bit rate in kbit/s */
+    int32_t first_valid, n_rows;         /* rows [first_valid, n_rows) are this batch's logical frames (dabphy_get_msc) */
+    uint32_t subch_id;                   /* SubChId as given in the list */
+    uint64_t offset;                     /* byte offset of row 0 in buf */
+} dabphy_msc_desc;
+int dabphy_msc_batch_size(dabphy_handle* h, size_t* buf_bytes, uint32_t* n_desc);
+int dabphy_get_msc_batch(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t desc_capacity, uint32_t* n_desc, uint8_t* buf, size_t buf_capacity);
+int dabphy_msc_drain_begin(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t desc_capacity, uint32_t* n_desc, uint8_t* buf, size_t buf_capacity);
+int dabphy_msc_drain_wait(dabphy_handle* h);
 int dabphy_get_impulse_response(dabphy_handle* h, float* out /* [n_ensembles][n_frames][2048] */);      /* onNewImpulseResponse */
 /* onNewNullSymbol (ofdm-processor.cpp:462-469): the 2656 oscillator-corrected samples of the null symbol that follows each
  * demodulated frame of the last batch, out[n_ensembles][n_frames][2656][2] (zeros where valid != 1).  Computed on request. */

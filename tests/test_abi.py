@@ -64,7 +64,7 @@ def test_sized_configuration(emu):
     assert lib.dabphy_abi_version() == capi.ABI_VERSION
     lib.dabphy_struct_size.restype = C.c_size_t
     assert lib.dabphy_struct_size(0) == C.sizeof(capi.Config) and lib.dabphy_struct_size(3) == C.sizeof(capi.Subchannel) and lib.dabphy_struct_size(4) == C.sizeof(capi.Protection)
-    assert lib.dabphy_struct_size(1) == C.sizeof(capi.FrameInfo) and lib.dabphy_struct_size(2) == capi.SF_EVENT_DTYPE.itemsize and lib.dabphy_struct_size(5) == capi.TII_DTYPE.itemsize
+    assert lib.dabphy_struct_size(1) == C.sizeof(capi.FrameInfo) and lib.dabphy_struct_size(2) == capi.SF_EVENT_DTYPE.itemsize and lib.dabphy_struct_size(5) == capi.TII_DTYPE.itemsize and lib.dabphy_struct_size(6) == capi.MSC_DESC_DTYPE.itemsize
     assert lib.dabphy_struct_size(99) == 0
 
     class Padded(C.Structure):

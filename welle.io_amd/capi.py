@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libdabphy_hip.so")
 
 T_U, T_S, FRAME_SYMS_LEN = 2048, 2552, 2048 + 75 * 2552
-ABI_VERSION = 5            # DABPHY_ABI_VERSION of the include/dabphy.h these structures mirror
+ABI_VERSION = 6            # DABPHY_ABI_VERSION of the include/dabphy.h these structures mirror
 
 
 class Config(C.Structure):
@@ -32,6 +32,11 @@ class Subchannel(C.Structure):
 TII_DTYPE = np.dtype([("frame", "<i4"), ("comb", "<i4"), ("pattern", "<i4"), ("delay_samples", "<i4"), ("error", "<f4")])
 SF_EVENT_DTYPE = np.dtype([("cif", "<i4"), ("corrected", "<i4"), ("uncorrectable", "<i4"), ("sync", "<i4"), ("format", "<i4"), ("num_aus", "<i4"),
                            ("au_start", "<i4", 7), ("au_crc_ok", "<i4"), ("sf_slot", "<i4")])
+
+
+FRAME_INFO_RAW = np.dtype({"names": ["sample_pos", "frame_no", "start_index", "valid", "fine_corrector", "coarse_corrector", "snr"],
+                           "formats": ["<i8", "<i8", "<i4", "<i4", "<i4", "<i4", "<f4"], "offsets": [0, 8, 16, 20, 24, 28, 32], "itemsize": 40})      # dabphy_frame_info
+MSC_DESC_DTYPE = np.dtype([("ensemble", "<u4"), ("subch_index", "<u4"), ("row_bytes", "<u4"), ("first_valid", "<i4"), ("n_rows", "<i4"), ("subch_id", "<u4"), ("offset", "<u8")])
 
 
 class DabPhyError(RuntimeError):
@@ -158,6 +163,12 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_wide_sync_stats(self.h, _p(wf), C.byref(a), C.byref(b)))
         return wf, a.value, b.value
 
+    def find_chain_stats(self):
+        """frames per ensemble whose window search ran in the find chain (of those accepted from the wide synchroniser pass)"""
+        cf = np.zeros(self.cfg.n_ensembles, np.int32)
+        self._chk(self.lib.dabphy_get_find_chain_stats(self.h, _p(cf)))
+        return cf
+
     def replayed_batches(self):
         a = C.c_uint64(0)
         self._chk(self.lib.dabphy_get_replayed_batches(self.h, C.byref(a)))
@@ -274,6 +285,33 @@ class DabPhy:
         self._chk(self.lib.dabphy_get_msc_ensemble(self.h, ensemble, idx, _p(out), C.c_size_t(out.nbytes), C.byref(fv), C.byref(nr)))
         return out, fv.value, nr.value
 
+    def msc_batch_size(self):
+        """(bytes, services) the bulk drain of the last batch needs (dabphy_msc_batch_size)"""
+        nb = C.c_size_t(0); nd = C.c_uint32(0)
+        self._chk(self.lib.dabphy_msc_batch_size(self.h, C.byref(nb), C.byref(nd)))
+        return nb.value, nd.value
+
+    def msc_drain_begin(self, buf=None, desc=None):
+        """dabphy_msc_drain_begin: queue the bulk drain of every selected sub-channel of every ensemble into `buf` (uint8; page-locked from
+        host_alloc for PCIe rate) and return (buf, desc records) at once; msc_drain_wait() completes it"""
+        nb, nd = self.msc_batch_size()
+        if buf is None:
+            buf = np.zeros(max(nb, 1), np.uint8)
+        if desc is None:
+            desc = np.zeros(max(nd, 1), MSC_DESC_DTYPE)
+        n = C.c_uint32(0)
+        self._chk(self.lib.dabphy_msc_drain_begin(self.h, _p(desc), C.c_uint32(len(desc)), C.byref(n), _p(buf), C.c_size_t(buf.nbytes)))
+        return buf, desc[:n.value]
+
+    def msc_drain_wait(self):
+        self._chk(self.lib.dabphy_msc_drain_wait(self.h))
+
+    def msc_batch(self, buf=None, desc=None):
+        """dabphy_get_msc_batch -> (buf, desc): service k's logical frames = buf[desc[k].offset:][: 4F * row_bytes].reshape(4F, row_bytes)[first_valid:n_rows]"""
+        buf, desc = self.msc_drain_begin(buf, desc)
+        self.msc_drain_wait()
+        return buf, desc
+
     def superframes_ensemble(self, ensemble, idx, bitrate):
         """-> (events [4F], n_events, corrected superframes [n_slots][120*bitrate/8]) of one ensemble's sub-channel idx"""
         F = self._last
@@ -336,11 +374,13 @@ class DabPhy:
         B, F = self.cfg.n_ensembles, self._last
         arr = (FrameInfo * (B * F))()
         self._chk(self.lib.dabphy_get_frame_info(self.h, arr))
+        raw = np.frombuffer(arr, dtype=FRAME_INFO_RAW)
         out = np.zeros((B, F), dtype=[("pos", np.int64), ("frame_no", np.int64), ("start_index", np.int32), ("valid", np.int32),
                                       ("fine", np.int32), ("coarse", np.int32), ("snr", np.float32)])
-        for i in range(B * F):
-            a = arr[i]
-            out.reshape(-1)[i] = (a.sample_pos, a.frame_no, a.start_index, a.valid, a.fine_corrector, a.coarse_corrector, a.snr)
+        flat = out.reshape(-1)
+        for dst, src in (("pos", "sample_pos"), ("frame_no", "frame_no"), ("start_index", "start_index"), ("valid", "valid"), ("fine", "fine_corrector"),
+                         ("coarse", "coarse_corrector"), ("snr", "snr")):
+            flat[dst] = raw[src]
         return out
 
     def fibs(self):

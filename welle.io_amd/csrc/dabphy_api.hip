@@ -15,6 +15,7 @@ size_t dabphy_struct_size(int32_t which)
         case DABPHY_STRUCT_SUBCHANNEL: return sizeof(dabphy_subchannel);
         case DABPHY_STRUCT_PROTECTION: return sizeof(dabphy_protection);
         case DABPHY_STRUCT_TII_MEASUREMENT: return sizeof(dabphy_tii_measurement);
+        case DABPHY_STRUCT_MSC_DESC: return sizeof(dabphy_msc_desc);
     }
     return 0;
 }
@@ -186,6 +187,8 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
     if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }
     if (h->fic_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
+    if (h->drain_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
+    if (h->ev_drain_done) e = hipEventDestroy(h->ev_drain_done);
     if (h->ev_aux_done) e = hipEventDestroy(h->ev_aux_done);
     for (int i = 0; i < 2; i++) if (h->ev_ingest[i]) e = hipEventDestroy(h->ev_ingest[i]);
     if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);
@@ -451,6 +454,7 @@ int apply_subchannels(dabphy_handle* h)
     const uint32_t B = h->cfg.n_ensembles;
     int r;
     HIPCHK(h, hipStreamSynchronize(h->stream));              // nothing queued still reads the classes that are about to go
+    if ((r = drain_wait(h))) return r;                       // (nor a bulk MSC drain in flight)
     HIPCHK(h, hipStreamSynchronize(h->aux_stream));
     std::vector<dabphy_handle::MscClass> old;
     old.swap(h->classes);

@@ -133,6 +133,19 @@ int dabphy_get_wide_sync_stats(dabphy_handle* h, int32_t* wide_frames, uint64_t*
     return DABPHY_OK;
 }
 
+int dabphy_get_find_chain_stats(dabphy_handle* h, int32_t* chain_frames)
+{
+    DeviceBind dev_(h);
+    if (!h || !chain_frames) return DABPHY_ERR_INVALID;
+    if (h->s_desc2[0].p) { int r0 = resolve_all_chains(h); if (r0) return r0; }
+    std::vector<RxState> st(h->cfg.n_ensembles);
+    if (h->sync_stream) HIPCHK(h, hipStreamSynchronize(h->sync_stream));
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->d_state, st.size() * sizeof(RxState), hipMemcpyDeviceToHost, h->stream));
+    int r = sync(h); if (r) return r;
+    for (size_t i = 0; i < st.size(); i++) chain_frames[i] = st[i].n_chain_frames;
+    return DABPHY_OK;
+}
+
 int dabphy_get_sync_stats(dabphy_handle* h, int32_t* lost, int32_t* exact_sums, int32_t* relock_inexact)
 {
     DeviceBind dev_(h);
@@ -158,13 +171,11 @@ int dabphy_get_fic_ratio(dabphy_handle* h, int32_t* ratio_percent)
 }
 
 namespace {
-// rows of one (ensemble, sub-channel) pair from its class's output [pair][4F][nbits / 8]; first_valid / n_rows as documented in include/dabphy.h
-int msc_rows_of(dabphy_handle* h, uint32_t b, dabphy_handle::PairRef w, uint8_t* out, int32_t* first_valid, int32_t* n_rows)
+// first_valid / n_rows of one (ensemble, sub-channel) pair as documented in include/dabphy.h (host arithmetic on the batch's descriptors)
+void msc_rows_info(const dabphy_handle* h, uint32_t b, dabphy_handle::PairRef w, int32_t* first_valid, int32_t* n_rows)
 {
     const uint32_t F = h->last_frames;
     const auto& cls = h->classes[w.cls];
-    const size_t bytes = cls.prot.nbits / 8, Rn = (size_t)4 * F;
-    HIPCHK(h, hipMemcpyAsync(out, cls.out.as<uint8_t>() + (size_t)w.pair * Rn * bytes, Rn * bytes, hipMemcpyDeviceToHost, h->stream));
     if (first_valid) {
         // DabAudio emits its first logical frame on the 17th CIF it is fed (dab-audio.cpp:146-149): counted from the CIF at which this
         // sub-channel was selected (0 for one that was there from the start of the stream)
@@ -176,8 +187,96 @@ int msc_rows_of(dabphy_handle* h, uint32_t b, dabphy_handle::PairRef w, uint8_t*
         for (uint32_t f = 0; f < F; f++) nv += h->h_desc[(size_t)b * F + f].valid == 1 ? 1 : 0;
         *n_rows = 4 * nv;
     }
+}
+// rows of one (ensemble, sub-channel) pair from its class's output [pair][4F][nbits / 8]
+int msc_rows_of(dabphy_handle* h, uint32_t b, dabphy_handle::PairRef w, uint8_t* out, int32_t* first_valid, int32_t* n_rows)
+{
+    const uint32_t F = h->last_frames;
+    const auto& cls = h->classes[w.cls];
+    const size_t bytes = cls.prot.nbits / 8, Rn = (size_t)4 * F;
+    HIPCHK(h, hipMemcpyAsync(out, cls.out.as<uint8_t>() + (size_t)w.pair * Rn * bytes, Rn * bytes, hipMemcpyDeviceToHost, h->stream));
+    msc_rows_info(h, b, w, first_valid, n_rows);
     return DABPHY_OK;
 }
+// the bulk drain's layout: class c's output [pairs][4F][bytes] at off[c] (256-byte aligned), one after the other
+size_t drain_layout(const dabphy_handle* h, std::vector<size_t>& off)
+{
+    size_t at = 0;
+    off.clear();
+    for (const auto& cls : h->classes) {
+        off.push_back(at);
+        at += (cls.pairs.size() * (size_t)4 * h->last_frames * (cls.prot.nbits / 8) + 255) & ~(size_t)255;
+    }
+    return at;
+}
+}
+
+int drain_wait(dabphy_handle* h)
+{
+    if (!h->drain_pending) return DABPHY_OK;
+    h->drain_pending = false;
+    HIPCHK(h, hipEventSynchronize(h->ev_drain_done));
+    return DABPHY_OK;
+}
+
+int dabphy_msc_batch_size(dabphy_handle* h, size_t* buf_bytes, uint32_t* n_desc)
+{
+    if (!h || !h->last_frames) return DABPHY_ERR_INVALID;
+    std::vector<size_t> off;
+    const size_t total = drain_layout(h, off);
+    if (buf_bytes) *buf_bytes = total;
+    if (n_desc) { uint32_t n = 0; for (const auto& w : h->where) n += (uint32_t)w.size(); *n_desc = n; }
+    return DABPHY_OK;
+}
+
+int dabphy_msc_drain_begin(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t desc_capacity, uint32_t* n_desc, uint8_t* buf, size_t buf_capacity)
+{
+    DeviceBind dev_(h);
+    if (!h || !h->last_frames || (!desc && desc_capacity) || !n_desc) return DABPHY_ERR_INVALID;
+    const uint32_t B = h->cfg.n_ensembles, F = h->last_frames;
+    std::vector<size_t> off;
+    const size_t total = drain_layout(h, off);
+    uint32_t n = 0; for (const auto& w : h->where) n += (uint32_t)w.size();
+    if (n > desc_capacity || total > buf_capacity || (total && !buf)) { h->err = "dabphy_msc_drain_begin: buffer or index table too small (dabphy_msc_batch_size)"; return DABPHY_ERR_INVALID; }
+    int r;
+    if ((r = drain_wait(h))) return r;                      // one drain at a time
+    if (!h->drain_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->drain_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_done, hipEventDisableTiming));
+    }
+    // (dabphy_process has returned: the class outputs are final, nothing on the main stream is pending)
+    for (size_t c = 0; c < h->classes.size(); c++) {
+        const auto& cls = h->classes[c];
+        const size_t bytes = cls.pairs.size() * (size_t)4 * F * (cls.prot.nbits / 8);
+        if (bytes) HIPCHK(h, hipMemcpyAsync(buf + off[c], cls.out.p, bytes, hipMemcpyDeviceToHost, h->drain_stream));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_drain_done, h->drain_stream));
+    h->drain_pending = true;
+    uint32_t k = 0;
+    for (uint32_t b = 0; b < B; b++)
+        for (size_t i = 0; i < h->where[b].size(); i++, k++) {
+            const dabphy_handle::PairRef w = h->where[b][i];
+            const auto& cls = h->classes[w.cls];
+            dabphy_msc_desc& d = desc[k];
+            d.ensemble = b; d.subch_index = (uint32_t)i; d.row_bytes = (uint32_t)(cls.prot.nbits / 8); d.subch_id = (uint32_t)cls.subch_id[w.pair];
+            d.offset = off[w.cls] + (uint64_t)w.pair * 4 * F * d.row_bytes;
+            msc_rows_info(h, b, w, &d.first_valid, &d.n_rows);
+        }
+    *n_desc = n;
+    return DABPHY_OK;
+}
+
+int dabphy_msc_drain_wait(dabphy_handle* h)
+{
+    DeviceBind dev_(h);
+    if (!h) return DABPHY_ERR_INVALID;
+    return drain_wait(h);
+}
+
+int dabphy_get_msc_batch(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t desc_capacity, uint32_t* n_desc, uint8_t* buf, size_t buf_capacity)
+{
+    int r = dabphy_msc_drain_begin(h, desc, desc_capacity, n_desc, buf, buf_capacity);
+    return r ? r : dabphy_msc_drain_wait(h);
 }
 
 int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t out_capacity, int32_t* first_valid, int32_t* n_rows)
@@ -193,9 +292,23 @@ int dabphy_get_msc(dabphy_handle* h, uint32_t subch_index, uint8_t* out, size_t 
         bytes = mine;
     }
     if (out_capacity < (size_t)B * 4 * F * bytes) { h->err = "dabphy_get_msc: output buffer too small"; return DABPHY_ERR_INVALID; }
-    for (uint32_t b = 0; b < B; b++) {
-        int r = msc_rows_of(h, b, h->where[b][subch_index], out + (size_t)b * 4 * F * bytes, first_valid ? first_valid + b : nullptr, n_rows ? n_rows + b : nullptr);
-        if (r) return r;
+    // Runs of ensembles whose pairs lie in one class at a constant distance (the same list everywhere: pair = b * M + m) leave in ONE
+    // strided copy: [run][4F * bytes] rows out of the class output [pair][4F][bytes].  A batch of different multiplexes falls apart into
+    // shorter runs, down to one copy per ensemble.
+    const size_t row = (size_t)4 * F * bytes;
+    for (uint32_t b0 = 0; b0 < B;) {
+        const dabphy_handle::PairRef w0 = h->where[b0][subch_index];
+        uint32_t b1 = b0 + 1; int step = 0;
+        if (b1 < B && h->where[b1][subch_index].cls == w0.cls && h->where[b1][subch_index].pair > w0.pair) {
+            step = h->where[b1][subch_index].pair - w0.pair;
+            for (b1++; b1 < B && h->where[b1][subch_index].cls == w0.cls && h->where[b1][subch_index].pair == w0.pair + (int)(b1 - b0) * step; b1++) {}
+        }
+        const auto& cls = h->classes[w0.cls];
+        const uint8_t* src = cls.out.as<uint8_t>() + (size_t)w0.pair * row;
+        if (b1 - b0 > 1) HIPCHK(h, hipMemcpy2DAsync(out + (size_t)b0 * row, row, src, (size_t)step * row, row, b1 - b0, hipMemcpyDeviceToHost, h->stream));
+        else HIPCHK(h, hipMemcpyAsync(out + (size_t)b0 * row, src, row, hipMemcpyDeviceToHost, h->stream));
+        for (uint32_t b = b0; b < b1; b++) msc_rows_info(h, b, h->where[b][subch_index], first_valid ? first_valid + b : nullptr, n_rows ? n_rows + b : nullptr);
+        b0 = b1;
     }
     return sync(h);
 }

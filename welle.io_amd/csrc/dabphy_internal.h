@@ -103,6 +103,8 @@ struct dabphy_handle {
     DevBuf s_raw2[2]; hipStream_t copy_stream = nullptr; hipEvent_t ev_ingest[2] = {nullptr, nullptr}; int raw_sel = 0;   // dabphy_stream_write_raw_async
     uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
     DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
+    // bulk MSC drain (dabphy_msc_drain_begin / _wait): the class outputs leave on a stream of their own while the next batch starts
+    hipStream_t drain_stream = nullptr; hipEvent_t ev_drain_done = nullptr; bool drain_pending = false;
     DevBuf sf_events, sf_count, sf_bytes, sf_stats, sf_gf, sf_accept; const FrameDesc* last_desc = nullptr;
     static constexpr int N_DESC = 3;    // descriptor buffers: the batch being decoded + up to two synchronised ahead
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
@@ -266,5 +268,6 @@ DABPHY_INTERNAL int sp_variant_for(int nsteps);
 // decision scratch was laid out
 DABPHY_INTERNAL bool sp_two_for(const dabphy_handle* h, uint64_t n_cw);
 DABPHY_INTERNAL void launch_sp(const FusedArgs& a, bool two, int lds_variant, hipStream_t s);
+DABPHY_INTERNAL int drain_wait(dabphy_handle* h);                                                // dabphy_getters.hip: host waits for a bulk MSC drain in flight
 DABPHY_INTERNAL size_t soft_ens_stride(const dabphy_handle* h);                                   // bytes between the soft-bit ring slices of two ensembles
 }

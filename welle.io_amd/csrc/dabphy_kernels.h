@@ -23,6 +23,9 @@ struct RxState {
     int32_t attempts;       // entries into the notSynced state since reset (ofdm-processor.cpp:256-262: what scan mode counts)
     int32_t first_lock_attempts; // `attempts` when the first window search succeeded (:351-355 onSignalPresence(true)); -1 = not yet
     int32_t n_wide_frames;  // frames accepted from the wide (all frames of a batch at once) synchroniser pass
+    int32_t n_chain_frames; // ... of which the window search ran in the find chain (k_sync_find_chain: the true window positions, correctors predicted)
+    int32_t calm_frames;    // consecutive tracked frames whose window index was T_g (saturating): below SYNC_CALM_MIN the ensemble's window is
+                            // moving (a sampling-clock offset, ofdm-processor.cpp:337-350) and the wide pass leaves its searches to the find chain
     // acquisition state machine (survives a call that ran out of samples mid-search)
     int32_t acq_phase;      // 0 priming sLevel, 1 first 50 samples, 2 looking for the dip, 3 looking for the end of the null
     int32_t acq_counter, acq_idx, acq_left;

@@ -115,7 +115,7 @@ int reset_synchroniser(dabphy_handle* h, bool decoder_too)
         s.acq_phase = 0; s.acq_left = T_F / 2; s.first_lock_attempts = -1; s.frame_no = frame_no; s.pos = pos;
         if (!decoder_too) {
             s.attempts = keep.attempts; s.first_lock_attempts = keep.first_lock_attempts; s.lost = keep.lost;
-            s.n_exact_sums = keep.n_exact_sums; s.n_relock_inexact = keep.n_relock_inexact; s.n_wide_frames = keep.n_wide_frames;
+            s.n_exact_sums = keep.n_exact_sums; s.n_relock_inexact = keep.n_relock_inexact; s.n_wide_frames = keep.n_wide_frames; s.n_chain_frames = keep.n_chain_frames;
         }
     }
     h->presynced = 0; h->ahead = 0;

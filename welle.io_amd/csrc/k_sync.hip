@@ -173,6 +173,7 @@ __device__ __forceinline__ void state_advance(const SyncArgs& A, const int b, Rx
     if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
     else if (fine < -1000 / 2) { coarse -= 1000; fine += 1000; }
     hist_append(A, b, st, d);
+    st.calm_frames = d.start_index == T_G ? (st.calm_frames < (1 << 20) ? st.calm_frames + 1 : st.calm_frames) : 0;
     st.pos = d.pos + (int64_t)d.start_index + T_U + 75 * (int64_t)T_S + T_NULL;
     st.local_phase = mod_rate64((int64_t)d.null_L - (int64_t)T_NULL * d.null_f);
     st.coarse = coarse; st.fine = fine; st.frame_no = d.frame_no + 1;
@@ -543,9 +544,15 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
     acquire_body<256>(A, blockIdx.x, l1, s_st, s_done, threadIdx.x);
 }
 
-template <bool WIDE>
-__device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, const int frame)
+// MODE 0: the serial chain (the state in HBM is the truth: acquisition first where needed, a failed search falls back to notSynced);
+// MODE 1: the wide pass (frame n from the state sync_predict gives it); MODE 2: the find chain (k_sync_find_chain: the caller hands in the
+// state the frame starts from and, when the search succeeded, gets back the state the NEXT frame starts from if the fine corrector does not
+// move).  Returns true when the descriptor is left pending (valid = 2) for k_sync_finish.
+constexpr int SYNC_CALM_MIN = 8;
+template <int MODE>
+__device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, const int frame, SyncIn& chain_st)
 {
+    constexpr bool WIDE = MODE != 0;
     // 17 KiB of LDS, reused phase by phase (FFT tile -> |IFFT| + window maxima)
     __shared__ __attribute__((aligned(16))) cf32 tile[T_U + 96];
     float* const lbuf = reinterpret_cast<float*>(tile);              // [T_U + 128], valid after the inverse transform
@@ -564,14 +571,20 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
         RxState& s_st = *reinterpret_cast<RxState*>(l1 + ACQ_TILE);
         acquire_body<FFT_THREADS>(A, b, l1, s_st, redi[0], t);
     }
-    const SyncIn st = WIDE ? sync_predict(sync_in_of(A.state[b]), frame) : sync_in_of(A.state[b]);
+    const SyncIn st = MODE == 2 ? chain_st : MODE == 1 ? sync_predict(sync_in_of(A.state[b]), frame) : sync_in_of(A.state[b]);
     FrameDesc& dout = A.desc[(size_t)b * A.n_frames + frame];
     FrameDesc d = desc_begin(st);
 
     // a whole frame (with the largest possible window index) must be available
     if (!st.synced || (!A.loop && st.pos + SYNC_NEED > A.n_valid)) {
         if (t == 0) dout = d;
-        return;
+        return false;
+    }
+    // the wide pass leaves an ensemble whose window is moving to the find chain: its predicted positions would be wrong from the first
+    // slip on (k_sync_validate then stops at this slot, which keeps valid = 0)
+    if (MODE == 1 && A.state[b].calm_frames < SYNC_CALM_MIN) {
+        if (t == 0) dout = d;
+        return false;
     }
 
     FftTwiddles w; fft_load_twiddles(w, A.tab.tw, twB, t);
@@ -709,7 +722,7 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
             g.synced = 0; g.lost = g.lost + 1; g.attempts = g.attempts + 1;                  // goto notSynced (:347-350 -> :256-262)
             hist_append(A, b, g, d);                   // the T_u samples of the failed attempt were pulled too
         }
-        return;
+        return false;
     }
     d.start_index = startIndex;
     if (!WIDE && t == 0 && A.state[b].first_lock_attempts < 0) A.state[b].first_lock_attempts = A.state[b].attempts;    // ofdm-processor.cpp:351-355
@@ -811,6 +824,16 @@ __device__ __forceinline__ void sync_find_body(const SyncArgs& A, const int b, c
     d.coarse_step = coarse - st.coarse;
     d.valid = 2;                                   // pending: k_sync_finish completes it
     if (t == 0) dout = d;
+    if (MODE == 2) {
+        // where the next frame starts if the fine corrector stays where it is (finish_desc + state_advance with fine unchanged;
+        // k_sync_validate_chain checks exactly that against what k_sync_finish really decided)
+        const int32_t null_L = mod_rate64((int64_t)d.L1 - (int64_t)75 * T_S * d.f_sym), null_f = coarse + st.fine;
+        chain_st.pos = d.pos + (int64_t)startIndex + T_U + 75 * (int64_t)T_S + T_NULL;
+        chain_st.frame_no = d.frame_no + 1;
+        chain_st.local_phase = mod_rate64((int64_t)null_L - (int64_t)T_NULL * null_f);
+        chain_st.coarse = coarse;
+    }
+    return true;
 }
 
 #ifndef SYNC_FIND_OCC
@@ -820,28 +843,59 @@ __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find(SyncAr
 {
     __builtin_amdgcn_s_setprio(3);
     if (A.redo_from && A.frame < A.redo_from[blockIdx.x]) return;     // accepted from the wide pass
-    sync_find_body<false>(A, blockIdx.x, A.frame);
+    SyncIn none{};
+    sync_find_body<0>(A, blockIdx.x, A.frame, none);
 }
 __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find_wide(SyncArgs A)
 {
-    sync_find_body<true>(A, blockIdx.y, blockIdx.x);
+    SyncIn none{};
+    sync_find_body<1>(A, blockIdx.y, blockIdx.x, none);
+}
+// The find chain: what the wide pass cannot predict is WHERE the window of frame n + 1 lies when the window index moves (a receiver
+// whose sampling clock is off by 1 ppm sees it slip every fifth frame, ofdm-processor.cpp:337-350) -- but that needs only the window
+// searches in order, not the cyclic-prefix sums: the fine corrector of a receiver in lock does not move (it steps by
+// (int16)(0.1 x residual Hz), ofdm-processor.cpp:450-451).  One work-group per ensemble walks the frames the wide pass's judge did not
+// accept (redo_out[b] ...), each search from the position the previous one really found, correctors as they are; the sums of all those
+// frames then run at once (k_sync_finish_wide again: it takes the pending descriptors) and k_sync_validate_chain accepts the frames
+// whose fine corrector indeed stayed.  Results are the serial chain's by construction; what is left (a corrector that moved, a failed
+// search, an ensemble out of lock) still goes to the serial chain.
+__global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find_chain(SyncArgs A)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x;
+    int n = A.redo_out[b];
+    if (n >= A.n_frames) return;
+    SyncIn st = sync_in_of(A.state[b]);                 // the true state in front of frame n (k_sync_validate has advanced it)
+    bool ok = true;
+    for (; n < A.n_frames; n++) {
+        if (ok) ok = sync_find_body<2>(A, b, n, st);
+        else if (threadIdx.x == 0) A.desc[(size_t)b * A.n_frames + n] = desc_begin(st);      // behind a failed search: nothing to go by (valid = 0)
+        __syncthreads();
+    }
 }
 
 // The wide pass's judge: one thread per ensemble walks the batch in order.  A frame is accepted iff the state its predecessors left
 // is the one it was computed from and it is an ordinary tracked frame; accepting it advances the state exactly as the serial chain
-// does (state_advance).  redo_from[b] = first slot the serial chain has to do (n_frames: none); *any_redo |= some ensemble has one.
-__global__ void __launch_bounds__(64) k_sync_validate(SyncArgs A)
+// does (state_advance).  redo_out[b] = first slot not settled (n_frames: none).
+// CHAIN = false: behind the wide pass proper (frames computed from sync_predict's states);
+// CHAIN = true: behind the find chain (frames from redo_out[b] on, each computed from the state its descriptor names: position, frame
+// number, oscillator phase, coarse + fine -- and with the fine corrector this ensemble had in front of frame redo_out[b], which
+// k_sync_finish_wide used for all of them); *any_redo |= some ensemble still has slots for the serial chain.
+template <bool CHAIN>
+__device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= A.n_ens) return;
     RxState& g = A.state[b];
     FrameDesc* const desc = A.desc + (size_t)b * A.n_frames;
     const SyncIn base = sync_in_of(g);
-    int n = 0;
+    int n = CHAIN ? A.redo_out[b] : 0;
     if (base.synced) {
         for (; n < A.n_frames; n++) {
-            const SyncIn p = sync_predict(base, n);
-            if (g.pos != p.pos || g.frame_no != p.frame_no || g.local_phase != p.local_phase || g.coarse != p.coarse || g.fine != p.fine) break;
+            if (!CHAIN) {
+                const SyncIn p = sync_predict(base, n);
+                if (g.pos != p.pos || g.frame_no != p.frame_no || g.local_phase != p.local_phase || g.coarse != p.coarse || g.fine != p.fine) break;
+            }
             if (!A.loop && g.pos + SYNC_NEED > A.n_valid) {
                 // out of samples: this slot and the ones behind it stay empty, as the serial chain leaves them
                 const FrameDesc e = desc_begin(sync_in_of(g));
@@ -850,16 +904,20 @@ __global__ void __launch_bounds__(64) k_sync_validate(SyncArgs A)
                 break;
             }
             const FrameDesc d = desc[n];
+            if (CHAIN && (g.pos != d.pos || g.frame_no != d.frame_no || g.local_phase != d.L0 || g.coarse + g.fine != d.f_prs || g.fine != base.fine)) break;
             if (d.valid != 1) break;                                   // failed window search: the serial chain takes it from here
             if (d.exact_sums) g.n_exact_sums += 1;
             if (g.first_lock_attempts < 0) g.first_lock_attempts = g.attempts;                  // ofdm-processor.cpp:351-355
             state_advance(A, b, g, d);
             g.n_wide_frames += 1;
+            if (CHAIN) g.n_chain_frames += 1;
         }
     }
     A.redo_out[b] = n;
-    if (n < A.n_frames) *A.any_redo = 1;
+    if (CHAIN && n < A.n_frames) *A.any_redo = 1;
 }
+__global__ void __launch_bounds__(64) k_sync_validate(SyncArgs A) { sync_validate_body<false>(A); }
+__global__ void __launch_bounds__(64) k_sync_validate_chain(SyncArgs A) { sync_validate_body<true>(A); }
 
 // Continuous mode (dabphy_set_track_slevel): the level follows the tracked frames one by one (3 ms per frame on one lane: meant for
 // the single-ensemble real-time receiver, where it is 3 % of a frame's 96 ms) instead of catching up when lock is lost.
@@ -888,6 +946,10 @@ void launch_sync_wide(const SyncArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_sync_find_wide, dim3(a.n_frames, a.n_ens), dim3(FFT_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_sync_validate, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+    // what the judge did not accept: the find chain, the sums of its frames, its judge (work-groups with nothing to do return at once)
+    hipLaunchKernelGGL(k_sync_find_chain, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_sync_validate_chain, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
 }
 void launch_sync_find(const SyncArgs& a, hipStream_t s)
 {
