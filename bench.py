@@ -297,6 +297,40 @@ def mixed_layouts_leg(capi, workload, torch, lib_path, B, F, steps, local, sched
     return out
 
 
+def msc_drain_leg(dev, torch, B, F, steps, n_services):
+    """What the headline leaves in HBM: the decoded logical frames of EVERY service (B x 18 sub-channels x 4F frames x 192 bytes).  Here they
+    all reach the host, every step, through the bulk drain (dabphy_msc_drain_begin: one device-to-host copy per protection class into
+    page-locked memory + an index table; msc-handler.cpp:129-158 / dab-audio.cpp:151-160 for a whole batch) OVERLAPPED with the next step:
+    the drain of batch k is in flight while batch k + 1 is synchronised and demodulated, its decoders wait for it on the device.  Timed on
+    the headline's handle right after the timed region; never `value`."""
+    nb, nd = dev.msc_batch_size()
+    assert nd == n_services, (nd, n_services)
+    pinned = dev.host_alloc((nb,), np.uint8)
+    desc = None                                                   # (the binding allocates the index table)
+    out = {}
+    try:
+        # the drain alone: the device otherwise idle
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter(); dev.msc_batch(pinned, desc); t.append(time.perf_counter() - t0)
+        out["drain_alone_ms"] = min(t) * 1e3; out["drain_alone_GBps"] = nb / min(t) / 1e9
+        # overlapped with the steps
+        dev.process(F); dev.superframes_stats()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            _, dsc = dev.msc_drain_begin(pinned, desc)            # batch k leaves ...
+            dev.process(F); dev.superframes_stats(); dev.fibs_host()      # ... while batch k + 1 is decoded
+            dev.msc_drain_wait()                                  # all services of batch k are on the host
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        rows = int((dsc["n_rows"] - dsc["first_valid"]).sum())
+        out.update(ms_per_step_all_services_on_the_host=dt * 1e3, value=B * F * FRAME_S / dt, unit="x real-time", services=int(nd), bytes_per_step=int(nb),
+                   logical_frames_per_step=rows, host_GBps=nb / dt / 1e9,
+                   what="every step: dabphy_msc_drain_begin (one copy per protection class into page-locked memory) -> the next dabphy_process -> dabphy_msc_drain_wait; the headline's handle, after its timed region")
+    finally:
+        dev.msc_drain_wait(); dev.host_free(pinned)
+    return out
+
+
 def channel_leg(capi, workload, torch, lib_path, B, F, steps, local, sched, kind, device="cuda"):
     """The headline's batch geometry on signals as a receiver MEETS them; timed after the headline, never `value`.
       kind "drift":   every ensemble has its own sampling-clock offset, +-1 ... +-50 ppm (log-uniform), sigma 0.02, a NON-looping stream:
@@ -696,6 +730,12 @@ def main():
             del dst
         except Exception as ex:
             line["roofline"]["measured_copy_error"] = "%s: %s" % (type(ex).__name__, ex)
+        if world == 1 and not args.no_extras:
+            try:
+                line["msc_drain"] = msc_drain_leg(dev, torch, B, F, args.steps, B * len(subchs))
+                line["msc_drain"]["vs_headline"] = line["msc_drain"]["value"] / value
+            except Exception as ex:
+                line["msc_drain"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         line["config"]["schedule"] = {0: "serial synchroniser", 1: "pipelined: the next batch's synchroniser starts behind this batch's demod kernel",
                                       2: "pipelined: the next batch's synchroniser starts at once (shares the device with the demod kernel)",
                                       3: "pipelined two batches ahead: the synchroniser of batch k + 2 starts behind batch k's demod kernel"}[sched]

@@ -26,6 +26,7 @@ import json, sys
 try:
     j = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
     print("value %.0f  ms %.3f  frac %.4f  stages %s" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], {k: round(v, 3) for k, v in j["stages_ms"].items()}))
+    if "msc_drain" in j: print("  msc_drain", {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in j["msc_drain"].items() if kk != "what"})
     for k, v in (j.get("extras") or {}).items():
         if isinstance(v, dict):
             print(" ", k, {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("value", "ms_per_step", "parity", "parity_error", "error", "wide_sync_stats", "replayed_batches", "demod_ms", "msc_viterbi_ms", "ms_per_step_all_services_on_the_host")})

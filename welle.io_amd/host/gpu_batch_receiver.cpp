@@ -33,7 +33,9 @@ GpuBatchReceiver::~GpuBatchReceiver()
 {
     alive = false;
     active.clear(); streams.clear();                    // the services' decoder threads end (after the frames already queued)
+    dabphy_msc_drain_wait(handle);
     dabphy_destroy(handle);
+    if (drain_buf) dabphy_host_free(drain_buf);
 }
 
 // ---- services: RadioReceiver's methods (radio-receiver.cpp:120-185), per ensemble
@@ -128,6 +130,25 @@ size_t GpuBatchReceiver::process(uint32_t n_frames)
         dirty[e] = 0;
     }
     if (dabphy_process(handle, n_frames) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
+    // every selected service's logical frames of this batch start their way to the host now, in one pass (one copy per protection
+    // class), and travel while the FIBs below are parsed
+    uint32_t n_desc = 0; bool draining = false;
+    {
+        size_t need = 0; uint32_t nd = 0;
+        if (dabphy_msc_batch_size(handle, &need, &nd) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
+        if (nd) {
+            if (need > drain_cap) {
+                if (drain_buf) dabphy_host_free(drain_buf);
+                drain_buf = nullptr; drain_cap = 0;
+                void* p = nullptr;
+                if (dabphy_host_alloc(need + need / 4, &p) != DABPHY_OK) throw std::runtime_error("GpuBatchReceiver: dabphy_host_alloc failed");
+                drain_buf = static_cast<uint8_t*>(p); drain_cap = need + need / 4;
+            }
+            if (drain_desc.size() < nd) drain_desc.resize(nd);
+            if (dabphy_msc_drain_begin(handle, drain_desc.data(), (uint32_t)drain_desc.size(), &n_desc, drain_buf, drain_cap) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
+            draining = true;
+        }
+    }
     std::vector<dabphy_frame_info> info(B * n_frames);
     std::vector<uint8_t> fibs(B * n_frames * 12 * 32), ok(B * n_frames * 12);
     dabphy_get_frame_info(handle, info.data());
@@ -163,15 +184,21 @@ size_t GpuBatchReceiver::process(uint32_t n_frames)
                 rci[e]->onTIIMeasurement(std::move(t));
             }
         }
-        // thread C of every selected service: its decoded logical frames of this batch, in CIF order (dab-audio.cpp:151-160)
-        for (size_t idx = 0; idx < active[e].size(); idx++) {
-            if (!active[e][idx]) continue;                  // removed since the batch was set up
-            SubchannelStream& st = *active[e][idx];
-            std::vector<uint8_t> out(4 * (size_t)n_frames * st.frame_bytes);
-            int32_t first_valid = 0, n_rows = 0;
-            if (dabphy_get_msc_ensemble(handle, (uint32_t)e, (uint32_t)idx, out.data(), out.size(), &first_valid, &n_rows) != DABPHY_OK) continue;
-            for (int c = first_valid; c < n_rows; c++) st.push(out.data() + (size_t)c * st.frame_bytes, alive);
+    }
+    // thread C of every selected service: its decoded logical frames of this batch, in CIF order (dab-audio.cpp:151-160).  Every
+    // service gets its whole batch in one queue entry, none waits for another; then the back-pressure of DabAudio::process
+    // (dab-audio.cpp:99-106), once per batch: the PHY goes on when every decoder is within kMaxQueued frames of it
+    if (draining) {
+        if (dabphy_msc_drain_wait(handle) != DABPHY_OK) throw std::runtime_error(dabphy_last_error(handle));
+        for (uint32_t k = 0; k < n_desc; k++) {
+            const dabphy_msc_desc& d = drain_desc[k];
+            if (d.ensemble >= B || d.subch_index >= active[d.ensemble].size() || !active[d.ensemble][d.subch_index]) continue;   // removed since the batch was set up
+            SubchannelStream& st = *active[d.ensemble][d.subch_index];
+            if ((int)d.row_bytes != st.frame_bytes || d.n_rows <= d.first_valid) continue;
+            st.push_rows(drain_buf + d.offset + (size_t)d.first_valid * d.row_bytes, d.n_rows - d.first_valid);
         }
+        for (size_t e = 0; e < B; e++)
+            for (auto& a : active[e]) if (a) a->wait_for_space(alive);
     }
     return decoded;
 }

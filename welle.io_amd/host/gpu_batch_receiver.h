@@ -19,7 +19,9 @@
 // (radio-receiver.cpp:120-185 -> MscHandler::addSubchannel / removeSubchannel, msc-handler.cpp:61-127): addServiceToDecode(e, ...) /
 // removeServiceToDecode(e, ...) mirror the facade's methods per ensemble, the selection reaches the library through
 // dabphy_set_subchannels_ensemble before the next batch, and process() hands every selected sub-channel's logical frames to a
-// DecoderAdapter of its own (subchannel_stream.h: one decoder thread per service, as DabAudio::run is).
+// DecoderAdapter of its own (subchannel_stream.h: one decoder thread per service, as DabAudio::run is).  All services of all ensembles
+// leave the device in ONE bulk drain per batch (dabphy_msc_drain_begin: one copy per protection class into page-locked memory, in flight
+// while the FIBs are parsed); every service is handed its whole batch without blocking, back-pressure is applied once per batch.
 #pragma once
 #include <atomic>
 #include <chrono>
@@ -78,6 +80,9 @@ class GpuBatchReceiver {
         std::vector<std::vector<std::shared_ptr<SubchannelStream>>> active;   // [ensemble]: the list the library decodes the current batch with, in its order
         std::vector<char> dirty;                                              // [ensemble]: `streams` changed since the library was told
         std::atomic<bool> alive{true};
+        // bulk drain of a batch's logical frames (dabphy_msc_drain_begin / _wait): page-locked landing buffer and index table, grown on demand
+        uint8_t* drain_buf = nullptr; size_t drain_cap = 0;
+        std::vector<dabphy_msc_desc> drain_desc;
         bool decode_tii = false;
         std::chrono::steady_clock::time_point t0;         // signal time 0 of every ensemble (construction time)
         bool use_signal_clock = true;

@@ -26,6 +26,13 @@ struct SubchannelStream {
     // one logical frame (3 * bitrate bytes, MSB first).  A full queue holds the caller back as DabAudio::process does on a full mscBuffer
     // (dab-audio.cpp:99-106); the wait ends when keep_waiting turns false (a receiver that is being stopped: the frame is dropped with it)
     void push(const uint8_t* frame_bytes_msb_first, const std::atomic<bool>& keep_waiting);
+    // a whole batch of logical frames (n_rows x frame_bytes, CIF order) in ONE queue entry, never blocking: the batch receiver feeds
+    // every service of every ensemble first and applies the back-pressure afterwards, once per batch (wait_for_space), so that a slow
+    // audio decoder holds up neither the other services' hand-over nor their decoding
+    void push_rows(const uint8_t* rows, int n_rows);
+    // blocks while more than kMaxQueued logical frames are waiting for this service's decoder (DabAudio::process waits the same way on
+    // its ring buffer, dab-audio.cpp:99-106); ends when keep_waiting turns false
+    void wait_for_space(const std::atomic<bool>& keep_waiting);
     Subchannel sub;
     int frame_bytes;
     static constexpr size_t kMaxQueued = 64;          // logical frames a sub-channel's decoder thread may lag behind the channel decoder
@@ -35,7 +42,8 @@ struct SubchannelStream {
     void run();
     DecoderAdapter adapter;
     std::mutex m; std::condition_variable cv, cv_space;
-    std::deque<std::vector<uint8_t>> q;
+    std::deque<std::vector<uint8_t>> q;                  // entries of one or more whole logical frames
+    size_t queued_frames = 0;
     bool closing = false;
     std::thread thread;
 };
