@@ -316,12 +316,19 @@ def msc_drain_leg(dev, torch, B, F, steps, n_services):
         out["drain_alone_ms"] = min(t) * 1e3; out["drain_alone_GBps"] = nb / min(t) / 1e9
         # overlapped with the steps
         dev.process(F); dev.superframes_stats()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize(); t0 = time.perf_counter(); acc = {}; t_begin = t_wait = 0.0
         for _ in range(steps):
+            ta = time.perf_counter()
             _, dsc = dev.msc_drain_begin(pinned, desc)            # batch k leaves ...
+            tb = time.perf_counter()
             dev.process(F); dev.superframes_stats(); dev.fibs_host()      # ... while batch k + 1 is decoded
+            tc = time.perf_counter()
             dev.msc_drain_wait()                                  # all services of batch k are on the host
+            t_begin += tb - ta; t_wait += time.perf_counter() - tc
+            for k, v in dev.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        out.update(stages_ms={k: v / steps for k, v in acc.items()}, host_ms_in_drain_begin=t_begin / steps * 1e3, host_ms_in_drain_wait=t_wait / steps * 1e3)
         rows = int((dsc["n_rows"] - dsc["first_valid"]).sum())
         out.update(ms_per_step_all_services_on_the_host=dt * 1e3, value=B * F * FRAME_S / dt, unit="x real-time", services=int(nd), bytes_per_step=int(nb),
                    logical_frames_per_step=rows, host_GBps=nb / dt / 1e9,
@@ -473,15 +480,24 @@ def main():
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # TEST ONLY (tests/test_dist_gloo.py, GPU-less machine): the N-rank GLUE of this file -- argument handling, rendezvous, per-step gather,
+    # max-over-ranks timing, every rank's own parity leg, the parked ranks, the line -- over gloo with every rank's handle on the kernels'
+    # CPU execution model (tests/hipemu).  Nothing of it is a measurement; the line says "data": "emulator".
+    emu = os.environ.get("DABPHY_BENCH_EMU") == "1"
+    assert emu or torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     assert world == args.gpus or "WORLD_SIZE" in os.environ, (world, args.gpus)
+    if "WORLD_SIZE" in os.environ and world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks\n" % (args.gpus, world)); sys.exit(2)
     if os.environ.get("DABPHY_SHARE_GPU") == "1":            # TEST ONLY (1-GPU box): several ranks on one device; RCCL refuses that, so the
         local = local % torch.cuda.device_count()            # collective then runs over gloo (DABPHY_DIST_BACKEND=gloo)
-    torch.cuda.set_device(local)
+    cdev = "cpu" if emu else "cuda"
+    dev_sync = (lambda: None) if emu else torch.cuda.synchronize
+    if not emu:
+        torch.cuda.set_device(local)
     dist = None; backend = None
     if world > 1 or os.environ.get("DABPHY_FORCE_DIST") == "1":    # (the env switch lets a 1-GPU box exercise the RCCL path with one rank)
         import torch.distributed as dist
-        backend = os.environ.get("DABPHY_DIST_BACKEND", "nccl")
+        backend = "gloo" if emu else os.environ.get("DABPHY_DIST_BACKEND", "nccl")
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
         # a rendezvous or an RCCL bring-up that hangs (a missing rank, an IPC handle the driver refuses) would otherwise sit silently
@@ -500,7 +516,7 @@ def main():
         dog.cancel()
     load_package()
     from welle_io_amd import capi, workload
-    from welle_io_amd.distributed import gather_fibs
+    from welle_io_amd.distributed import FibGatherer
 
     B, F = args.ensembles, args.frames
     rec_frames = workload.rec_frames_for(F)                # the looping recording is at least one batch long: a step reads every sample once
@@ -511,24 +527,28 @@ def main():
     def _slow_signal():
         sys.stderr.write("bench.py rank %d/%d: building the synthetic signal took more than 900 s -- giving up\n" % (rank, world)); sys.stderr.flush(); os._exit(4)
     dog2 = threading.Timer(900.0, _slow_signal); dog2.daemon = True; dog2.start()
-    iq, cfo_hz, base, txs = workload.make_batch(B, rank=rank, cfo_max_hz=args.cfo_max_hz, device="cuda", rec_frames=rec_frames)
+    iq, cfo_hz, base, txs = workload.make_batch(B, rank=rank, cfo_max_hz=args.cfo_max_hz, device=cdev, rec_frames=rec_frames, n_distinct=min(4, B))
     dog2.cancel()
     N = iq.shape[1]
-    torch.cuda.synchronize()
+    dev_sync()
     subchs = txs[0].subchs
-    lib_path = os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so"))
+    lib_path = os.environ.get("DABPHY_LIB", os.path.join(ROOT, "tests", "hipemu", "libdabphy_emu.so") if emu else os.path.join(PKG_DIR, "libdabphy_hip.so"))
     chunk = int(os.environ.get("DABPHY_DEMOD_CHUNK", "0"))
     sched = int(os.environ.get("DABPHY_PIPELINE", "1"))
-    dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=sched, demod_chunk=chunk)
+    dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=0 if emu else local, pipeline_sync=sched, demod_chunk=chunk)
+
+    # the one collective of the path: send buffer, rank 0's receive list and its page-locked landing area exist before the first step
+    gatherer = FibGatherer(dist, rank, world, (B, F, 12, 32), (B, F, 12), ("cuda:%d" % local) if backend == "nccl" else "cpu") if dist is not None else None
 
     def step():
         dev.process(F)
         sf = dev.superframes_stats()                       # DAB+ superframe filter of all 18 sub-channels on the device: Fire-code sync, RS, AU CRCs
         if dist is not None:                               # final FIC gather to rank 0 over RCCL/xGMI, straight from the library's HBM buffers
-            d_fib, d_ok = dev.fibs_device()
-            if backend != "nccl":                          # (gloo, test only: host tensors)
-                d_fib, d_ok = d_fib.cpu(), d_ok.cpu()
-            got = gather_fibs(dist, d_fib, d_ok, rank, world)
+            if backend == "nccl":
+                d_fib, d_ok = dev.fibs_device()
+            else:                                          # (gloo, test only: the library's page-locked host copies)
+                d_fib, d_ok = dev.fibs_host()
+            got = gatherer.gather(d_fib, d_ok)
             fib, ok = got[0] if rank == 0 else (None, None)     # rank 0 now holds every rank's FIBs on its host
         else:
             fib, ok = dev.fibs_host()                      # decoded FIBs + CRC flags on the host (page-locked copies that came back with the batch)
@@ -536,12 +556,13 @@ def main():
 
     # the device idles at a fraction of its clock while the signal is built: bring it up before anything is decoded, so that the
     # warm-up steps (and a profiler's per-kernel averages over the whole run) see the clocks the timed steps see
-    spin = torch.randn(4096, 4096, device="cuda")
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.25:
-        spin = torch.tanh(spin @ spin)
-        torch.cuda.synchronize()
-    del spin
+    if not emu:
+        spin = torch.randn(4096, 4096, device="cuda")
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.25:
+            spin = torch.tanh(spin @ spin)
+            torch.cuda.synchronize()
+        del spin
     # warm-up: acquisition, time-de-interleaver fill, superframe synchronisation.  Rank 0 logs what two ensembles of the batch (first
     # and last) deliver from the very first frame on: the parity leg below compares it with CPU receivers decoding the same rows.
     # Rank 0 of a single-GPU run: eight ensembles spread over the batch (all four recordings, both ends), compared below with the real
@@ -583,13 +604,13 @@ def main():
     stage_acc = {}
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         for k, v in dev.stage_times().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
-    torch.cuda.synchronize()
+    dev_sync()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -647,7 +668,7 @@ def main():
                 sys.stderr.write("bench.py rank %d/%d: rank 0 did not finish its CPU baseline within 1500 s -- giving up\n" % (rank, world)); sys.stderr.flush(); os._exit(5)
             time.sleep(0.25)
     if rank == 0:
-        n_simd = 4 * torch.cuda.get_device_properties(local).multi_processor_count
+        n_simd = 1024 if emu else 4 * torch.cuda.get_device_properties(local).multi_processor_count
         ms_step = dt / args.steps * 1e3
         value = world * B * F * FRAME_S / (dt / args.steps)
         stages = {k: v / args.steps for k, v in stage_acc.items()}
@@ -659,7 +680,7 @@ def main():
         line = {
             "metric": "DAB Mode-I ensembles/s (x real-time)", "value": value, "unit": "x real-time (ensembles decoded concurrently)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (FFT/demap) + u16 (Viterbi metrics) + u8 (GF(256))", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (FFT/demap) + u16 (Viterbi metrics) + u8 (GF(256))", "data": "emulator: NOT a measurement (DABPHY_BENCH_EMU=1: the N-rank glue on the kernels' CPU execution model)" if emu else "synthetic",
             "config": {"workload": "1xMI355X: batch of %d synthetic Mode-I ensembles x %d frames (2.048 Msps cf32, HBM-resident, 18 x 64 kbit/s DAB+ EEP-3A sub-channels each), full chain incl. Viterbi + Reed-Solomon" % (B, F),
                        "ensembles_per_gpu": B, "frames_per_step": F, "recording_frames": rec_frames, "cfo_hz": "uniform +-%g per ensemble" % args.cfo_max_hz, "frames_per_s": world * B * F / (dt / args.steps), "sharding": "by ensemble, %d per GPU" % B,
                        "demod_chunk": dev.demod_chunk(), "exact_batch_mode": "on (dabphy_config.no_batch_replay = 0): batches decoded a second time in this run: %d" % dev.replayed_batches(), "superframe_wide_pass": "(ensemble, sub-channel) batches settled by the filter's wide pass / tried: %d / %d (the rest walked frame by frame)" % dev.wide_superframe_stats(), "parity_test": "tests/test_gpu_bench_config.py decodes this configuration against the oracle"},
@@ -714,6 +735,8 @@ def main():
         # (dabphy_time_copy, the recipe MI355X_MICROARCH.md quotes 6.29 TB/s for; tools/ubench/copy_f4.hip sweeps it), 2 GiB in + 2 GiB out
         # per pass; torch's copy_ beside it (round 3's denominator: it flattered)
         try:
+            if emu:
+                raise RuntimeError("emulator run: no copy measured")
             sweep = {k: dev.time_copy(2 << 30, k, 5) for k in (2, 4, 8, 16)}
             cg = max(sweep.values())
             line["roofline"]["measured_copy_GBps"] = cg

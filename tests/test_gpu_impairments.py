@@ -54,4 +54,4 @@ def test_find_chain_follows_drifting_windows_at_the_benchmark_geometry(gpu):
     every FIB, corrector, soft bit, MSC byte and superframe total of the checked ensembles equals the oracle's"""
     P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 1, 2, 3, 254, 255], n_steps=2,
                          channels=[dict(ppm=60.0), dict(ppm=-100.0), dict(ppm=3.0), dict(ppm=-30.0)],
-                         min_chain_frames=256 * 40, cfo_max_hz=4.0)
+                         min_chain_frames=256 * 32, cfo_max_hz=4.0)

@@ -113,12 +113,14 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreate(&h->ev_chain_beg[i]) != hipSuccess || hipEventCreate(&h->ev_chain_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) if (hipEventCreateWithFlags(&h->ev_wide_done[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     {
-        void* p = nullptr;
-        if (hipMalloc(&p, sizeof(int32_t) * dabphy_handle::N_DESC) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
-        h->owned.push_back(p); h->d_any_redo = reinterpret_cast<int32_t*>(p);
+        // the wide synchroniser pass's verdict flags: page-locked HOST memory the last judge kernel writes directly (d_any_redo = the
+        // device's address of the same words)
+        void* p = nullptr; void* dp = nullptr;
         if (hipHostMalloc(&p, sizeof(int32_t) * dabphy_handle::N_DESC, hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
         h->h_any_redo = reinterpret_cast<int32_t*>(p);
         for (int i = 0; i < dabphy_handle::N_DESC; i++) h->h_any_redo[i] = 0;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(DABPHY_ERR_HIP);
+        h->d_any_redo = reinterpret_cast<int32_t*>(dp);
     }
     {
         void* p = nullptr; const size_t n = (size_t)cfg->n_ensembles * cfg->max_frames;

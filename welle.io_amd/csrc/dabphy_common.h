@@ -17,6 +17,9 @@
 #endif
 #define DABPHY_WRONG_RESULTS_BUILD 1
 #endif
+#if (defined(DEMOD_EXP_NODEMAP) || defined(DEMOD_EXP_NOFFT) || defined(DEMOD_EXP_OSC_F32)) && !defined(DABPHY_EXPERIMENTS)
+#error "DEMOD_EXP_* switches are timing experiments that demodulate wrong results: build them with -DDABPHY_EXPERIMENTS"
+#endif
 #if defined(DEMOD_FORCE_CHECKED) && !defined(DABPHY_EXPERIMENTS)
 #error "DEMOD_FORCE_CHECKED is a timing experiment: build it with -DDABPHY_EXPERIMENTS"
 #endif

@@ -248,7 +248,11 @@ int dabphy_msc_drain_begin(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t des
     for (size_t c = 0; c < h->classes.size(); c++) {
         const auto& cls = h->classes[c];
         const size_t bytes = cls.pairs.size() * (size_t)4 * F * (cls.prot.nbits / 8);
-        if (bytes) HIPCHK(h, hipMemcpyAsync(buf + off[c], cls.out.p, bytes, hipMemcpyDeviceToHost, h->drain_stream));
+        // (pieces of a few MB: a copy engine works its queues off packet by packet, and one 100 MB packet would hold up the small
+        // transfers of the next dabphy_process -- descriptors, FIBs -- that share the engine)
+        constexpr size_t PIECE = (size_t)4 << 20;
+        for (size_t at = 0; at < bytes; at += PIECE)
+            HIPCHK(h, hipMemcpyAsync(buf + off[c] + at, cls.out.as<uint8_t>() + at, std::min(PIECE, bytes - at), hipMemcpyDeviceToHost, h->drain_stream));
     }
     HIPCHK(h, hipEventRecord(h->ev_drain_done, h->drain_stream));
     h->drain_pending = true;

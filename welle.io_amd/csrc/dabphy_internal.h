@@ -140,7 +140,7 @@ struct dabphy_handle {
     // wide synchroniser pass (all frames of a batch at once, k_sync_find_wide/_finish_wide/_validate) and its serial fall-back
     bool wide_sync = true;            // cfg.serial_sync == 0 (DABPHY_SYNC_WIDE overrides)
     DevBuf s_redo[N_DESC];            // [B] first frame slot the wide pass did not settle
-    int32_t* d_any_redo = nullptr;    // [N_DESC] device flags; h_any_redo: their page-locked host copies
+    int32_t* d_any_redo = nullptr;    // [N_DESC] verdict flags in page-locked host memory: h_any_redo = the host's address, d_any_redo = the device's
     int32_t* h_any_redo = nullptr;
     hipEvent_t ev_wide_done[N_DESC]{};
     bool wide_pending[N_DESC]{};      // the wide pass of this descriptor buffer has been queued, its verdict not yet read

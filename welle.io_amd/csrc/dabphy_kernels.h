@@ -84,7 +84,8 @@ struct SyncArgs {
     FrameDesc* hist; int hist_cap;                       // [B][hist_cap] ring of the window searches since the last acquisition (sLevel replay)
     float level_max;                                     // upper bound of OFDMProcessor::sLevel for this stream (3e38: unknown): where the bracketing replay starts from above
     const int32_t* redo_from;                            // serial chain: [B] first frame slot the wide pass did not settle (nullptr: no wide pass ran)
-    int32_t* redo_out; int32_t* any_redo;                // k_sync_validate: [B] and a flag
+    int32_t* redo_out; int32_t* any_redo;                // k_sync_validate: [B] and a flag (page-locked HOST memory, written by the last judge of the pass: no copy stands between the verdict and the host)
+    int last_round;                                      // k_sync_validate_chain: this is the pass's last judge (it raises any_redo for what is left)
 };
 
 struct DemodArgs {

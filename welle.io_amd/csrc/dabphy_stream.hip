@@ -52,10 +52,11 @@ int queue_chain(dabphy_handle* h, int sel, uint32_t F)
     { hipError_t e = hipEventRecord(h->ev_chain_beg[sel], h->sync_stream); (void)e; }
     // one frame per call (the real-time facade) gains nothing from the wide pass; two batches ahead its verdict would come too late
     if (h->wide_sync && F >= 2 && h->cfg.pipeline_sync != 3 && !h->track_slevel) {
-        HIPCHK(h, hipMemsetAsync(h->d_any_redo + sel, 0, sizeof(int32_t), h->sync_stream));
+        // the verdict lands in page-locked host memory straight from the last judge kernel (no copy that could queue behind a bulk
+        // transfer on the DMA engines); the host clears it here: the buffer's previous pass has been resolved
+        h->h_any_redo[sel] = 0;
         sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel;
         launch_sync_wide(sa, h->sync_stream);
-        HIPCHK(h, hipMemcpyAsync(h->h_any_redo + sel, h->d_any_redo + sel, sizeof(int32_t), hipMemcpyDeviceToHost, h->sync_stream));
         HIPCHK(h, hipEventRecord(h->ev_wide_done[sel], h->sync_stream));
         h->wide_pending[sel] = true; h->n_wide_passes++;
     } else {

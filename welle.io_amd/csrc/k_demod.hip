@@ -64,6 +64,16 @@ __device__ __forceinline__ void osc_half(cf32 (&o)[8], const OscChain& k, const 
     }
     // e[j] = base * exp(-j 2 pi (128 h + 256 j) f / RATE) as a tree of depth 3 (steps of 256, 512, 1024 samples) instead of a chain of
     // seven dependent double-precision complex multiplications: same operation count, no latency chain (and a shorter error chain)
+#ifdef DEMOD_EXP_OSC_F32               // (timing experiment only, profiles/r06_demod_split.txt: the same tree in single precision -- what the
+    {                                  //  double-precision arithmetic itself costs; the values are wrong in the last bits)
+        auto fm = [](cf32 a, cf32 b) { cf32 r; r.re = a.re * b.re - a.im * b.im; r.im = a.re * b.im + a.im * b.re; return r; };
+        auto f32 = [](dc64 a) { cf32 r; r.re = (float)a.re; r.im = (float)a.im; return r; };
+        const cf32 b0 = f32(k.base), s128 = f32(k.d128), s256 = f32(k.d256), s512 = f32(k.d512), s1024 = f32(k.d1024);
+        o[0] = h ? fm(b0, s128) : b0; o[1] = fm(o[0], s256); o[2] = fm(o[0], s512); o[3] = fm(o[1], s512);
+        o[4] = fm(o[0], s1024); o[5] = fm(o[1], s1024); o[6] = fm(o[2], s1024); o[7] = fm(o[3], s1024);
+        return;
+    }
+#endif
     dc64 e[8];
     e[0] = h ? osc_mul(k.base, k.d128) : k.base;
     e[1] = osc_mul(e[0], k.d256);
@@ -281,6 +291,18 @@ __global__ void __launch_bounds__(FFT_THREADS, DEMOD_WAVES) k_demod(DemodArgs A)
         cur.ph -= ms.sTS; if (cur.ph < 0) cur.ph += INPUT_RATE;
         // the base is re-anchored every OSC_REANCHOR symbols: the unchecked conversion's error budget (osc_exact.h) counts on it
         if (A.mix && s + 1 < s_end) osc.base = osc_mul(base0, s_symstep[s + 1 - s_begin]);
+#ifdef DEMOD_EXP_NODEMAP            // (timing experiment only, profiles/r06_demod_split.txt: no differential product, no 127 / |r| scaling, no scatter -- the
+        {                              //  soft-bit stores stay: 24 bytes per thread and symbol straight from the transform's registers)
+            uint32_t* sb = reinterpret_cast<uint32_t*>(softbuf);
+#pragma unroll
+            for (int q = 0; q < 6; q++) {           // (every output of the transform stays alive: 32 floats folded into 6 words)
+                uint32_t acc = __float_as_uint(v[q].re) ^ __float_as_uint(v[q].im) ^ __float_as_uint(v[q + 6].re) ^ __float_as_uint(v[q + 6].im);
+                if (q < 4) acc ^= __float_as_uint(v[q + 12].re) ^ __float_as_uint(v[q + 12].im);
+                sb[t + 128 * q] = acc;
+            }
+            continue;
+        }
+#endif
         cf32 r1[N_SLOTS]; float l1[N_SLOTS];
         {
             cf32 cs[N_SLOTS]; carrier_slots(cs, v, t);

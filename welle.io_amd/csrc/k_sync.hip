@@ -549,6 +549,7 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
 // state the frame starts from and, when the search succeeded, gets back the state the NEXT frame starts from if the fine corrector does not
 // move).  Returns true when the descriptor is left pending (valid = 2) for k_sync_finish.
 constexpr int SYNC_CALM_MIN = 8;
+constexpr int SYNC_CHAIN_ROUNDS = 3;
 template <int MODE>
 __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, const int frame, SyncIn& chain_st)
 {
@@ -914,7 +915,7 @@ __device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
         }
     }
     A.redo_out[b] = n;
-    if (CHAIN && n < A.n_frames) *A.any_redo = 1;
+    if (CHAIN && A.last_round && n < A.n_frames) *A.any_redo = 1;
 }
 __global__ void __launch_bounds__(64) k_sync_validate(SyncArgs A) { sync_validate_body<false>(A); }
 __global__ void __launch_bounds__(64) k_sync_validate_chain(SyncArgs A) { sync_validate_body<true>(A); }
@@ -946,10 +947,16 @@ void launch_sync_wide(const SyncArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_sync_find_wide, dim3(a.n_frames, a.n_ens), dim3(FFT_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_sync_validate, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
-    // what the judge did not accept: the find chain, the sums of its frames, its judge (work-groups with nothing to do return at once)
-    hipLaunchKernelGGL(k_sync_find_chain, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_sync_validate_chain, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+    // what the judge did not accept: the find chain, the sums of its frames, its judge (work-groups with nothing to do return at once).
+    // A fine corrector that moves ends an ensemble's round (its later searches were made with the old one): the next round starts from
+    // there.  SYNC_CHAIN_ROUNDS rounds are queued whatever happens; what is left after the last one goes to the serial chain.
+    SyncArgs c = a;
+    for (int r = 0; r < SYNC_CHAIN_ROUNDS; r++) {
+        c.last_round = r == SYNC_CHAIN_ROUNDS - 1;
+        hipLaunchKernelGGL(k_sync_find_chain, dim3(c.n_ens), dim3(FFT_THREADS), 0, s, c);
+        hipLaunchKernelGGL(k_sync_finish_wide, dim3(c.n_frames, c.n_ens), dim3(FINISH_THREADS), 0, s, c);
+        hipLaunchKernelGGL(k_sync_validate_chain, dim3((c.n_ens + 63) / 64), dim3(64), 0, s, c);
+    }
 }
 void launch_sync_find(const SyncArgs& a, hipStream_t s)
 {

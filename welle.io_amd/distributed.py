@@ -32,3 +32,43 @@ def gather_fibs(dist, fib, ok, rank, world, device=None):
         a = g.cpu().numpy()
         out.append((a[:nf].reshape(tuple(fib.shape)), a[nf:].reshape(tuple(ok.shape))))
     return out
+
+
+class FibGatherer:
+    """gather_fibs with everything allocated ONCE (bench.py's N > 1 line times this inside its step): the rank's send buffer, rank 0's
+    receive list and rank 0's page-locked landing area for all ranks' FIBs + CRC flags.  Per step: two device copies into the send
+    buffer, ONE collective (dist.gather to rank 0), and on rank 0 one asynchronous copy per rank into the page-locked tensor and one
+    synchronisation; the arrays handed out are views of that tensor (valid until the next call).
+    shape_fib = (B_local, F, 12, 32), shape_ok = (B_local, F, 12); device: where the collective runs ("cuda:i" for RCCL, "cpu" for gloo)."""
+
+    def __init__(self, dist, rank, world, shape_fib, shape_ok, device):
+        import torch
+        self.dist, self.rank, self.world = dist, rank, world
+        self.shape_fib, self.shape_ok = tuple(shape_fib), tuple(shape_ok)
+        self.nf, self.no = int(np.prod(shape_fib)), int(np.prod(shape_ok))
+        self.device = torch.device(device)
+        n = self.nf + self.no
+        self.send = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self.recv = [torch.empty(n, dtype=torch.uint8, device=self.device) for _ in range(world)] if rank == 0 else None
+        self.host = None
+        if rank == 0:
+            self.host = torch.empty((world, n), dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+            self.views = [(self.host[r, :self.nf].numpy().reshape(self.shape_fib), self.host[r, self.nf:].numpy().reshape(self.shape_ok)) for r in range(world)]
+
+    def gather(self, fib, ok):
+        """fib / ok: torch tensors (device buffers of the library, or host tensors for gloo) or numpy arrays of the shapes given at
+        construction -> rank 0: list of (fib, ok) numpy views per rank, in rank order; other ranks: None"""
+        import torch
+        if not torch.is_tensor(fib):
+            fib, ok = torch.from_numpy(np.ascontiguousarray(fib)), torch.from_numpy(np.ascontiguousarray(ok))
+        assert fib.numel() == self.nf and ok.numel() == self.no, (tuple(fib.shape), tuple(ok.shape), self.shape_fib, self.shape_ok)
+        self.send[:self.nf].copy_(fib.reshape(-1), non_blocking=True)
+        self.send[self.nf:].copy_(ok.reshape(-1), non_blocking=True)
+        self.dist.gather(self.send, self.recv, dst=0)
+        if self.rank != 0:
+            return None
+        for r in range(self.world):
+            self.host[r].copy_(self.recv[r], non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return self.views
