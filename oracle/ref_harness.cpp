@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <atomic>
 #include <thread>
+#include <sys/stat.h>
 #include <chrono>
 #include <vector>
 #include <mutex>
@@ -206,8 +207,26 @@ int ref_receiver_run(ref_run_io* io)
         }
         in.armed = true;
         while (!rec.failed) std::this_thread::sleep_for(std::chrono::milliseconds(2));
-        // let thread B finish the frame in flight and thread C drain its ring buffers
-        std::this_thread::sleep_for(std::chrono::milliseconds(300));
+        // let thread B finish the frame in flight and thread C drain its ring buffers: until nothing has moved for 500 ms -- FIB count,
+        // dump file sizes, superframes seen -- (a fixed 300 ms was too short for a slow decoder build on a loaded machine: RadioReceiver::stop drops
+        // what the sub-channels' ring buffers still hold), at most 20 s
+        {
+            auto activity = [&]() {
+                long long a = rec.n_fib;
+                for (int i = 0; i < io->n_subch; i++) {
+                    struct stat st;
+                    if (io->subch[i].dump_path[0] && stat(io->subch[i].dump_path, &st) == 0) a += (long long)st.st_size;      // (buffered: moves every 4 KiB)
+                    a += handlers[i].rs_calls;                                                                                // (every superframe of a DAB+ service)
+                }
+                return a;
+            };
+            long long last = activity(); int quiet_ms = 0;
+            for (int waited = 0; quiet_ms < 500 && waited < 20000; waited += 20) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+                const long long now = activity();
+                if (now != last) { last = now; quiet_ms = 0; } else quiet_ms += 20;
+            }
+        }
         rx.stop();
         rec.rx = nullptr;
     }   // ~RadioReceiver joins threads and closes the dump files

@@ -25,30 +25,55 @@ if not os.path.exists(R.GPU_HIP_SO):
 run(6)                                                        # warm-up: library, tables
 t1, _ = run(40)
 t2, b = run(120)
-def run_build(lib, nf):
-    """the reference's own RadioReceiver (all its threads) behind the recording harness, from the build `lib`, over nf frames"""
+def run_build(lib, nf, n_services=2):
+    """the reference's own RadioReceiver (all its threads) behind the recording harness, from the build `lib`, over nf frames;
+    -> (wall seconds, CPU seconds of the whole process: every thread of the receiver, user + system, result)"""
+    import resource
     x, tx = synth.make_stream(nf, snr_db=20, cfo_hz=40, delay=100, seed=3, return_tx=True)
-    t = time.time()
-    a = R.receiver_run(x, subchs=[tx.subchs[2], tx.subchs[11]], lib=lib)
-    return time.time() - t, a
+    subs = [tx.subchs[2], tx.subchs[11]] if n_services == 2 else list(tx.subchs[:n_services])
+    r0 = resource.getrusage(resource.RUSAGE_SELF); t = time.time()
+    a = R.receiver_run(x, subchs=subs, lib=lib)
+    dt = time.time() - t; r1 = resource.getrusage(resource.RUSAGE_SELF)
+    return dt, (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime), a
+
+
+def seam_stats(lib):
+    """device calls / code words of the Viterbi seam's shared decoder (welle.io_amd/host/seams/viterbi_seam.cpp) so far in this process"""
+    import ctypes as C
+    try:
+        L = C.CDLL(lib); a = C.c_ulonglong(0); b = C.c_ulonglong(0)
+        L.dabphy_seam_viterbi_stats(C.byref(a), C.byref(b))
+        return a.value, b.value
+    except Exception:
+        return None
 
 
 def level2():
     """INTEGRATION.md level 2 (BASELINE config 2): the reference backend with ONE source file replaced by a seam binding, next to the
-    unmodified build on the same host: ms per 96 ms frame (slope between 30 and 90 frames), one ensemble, two services selected"""
+    unmodified build on the same host, one ensemble: wall ms and CPU ms (all threads of the receiver) per 96 ms frame (slopes between 30
+    and 90 frames; the harness waits 0.5 s for the decoders to go quiet: that wait is in neither slope), with two services selected and
+    with all 18 -- where the channel decoders are what the host's cores do (viterbi.cpp: 24 of the reference's 30 CPU ms per frame)"""
     out = {}
     for name, lib, what in (("reference", None, "the unmodified reference backend (CPU)"),
                             ("l2a", R.level2_lib("a", "hip"), "ofdm-decoder.cpp -> seams/ofdm_decoder_seam.cpp: FFT + DQPSK demap + frequency de-interleaver on the device, Viterbi on the CPU"),
-                            ("l2b", R.level2_lib("b", "hip"), "viterbi.cpp -> seams/viterbi_seam.cpp: every Viterbi::deconvolve on the device (one code word per call), the rest on the CPU")):
+                            ("l2b", R.level2_lib("b", "hip"), "viterbi.cpp -> seams/viterbi_seam.cpp: every Viterbi::deconvolve on the device through ONE shared handle; concurrent calls (the sub-channels of a CIF) are combined into one batch per code word length, the rest on the CPU")):
         if lib is not None and not os.path.exists(lib):
             out[name] = {"error": "%s not built" % os.path.basename(lib)}
             continue
         try:
             run_build(lib, 6)
-            ta, _ = run_build(lib, 30)
-            tb, a = run_build(lib, 90)
+            ta, ca, _ = run_build(lib, 30)
+            tb, cb, a = run_build(lib, 90)
             ms = (tb - ta) / 60 * 1e3
-            out[name] = {"what": what, "ms_per_frame": ms, "x_realtime": 96.0 / ms, "fib_crc_ok": int(a["fib"][:, 0].sum()), "fibs": int(len(a["fib"]))}
+            out[name] = {"what": what, "ms_per_frame": ms, "cpu_ms_per_frame": (cb - ca) / 60 * 1e3, "x_realtime": 96.0 / ms, "fib_crc_ok": int(a["fib"][:, 0].sum()), "fibs": int(len(a["fib"]))}
+            if name != "l2a":
+                s0 = seam_stats(lib) if name == "l2b" else None
+                ta, ca, _ = run_build(lib, 30, 18)
+                tb, cb, a = run_build(lib, 90, 18)
+                out[name]["all_18_services"] = {"ms_per_frame": (tb - ta) / 60 * 1e3, "cpu_ms_per_frame": (cb - ca) / 60 * 1e3}
+                s1 = seam_stats(lib) if name == "l2b" else None
+                if s0 and s1 and s1[0] > s0[0]:
+                    out[name]["all_18_services"]["code_words_per_device_call"] = (s1[1] - s0[1]) / (s1[0] - s0[0])
         except Exception as ex:
             out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return out
