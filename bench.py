@@ -412,6 +412,21 @@ def channel_leg(capi, workload, torch, lib_path, B, F, steps, local, sched, kind
         out.update(parity=False, parity_error=str(ex))
     finally:
         dev.close()
+    if kind == "drift" and device == "cuda" and sched in (1, 3):
+        # the same signal with the next batch's synchroniser always queued BEHIND the decoder (dabphy_config.sync_early = 1; the default
+        # moves it in front while it meets ensembles whose window moves): timing only
+        try:
+            dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=sched, loop=loop, sync_early=1)
+            for _ in range(n_warm):
+                dev.process(F); dev.superframes_stats()
+            sync_(); t0 = time.perf_counter()
+            for _ in range(steps):
+                dev.process(F); dev.superframes_stats(); dev.fibs_host()
+            sync_(); dt = (time.perf_counter() - t0) / steps
+            out["synchroniser_always_behind_the_decoder"] = {"ms_per_step": dt * 1e3, "value": B * F * FRAME_S / dt, "stages_ms": dev.stage_times()}
+            dev.close()
+        except Exception as ex:
+            out["synchroniser_always_behind_the_decoder"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return out
 
 

@@ -97,6 +97,11 @@ typedef struct {
                                        k_traceback_sp2: a lane per code word, a wave per stretch of it); larger batches one LANE per code word
                                        (k_viterbi_fused: the throughput shape).  1: always lane-per-code-word; 2: always k_viterbi_sp2;
                                        3: always k_viterbi_sp.  Same bytes whichever runs. */
+    int32_t sync_early;             /* pipelined schedules 1 and 3: where the NEXT batch's synchroniser is queued relative to this batch's decoder.
+                                       0 (default): behind it -- its wide pass is throughput work that fits the step's tail -- unless the last pass
+                                       met ensembles whose PRS window moves (a sampling-clock offset: their window searches then run one after
+                                       the other in the find chain, latency-bound work that belongs BESIDE the decoder, not behind it): then in
+                                       front of it, for as long as such ensembles are seen.  1: always behind.  2: always in front.  Same bytes. */
 } dabphy_config;
 #define DABPHY_CONFIG_INIT { (uint32_t)sizeof(dabphy_config) }      /* dabphy_config cfg = DABPHY_CONFIG_INIT;  -- sized, every option at its default */
 

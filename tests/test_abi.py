@@ -73,11 +73,17 @@ def test_sized_configuration(emu):
     C.memset(C.byref(p.cfg), 0, C.sizeof(capi.Config))
     p.cfg.n_ensembles = 1; p.cfg.max_frames = 2; p.cfg.fft_placement = 2; p.cfg.freqsync_method = 2
     h = C.c_void_p()
-    # round 3's fields + the size member, no decode_shape: the poison behind it must not be read
-    p.cfg.struct_size = C.sizeof(capi.Config) - 4; p.cfg.decode_shape = 0x7f7f7f7f
+    # round 3's fields + the size member, no decode_shape, no sync_early: the poison behind them must not be read
+    p.cfg.struct_size = C.sizeof(capi.Config) - 8; p.cfg.decode_shape = 0x7f7f7f7f; p.cfg.sync_early = 0x7f7f7f7f
     assert lib.dabphy_create_v2(C.byref(p), C.byref(h)) == 0
     got = capi.Config(C.sizeof(capi.Config))
-    assert lib.dabphy_get_config_v2(h, C.byref(got)) == 0 and got.decode_shape == 0 and got.max_frames == 2 and got.struct_size == C.sizeof(capi.Config)
+    assert lib.dabphy_get_config_v2(h, C.byref(got)) == 0 and got.decode_shape == 0 and got.sync_early == 0 and got.max_frames == 2 and got.struct_size == C.sizeof(capi.Config)
+    lib.dabphy_destroy(h)
+    # round 5's structure (decode_shape, no sync_early)
+    p.cfg.struct_size = C.sizeof(capi.Config) - 4; p.cfg.decode_shape = 1; h = C.c_void_p()
+    assert lib.dabphy_create_v2(C.byref(p), C.byref(h)) == 0
+    got = capi.Config(C.sizeof(capi.Config))
+    assert lib.dabphy_get_config_v2(h, C.byref(got)) == 0 and got.decode_shape == 1 and got.sync_early == 0
     short = capi.Config(12); short.max_frames = 99
     assert lib.dabphy_get_config_v2(h, C.byref(short)) == 0 and short.struct_size == 12 and short.max_frames == 2 and short.device == 0 and short.fft_placement == 0
     lib.dabphy_destroy(h)

@@ -18,7 +18,7 @@ ABI_VERSION = 6            # DABPHY_ABI_VERSION of the include/dabphy.h these st
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_ensembles", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
                 ("fft_placement", C.c_int32), ("disable_coarse", C.c_int32), ("want_constellation", C.c_int32),
-                ("want_impulse_response", C.c_int32), ("demod_chunk", C.c_int32), ("freqsync_method", C.c_int32), ("pipeline_sync", C.c_int32), ("serial_sync", C.c_int32), ("no_batch_replay", C.c_int32), ("decode_shape", C.c_int32)]
+                ("want_impulse_response", C.c_int32), ("demod_chunk", C.c_int32), ("freqsync_method", C.c_int32), ("pipeline_sync", C.c_int32), ("serial_sync", C.c_int32), ("no_batch_replay", C.c_int32), ("decode_shape", C.c_int32), ("sync_early", C.c_int32)]
 
 
 class Protection(C.Structure):
@@ -59,10 +59,10 @@ def load_library(path=None):
 
 class DabPhy:
     def __init__(self, n_ensembles=1, max_frames=1, device=0, lib_path=None, fft_placement=2, disable_coarse=False,
-                 want_constellation=True, want_impulse_response=True, demod_chunk=0, pipeline_sync=False, freqsync_method=2, serial_sync=False, exact_batch=True, decode_shape=0):
+                 want_constellation=True, want_impulse_response=True, demod_chunk=0, pipeline_sync=False, freqsync_method=2, serial_sync=False, exact_batch=True, decode_shape=0, sync_early=0):
         self.lib = load_library(lib_path)
         cfg = Config(C.sizeof(Config), n_ensembles, max_frames, device, fft_placement, int(disable_coarse), int(want_constellation),
-                     int(want_impulse_response), demod_chunk, freqsync_method, int(pipeline_sync), int(serial_sync), int(not exact_batch), int(decode_shape))   # pipeline_sync: False/True/2
+                     int(want_impulse_response), demod_chunk, freqsync_method, int(pipeline_sync), int(serial_sync), int(not exact_batch), int(decode_shape), int(sync_early))   # pipeline_sync: False/True/2
         self.cfg = cfg
         self.h = C.c_void_p()
         if self.lib.dabphy_abi_version() != ABI_VERSION:

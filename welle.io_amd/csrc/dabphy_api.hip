@@ -26,7 +26,7 @@ struct dabphy_config_r3 {
     uint32_t n_ensembles, max_frames; int32_t device, fft_placement, disable_coarse, want_constellation, want_impulse_response, demod_chunk,
              freqsync_method, pipeline_sync, serial_sync, no_batch_replay;
 };
-static_assert(sizeof(dabphy_config_r3) == 48 && offsetof(dabphy_config, n_ensembles) == 4 && sizeof(dabphy_config) == 4 + sizeof(dabphy_config_r3) + 4, "dabphy_config: fields are appended only");
+static_assert(sizeof(dabphy_config_r3) == 48 && offsetof(dabphy_config, n_ensembles) == 4 && sizeof(dabphy_config) == 4 + sizeof(dabphy_config_r3) + 8, "dabphy_config: fields are appended only");
 int dabphy_create(const dabphy_config_r3* old, dabphy_handle** out)
 {
     if (!old || !out) return DABPHY_ERR_INVALID;
@@ -68,7 +68,7 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
-    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 3) return fail(DABPHY_ERR_INVALID);
+    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 3 || h->cfg.sync_early < 0 || h->cfg.sync_early > 2) return fail(DABPHY_ERR_INVALID);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
@@ -116,9 +116,10 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
         // the wide synchroniser pass's verdict flags: page-locked HOST memory the last judge kernel writes directly (d_any_redo = the
         // device's address of the same words)
         void* p = nullptr; void* dp = nullptr;
-        if (hipHostMalloc(&p, sizeof(int32_t) * dabphy_handle::N_DESC, hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
+        // ([N_DESC] "the serial chain has slots left" + [N_DESC] "the find chain settled frames": ensembles whose window moves)
+        if (hipHostMalloc(&p, sizeof(int32_t) * 2 * dabphy_handle::N_DESC, hipHostMallocDefault) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
         h->h_any_redo = reinterpret_cast<int32_t*>(p);
-        for (int i = 0; i < dabphy_handle::N_DESC; i++) h->h_any_redo[i] = 0;
+        for (int i = 0; i < 2 * dabphy_handle::N_DESC; i++) h->h_any_redo[i] = 0;
         if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(DABPHY_ERR_HIP);
         h->d_any_redo = reinterpret_cast<int32_t*>(dp);
     }

@@ -142,6 +142,7 @@ struct dabphy_handle {
     DevBuf s_redo[N_DESC];            // [B] first frame slot the wide pass did not settle
     int32_t* d_any_redo = nullptr;    // [N_DESC] verdict flags in page-locked host memory: h_any_redo = the host's address, d_any_redo = the device's
     int32_t* h_any_redo = nullptr;
+    bool drift_seen = false;          // the last resolved pass settled frames through the find chain (ensembles whose PRS window moves): cfg.sync_early == 0 then queues the next batch's synchroniser in FRONT of the decoder
     hipEvent_t ev_wide_done[N_DESC]{};
     bool wide_pending[N_DESC]{};      // the wide pass of this descriptor buffer has been queued, its verdict not yet read
     uint64_t chain_valid[N_DESC]{}; uint32_t chain_frames[N_DESC]{};   // n_valid and n_frames the chain of this buffer was queued with

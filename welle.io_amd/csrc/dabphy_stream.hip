@@ -37,6 +37,7 @@ void launch_serial_chain(dabphy_handle* h, SyncArgs sa)
         if (h->track_slevel) launch_slevel_catchup(sa, h->sync_stream);
     }
 }
+constexpr int N_DESC_ = dabphy_handle::N_DESC;
 int queue_chain(dabphy_handle* h, int sel, uint32_t F)
 {
     SyncArgs sa = sync_args(h, sel, F, h->s_valid);
@@ -54,8 +55,8 @@ int queue_chain(dabphy_handle* h, int sel, uint32_t F)
     if (h->wide_sync && F >= 2 && h->cfg.pipeline_sync != 3 && !h->track_slevel) {
         // the verdict lands in page-locked host memory straight from the last judge kernel (no copy that could queue behind a bulk
         // transfer on the DMA engines); the host clears it here: the buffer's previous pass has been resolved
-        h->h_any_redo[sel] = 0;
-        sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel;
+        h->h_any_redo[sel] = 0; h->h_any_redo[N_DESC_ + sel] = 0;
+        sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel; sa.any_chain = h->d_any_redo + N_DESC_ + sel;
         launch_sync_wide(sa, h->sync_stream);
         HIPCHK(h, hipEventRecord(h->ev_wide_done[sel], h->sync_stream));
         h->wide_pending[sel] = true; h->n_wide_passes++;
@@ -71,6 +72,7 @@ int resolve_chain(dabphy_handle* h, int sel)
     if (!h->wide_pending[sel]) return DABPHY_OK;
     HIPCHK(h, hipEventSynchronize(h->ev_wide_done[sel]));
     h->wide_pending[sel] = false;
+    h->drift_seen = h->h_any_redo[N_DESC_ + sel] != 0;         // ensembles whose window moves: their searches ran in the find chain
     if (h->h_any_redo[sel]) {
         SyncArgs sa = sync_args(h, sel, h->chain_frames[sel], h->chain_valid[sel]);
         sa.redo_from = h->s_redo[sel].as<int32_t>();

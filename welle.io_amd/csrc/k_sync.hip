@@ -911,7 +911,7 @@ __device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
             if (g.first_lock_attempts < 0) g.first_lock_attempts = g.attempts;                  // ofdm-processor.cpp:351-355
             state_advance(A, b, g, d);
             g.n_wide_frames += 1;
-            if (CHAIN) g.n_chain_frames += 1;
+            if (CHAIN) { g.n_chain_frames += 1; if (A.any_chain) *A.any_chain = 1; }
         }
     }
     A.redo_out[b] = n;
