@@ -141,6 +141,11 @@ static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned 
     return r;
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_fence(int, const char*) {}
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T> static inline T __hip_atomic_load(T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+template <typename T> static inline void __hip_atomic_store(T* p, T v, int, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 // v_mov_b32 dpp row_shl:k (dpp_ctrl 0x101..0x10f): lane i reads lane i+k of its row of 16, 0 beyond the row (bound_ctrl)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {

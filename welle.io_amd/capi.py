@@ -236,6 +236,10 @@ class DabPhy:
         self._chk(self.lib.dabphy_time_copy(self.h, C.c_uint64(nbytes), blocks_per_cu, iters, C.byref(a)))
         return a.value
 
+    def traceback_split(self, on=True):
+        """the lane-per-code-word kernel's traceback as a pass of its own beside the forward pass (dabphy_test_traceback_split)"""
+        self._chk(self.lib.dabphy_test_traceback_split(self.h, int(on)))
+
     def last_decode_plan(self):
         """(1 = lane per code word / 2 = state-parallel / 0 = nothing decoded yet, protection classes in the fused launch) of the last process()"""
         a = C.c_int32(0); b = C.c_int32(0)

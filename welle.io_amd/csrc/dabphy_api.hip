@@ -160,6 +160,7 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     if (const char* e = getenv("DABPHY_SP2_TB_WARM")) h->sp2_tb_warm = (uint32_t)atoll(e);
     if (const char* e = getenv("DABPHY_SP2_TB_RESIDENT")) h->sp2_tb_resident = (uint32_t)atoll(e);
     if (const char* e = getenv("DABPHY_CHAIN_EARLY")) h->chain_early = atoi(e) != 0;
+    if (const char* e = getenv("DABPHY_TB_SPLIT")) h->tb_split = atoi(e) != 0;      // (the fused decode's traceback as a pass of its own: dabphy_test_traceback_split)
 #endif
     for (int i = 0; i < dabphy_handle::ST_COUNT; i++)
         if (hipEventCreate(&h->ev_beg[i]) != hipSuccess || hipEventCreate(&h->ev_end[i]) != hipSuccess) return fail(DABPHY_ERR_HIP);
@@ -191,6 +192,9 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }
     if (h->fic_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
     if (h->drain_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
+    if (h->tb_stream) { e = hipStreamSynchronize(h->tb_stream); e = hipStreamDestroy(h->tb_stream); }
+    if (h->ev_tb_fork) e = hipEventDestroy(h->ev_tb_fork);
+    if (h->ev_tb_join) e = hipEventDestroy(h->ev_tb_join);
     if (h->ev_drain_done) e = hipEventDestroy(h->ev_drain_done);
     if (h->ev_aux_done) e = hipEventDestroy(h->ev_aux_done);
     for (int i = 0; i < 2; i++) if (h->ev_ingest[i]) e = hipEventDestroy(h->ev_ingest[i]);
@@ -210,7 +214,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->snap_tii.p) e = hipFree(h->snap_tii.p);
     if (h->ev_fic_done) e = hipEventDestroy(h->ev_fic_done);
     if (h->ev_fused_done) e = hipEventDestroy(h->ev_fused_done);
-    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fused_dec_off, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2], &h->sp1_cls, &h->sp1_work}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
+    { DevBuf* fb[] = {&h->fused_cls, &h->fused_work, &h->fused_dec_off, &h->fused_done, &h->fic_steps[0], &h->fic_steps[1], &h->fic_steps[2], &h->sp1_cls, &h->sp1_work}; for (DevBuf* b : fb) if (b->p) e = hipFree(b->p); }
     if (h->h_sp1) e = hipHostFree(h->h_sp1);
     if (h->h_sf_batch) e = hipHostFree(h->h_sf_batch);
     for (int i = 0; i < dabphy_handle::N_DESC; i++) { if (h->ev_chain_beg[i]) e = hipEventDestroy(h->ev_chain_beg[i]); if (h->ev_chain_end[i]) e = hipEventDestroy(h->ev_chain_end[i]); }
@@ -711,6 +715,13 @@ int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, 
     return sync(h);
 }
 
+int dabphy_test_traceback_split(dabphy_handle* h, int32_t on)
+{
+    if (!h) return DABPHY_ERR_INVALID;
+    h->tb_split = on != 0;                                   // (takes effect with the next batch's launch plan)
+    return DABPHY_OK;
+}
+
 int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
 {
     DeviceBind dev_(h);
@@ -723,7 +734,8 @@ int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(h, hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); h->err = "hipEventCreate failed"; return DABPHY_ERR_HIP; }
-    auto again = [&]() { if (P.use_sp) launch_sp(P.args, P.sp_two, P.sp_variant, h->stream); else launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream); };
+    const FusedSplit sp{h->tb_stream, h->ev_tb_fork, h->ev_tb_join};
+    auto again = [&]() { if (P.use_sp) launch_sp(P.args, P.sp_two, P.sp_variant, h->stream); else launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream, P.args.done ? &sp : nullptr); };
     again();                                                                  // (same inputs, same outputs: the launch is idempotent)
     hipError_t e = hipEventRecord(e0, h->stream);
     for (uint32_t i = 0; i < iters; i++) again();

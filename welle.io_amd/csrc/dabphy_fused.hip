@@ -86,7 +86,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
 {
     auto& P = h->fplan;
     // (everything below is a function of the batch depth, the class set and the buffers' addresses: buf_gen moves with the last two)
-    if (P.valid && P.F == F && P.want_fic == want_fic && P.buf_gen == h->buf_gen) return DABPHY_OK;
+    if (P.valid && P.F == F && P.want_fic == want_fic && P.buf_gen == h->buf_gen && P.tb_split == h->tb_split) return DABPHY_OK;
     const uint32_t B = h->cfg.n_ensembles;
     const int R = 4 * (int)F;
     const int v = R >= FUSED_MIN_CIFS[0] ? 0 : R >= FUSED_MIN_CIFS[1] ? 1 : 2;
@@ -153,12 +153,22 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     // Decision scratch of the lane-per-code-word kernel: one region per WORK-GROUP sized for the longest code word of the launch (reused by
     // every group the wave pulls: the headline's shape) -- unless a few very long code words ride among many short ones (one 384 kbit/s
     // service in a multiplex of small ones: 9222 steps x 5120 waves = 24 GB): then one region per GROUP, each of its own length.
-    const bool dec_by_item = !use_sp && item_rows < (uint64_t)n_slots * max_steps && item_rows < 0xffffffffull;
+    // (the traceback as a pass of its own reads a group's decisions after the wave that wrote them has gone on to the next group: per group)
+    const bool tb_split = h->tb_split && !use_sp && item_rows < 0xffffffffull && !work.empty();
+    const bool dec_by_item = !use_sp && (tb_split || item_rows < (uint64_t)n_slots * max_steps) && item_rows < 0xffffffffull;
     int r;
     if (!work.empty()) {
         const size_t dec_cells = use_sp ? (size_t)n_slots * sp_cells : dec_by_item ? (size_t)item_rows * 64 : (size_t)n_slots * max_steps * 64;
         if ((r = ensure(h, h->vdec, dec_cells * sizeof(uint2)))) return r;
         if (dec_by_item && (r = ensure(h, h->fused_dec_off, item_off.size() * sizeof(uint32_t)))) return r;
+        if (tb_split) {
+            if ((r = ensure(h, h->fused_done, (work.size() + 1) * sizeof(uint32_t)))) return r;
+            if (!h->tb_stream) {
+                HIPCHK(h, hipStreamCreateWithFlags(&h->tb_stream, hipStreamNonBlocking));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_tb_fork, hipEventDisableTiming));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_tb_join, hipEventDisableTiming));
+            }
+        }
         if ((r = ensure(h, h->fused_cls, cls.size() * sizeof(FusedClass)))) return r;
         if ((r = ensure(h, h->fused_work, work.size() * sizeof(uint32_t)))) return r;
         if (!h->d_fused_next) {
@@ -184,7 +194,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     }
     if (debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: decode plan for %u frames per call: %s, %zu of %zu classes%s, %zu groups, %d work-groups, decision scratch %s\n", F, use_sp ? (sp_two ? "state-parallel, two code words per wavefront" : "state-parallel") : "lane-per-code-word", idx.size(), h->classes.size(), fic_in ? " + FIC" : "", work.size(), n_slots, dec_by_item ? "per group" : "per work-group");
     P.valid = true; P.F = F; P.want_fic = want_fic; P.fic_in = fic_in; P.variant = v; P.n_slots = n_slots;
-    P.use_sp = use_sp; P.sp_variant = sp_variant; P.sp_two = sp_two; P.dec_by_item = dec_by_item;
+    P.use_sp = use_sp; P.sp_variant = sp_variant; P.sp_two = sp_two; P.dec_by_item = dec_by_item; P.tb_split = h->tb_split;
     P.dec_slot_cells = use_sp ? sp_cells : max_steps * 64;
     P.class_idx = idx; P.buf_gen = h->buf_gen;
     FusedArgs a{};
@@ -193,6 +203,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     a.cls = h->fused_cls.as<FusedClass>(); a.work = h->fused_work.as<uint32_t>(); a.n_work = (uint32_t)work.size(); a.next = h->d_fused_next;
     a.dec = h->vdec.as<uint2>(); a.dec_slot_cells = P.dec_slot_cells; a.prbs_words = h->d_prbs_words;
     a.dec_off = dec_by_item ? h->fused_dec_off.as<uint32_t>() : nullptr;
+    if (tb_split) { a.done = h->fused_done.as<uint32_t>(); a.next_tb = a.done + work.size(); }
     a.sp2_warm = (int)h->sp2_tb_warm; a.sp2_resident = (int)h->sp2_tb_resident;
     P.args = a;
     return DABPHY_OK;

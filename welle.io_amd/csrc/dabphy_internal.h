@@ -119,11 +119,14 @@ struct dabphy_handle {
         bool use_sp = false; int sp_variant = 0; bool sp_two = false;   // ... two code words per wavefront (k_viterbi_sp2)         // the batch is small: one wavefront per code word (k_viterbi_sp) instead of 64 code words per wavefront
         std::vector<int> class_idx;                      // classes decoded by the fused launch (the others take k_msc_gather + k_viterbi)
         std::vector<FusedClass> host_cls; std::vector<uint32_t> host_work, host_dec_off;
+        bool tb_split = false;                           // the launch publishes its groups' decisions for k_traceback_fused (decision scratch then always per group)
         bool dec_by_item = false;                        // decision scratch per group of 64 code words instead of per work-group (dabphy_fused.hip)
         FusedArgs args{}; uint64_t buf_gen = 0;          // the launch as it was last queued (dabphy_time_fused_msc re-runs it alone while buf_gen is current)
         bool launched = false;
     } fplan;
     DevBuf fused_cls, fused_work, fused_dec_off; uint32_t* d_fused_next = nullptr;
+    // the traceback of the lane-per-code-word kernel as a pass of its own beside the forward pass (k_traceback_fused): per-item flags + cursor, its stream
+    bool tb_split = false; DevBuf fused_done; hipStream_t tb_stream = nullptr; hipEvent_t ev_tb_fork = nullptr, ev_tb_join = nullptr;
     bool sp1_two = false;                                // the last one-class launch prepared goes to k_viterbi_sp2
     DevBuf sp1_cls, sp1_work; void* h_sp1 = nullptr;     // one-class state-parallel launches (the seams, the replay's one-frame FIC): descriptor + work list, page-locked staging
     DevBuf fic_steps[FUSED_VARIANTS]; int fic_windows[FUSED_VARIANTS] = {0, 0, 0};

@@ -203,6 +203,9 @@ struct FusedArgs {
     uint2* dec; size_t dec_slot_cells;         // decision scratch of work-group i: dec + i * dec_slot_cells ([step][64 lanes] cells)
     const uint32_t* dec_off;                   // k_viterbi_fused: nullptr, or the scratch goes by work ITEM: item i at dec + dec_off[i] * 64 cells
     const uint32_t* prbs_words;
+    // k_viterbi_fused with the traceback as a pass of its own BESIDE the forward pass (nullptr: the wave that ran a group's trellis walks
+    // it back itself): done[item] is raised when a group's decisions are complete, next_tb is the cursor of the waves that walk back
+    uint32_t* done; uint32_t* next_tb;
     // k_viterbi_sp's one-class launches (dabphy_fused.hip: sp_single): the replay's one-frame FIC, the linear seams
     int fic_frame_sel;                         // kind 1: 0 = every frame of the batch; f + 1 = frame f only (n_cw = 4 B)
     size_t fic_frame_stride;                   // kind 1: bytes between frame slots of `soft` (0: SOFT_PER_FRAME, the ring)
@@ -211,7 +214,9 @@ struct FusedArgs {
     int sp2_resident;                          // k_traceback_sp2: groups of 64 code words up to which a launch cuts the code word into four stretches (above: three)
 };
 // variant = index into FUSED_ROWS; n_slots = work-groups (one wave each) to launch
-void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s);
+// split: the stream the traceback waves are launched on and the two events that fork it off `s` and join it back (a.done != nullptr)
+struct FusedSplit { hipStream_t tb_stream; hipEvent_t fork, join; };
+void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s, const FusedSplit* split = nullptr);
 int fused_wave_slots(int variant);             // resident waves of that variant on the current device
 // State-parallel decode of the same work (k_viterbi_sp.hip): one wavefront per CODE WORD, lanes = the 64 trellis states -- the shape for
 // batches too small to fill the device with 64-code-word waves.  lds_variant = index into SP_MAXSTEPS (the longest code word of the launch);

@@ -338,7 +338,64 @@ template <int ROWS> struct FmGeom {
 #ifndef VITM_OCC
 #define VITM_OCC 5
 #endif
-template <int ROWS, int OCC>
+// ---- the traceback as a pass of its own (FusedArgs::done != nullptr).  A group's decisions go to a scratch region of its own; the wave
+// that ran its trellis RELEASES them (agent scope: the per-XCD L2s are not coherent with each other) and raises done[item]; whoever
+// pulls the item from the next_tb cursor -- the waves of k_traceback_fused, which need 32 registers and ride as a SIXTH wave per SIMD beside
+// five forward waves of 96, and at the end of the launch the forward waves themselves -- waits for the flag, acquires and walks back.
+// The forward pass is bound by vector issue, the walk by its reads: side by side instead of one after the other in every wave.
+__device__ __forceinline__ void tb_publish(const FusedArgs& A, uint32_t item, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    lds_dma_wait();                                        // s_waitcnt vmcnt(0) of our own (the compiler may drop the fence's when it knows the counter empty: MI355X_MICROARCH.md, inter-workgroup visibility)
+    if (lane == 0) __hip_atomic_store(A.done + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// LEAN = the 32-register form (eight decision words in flight, no double buffering); otherwise `traceback` as the forward waves have it
+template <bool LEAN>
+__device__ __forceinline__ void tb_consume(const FusedArgs& A, int lane)
+{
+    const DABPHY_CONST_AS uint32_t* const dec_off = as_constant(A.dec_off);
+    const DABPHY_CONST_AS FusedClass* const classes = as_constant(A.cls);
+    const DABPHY_CONST_AS uint32_t* const work = as_constant(A.work);
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+#pragma unroll 1
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(A.next_tb, 1u);
+        item = (uint32_t)uniform_i32(__shfl((int)item, 0));
+        if (item >= A.n_work) break;
+        while (__hip_atomic_load(A.done + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t wk = work[item];
+        const DABPHY_CONST_AS FusedClass& C = classes[wk >> 24];
+        const int g = (int)(wk & 0xffffffu);
+        const int nbits = C.nbits, n_cw = C.n_cw;
+        const BufRsrc dec_rs = buf_rsrc(A.dec + (size_t)dec_off[item] * 64);
+        const int cw_out = g * 64 + lane;
+        uint32_t* const out = reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_out * (nbits / 32);
+        const bool live = cw_out < n_cw;
+        if constexpr (!LEAN) {
+            traceback([&](int st) { return buf_load_b64<FM_DEC_LOAD_AUX>(dec_rs, lane8, (uint32_t)st * 512u); }, nbits, out, live, C.dedisperse, A.prbs_words);
+        } else {
+            uint32_t J = 0, outw = 0;
+            uint32_t rho = (uint32_t)acs::dec_rot((nbits - 1) % 6);
+#pragma unroll 1
+            for (int n = nbits - 1; n >= 0; n -= 8) {                // (nbits is a multiple of 8: 768, 24 * bit rate)
+                uint2 dq[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) dq[k] = buf_load_b64<FM_DEC_LOAD_AUX>(dec_rs, lane8, (uint32_t)(n - k + 6) * 512u);
+#pragma unroll
+                for (int k = 0; k < 8; k++) { acs::back(dq[k], J, outw, rho); rho = rho == 5 ? 0 : rho + 1; }
+                if (((n - 7) & 31) == 0) {
+                    const int wi = (n - 7) >> 5;
+                    const uint32_t word = acs::back_word(outw);
+                    if (live) out[wi] = C.dedisperse ? word ^ A.prbs_words[wi] : word;
+                }
+            }
+        }
+    }
+}
+
+template <int ROWS, int OCC, bool SPLIT>
 __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
 {
   using G = FmGeom<ROWS>;
@@ -520,12 +577,25 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
     lds_dma_wait();                                                  // (no load may still be in flight when the next group reuses the slots)
 
 #ifndef FM_EXP_NOTRACE            // (timing experiment only)
-    // traceback: as in k_viterbi, the decision words through the same buffer resource the stores took
-    const int cw_out = g * 64 + lane;                                // (recomputed: nothing but the trellis lives across the step loop)
-    traceback([&](int st) { return buf_load_b64<FM_DEC_LOAD_AUX>(dec_rs, lane8, (uint32_t)st * 512u); }, nbits,
-              reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_out * (nbits / 32), cw_out < n_cw, C.dedisperse, A.prbs_words);
+    if constexpr (SPLIT) {
+        tb_publish(A, item, lane);                                   // this group's decisions are complete: somebody else walks them back
+    } else {
+        // traceback: as in k_viterbi, the decision words through the same buffer resource the stores took
+        const int cw_out = g * 64 + lane;                            // (recomputed: nothing but the trellis lives across the step loop)
+        traceback([&](int st) { return buf_load_b64<FM_DEC_LOAD_AUX>(dec_rs, lane8, (uint32_t)st * 512u); }, nbits,
+                  reinterpret_cast<uint32_t*>(C.out) + (size_t)cw_out * (nbits / 32), cw_out < n_cw, C.dedisperse, A.prbs_words);
+    }
 #endif
   }
+#ifndef FM_EXP_NOTRACE
+  if constexpr (SPLIT) tb_consume<false>(A, lane);                   // no trellis left to run: this wave walks back too (the last groups' walks get every wave of the device)
+#endif
+}
+
+// the traceback waves: 32 registers, no LDS -- one per SIMD rides beside the five forward waves for the whole launch
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) k_traceback_fused(FusedArgs A)
+{
+    tb_consume<true>(A, threadIdx.x);
 }
 
 static int device_simds()
@@ -549,14 +619,29 @@ int fused_wave_slots(int variant)
 #endif
     return occ * device_simds();
 }
-void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s)
+void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStream_t s, const FusedSplit* split)
 {
     if (a.n_work == 0 || n_slots <= 0) return;
     // One work-group (= one wave) per resident wave slot, or fewer when there is less work; the groups are pulled from the list.
     hipError_t e = hipMemsetAsync(a.next, 0, sizeof(uint32_t), s); (void)e;
-    if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0]>), dim3(n_slots), dim3(64), 0, s, a);
-    else if (variant == 1) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[1], FUSED_OCC[1]>), dim3(n_slots), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[2], FUSED_OCC[2]>), dim3(n_slots), dim3(64), 0, s, a);
+    if (a.done && split) {
+        // the traceback beside the forward pass: flags and the second cursor cleared, the traceback waves forked off onto their own stream
+        // (forward launch first: the GPU-less execution model runs launches to completion in order), joined back behind the launch
+        e = hipMemsetAsync(a.done, 0, ((size_t)a.n_work + 1) * sizeof(uint32_t), s);
+        e = hipEventRecord(split->fork, s);
+        e = hipStreamWaitEvent(split->tb_stream, split->fork, 0);
+        if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0], true>), dim3(n_slots), dim3(64), 0, s, a);
+        else if (variant == 1) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[1], FUSED_OCC[1], true>), dim3(n_slots), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[2], FUSED_OCC[2], true>), dim3(n_slots), dim3(64), 0, s, a);
+        const int n_tb = std::min<int>((int)a.n_work, device_simds());
+        hipLaunchKernelGGL(k_traceback_fused, dim3(n_tb), dim3(64), 0, split->tb_stream, a);
+        e = hipEventRecord(split->join, split->tb_stream);
+        e = hipStreamWaitEvent(s, split->join, 0);
+        return;
+    }
+    if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0], false>), dim3(n_slots), dim3(64), 0, s, a);
+    else if (variant == 1) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[1], FUSED_OCC[1], false>), dim3(n_slots), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[2], FUSED_OCC[2], false>), dim3(n_slots), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------ new pairs
