@@ -352,8 +352,8 @@ int dabphy_get_msc_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t subch_
  *   dabphy_msc_batch_size        bytes `buf` must hold and records `desc` must hold for the last batch (either pointer may be NULL)
  *   dabphy_get_msc_batch         queue the copies, wait for them, return (n_desc = records written)
  *   dabphy_msc_drain_begin       queue the copies on a stream of their own and return at once: the NEXT dabphy_process may be called while
- *                                they are in flight -- its decoder waits on the device for the drain before it overwrites a class output,
- *                                its synchroniser and FFT stage do not --; `desc` is complete on return, `buf` when
+ *                                they are in flight (the class outputs are first copied to a staging area in HBM -- tens of microseconds on
+ *                                the device -- so that no decoder ever waits for the host link); `desc` is complete on return, `buf` when
  *   dabphy_msc_drain_wait        returns (also called by dabphy_destroy / dabphy_reset and before the sub-channel lists are re-applied).
  * DABPHY_ERR_INVALID when a capacity is too small (nothing is queued then). */
 typedef struct {

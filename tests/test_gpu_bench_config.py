@@ -25,7 +25,7 @@ def base_streams(frames_per_step=20):
     return _base[n]
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 3])          # (schedule 2: the 20-frame twin below and tests/test_emu_stream.py)
 def test_benchmarked_configuration(gpu, mode):
     P.check_bench_config(capi, GPU_LIB, 256, 32, mode, check_ens=[0, 1, 2, 77, 128, 129, 191, 254, 255], n_steps=3, base=base_streams(32), expect_chunk=25)
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def run_bench(args, env_extra=None, timeout=900):
-    env = dict(os.environ, **(env_extra or {}))
+    env = dict(os.environ, DABPHY_BENCH_QUICK="1", **(env_extra or {}))      # (a quarter of the CPU baseline's sample, shorter facade streams: the contract is checked, not the figures)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -43,15 +43,24 @@ def test_single_gpu_line_and_parity_leg(gpu):
     # ... and the batch of independent ensembles (five multiplexes, five selections): throughput, Viterbi stage time, its own parity leg
     mix = j["extras"]["mixed_layouts"]
     assert mix.get("parity") is True and mix["value"] > 0 and mix["msc_viterbi_ms"] > 0, mix
+    # the headline's geometry on signals as a receiver meets them: drifting sample clocks (the find chain), 6-10 dB; own parity legs
+    for kind in ("drift", "low_snr"):
+        leg = j["extras"][kind]
+        assert leg.get("parity") is True and leg["value"] > 0 and leg["wide_sync_stats"]["frames"] > 0, leg
+    assert j["extras"]["drift"]["wide_sync_stats"]["frames_accepted_from_the_wide_pass"] > 0
+    # every service's logical frames on the host, every step, through the bulk drain overlapped with the next step
+    assert j["msc_drain"]["services"] == 8 * 18 and j["msc_drain"]["value"] > 0 and j["msc_drain"]["logical_frames_per_step"] == 8 * 18 * 40, j["msc_drain"]
     # INTEGRATION level 2 as a build: the reference backend with one file replaced by a seam binding, next to the unmodified build
     l2 = j["facade"].get("level2", {})
     assert all(l2.get(k, {}).get("x_realtime", 0) > 0 for k in ("reference", "l2a", "l2b")), l2
+    # the Viterbi seam's shared decoder combines the sub-channels of a CIF: more than one code word per device call with 18 services
+    assert l2["l2b"]["all_18_services"]["code_words_per_device_call"] > 1.5 and l2["l2b"]["all_18_services"]["cpu_ms_per_frame"] > 0, l2["l2b"]
     assert j["roofline"]["measured_copy_GBps"] > 1000 and 0 < j["roofline"]["frac_of_achievable"] < 1.2
     assert j["profile_build"]["src_sha256"] and j["profile_build"]["lib_sha256"]
 
 
 def test_rccl_gather_of_device_buffers_one_rank(gpu):
-    j = run_bench(["--gpus", "1", "--steps", "2", "--ensembles", "8", "--frames", "10", "--no-alt-schedule", "--no-cpu-baseline"], {"DABPHY_FORCE_DIST": "1"})
+    j = run_bench(["--gpus", "1", "--steps", "2", "--ensembles", "8", "--frames", "10", "--no-alt-schedule", "--no-cpu-baseline", "--no-extras"], {"DABPHY_FORCE_DIST": "1"})
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["value"] > 0
 
 

@@ -40,10 +40,10 @@ def test_impaired_stream_low_snr(gpu, channel, placement):
 
 
 def test_benchmark_geometry_with_drifting_ensembles(gpu):
-    """256 ensembles x 32 frames per call, the bench handle: recordings through +60 / -100 / +40 ppm (with fading and an echo) / -30 ppm,
+    """64 ensembles x 32 frames per call (the 256 x 32 geometry: the next test), the bench handle: recordings through +60 / -100 / +40 ppm (with fading and an echo) / -30 ppm,
     so the window index moves in every frame and the fine correctors are still converging: the wide pass's prediction fails, the find
     chain stops at every frame whose fine corrector moved, the serial chain takes those"""
-    P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 1, 2, 255], n_steps=2,
+    P.check_bench_config(capi, GPU_LIB, 64, 32, 1, check_ens=[0, 1, 2, 63], n_steps=2,
                          channels=[dict(ppm=60.0), dict(ppm=-100.0), dict(ppm=40.0, fade=(0.3, 7.0), echoes=[(150, 0.5j)]), dict(ppm=-30.0)],
                          min_wide_fallbacks=1)
 

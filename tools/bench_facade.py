@@ -48,10 +48,14 @@ def seam_stats(lib):
         return None
 
 
+QUICK = os.environ.get("DABPHY_BENCH_QUICK") == "1"      # tests only: shorter streams (the test checks that the figures exist, not what they are)
+N_A, N_B = (12, 36) if QUICK else (30, 90)
+
+
 def level2():
     """INTEGRATION.md level 2 (BASELINE config 2): the reference backend with ONE source file replaced by a seam binding, next to the
     unmodified build on the same host, one ensemble: wall ms and CPU ms (all threads of the receiver) per 96 ms frame (slopes between 30
-    and 90 frames; the harness waits 0.5 s for the decoders to go quiet: that wait is in neither slope), with two services selected and
+    and 90 frames -- 12 and 36 with DABPHY_BENCH_QUICK=1 --; the harness waits 0.5 s for the decoders to go quiet: that wait is in neither slope), with two services selected and
     with all 18 -- where the channel decoders are what the host's cores do (viterbi.cpp: 24 of the reference's 30 CPU ms per frame)"""
     out = {}
     for name, lib, what in (("reference", None, "the unmodified reference backend (CPU)"),
@@ -62,15 +66,15 @@ def level2():
             continue
         try:
             run_build(lib, 6)
-            ta, ca, _ = run_build(lib, 30)
-            tb, cb, a = run_build(lib, 90)
-            ms = (tb - ta) / 60 * 1e3
-            out[name] = {"what": what, "ms_per_frame": ms, "cpu_ms_per_frame": (cb - ca) / 60 * 1e3, "x_realtime": 96.0 / ms, "fib_crc_ok": int(a["fib"][:, 0].sum()), "fibs": int(len(a["fib"]))}
+            ta, ca, _ = run_build(lib, N_A)
+            tb, cb, a = run_build(lib, N_B)
+            ms = (tb - ta) / (N_B - N_A) * 1e3
+            out[name] = {"what": what, "ms_per_frame": ms, "cpu_ms_per_frame": (cb - ca) / (N_B - N_A) * 1e3, "x_realtime": 96.0 / ms, "fib_crc_ok": int(a["fib"][:, 0].sum()), "fibs": int(len(a["fib"]))}
             if name != "l2a":
                 s0 = seam_stats(lib) if name == "l2b" else None
-                ta, ca, _ = run_build(lib, 30, 18)
-                tb, cb, a = run_build(lib, 90, 18)
-                out[name]["all_18_services"] = {"ms_per_frame": (tb - ta) / 60 * 1e3, "cpu_ms_per_frame": (cb - ca) / 60 * 1e3}
+                ta, ca, _ = run_build(lib, N_A, 18)
+                tb, cb, a = run_build(lib, N_B, 18)
+                out[name]["all_18_services"] = {"ms_per_frame": (tb - ta) / (N_B - N_A) * 1e3, "cpu_ms_per_frame": (cb - ca) / (N_B - N_A) * 1e3}
                 s1 = seam_stats(lib) if name == "l2b" else None
                 if s0 and s1 and s1[0] > s0[0]:
                     out[name]["all_18_services"]["code_words_per_device_call"] = (s1[1] - s0[1]) / (s1[0] - s0[0])

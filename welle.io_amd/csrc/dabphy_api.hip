@@ -196,6 +196,8 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->ev_tb_fork) e = hipEventDestroy(h->ev_tb_fork);
     if (h->ev_tb_join) e = hipEventDestroy(h->ev_tb_join);
     if (h->ev_drain_done) e = hipEventDestroy(h->ev_drain_done);
+    if (h->ev_drain_staged) e = hipEventDestroy(h->ev_drain_staged);
+    if (h->drain_stage.p) e = hipFree(h->drain_stage.p);
     if (h->ev_aux_done) e = hipEventDestroy(h->ev_aux_done);
     for (int i = 0; i < 2; i++) if (h->ev_ingest[i]) e = hipEventDestroy(h->ev_ingest[i]);
     if (h->ev_demod_done) e = hipEventDestroy(h->ev_demod_done);

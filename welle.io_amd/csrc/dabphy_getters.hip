@@ -243,16 +243,27 @@ int dabphy_msc_drain_begin(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t des
     if (!h->drain_stream) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->drain_stream, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_done, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_staged, hipEventDisableTiming));
     }
-    // (dabphy_process has returned: the class outputs are final, nothing on the main stream is pending)
+    // (dabphy_process has returned: the class outputs are final, nothing on the main stream is pending.)  The outputs first go to a
+    // staging area in HBM -- a device copy on the main stream, tens of microseconds for a hundred MB, ordered in front of the next batch's
+    // kernels like any other work there -- and cross PCIe from the staging area: the next batch's decoders never wait for the host link
+    // (the class outputs are theirs again the moment the device copy is done), the drain has a whole step to arrive.
+    { const void* before = h->drain_stage.p; if ((r = ensure(h, h->drain_stage, total))) return r; if (h->drain_stage.p != before) HIPCHK(h, hipMemsetAsync(h->drain_stage.p, 0, h->drain_stage.cap, h->stream)); }      // (the padding between two classes crosses to the host too: zeros, not stale HBM)
+    int n_cu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->cfg.device) == hipSuccess) n_cu = pr.multiProcessorCount; }
     for (size_t c = 0; c < h->classes.size(); c++) {
         const auto& cls = h->classes[c];
-        const size_t bytes = cls.pairs.size() * (size_t)4 * F * (cls.prot.nbits / 8);
+        const size_t bytes = (cls.pairs.size() * (size_t)4 * F * (cls.prot.nbits / 8) + 15) & ~(size_t)15;     // (whole 16-byte pieces: the regions are 256-byte aligned and padded)
+        if (bytes) launch_copy_f4(cls.out.p, h->drain_stage.as<uint8_t>() + off[c], bytes / 16, 4 * n_cu, h->stream);
+    }
+    HIPCHK(h, hipEventRecord(h->ev_drain_staged, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->drain_stream, h->ev_drain_staged, 0));
+    {
         // (pieces of a few MB: a copy engine works its queues off packet by packet, and one 100 MB packet would hold up the small
         // transfers of the next dabphy_process -- descriptors, FIBs -- that share the engine)
         constexpr size_t PIECE = (size_t)4 << 20;
-        for (size_t at = 0; at < bytes; at += PIECE)
-            HIPCHK(h, hipMemcpyAsync(buf + off[c] + at, cls.out.as<uint8_t>() + at, std::min(PIECE, bytes - at), hipMemcpyDeviceToHost, h->drain_stream));
+        for (size_t at = 0; at < total; at += PIECE)
+            HIPCHK(h, hipMemcpyAsync(buf + at, h->drain_stage.as<uint8_t>() + at, std::min(PIECE, total - at), hipMemcpyDeviceToHost, h->drain_stream));
     }
     HIPCHK(h, hipEventRecord(h->ev_drain_done, h->drain_stream));
     h->drain_pending = true;

@@ -104,7 +104,7 @@ struct dabphy_handle {
     uint64_t s_enqueued = 0; int commit_slot = -1;    // samples handed to the copy stream so far; slot whose event covers the committed ones
     DevBuf s_null;                          // null symbols on request (dabphy_get_null_symbols)
     // bulk MSC drain (dabphy_msc_drain_begin / _wait): the class outputs leave on a stream of their own while the next batch starts
-    hipStream_t drain_stream = nullptr; hipEvent_t ev_drain_done = nullptr; bool drain_pending = false;
+    hipStream_t drain_stream = nullptr; hipEvent_t ev_drain_done = nullptr, ev_drain_staged = nullptr; bool drain_pending = false; DevBuf drain_stage;
     DevBuf sf_events, sf_count, sf_bytes, sf_stats, sf_gf, sf_accept; const FrameDesc* last_desc = nullptr;
     static constexpr int N_DESC = 3;    // descriptor buffers: the batch being decoded + up to two synchronised ahead
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;

@@ -58,7 +58,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         }
         for (auto& cls : h->classes) {
             const size_t n_groups = ((size_t)4 * F * cls.pairs.size() + 63) / 64;
-            if (cls.out.cap < n_groups * 64 * (cls.prot.nbits / 8) && (r = drain_wait(h))) return r;      // (a bulk drain still reads the buffer that is about to be replaced)
             if ((r = ensure(h, cls.out, n_groups * 64 * (cls.prot.nbits / 8)))) return r;
         }
         if (h->sf_auto && (r = prepare_superframes(h, F))) return r;
@@ -237,9 +236,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
         HIPCHK(h, hipEventRecord(h->ev_aux_done, fs));
     }
-    // a bulk MSC drain of the previous batch (dabphy_msc_drain_begin) may still be reading the class outputs: the decoders wait for it ON
-    // THE DEVICE; the synchroniser and the FFT stage above did not
-    if (h->drain_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_drain_done, 0));
     // pairs selected since the last batch learn the CIF count they start at (their time de-interleaver fills from here, dab-audio.cpp:146-149)
     for (auto& cls : h->classes) if (cls.cif0_pending) launch_pair_cif0(cls.pair_tab.as<MscPair>(), (int)cls.pairs.size(), d_desc, (int)F, h->stream);
     // MSC (+ FIC): every class the plan holds in ONE launch; the stage events bracket all of it

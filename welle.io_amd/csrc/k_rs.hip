@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64) k_superframe_settle(SfBatch Bt)
 // frame with the reference's state machine -- 5-frame sliding window, Reed-Solomon on a copy, Fire-code / AU-table check, AU CRCs, and
 // after a hit a fresh window -- carrying frame_count + the raw window to the next batch.  Runs for what the wide pass did not settle.
 template <int SF_MAX>       // superframe bytes the instance can hold (120 * bitrate / 8)
-__global__ void __launch_bounds__(64, SF_MAX <= 960 ? 5 : SF_MAX <= 2880 ? 4 : 2) k_superframe(SfBatch Bt)
+__global__ void __launch_bounds__(64, SF_MAX <= 2880 ? 4 : 2) k_superframe(SfBatch Bt)      // (four waves per SIMD: at five the 960-byte build spilled ten registers)
 {
     uint32_t bx = blockIdx.x;
     const SfArgs A = sf_args_of(Bt, bx);

@@ -683,9 +683,11 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
             for (int k = 16 * t + 15; k <= 16 * t + 99; k++) common = fmaxf(common, lbuf[k]);
             float suf[16];                                              // suf[k] = max(lbuf[16t+k .. 16t+14])
             float run = -10000.0f;
+#pragma unroll
             for (int k = 14; k >= 0; k--) { run = fmaxf(run, lbuf[16 * t + k]); suf[k] = run; }
             suf[15] = -10000.0f;
             run = -10000.0f;                                            // prefix over lbuf[16t+100 .. 16t+99+k]
+#pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int i = 16 * t + k;
                 if (k > 0) run = fmaxf(run, lbuf[16 * t + 99 + k]);
@@ -756,7 +758,9 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
                     }
                     correction = maxIndex - (T_U - K_CARR) / 2;
                 } else {
-                    float refArg[24], cv[72 + 24];
+                    // (24 + 96 floats in the reduction scratch, not in a thread's own arrays: dynamically indexed locals are scratch memory)
+                    static_assert(24 + 72 + 24 <= FFT_THREADS, "CorrelatePRS work arrays fit the reduction scratch");
+                    float* const refArg = redf; float* const cv = redf + 24;
                     for (int i = 0; i < 24; i++) {
                         const cf32 z = cmul(A.tab.ref[(T_U + i) % T_U], cconj(A.tab.ref[(T_U + i + 1) % T_U]));
                         refArg[i] = fdlibm_atan2f(z.im, z.re);
@@ -860,7 +864,7 @@ __global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find_wide(S
 // frames then run at once (k_sync_finish_wide again: it takes the pending descriptors) and k_sync_validate_chain accepts the frames
 // whose fine corrector indeed stayed.  Results are the serial chain's by construction; what is left (a corrector that moved, a failed
 // search, an ensemble out of lock) still goes to the serial chain.
-__global__ void __launch_bounds__(FFT_THREADS, SYNC_FIND_OCC) k_sync_find_chain(SyncArgs A)
+__global__ void __launch_bounds__(FFT_THREADS, 1) k_sync_find_chain(SyncArgs A)      // (one work-group per ensemble, a wave per SIMD: the whole register file, what does not fit the 256 architected registers spills to accumulation registers, not to memory)
 {
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x;
