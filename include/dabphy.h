@@ -43,7 +43,8 @@ typedef enum {
 
 /* ---- ABI versioning.  Structures cross this boundary by layout, and the library and its callers are built separately:
  *   dabphy_config            is SIZED: its first member is the sizeof() the caller was compiled with.  Fields are only ever appended;
- *                            dabphy_create reads the fields the caller's header knew and takes the documented default (0) for the rest,
+ *                            dabphy_create reads the fields the caller's header knew and takes the default for the rest (0, except
+ *                            fft_placement and freqsync_method: 2 = the reference's own defaults, radio-receiver-options.h:66-84),
  *                            and refuses a structure LARGER than its own (fields it does not know: DABPHY_ERR_INVALID).
  *   every other structure    (dabphy_frame_info, dabphy_sf_event, dabphy_subchannel, dabphy_protection, dabphy_tii_measurement, dabphy_msc_desc) is pinned
  *                            by DABPHY_ABI_VERSION: a change of any of them bumps it.  A caller checks once, e.g. in its constructor:
@@ -51,7 +52,9 @@ typedef enum {
  *                                finer diagnosis).
  *   objects built against the headers of rounds 1-3 call the exported symbols `dabphy_create` / `dabphy_get_config` with the UNSIZED
  *   48-byte configuration of those rounds: those entry points stay, frozen to that layout (new fields at their defaults); this header's
- *   dabphy_create / dabphy_get_config are the _v2 symbols (the sized form). */
+ *   dabphy_create / dabphy_get_config are the _v2 symbols (the sized form).  Objects built against ROUND 4's header (an unsized 52-byte
+ *   structure that ended in decode_shape) bind the same exported symbols and cannot be told from round 3's: their decode_shape is not
+ *   read (the automatic choice applies) and dabphy_get_config does not write it -- rebuild them against this header. */
 #define DABPHY_ABI_VERSION 6u
 uint32_t dabphy_abi_version(void);
 typedef enum { DABPHY_STRUCT_CONFIG = 0, DABPHY_STRUCT_FRAME_INFO = 1, DABPHY_STRUCT_SF_EVENT = 2, DABPHY_STRUCT_SUBCHANNEL = 3,

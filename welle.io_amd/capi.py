@@ -241,7 +241,7 @@ class DabPhy:
         self._chk(self.lib.dabphy_test_traceback_split(self.h, int(on)))
 
     def last_decode_plan(self):
-        """(1 = lane per code word / 2 = state-parallel / 0 = nothing decoded yet, protection classes in the fused launch) of the last process()"""
+        """(kernel that decoded the last process(), numbered like dabphy_config.decode_shape: 1 = lane per code word (k_viterbi_fused), 2 = state-parallel with two code words per wavefront (k_viterbi_sp2 + k_traceback_sp2), 3 = state-parallel with one (k_viterbi_sp), 0 = nothing decoded yet; protection classes in that launch)"""
         a = C.c_int32(0); b = C.c_int32(0)
         self._chk(self.lib.dabphy_last_decode_plan(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value

@@ -477,7 +477,9 @@ int apply_subchannels(dabphy_handle* h)
         for (auto& c : old) free_class(c);
         for (auto& c : h->classes) free_class(c);
         h->classes.clear();
-        for (uint32_t b = 0; b < B; b++) { h->subch_e[b].clear(); h->where[b].clear(); }
+        // (the rejected request goes too: dabphy_get_subchannel_count then reports what is in effect -- nothing -- instead of sub-channels
+        // that are never decoded, and the next dabphy_process has nothing stale to apply)
+        for (uint32_t b = 0; b < B; b++) { h->subch_e[b].clear(); h->where[b].clear(); h->subch_next[b].clear(); }
         return code;
     };
     struct Carry { int old_cls, old_pair; };

@@ -111,7 +111,13 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     uint64_t total_cw = (uint64_t)B * F * 4 * (want_fic && h->fused_fic ? 1 : 0);
     bool sp_ok = h->fused_msc && h->cfg.decode_shape != 1 && (h->sp_max_codewords > 0 || h->cfg.decode_shape >= 2);
     for (auto& c : h->classes) { total_cw += (uint64_t)4 * F * c.pairs.size(); sp_ok = sp_ok && (c.prot.nbits + 6) % 6 == 0 && c.prot.nbits + 6 <= SP_MAXSTEPS[SP_VARIANTS - 1]; }
-    const bool use_sp = sp_ok && (h->cfg.decode_shape >= 2 || total_cw <= h->sp_max_codewords);
+    // ... and its decision scratch is sized per code word from the LONGEST code word of the launch (a 256-byte history row per 30 steps):
+    // one 384 kbit/s class among small ones makes that 79 KB per code word, 3.2 GB at the code word limit.  The automatic choice therefore
+    // also asks for the scratch to stay below a GiB (the lane-per-code-word kernel sizes its scratch per group: dec_by_item)
+    size_t longest = want_fic && h->fused_fic ? 774 : 0;
+    for (auto& c : h->classes) longest = std::max(longest, (size_t)c.prot.nbits + 6);
+    const uint64_t sp_scratch = total_cw * (uint64_t)(longest / 30 + 1) * 32 * sizeof(uint2);
+    const bool use_sp = sp_ok && (h->cfg.decode_shape >= 2 || (total_cw <= h->sp_max_codewords && sp_scratch <= ((uint64_t)1 << 30)));
     for (size_t i = 0; i < h->classes.size(); i++) {
         auto& c = h->classes[i];
         const int P = (int)c.pairs.size();
