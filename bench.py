@@ -803,8 +803,8 @@ def main():
             if dev is not None and world > 1:
                 pass                                     # (the handle stays open: nothing of the baseline runs on the device)
             rows = {e: iq[e].cpu().numpy() for e in check}
-            # (DABPHY_BENCH_QUICK=1, tests/test_gpu_bench_entry.py only: a quarter of the sample -- the test checks the line's contract, not its figures)
-            line["cpu_baseline"], pc = cpu_baseline(rows, n_loops=max(1, (60 if os.environ.get("DABPHY_BENCH_QUICK") == "1" else 240) // rec_frames), gpu_logs=logs)
+            # (DABPHY_BENCH_QUICK=1, tests/test_gpu_bench_entry.py only: half the sample -- the test checks the line's contract, not its figures)
+            line["cpu_baseline"], pc = cpu_baseline(rows, n_loops=max(1, (120 if os.environ.get("DABPHY_BENCH_QUICK") == "1" else 240) // rec_frames), gpu_logs=logs)
             if world == 1:
                 line["parity_check"] = pc
                 line["parity_check"].update(ranks_ok=1, ranks=1)

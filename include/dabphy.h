@@ -425,8 +425,15 @@ int dabphy_superframes_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t su
  * addition to, dabphy_superframes for this batch); nothing but totals leaves the device:
  * stats [n_ensembles][4] = synchronised superframes, corrected symbols, uncorrectable attempts, access units failing their CRC */
 int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats);
-/* on: every following dabphy_process queues that all-sub-channel filter pass itself, behind the MSC Viterbi kernels of the same
- * submission (no host round trip between decode and filter); dabphy_superframes_stats then only fetches the totals of the batch. */
+/* on = 1: every following dabphy_process queues that all-sub-channel filter pass itself, behind the MSC Viterbi kernels of the same
+ * submission (no host round trip between decode and filter); dabphy_superframes_stats then only fetches the totals of the batch.
+ * on = 2: the pass of a batch is DEFERRED to the next dabphy_process, which queues it beside its own FFT stage on a stream of its own
+ * (nothing of the next batch needs the filter's results before its decoders overwrite the class outputs, and those wait for the pass
+ * on the device): the filter leaves the step's tail.  dabphy_superframes_stats then returns the totals of the batch BEFORE the last
+ * dabphy_process (zeros after the first one); one more call without a dabphy_process in between runs the last batch's pass at once and
+ * returns its totals (the end of a stream).  Every batch is filtered exactly once either way, with the same results.  A change of
+ * the sub-channel lists, dabphy_reset and switching the mode run or drop what is pending first.
+ * on = 0: dabphy_superframes_stats runs the pass when it is called. */
 int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on);
 
 /* ---- TIIDecoder (tii-decoder.cpp:189-383), fed by OFDMProcessor::run with the PRS and the trailing NULL symbol of every

@@ -732,8 +732,10 @@ def check_timing_driver_refuses_a_stale_launch(d_factory):
 # ---- the configuration bench.py times (welle_io_amd/workload.py): B x F batch, looping ring, coarse corrector enabled, pipelined
 # synchroniser, all 18 sub-channels, superframe filter inside process() -- against the oracle on the very same samples
 def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_steps=3, demod_chunk=0, device="cuda", subs_idx=(0, 7, 17),
-                       base=None, expect_chunk=None, channels=None, min_wide_fallbacks=None, decode_shape=0, min_chain_frames=None, cfo_max_hz=60.0):
-    """channels: one channel (synth.apply_channel) per distinct recording -- the recordings then run through it ONCE over the whole test
+                       base=None, expect_chunk=None, channels=None, min_wide_fallbacks=None, decode_shape=0, min_chain_frames=None, cfo_max_hz=60.0, deferred_filter=False, sync_early=0):
+    """deferred_filter: dabphy_set_auto_superframes(2) -- superframes_stats() returns the totals of the batch BEFORE the last process(); one more
+    call at the end fetches the last batch's: the sums over the run are those of the immediate mode.
+    channels: one channel (synth.apply_channel) per distinct recording -- the recordings then run through it ONCE over the whole test
     (a drifting sampling clock has no seamless loop point) and the ring does not loop.  min_wide_fallbacks: the wide synchroniser pass
     must have handed at least that many batches back to the frame-by-frame chain (what per-ensemble drift does in every batch)"""
     from welle_io_amd import workload
@@ -746,7 +748,8 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
         base = (np.stack(rows).astype(np.complex64), txs)
     iq, cfo, base_np, txs = workload.make_batch(B, device=device, base=base, cfo_max_hz=cfo_max_hz)
     subchs = txs[0].subchs
-    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False, loop=loop, decode_shape=decode_shape)
+    d = workload.open_receiver(capi_mod, lib_path, iq, F, subchs, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, profiling=False, loop=loop, decode_shape=decode_shape,
+                               deferred_filter=deferred_filter, sync_early=sync_early)
     logs = {b: dict(fib=[], ok=[], corr=[], soft=[], msc=[[] for _ in subs_idx], sf=np.zeros(4, np.int64), n_logical=0) for b in check_ens}
     try:
         if expect_chunk is not None:
@@ -768,6 +771,12 @@ def check_bench_config(capi_mod, lib_path, B, F, pipeline_sync, check_ens, n_ste
                     L["msc"][k].append(m[b, fv[b]:4 * len(valid)].tobytes())
                 L["n_logical"] += max(0, 4 * len(valid) - int(mscs[0][1][b]))
                 L["sf"] += sf[b]
+        if deferred_filter:
+            assert step == n_steps - 1
+            sf = d.superframes_stats()                  # (the last batch's pass runs now)
+            for b in check_ens:
+                logs[b]["sf"] += sf[b]
+            assert not d.superframes_stats().any()      # nothing pending, nothing unfetched: zeros
         wide = d.wide_sync_stats(); chain = d.find_chain_stats()
     finally:
         d.close()

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def run_bench(args, env_extra=None, timeout=900):
-    env = dict(os.environ, DABPHY_BENCH_QUICK="1", **(env_extra or {}))      # (a quarter of the CPU baseline's sample, shorter facade streams: the contract is checked, not the figures)
+    env = dict(os.environ, DABPHY_BENCH_QUICK="1", **(env_extra or {}))      # (half the CPU baseline's sample, shorter facade streams: the contract is checked, not the figures)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -189,7 +189,7 @@ class DabPhy:
     def set_track_slevel(self, on=True):
         self._chk(self.lib.dabphy_set_track_slevel(self.h, int(on)))
 
-    def set_auto_superframes(self, on=True):
+    def set_auto_superframes(self, on=True):        # (on = 2: the filter pass of a batch deferred to the next process(), beside its FFT stage)
         """run the all-sub-channel superframe filter inside every process() call; superframes_stats() then only fetches the totals"""
         self._chk(self.lib.dabphy_set_auto_superframes(self.h, int(on)))
 

@@ -168,7 +168,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
         if ((r = ensure(h, h->vdec, dec_cells * sizeof(uint2)))) return r;
         if (dec_by_item && (r = ensure(h, h->fused_dec_off, item_off.size() * sizeof(uint32_t)))) return r;
         if (tb_split) {
-            if ((r = ensure(h, h->fused_done, (work.size() + 1) * sizeof(uint32_t)))) return r;
+            if ((r = ensure(h, h->fused_done, (work.size() + 2) * sizeof(uint32_t)))) return r;
             if (!h->tb_stream) {
                 HIPCHK(h, hipStreamCreateWithFlags(&h->tb_stream, hipStreamNonBlocking));
                 HIPCHK(h, hipEventCreateWithFlags(&h->ev_tb_fork, hipEventDisableTiming));

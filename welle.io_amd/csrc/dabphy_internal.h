@@ -176,6 +176,10 @@ struct dabphy_handle {
     // TII (RadioReceiverOptions::decodeTII): constants, per-batch scratch, per-ensemble sums that live across batches
     bool tii_on = false; bool tii_ran = false;
     bool track_slevel = false;        // dabphy_set_track_slevel: sLevel follows every tracked frame instead of catching up at a loss of lock
+    // dabphy_set_auto_superframes(2): the filter pass of batch k runs beside batch k + 1's FFT stage, on a stream of its own
+    bool sf_deferred = false, sf_def_pending = false, sf_def_unfetched = false, sf_def_inflight = false;
+    const FrameDesc* sf_def_desc = nullptr; uint32_t sf_def_frames = 0;
+    hipStream_t rs_stream = nullptr; hipEvent_t ev_rs_done = nullptr;
     bool sf_auto = false, sf_stats_ready = false;   // dabphy_set_auto_superframes: the all-sub-channel filter rides in dabphy_process's submission
     DevBuf tii_rot, tii_rank, tii_pat, tii_err, tii_likely, tii_state, tii_events, tii_nev, tii_ovf;
     uint32_t tii_max_events = 0;
@@ -257,11 +261,13 @@ DABPHY_INTERNAL void launch_serial_chain(dabphy_handle* h, SyncArgs sa);
 DABPHY_INTERNAL int queue_chain(dabphy_handle* h, int sel, uint32_t F);
 DABPHY_INTERNAL int resolve_chain(dabphy_handle* h, int sel);
 DABPHY_INTERNAL int prepare_superframes(dabphy_handle* h, uint32_t F);       // dabphy_superframes.hip
-DABPHY_INTERNAL int run_superframes(dabphy_handle* h, const std::vector<dabphy::SfSel>& sel, int32_t* stats, hipStream_t st = nullptr);
+DABPHY_INTERNAL int run_superframes(dabphy_handle* h, const std::vector<dabphy::SfSel>& sel, int32_t* stats, hipStream_t st = nullptr, const FrameDesc* desc = nullptr, uint32_t n_frames = 0);
 DABPHY_INTERNAL int apply_subchannels(dabphy_handle* h);                                          // dabphy_api.hip
 DABPHY_INTERNAL int upload_pairs(dabphy_handle* h, dabphy_handle::MscClass& cls);
 DABPHY_INTERNAL void free_class(dabphy_handle::MscClass& c);
-DABPHY_INTERNAL int launch_superframe_stats(dabphy_handle* h);
+DABPHY_INTERNAL int launch_superframe_stats(dabphy_handle* h, hipStream_t st = nullptr, const FrameDesc* desc = nullptr, uint32_t n_frames = 0);
+DABPHY_INTERNAL int launch_deferred_superframes(dabphy_handle* h);       // dabphy_set_auto_superframes(2): the pending pass of the previous batch, on rs_stream
+DABPHY_INTERNAL int flush_deferred_superframes(dabphy_handle* h);        // ... now, and wait for it
 DABPHY_INTERNAL int fused_class_tables(dabphy_handle* h, const dabphy_protection& prot, bool fic, DevBuf (&steps)[FUSED_VARIANTS], int (&n_windows)[FUSED_VARIANTS]);   // dabphy_fused.hip
 DABPHY_INTERNAL int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic);
 DABPHY_INTERNAL bool sp_single_ok(const dabphy_handle* h, uint64_t n_cw, int nsteps);

@@ -21,6 +21,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     const uint32_t B = h->cfg.n_ensembles, F = n_frames;
     const int ring_frames = (int)h->cfg.max_frames + 5;
     int r;
+    if (h->subch_dirty && (h->sf_def_pending || h->sf_def_inflight) && (r = flush_deferred_superframes(h))) return r;      // (the deferred filter pass of the last batch belongs to the classes that are about to be rebuilt)
     if ((r = apply_subchannels(h))) return r;                // per-ensemble sub-channel changes since the last batch (dabphy_set_subchannels_ensemble)
     for (int k = 0; k < dabphy_handle::N_DESC; k++) {
         if ((r = ensure(h, h->s_desc2[k], (size_t)B * h->cfg.max_frames * sizeof(FrameDesc)))) return r;
@@ -85,7 +86,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->exact_batch) {
             if ((r = ensure(h, h->snap_dec, (size_t)B * sizeof(DecState)))) return r;
             if (h->tii_state.p && (r = ensure(h, h->snap_tii, h->tii_state.cap))) return r;
-            for (auto& cls : h->classes) if (cls.sf_state.p && (r = ensure(h, cls.sf_snap, cls.sf_state.cap))) return r;
+            if (!h->sf_deferred) for (auto& cls : h->classes) if (cls.sf_state.p && (r = ensure(h, cls.sf_snap, cls.sf_state.cap))) return r;      // (deferred filter: this batch's pass has not run when the batch is decoded again, nothing to put back)
         }
         // (an ensure() above may have moved a buffer the plan names: then it is stale -- plan again, nothing moves the second time)
         if (h->fplan.buf_gen != h->buf_gen && (r = fused_plan(h, F, true))) return r;
@@ -194,6 +195,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
         for (; h->ahead < 1 + depth; h->ahead++) if ((r = queue_chain(h, (cur + h->ahead) % ND, F))) return r;
     }
+    // dabphy_set_auto_superframes(2): the PREVIOUS batch's superframe filter pass, beside this batch's FFT stage; this batch's decoders
+    // wait for it on the device before they overwrite the class outputs it reads
+    if (!replay && h->sf_auto && h->sf_deferred && (r = launch_deferred_superframes(h))) return r;
+    if (h->sf_def_inflight) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_rs_done, 0));
     SnrArgs sn{}; sn.state = h->d_dec; sn.desc = d_desc; sn.n_ens = (int)B; sn.n_frames = (int)F; sn.prs_mag = da.prs_mag; sn.snr_out = h->s_snr.as<float>();
 
     // SNR + FIC + TII beside the MSC decode, on the auxiliary stream.  The FIC's 4 code words per frame ride in the fused launch
@@ -288,7 +293,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         }
         if (!first_two) mark(dabphy_handle::ST_MSC_GATHER, true);       // (gather + decode pairs of all such classes)
     }
-    if (h->sf_auto) {
+    if (h->sf_auto && !h->sf_deferred) {
         if ((r = launch_superframe_stats(h))) return r;
         h->sf_stats_ready = true;
         HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
@@ -301,7 +306,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         // batch's chain was queued: queue_chain)
         HIPCHK(h, hipMemcpyAsync(h->snap_dec.p, h->d_dec, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
         if (h->tii_state.p && h->snap_tii.p) HIPCHK(h, hipMemcpyAsync(h->snap_tii.p, h->tii_state.p, h->tii_state.cap, hipMemcpyDeviceToDevice, h->stream));
-        for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_snap.p, cls.sf_state.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));
+        if (!h->sf_deferred) for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_snap.p, cls.sf_state.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_any_eff, 0, sizeof(int32_t), h->stream));
     }
     if ((r = decode(false))) return r;
@@ -329,7 +334,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         if (h->snap_hist[cur].p && h->s_hist.p) HIPCHK(h, hipMemcpyAsync(h->s_hist.p, h->snap_hist[cur].p, (size_t)B * HIST_CAP * sizeof(FrameDesc), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_dec, h->snap_dec.p, sizeof(DecState) * B, hipMemcpyDeviceToDevice, h->stream));
         if (h->tii_state.p && h->snap_tii.p) HIPCHK(h, hipMemcpyAsync(h->tii_state.p, h->snap_tii.p, h->tii_state.cap, hipMemcpyDeviceToDevice, h->stream));
-        for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_state.p, cls.sf_snap.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));
+        if (!h->sf_deferred) for (auto& cls : h->classes) if (cls.sf_state.p && cls.sf_snap.p) HIPCHK(h, hipMemcpyAsync(cls.sf_state.p, cls.sf_snap.p, cls.sf_state.cap, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_any_eff, 0, sizeof(int32_t), h->stream));
         if ((r = decode(true))) return r;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fic_done, 0));
@@ -340,10 +345,21 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         for (int i = 1; i <= depth; i++) if ((r = queue_chain(h, (cur + i) % ND, F))) return r;
         h->n_replayed_batches++;
     }
+    if (h->sf_auto && h->sf_deferred) {
+        // (the main stream has waited for the previous batch's pass: its totals are in host memory; this batch's pass is the next call's)
+        h->sf_def_inflight = false;
+        h->sf_def_pending = true; h->sf_def_desc = d_desc; h->sf_def_frames = F;
+    }
     // the host's mirror of the pair tables follows what k_pair_cif0 wrote (same rule, from the host's copy of the descriptors)
     for (auto& cls : h->classes) if (cls.cif0_pending) {
         for (MscPair& p : cls.pairs) if (p.cif0 < 0) p.cif0 = 4 * h->h_desc[(size_t)p.ens * F].frame_no;
         cls.cif0_pending = false;
+    }
+    if (h->fplan.args.done && h->fplan.launched && !h->fplan.use_sp) {
+        // split traceback: walkers that gave up on a group's flag (k_viterbi.hip: tb_consume) would have decoded garbage -- never silently
+        uint32_t gave_up = 0;
+        HIPCHK(h, hipMemcpy(&gave_up, h->fplan.args.done + h->fplan.args.n_work + 1, sizeof gave_up, hipMemcpyDeviceToHost));
+        if (gave_up) { h->err = "split traceback: " + std::to_string(gave_up) + " groups were walked back without their decisions having been published"; return DABPHY_ERR_HIP; }
     }
     if (g_tl_on) { for (int i = 0; i < 5; i++) g_tl.acc[i] += tl[i]; g_tl.n++; if (g_tl.n % 8 == 0) fprintf(stderr, "dabphy timing [us]: before resolve %.1f, resolved %.1f, demod launched %.1f, all launched %.1f, synced %.1f (n=%ld)\n", g_tl.acc[0] / g_tl.n, g_tl.acc[1] / g_tl.n, g_tl.acc[2] / g_tl.n, g_tl.acc[3] / g_tl.n, g_tl.acc[4] / g_tl.n, g_tl.n); }
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }

@@ -134,6 +134,8 @@ int dabphy_reset(dabphy_handle* h)
     h->desc_sel = 0; h->n_wide_passes = h->n_wide_fallbacks = 0; h->n_replayed_batches = 0;
     HIPCHK(h, hipMemsetAsync(h->d_dec, 0, sizeof(DecState) * h->cfg.n_ensembles, h->stream));
     h->last_frames = 0; h->last_desc = nullptr;
+    if (h->rs_stream) HIPCHK(h, hipStreamSynchronize(h->rs_stream));
+    h->sf_def_pending = h->sf_def_unfetched = h->sf_def_inflight = false;      // (a deferred filter pass of the stream that ends here is dropped with it)
     for (auto& c : h->classes) if (c.sf_state.p) HIPCHK(h, hipMemsetAsync(c.sf_state.p, 0, c.sf_state.cap, h->stream));   // decoders restart too (RadioReceiver::restart_decoder)
     // ... and the frame count starts over: every selected sub-channel's time de-interleaver fills again from the first CIF decoded
     for (auto& c : h->classes) { for (MscPair& p : c.pairs) p.cif0 = -1; int r2 = upload_pairs(h, c); if (r2) return r2; }

@@ -117,9 +117,10 @@ int dabphy_rs_decode_msc(dabphy_handle* h, int32_t subch_index, const int32_t* f
 // classes of a bucket (kernel LDS size) go in ONE launch each of the wide pass, the verdict and the serial walk; their argument blocks
 // travel through a page-locked staging area that the caller must not reuse before the stream has been synchronised (every caller
 // synchronises before it returns, dabphy_process at its end).
-int run_superframes(dabphy_handle* h, const std::vector<SfSel>& sel, int32_t* stats, hipStream_t st)
+int run_superframes(dabphy_handle* h, const std::vector<SfSel>& sel, int32_t* stats, hipStream_t st, const FrameDesc* desc, uint32_t n_frames)
 {
-    const uint32_t F = h->last_frames;
+    const uint32_t F = n_frames ? n_frames : h->last_frames;        // (a deferred pass names the batch it belongs to: the handle has moved on)
+    if (!desc) desc = h->last_desc;
     const int n_cif = (int)(4 * F), n_slots = n_cif / 5 + 1;
     int r;
     if ((r = prepare_superframes(h, F))) return r;
@@ -138,7 +139,7 @@ int run_superframes(dabphy_handle* h, const std::vector<SfSel>& sel, int32_t* st
         a.out = cls.out.as<uint8_t>(); a.n_cif = n_cif; a.n_pairs = (int)cls.pairs.size(); a.pairs = cls.pair_tab.as<MscPair>(); a.frame_bytes = fb;
         a.run = e.d_run; a.n_run = e.d_run ? e.n_run : a.n_pairs;
         if (a.n_run <= 0) continue;
-        a.s = bitrate / 8; a.desc = h->last_desc; a.n_frames = (int)F;
+        a.s = bitrate / 8; a.desc = desc; a.n_frames = (int)F;
         a.state = cls.sf_state.as<uint8_t>(); a.state_stride = cls.sf_stride();
         a.events = h->sf_events.as<SfEvent>() + cls.sf_pair0 * n_cif; a.n_events = h->sf_count.as<int32_t>() + cls.sf_pair0;
         a.sf = h->sf_bytes.as<uint8_t>() + cls.sf_bytes0; a.n_slots = n_slots; a.stats = stats;
@@ -228,26 +229,56 @@ int dabphy_superframes_ensemble(dabphy_handle* h, uint32_t ensemble, uint32_t su
 }
 
 // SuperframeFilter over every DAB+ sub-channel of every ensemble: the classes of a bucket in one launch each on the main stream, totals into sf_stats
-int launch_superframe_stats(dabphy_handle* h)
+int launch_superframe_stats(dabphy_handle* h, hipStream_t st, const FrameDesc* desc, uint32_t n_frames)
 {
     const uint32_t B = h->cfg.n_ensembles;
+    if (!st) st = h->stream;
     int r;
     if ((r = ensure(h, h->sf_stats, sizeof(int32_t) * 4 * B))) return r;
-    HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->sf_stats.p, 0, sizeof(int32_t) * 4 * B, st));
     std::vector<SfSel> sel;
     for (size_t ci = 0; ci < h->classes.size(); ci++) if (h->classes[ci].dabplus_rate()) sel.push_back(SfSel{(int)ci, nullptr, 0});
     if (sel.empty()) return 0;
-    if (h->profiling) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], h->stream); (void)e; }
-    if ((r = run_superframes(h, sel, h->sf_stats.as<int32_t>(), h->stream))) return r;
-    if (h->profiling) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], h->stream); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
+    if (h->profiling) { hipError_t e = hipEventRecord(h->ev_beg[dabphy_handle::ST_RS], st); (void)e; }
+    if ((r = run_superframes(h, sel, h->sf_stats.as<int32_t>(), st, desc, n_frames))) return r;
+    if (h->profiling) { hipError_t e = hipEventRecord(h->ev_end[dabphy_handle::ST_RS], st); (void)e; h->ev_used[dabphy_handle::ST_RS] = true; }
     return 0;
+}
+
+// dabphy_set_auto_superframes(2).  The filter pass of a batch needs nothing but the batch's class outputs and descriptors and the
+// windows it carries; nothing of the NEXT batch needs its results before that batch's decoders overwrite the class outputs.  So the pass of
+// batch k is queued by dabphy_process(k + 1), behind that batch's demod launch, on a stream of its own: it runs beside the FFT stage
+// instead of in the step's tail, and the decoders of batch k + 1 wait for it on the device (it is long done by then).
+int launch_deferred_superframes(dabphy_handle* h)
+{
+    if (!h->sf_def_pending) return DABPHY_OK;
+    const uint32_t B = h->cfg.n_ensembles;
+    if (!h->rs_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->rs_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_rs_done, hipEventDisableTiming));
+    }
+    int r;
+    if ((r = launch_superframe_stats(h, h->rs_stream, h->sf_def_desc, h->sf_def_frames))) return r;
+    HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->rs_stream));
+    HIPCHK(h, hipEventRecord(h->ev_rs_done, h->rs_stream));
+    h->sf_def_pending = false; h->sf_def_inflight = true; h->sf_def_unfetched = true;
+    return DABPHY_OK;
+}
+int flush_deferred_superframes(dabphy_handle* h)
+{
+    int r;
+    if ((r = launch_deferred_superframes(h))) return r;
+    if (h->sf_def_inflight) { HIPCHK(h, hipEventSynchronize(h->ev_rs_done)); h->sf_def_inflight = false; }
+    return DABPHY_OK;
 }
 
 int dabphy_set_auto_superframes(dabphy_handle* h, int32_t on)
 {
     DeviceBind dev_(h);
     if (!h) return DABPHY_ERR_INVALID;
+    if (h->sf_deferred && on != 2) { int r = flush_deferred_superframes(h); if (r) return r; }      // (leaving the deferred mode: nothing stays pending)
     h->sf_auto = on != 0;
+    h->sf_deferred = on == 2;
     return DABPHY_OK;
 }
 
@@ -256,6 +287,16 @@ int dabphy_superframes_stats(dabphy_handle* h, int32_t* stats)
     DeviceBind dev_(h);
     if (!h || !stats || !h->last_frames || !h->last_desc) return DABPHY_ERR_INVALID;
     int r;
+    if (h->sf_auto && h->sf_deferred) {
+        // the totals of the pass that ran last and has not been fetched (the batch BEFORE the last dabphy_process); if there is none,
+        // the pending pass of the last batch runs now (the end of a stream: one more call fetches the last batch's totals)
+        if (!h->sf_def_unfetched && h->sf_def_pending) { if ((r = launch_deferred_superframes(h))) return r; }
+        if (h->sf_def_inflight) { HIPCHK(h, hipEventSynchronize(h->ev_rs_done)); h->sf_def_inflight = false; }
+        if (h->sf_def_unfetched) memcpy(stats, h->h_sf_stats, sizeof(int32_t) * 4 * h->cfg.n_ensembles);
+        else memset(stats, 0, sizeof(int32_t) * 4 * h->cfg.n_ensembles);
+        h->sf_def_unfetched = false;
+        return DABPHY_OK;
+    }
     if (h->sf_stats_ready && h->h_sf_stats_valid) {      // the filter rode in dabphy_process and its totals came back with the batch
         h->sf_stats_ready = false; h->h_sf_stats_valid = false;
         memcpy(stats, h->h_sf_stats, sizeof(int32_t) * 4 * h->cfg.n_ensembles);

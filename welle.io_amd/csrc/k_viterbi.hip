@@ -363,7 +363,14 @@ __device__ __forceinline__ void tb_consume(const FusedArgs& A, int lane)
         if (lane == 0) item = atomicAdd(A.next_tb, 1u);
         item = (uint32_t)uniform_i32(__shfl((int)item, 0));
         if (item >= A.n_work) break;
-        while (__hip_atomic_load(A.done + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(32);
+        // (bounded: a flag that never comes -- a forward wave that died, a protocol error -- must not hang the device.  After ~2^21 polls,
+        // seconds, the wave gives up, counts the item in done[n_work + 1] and walks back whatever the scratch holds: the host checks the
+        // counter after the launch and fails the call)
+        uint32_t polls = 0;
+        while (__hip_atomic_load(A.done + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++polls > (1u << 21)) { if (lane == 0) atomicAdd(A.done + A.n_work + 1, 1u); break; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint32_t wk = work[item];
         const DABPHY_CONST_AS FusedClass& C = classes[wk >> 24];
@@ -627,7 +634,7 @@ void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStrea
     if (a.done && split) {
         // the traceback beside the forward pass: flags and the second cursor cleared, the traceback waves forked off onto their own stream
         // (forward launch first: the GPU-less execution model runs launches to completion in order), joined back behind the launch
-        e = hipMemsetAsync(a.done, 0, ((size_t)a.n_work + 1) * sizeof(uint32_t), s);
+        e = hipMemsetAsync(a.done, 0, ((size_t)a.n_work + 2) * sizeof(uint32_t), s);      // flags, the walkers' cursor, the count of flags given up on
         e = hipEventRecord(split->fork, s);
         e = hipStreamWaitEvent(split->tb_stream, split->fork, 0);
         if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0], true>), dim3(n_slots), dim3(64), 0, s, a);

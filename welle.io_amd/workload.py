@@ -209,9 +209,10 @@ def make_channel_batch(B, n_frames, rank=0, n_distinct=4, cfo_max_hz=60.0, sigma
     return iq, dict(cfo_hz=cfo_hz, ppm=ppm_b, snr_db=snr_b, sigma=sig_b), base_np, txs
 
 
-def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demod_chunk=0, profiling=True, loop=True, decode_shape=0, sync_early=0):
+def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demod_chunk=0, profiling=True, loop=True, decode_shape=0, sync_early=0, deferred_filter=False):
     """the handle bench.py times: batch geometry B x F, looping HBM-resident ring, coarse corrector enabled, no constellation / CIR
-    taps, all sub-channels decoded, superframe filter inside process()"""
+    taps, all sub-channels decoded, superframe filter inside process() (deferred_filter: the pass of a batch rides beside the NEXT batch's
+    FFT stage, dabphy_set_auto_superframes(2); superframes_stats() then returns the totals of the batch before the last process())"""
     B, N = iq.shape
     dev = capi.DabPhy(n_ensembles=B, max_frames=F, device=device, lib_path=lib_path, want_constellation=False, want_impulse_response=False,
                       disable_coarse=False, pipeline_sync=pipeline_sync, demod_chunk=demod_chunk, decode_shape=decode_shape, sync_early=sync_early)
@@ -228,5 +229,5 @@ def open_receiver(capi, lib_path, iq, F, subchs, device=0, pipeline_sync=1, demo
         dev.set_subchannels([(s.subch_id, s.start_cu, s.size_cu, dev_protection(dev, s)) for s in subchs])
     if profiling:
         dev.set_profiling(True)
-    dev.set_auto_superframes(True)
+    dev.set_auto_superframes(2 if deferred_filter else True)
     return dev
