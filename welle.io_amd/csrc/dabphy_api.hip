@@ -724,7 +724,8 @@ int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, 
 int dabphy_test_traceback_split(dabphy_handle* h, int32_t on)
 {
     if (!h) return DABPHY_ERR_INVALID;
-    h->tb_split = on != 0;                                   // (takes effect with the next batch's launch plan)
+    h->tb_split = (on & 1) != 0;                             // (takes effect with the next batch's launch plan)
+    h->tb_no_walkers = (on & 2) != 0;                        // (diagnosis: no k_traceback_fused launch -- the forward waves walk everything back at the end of theirs)
     return DABPHY_OK;
 }
 
@@ -740,7 +741,7 @@ int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(h, hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); h->err = "hipEventCreate failed"; return DABPHY_ERR_HIP; }
-    const FusedSplit sp{h->tb_stream, h->ev_tb_fork, h->ev_tb_join};
+    const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join};
     auto again = [&]() { if (P.use_sp) launch_sp(P.args, P.sp_two, P.sp_variant, h->stream); else launch_viterbi_fused(P.args, P.variant, P.n_slots, h->stream, P.args.done ? &sp : nullptr); };
     again();                                                                  // (same inputs, same outputs: the launch is idempotent)
     hipError_t e = hipEventRecord(e0, h->stream);

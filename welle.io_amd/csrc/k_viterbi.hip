@@ -635,15 +635,16 @@ void launch_viterbi_fused(const FusedArgs& a, int variant, int n_slots, hipStrea
         // the traceback beside the forward pass: flags and the second cursor cleared, the traceback waves forked off onto their own stream
         // (forward launch first: the GPU-less execution model runs launches to completion in order), joined back behind the launch
         e = hipMemsetAsync(a.done, 0, ((size_t)a.n_work + 2) * sizeof(uint32_t), s);      // flags, the walkers' cursor, the count of flags given up on
-        e = hipEventRecord(split->fork, s);
-        e = hipStreamWaitEvent(split->tb_stream, split->fork, 0);
+        if (split->tb_stream) { e = hipEventRecord(split->fork, s); e = hipStreamWaitEvent(split->tb_stream, split->fork, 0); }
         if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0], true>), dim3(n_slots), dim3(64), 0, s, a);
         else if (variant == 1) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[1], FUSED_OCC[1], true>), dim3(n_slots), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[2], FUSED_OCC[2], true>), dim3(n_slots), dim3(64), 0, s, a);
-        const int n_tb = std::min<int>((int)a.n_work, device_simds());
-        hipLaunchKernelGGL(k_traceback_fused, dim3(n_tb), dim3(64), 0, split->tb_stream, a);
-        e = hipEventRecord(split->join, split->tb_stream);
-        e = hipStreamWaitEvent(s, split->join, 0);
+        if (split->tb_stream) {                         // (nullptr = diagnosis: the forward waves walk everything back at the end of theirs)
+            const int n_tb = std::min<int>((int)a.n_work, device_simds());
+            hipLaunchKernelGGL(k_traceback_fused, dim3(n_tb), dim3(64), 0, split->tb_stream, a);
+            e = hipEventRecord(split->join, split->tb_stream);
+            e = hipStreamWaitEvent(s, split->join, 0);
+        }
         return;
     }
     if (variant == 0) hipLaunchKernelGGL((k_viterbi_fused<FUSED_ROWS[0], FUSED_OCC[0], false>), dim3(n_slots), dim3(64), 0, s, a);
