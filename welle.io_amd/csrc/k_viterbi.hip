@@ -347,7 +347,9 @@ __device__ __forceinline__ void tb_publish(const FusedArgs& A, uint32_t item, in
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     lds_dma_wait();                                        // s_waitcnt vmcnt(0) of our own (the compiler may drop the fence's when it knows the counter empty: MI355X_MICROARCH.md, inter-workgroup visibility)
-    if (lane == 0) __hip_atomic_store(A.done + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (flag and poll are read-modify-write atomics on both sides: they execute where the per-XCD L2s cannot hold a stale copy.  A plain
+    // or sc1 load polled from another XCD kept returning the zero it had first fetched: measured, round 6 -- the launch never ended)
+    if (lane == 0) atomicExch(A.done + item, 1u);
 }
 // LEAN = the 32-register form (eight decision words in flight, no double buffering); otherwise `traceback` as the forward waves have it
 template <bool LEAN>
@@ -363,13 +365,17 @@ __device__ __forceinline__ void tb_consume(const FusedArgs& A, int lane)
         if (lane == 0) item = atomicAdd(A.next_tb, 1u);
         item = (uint32_t)uniform_i32(__shfl((int)item, 0));
         if (item >= A.n_work) break;
-        // (bounded: a flag that never comes -- a forward wave that died, a protocol error -- must not hang the device.  After ~2^21 polls,
-        // seconds, the wave gives up, counts the item in done[n_work + 1] and walks back whatever the scratch holds: the host checks the
+        // (bounded: a flag that never comes -- a forward wave that died, a protocol error -- must not hang the device.  After 2^19 polls,
+        // a few seconds, the wave gives up, counts the item in done[n_work + 1] and walks back whatever the scratch holds: the host checks the
         // counter after the launch and fails the call)
         uint32_t polls = 0;
-        while (__hip_atomic_load(A.done + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++polls > (1u << 21)) { if (lane == 0) atomicAdd(A.done + A.n_work + 1, 1u); break; }
+        for (;;) {
+            uint32_t f = 0;
+            if (lane == 0) f = atomicAdd(A.done + item, 0u);
+            f = (uint32_t)uniform_i32(__shfl((int)f, 0));
+            if (f) break;
+            __builtin_amdgcn_s_sleep(127);
+            if (++polls > (1u << 19)) { if (lane == 0) atomicAdd(A.done + A.n_work + 1, 1u); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint32_t wk = work[item];
