@@ -195,6 +195,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->tb_stream) { e = hipStreamSynchronize(h->tb_stream); e = hipStreamDestroy(h->tb_stream); }
     if (h->rs_stream) { e = hipStreamSynchronize(h->rs_stream); e = hipStreamDestroy(h->rs_stream); }
     if (h->ev_rs_done) e = hipEventDestroy(h->ev_rs_done);
+    if (h->h_tb_gave_up) e = hipHostFree(h->h_tb_gave_up);
     if (h->ev_tb_fork) e = hipEventDestroy(h->ev_tb_fork);
     if (h->ev_tb_join) e = hipEventDestroy(h->ev_tb_join);
     if (h->ev_drain_done) e = hipEventDestroy(h->ev_drain_done);
@@ -725,6 +726,7 @@ int dabphy_test_traceback_split(dabphy_handle* h, int32_t on)
 {
     if (!h) return DABPHY_ERR_INVALID;
     h->tb_split = (on & 1) != 0;                             // (takes effect with the next batch's launch plan)
+    h->tb_no_tail = (on & 4) != 0;                           // (diagnosis: the forward waves do not walk back at the end of theirs)
     h->tb_no_walkers = (on & 2) != 0;                        // (diagnosis: no k_traceback_fused launch -- the forward waves walk everything back at the end of theirs)
     return DABPHY_OK;
 }

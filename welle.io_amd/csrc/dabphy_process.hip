@@ -251,8 +251,12 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         h->fplan.args = fa; h->fplan.launched = true;
         mark(dabphy_handle::ST_MSC_VITERBI, false);
         if (h->fplan.use_sp) launch_sp(fa, h->fplan.sp_two, h->fplan.sp_variant, h->stream);
-        else { const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join}; launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream, fa.done ? &sp : nullptr); }
+        else { if (h->tb_no_tail && fa.done) fa.sp2_warm = -1; const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join}; launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream, fa.done ? &sp : nullptr); }
         mark(dabphy_handle::ST_MSC_VITERBI, true);
+        if (fa.done) {
+            if (!h->h_tb_gave_up) { void* p = nullptr; HIPCHK(h, hipHostMalloc(&p, sizeof(uint32_t), hipHostMallocDefault)); h->h_tb_gave_up = reinterpret_cast<uint32_t*>(p); }
+            HIPCHK(h, hipMemcpyAsync(h->h_tb_gave_up, fa.done + fa.n_work + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        }
         if (fic_fused) HIPCHK(h, hipEventRecord(h->ev_fused_done, h->stream));
     }
     {
@@ -357,9 +361,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     }
     if (h->fplan.args.done && h->fplan.launched && !h->fplan.use_sp) {
         // split traceback: walkers that gave up on a group's flag (k_viterbi.hip: tb_consume) would have decoded garbage -- never silently
-        uint32_t gave_up = 0;
-        HIPCHK(h, hipMemcpy(&gave_up, h->fplan.args.done + h->fplan.args.n_work + 1, sizeof gave_up, hipMemcpyDeviceToHost));
-        if (gave_up) { h->err = "split traceback: " + std::to_string(gave_up) + " groups were walked back without their decisions having been published"; return DABPHY_ERR_HIP; }
+        // (the counter came back with the batch: a copy queued behind the launch, in front of the call's final synchronisation)
+        if (h->h_tb_gave_up && *h->h_tb_gave_up) { h->err = "split traceback: " + std::to_string(*h->h_tb_gave_up) + " groups were walked back without their decisions having been published"; return DABPHY_ERR_HIP; }
     }
     if (g_tl_on) { for (int i = 0; i < 5; i++) g_tl.acc[i] += tl[i]; g_tl.n++; if (g_tl.n % 8 == 0) fprintf(stderr, "dabphy timing [us]: before resolve %.1f, resolved %.1f, demod launched %.1f, all launched %.1f, synced %.1f (n=%ld)\n", g_tl.acc[0] / g_tl.n, g_tl.acc[1] / g_tl.n, g_tl.acc[2] / g_tl.n, g_tl.acc[3] / g_tl.n, g_tl.acc[4] / g_tl.n, g_tl.n); }
     { float t = 0; h->chain_ms = (hipEventElapsedTime(&t, h->ev_chain_beg[cur], h->ev_chain_end[cur]) == hipSuccess) ? t : 0.0f; }

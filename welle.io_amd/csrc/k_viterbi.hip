@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
 #endif
   }
 #ifndef FM_EXP_NOTRACE
-  if constexpr (SPLIT) tb_consume<false>(A, lane);                   // no trellis left to run: this wave walks back too (the last groups' walks get every wave of the device)
+  if constexpr (SPLIT) if (A.sp2_warm >= 0) tb_consume<false>(A, lane);                   // no trellis left to run: this wave walks back too (the last groups' walks get every wave of the device)
 #endif
 }
 
