@@ -251,7 +251,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         h->fplan.args = fa; h->fplan.launched = true;
         mark(dabphy_handle::ST_MSC_VITERBI, false);
         if (h->fplan.use_sp) launch_sp(fa, h->fplan.sp_two, h->fplan.sp_variant, h->stream);
-        else { if (h->tb_no_tail && fa.done) fa.sp2_warm = -1; const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join}; launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream, fa.done ? &sp : nullptr); }
+        else { if (h->tb_no_tail && fa.done) fa.sp2_warm = -1; if (h->tb_no_fence && fa.done) fa.sp2_resident = -1; const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join}; launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream, fa.done ? &sp : nullptr); }
         mark(dabphy_handle::ST_MSC_VITERBI, true);
         if (fa.done) {
             if (!h->h_tb_gave_up) { void* p = nullptr; HIPCHK(h, hipHostMalloc(&p, sizeof(uint32_t), hipHostMallocDefault)); h->h_tb_gave_up = reinterpret_cast<uint32_t*>(p); }

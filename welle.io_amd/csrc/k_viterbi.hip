@@ -345,7 +345,7 @@ template <int ROWS> struct FmGeom {
 // The forward pass is bound by vector issue, the walk by its reads: side by side instead of one after the other in every wave.
 __device__ __forceinline__ void tb_publish(const FusedArgs& A, uint32_t item, int lane)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (A.sp2_resident >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (< 0: diagnosis only)
     lds_dma_wait();                                        // s_waitcnt vmcnt(0) of our own (the compiler may drop the fence's when it knows the counter empty: MI355X_MICROARCH.md, inter-workgroup visibility)
     // (flag and poll are read-modify-write atomics on both sides: they execute where the per-XCD L2s cannot hold a stale copy.  A plain
     // or sc1 load polled from another XCD kept returning the zero it had first fetched: measured, round 6 -- the launch never ended)
