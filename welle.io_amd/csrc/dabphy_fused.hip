@@ -161,7 +161,7 @@ int fused_plan(dabphy_handle* h, uint32_t F, bool want_fic)
     // service in a multiplex of small ones: 9222 steps x 5120 waves = 24 GB): then one region per GROUP, each of its own length.
     // (the traceback as a pass of its own reads a group's decisions after the wave that wrote them has gone on to the next group: per group)
     const bool tb_split = h->tb_split && !use_sp && item_rows < 0xffffffffull && !work.empty();
-    const bool dec_by_item = !use_sp && (tb_split || item_rows < (uint64_t)n_slots * max_steps) && item_rows < 0xffffffffull;
+    const bool dec_by_item = !use_sp && (tb_split || debug_env("DABPHY_FORCE_DEC_BY_ITEM") || item_rows < (uint64_t)n_slots * max_steps) && item_rows < 0xffffffffull;
     int r;
     if (!work.empty()) {
         const size_t dec_cells = use_sp ? (size_t)n_slots * sp_cells : dec_by_item ? (size_t)item_rows * 64 : (size_t)n_slots * max_steps * 64;
