@@ -349,7 +349,7 @@ __device__ __forceinline__ void tb_publish(const FusedArgs& A, uint32_t item, in
     lds_dma_wait();                                        // s_waitcnt vmcnt(0) of our own (the compiler may drop the fence's when it knows the counter empty: MI355X_MICROARCH.md, inter-workgroup visibility)
     // (flag and poll are read-modify-write atomics on both sides: they execute where the per-XCD L2s cannot hold a stale copy.  A plain
     // or sc1 load polled from another XCD kept returning the zero it had first fetched: measured, round 6 -- the launch never ended)
-    if (lane == 0) atomicExch(A.done + item, 1u);
+    (void)lane; __hip_atomic_store(A.done + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every lane the same word: no divergent region around a store whose address is wave-uniform)
 }
 // LEAN = the 32-register form (eight decision words in flight, no double buffering); otherwise `traceback` as the forward waves have it
 template <bool LEAN>
