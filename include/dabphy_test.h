@@ -22,9 +22,11 @@ int dabphy_time_demod(dabphy_handle* h, const float* frames, uint32_t n_src, uin
 int dabphy_time_viterbi(dabphy_handle* h, uint32_t nbits, uint32_t n_codewords, uint32_t iters, float* ms_gather,
                         float* ms_decode);
 int dabphy_time_fused_msc(dabphy_handle* h, uint32_t iters, float* ms);
-/* The traceback of the lane-per-code-word Viterbi kernel as a pass of its own BESIDE the forward pass (k_traceback_fused: 32-register waves
- * that ride as a sixth wave per SIMD next to five forward waves and walk back the groups whose decisions the forward waves have published;
- * profiles/r06_viterbi_split.txt) instead of inside the wave that ran the trellis.  Same bytes; on = 1 / 0, from the next batch on. */
+/* EXPERIMENT of round 6, off by default (profiles/r06_viterbi_split.txt: a measured loss).  on = 1: the forward waves of the lane-per-code-word
+ * Viterbi kernel publish every group's decisions (per-group scratch, agent-scope release, a flag) and walk back only when no trellis is left
+ * to run -- the walks of the whole launch then overlap the forward passes of other waves instead of following each group's own.  Same bytes,
+ * 6.46 against 5.74-5.87 ms for the launch alone.  on = 3 adds the 24-register walker waves (k_traceback_fused, a sixth wave per SIMD): they
+ * read stale decisions across XCDs -- WRONG bytes -- and are there for the record only.  From the next batch on. */
 int dabphy_test_traceback_split(dabphy_handle* h, int32_t on);
 /* dabphy_time_copy: a plain device-to-device copy of `bytes` bytes (16 bytes per lane and request, grid-stride, blocks_per_cu work-groups
  *   of 256 threads per compute unit, 0 = 4), `iters` passes after three warm-up passes; *gbytes_per_s = bytes read + bytes written per

@@ -726,9 +726,10 @@ int dabphy_test_traceback_split(dabphy_handle* h, int32_t on)
 {
     if (!h) return DABPHY_ERR_INVALID;
     h->tb_split = (on & 1) != 0;                             // (takes effect with the next batch's launch plan)
-    h->tb_no_fence = (on & 8) != 0;                          // (diagnosis: no release fence in front of the flag)
-    h->tb_no_tail = (on & 4) != 0;                           // (diagnosis: the forward waves do not walk back at the end of theirs)
-    h->tb_no_walkers = (on & 2) != 0;                        // (diagnosis: no k_traceback_fused launch -- the forward waves walk everything back at the end of theirs)
+    // (bit 1: also launch the 24-register walker waves, k_traceback_fused.  As measured in round 6 they read STALE decisions from their
+    // XCD's L2 on the second batch -- the scratch addresses repeat from batch to batch and an agent-scope acquire does not evict L2 --:
+    // wrong bytes.  Kept for the experiment's record only; without the bit the forward waves walk everything back themselves)
+    h->tb_no_walkers = (on & 2) == 0;
     return DABPHY_OK;
 }
 

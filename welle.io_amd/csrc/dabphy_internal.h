@@ -127,7 +127,7 @@ struct dabphy_handle {
     DevBuf fused_cls, fused_work, fused_dec_off; uint32_t* d_fused_next = nullptr;
     // the traceback of the lane-per-code-word kernel as a pass of its own beside the forward pass (k_traceback_fused): per-item flags + cursor, its stream
     uint32_t* h_tb_gave_up = nullptr;                    // page-locked: walkers that gave up on a flag in the last launch (must be 0)
-    bool tb_split = false; bool tb_no_walkers = false, tb_no_tail = false, tb_no_fence = false; DevBuf fused_done; hipStream_t tb_stream = nullptr; hipEvent_t ev_tb_fork = nullptr, ev_tb_join = nullptr;
+    bool tb_split = false; bool tb_no_walkers = true; DevBuf fused_done; hipStream_t tb_stream = nullptr; hipEvent_t ev_tb_fork = nullptr, ev_tb_join = nullptr;
     bool sp1_two = false;                                // the last one-class launch prepared goes to k_viterbi_sp2
     DevBuf sp1_cls, sp1_work; void* h_sp1 = nullptr;     // one-class state-parallel launches (the seams, the replay's one-frame FIC): descriptor + work list, page-locked staging
     DevBuf fic_steps[FUSED_VARIANTS]; int fic_windows[FUSED_VARIANTS] = {0, 0, 0};

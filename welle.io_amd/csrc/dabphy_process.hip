@@ -251,7 +251,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         h->fplan.args = fa; h->fplan.launched = true;
         mark(dabphy_handle::ST_MSC_VITERBI, false);
         if (h->fplan.use_sp) launch_sp(fa, h->fplan.sp_two, h->fplan.sp_variant, h->stream);
-        else { if (fa.done && debug_env("DABPHY_DEBUG")) fprintf(stderr, "dabphy: split launch: n_work %u n_slots %d variant %d dec %p done %p next_tb %p dec_off %p\n", fa.n_work, h->fplan.n_slots, h->fplan.variant, (void*)fa.dec, (void*)fa.done, (void*)fa.next_tb, (const void*)fa.dec_off); if (h->tb_no_tail && fa.done) fa.sp2_warm = -1; if (h->tb_no_fence && fa.done) fa.sp2_resident = -1; const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join}; launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream, fa.done ? &sp : nullptr); }
+        else { const FusedSplit sp{h->tb_no_walkers ? nullptr : h->tb_stream, h->ev_tb_fork, h->ev_tb_join}; launch_viterbi_fused(fa, h->fplan.variant, h->fplan.n_slots, h->stream, fa.done ? &sp : nullptr); }
         mark(dabphy_handle::ST_MSC_VITERBI, true);
         if (fa.done) {
             if (!h->h_tb_gave_up) { void* p = nullptr; HIPCHK(h, hipHostMalloc(&p, sizeof(uint32_t), hipHostMallocDefault)); h->h_tb_gave_up = reinterpret_cast<uint32_t*>(p); }
@@ -323,7 +323,6 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_aux_done, 0));
     h->last_frames = F;
     tick(3);
-    if (h->fplan.args.done && debug_env("DABPHY_DEBUG")) { fprintf(stderr, "dabphy: all launched, waiting for the main stream\n"); hipError_t e1 = hipStreamSynchronize(h->stream); fprintf(stderr, "dabphy: main stream drained: %s\n", hipGetErrorString(e1)); }
     if ((r = sync(h))) return r;
     tick(4);
     if (replay_armed(h, F) && *h->h_any_eff) {

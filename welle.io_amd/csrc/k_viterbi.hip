@@ -345,10 +345,11 @@ template <int ROWS> struct FmGeom {
 // The forward pass is bound by vector issue, the walk by its reads: side by side instead of one after the other in every wave.
 __device__ __forceinline__ void tb_publish(const FusedArgs& A, uint32_t item, int lane)
 {
-    if (A.sp2_resident >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (< 0: diagnosis only)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     lds_dma_wait();                                        // s_waitcnt vmcnt(0) of our own (the compiler may drop the fence's when it knows the counter empty: MI355X_MICROARCH.md, inter-workgroup visibility)
-    // (flag and poll are read-modify-write atomics on both sides: they execute where the per-XCD L2s cannot hold a stale copy.  A plain
-    // or sc1 load polled from another XCD kept returning the zero it had first fetched: measured, round 6 -- the launch never ended)
+    // (the flag is polled with read-modify-write atomics: they execute where no per-XCD L2 can hold a stale copy.  The store is issued by
+    // EVERY lane, same word, same value: with `if (lane == 0)` around it hipcc 7.2 structurised the work loop into a lane-masked loop that
+    // never terminated on the device -- profiles/r06_viterbi_split.txt)
     (void)lane; __hip_atomic_store(A.done + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every lane the same word: no divergent region around a store whose address is wave-uniform)
 }
 // LEAN = the 32-register form (eight decision words in flight, no double buffering); otherwise `traceback` as the forward waves have it
@@ -601,7 +602,7 @@ __global__ void __launch_bounds__(64, OCC) k_viterbi_fused(FusedArgs A)
 #endif
   }
 #ifndef FM_EXP_NOTRACE
-  if constexpr (SPLIT) if (A.sp2_warm >= 0) tb_consume<false>(A, lane);                   // no trellis left to run: this wave walks back too (the last groups' walks get every wave of the device)
+  if constexpr (SPLIT) tb_consume<false>(A, lane);                   // no trellis left to run: this wave walks back too (the last groups' walks get every wave of the device)
 #endif
 }
 
