@@ -414,7 +414,7 @@ def channel_leg(capi, workload, torch, lib_path, B, F, steps, local, sched, kind
         dev.close()
     if kind == "drift" and device == "cuda" and sched in (1, 3):
         # the same signal with the next batch's synchroniser always queued BEHIND the decoder (dabphy_config.sync_early = 1; the default
-        # moves it in front while it meets ensembles whose window moves): timing only
+        # is in front): timing only
         try:
             dev = workload.open_receiver(capi, lib_path, iq, F, subchs, device=local, pipeline_sync=sched, loop=loop, sync_early=1)
             for _ in range(n_warm):

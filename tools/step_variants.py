@@ -1,7 +1,7 @@
 """Not a test: the pipelined step of the benchmark batch under the round-6 scheduling options, A/B on one box, interleaved rounds
 (profiles/r06_step_variants.txt):
   base       the next batch's synchroniser behind the decoder (sync_early = 1), superframe filter at the end of the step (auto = 1)
-  early      ... in front of the decoder (dabphy_config.sync_early = 2)
+  early      ... in front of the decoder (dabphy_config.sync_early = 0, the default since round 6)
   deferred   the filter pass of batch k beside batch k + 1's FFT stage (dabphy_set_auto_superframes(2))
   both       early + deferred
   both+split ... and the lane-per-code-word kernel's traceback as a pass of its own (dabphy_test_traceback_split)
@@ -22,9 +22,9 @@ from welle_io_amd import capi, workload  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-ALL = {"base": dict(sync_early=1, deferred=False, split=False), "early": dict(sync_early=2, deferred=False, split=False),
-       "deferred": dict(sync_early=1, deferred=True, split=False), "both": dict(sync_early=2, deferred=True, split=False),
-       "both+split": dict(sync_early=2, deferred=True, split=True)}
+ALL = {"base": dict(sync_early=1, deferred=False, split=False), "early": dict(sync_early=0, deferred=False, split=False),
+       "deferred": dict(sync_early=1, deferred=True, split=False), "both": dict(sync_early=0, deferred=True, split=False),
+       "both+split": dict(sync_early=0, deferred=True, split=True)}
 names = sys.argv[3:] or ["base", "early", "deferred", "both"]
 lib = os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so"))
 iq, cfo, base, txs = workload.make_batch(B, rec_frames=workload.rec_frames_for(F))

@@ -193,7 +193,6 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->fic_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
     if (h->drain_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
     if (h->tb_stream) { e = hipStreamSynchronize(h->tb_stream); e = hipStreamDestroy(h->tb_stream); }
-    if (h->rs_stream) { e = hipStreamSynchronize(h->rs_stream); e = hipStreamDestroy(h->rs_stream); }
     if (h->ev_rs_done) e = hipEventDestroy(h->ev_rs_done);
     if (h->h_tb_gave_up) e = hipHostFree(h->h_tb_gave_up);
     if (h->ev_tb_fork) e = hipEventDestroy(h->ev_tb_fork);

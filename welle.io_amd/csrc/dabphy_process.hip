@@ -185,10 +185,11 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     tick(2);
     mark(dabphy_handle::ST_DEMOD, true);
     if (!replay && (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3)) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
-    // (cfg.sync_early: in front of the decoder always (2), never (1), or -- 0 -- while the last pass met ensembles whose window moves: their
-    // window searches run one after the other in the find chain, a millisecond of latency-bound work for one work-group per ensemble that
-    // costs the decoder next to nothing beside it and the whole step its length behind it)
-    const bool early = h->chain_early || (h->cfg.pipeline_sync != 2 && (h->cfg.sync_early == 2 || (h->cfg.sync_early == 0 && h->drift_seen)));
+    // (cfg.sync_early: in front of the decoder (0, the default: measured 3 % on the headline since the synchroniser's tail -- find chain
+    // rounds, verdicts -- no longer waits for the decoder's persistent waves to retire, and what drifting ensembles need: their window
+    // searches run one after the other, a millisecond of latency-bound work for one work-group per ensemble); behind it (1); or in front
+    // only while the last pass met ensembles whose window moves (2))
+    const bool early = h->chain_early || (h->cfg.pipeline_sync != 2 && (h->cfg.sync_early == 0 || (h->cfg.sync_early == 2 && h->drift_seen)));
     if (!replay && depth && early) {
         // the next batch's synchroniser is handed to the device BEFORE this batch's decoder (whose persistent waves would otherwise hold
         // every wave slot until the end of the step: the synchroniser then runs in the step's tail)

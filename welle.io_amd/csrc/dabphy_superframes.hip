@@ -253,8 +253,11 @@ int launch_deferred_superframes(dabphy_handle* h)
 {
     if (!h->sf_def_pending) return DABPHY_OK;
     const uint32_t B = h->cfg.n_ensembles;
+    // (on the AUXILIARY stream, which is idle until this batch's demod kernel has finished: a stream of its own would be the handle's
+    // eighth, and the runtime multiplexes streams onto four hardware queues -- the first version shared one with the main stream and ran
+    // behind the demod kernel instead of beside it: profiles/r06_step_variants.txt)
     if (!h->rs_stream) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->rs_stream, hipStreamNonBlocking));
+        h->rs_stream = h->aux_stream;
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_rs_done, hipEventDisableTiming));
     }
     int r;
