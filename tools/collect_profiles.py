@@ -19,6 +19,8 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 B, F = int(os.environ.get("PROF_B", "256")), int(os.environ.get("PROF_F", "32"))
 
 shutil.copy(os.path.join(SRC, "stats_kernel_stats.csv"), os.path.join(DST, TAG + "_bench_kernel_stats.csv"))
+if os.path.exists(os.path.join(SRC, "drift_kernel_stats.csv")):          # the drift leg alone under the kernel tracer (tools/bench_channel.py)
+    shutil.copy(os.path.join(SRC, "drift_kernel_stats.csv"), os.path.join(DST, TAG + "_drift_kernel_stats.csv"))
 
 
 def rows(name):
@@ -196,7 +198,25 @@ try:
                 e = ex.get(name)
                 if e and "value" in e:
                     lines.append("* extras.%s: %.0f x, %.3f ms per step, decoder %.3f ms, superframe filter %.3f ms, parity %s" % (name, e["value"], e["ms_per_step"], e["msc_viterbi_ms"], e["stages_ms"].get("rs", float("nan")), e.get("parity")))
+            for name in ("drift", "low_snr"):
+                e = ex.get(name)
+                if e and "value" in e:
+                    w = e.get("wide_sync_stats", {})
+                    lines.append("* extras.%s: %.0f x (%.3f of the headline), %.3f ms per step (demod %.3f, decoder %.3f, filter %.3f, synchroniser chain %.3f from its gate); frames accepted from the wide pass / find chain %s of %s, passes that needed the serial chain %s of %s, batches decoded twice %s; Reed-Solomon corrected %s symbols; parity %s%s" % (
+                        name, e["value"], e["value"] / j["value"], e["ms_per_step"], e["stages_ms"].get("demod", float("nan")), e["stages_ms"].get("msc_viterbi", float("nan")), e["stages_ms"].get("rs", float("nan")), e["stages_ms"].get("sync", float("nan")),
+                        w.get("frames_accepted_from_the_wide_pass"), w.get("frames"), w.get("passes_that_needed_the_serial_chain"), w.get("passes"), e.get("replayed_batches"), (e.get("superframes") or {}).get("rs_corrected_symbols"), e.get("parity"),
+                        ("; synchroniser always behind the decoder (sync_early = 1): %.3f ms per step" % e["synchroniser_always_behind_the_decoder"]["ms_per_step"]) if "ms_per_step" in (e.get("synchroniser_always_behind_the_decoder") or {}) else ""))
+            md = j.get("msc_drain")
+            if md and "value" in md:
+                lines.append("* msc_drain: every step ALL %d services' logical frames on the host (%d bytes, %d frames) through the bulk drain overlapped with the next step: %.3f ms per step = %.0f x (%.3f of the headline), %.1f GB/s into page-locked memory; the drain alone %.3f ms (%.1f GB/s)" % (
+                    md["services"], md["bytes_per_step"], md["logical_frames_per_step"], md["ms_per_step_all_services_on_the_host"], md["value"], md["vs_headline"], md["host_GBps"], md["drain_alone_ms"], md["drain_alone_GBps"]))
             fc = j.get("facade")
+            if fc and "level2" in fc:
+                for k, v in fc["level2"].items():
+                    if "cpu_ms_per_frame" in v:
+                        a = v.get("all_18_services", {})
+                        lines.append("* level 2 `%s`: %.2f ms wall / %.2f ms CPU per frame with two services%s" % (k, v["ms_per_frame"], v["cpu_ms_per_frame"],
+                                     ("; all 18 services: %.2f wall / %.2f CPU%s" % (a["ms_per_frame"], a["cpu_ms_per_frame"], (", %.1f code words per device call" % a["code_words_per_device_call"]) if "code_words_per_device_call" in a else "")) if "ms_per_frame" in a else ""))
             if fc and "ms_per_frame" in fc:
                 lines.append("* facade: %.3f ms per 96 ms frame; level 2 builds (ms per frame): %s" % (fc["ms_per_frame"], ", ".join("%s %.2f" % (k, v["ms_per_frame"]) for k, v in fc.get("level2", {}).items() if "ms_per_frame" in v)))
         except Exception as ex_:

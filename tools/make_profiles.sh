@@ -5,6 +5,7 @@
 #   gpurun_out/prof/pmc_write_*      --pmc WRITE_SIZE   (own pass)
 #   gpurun_out/prof/pmc_vit_*        SQ instruction / LDS counters of k_viterbi and k_msc_gather (own pass)
 #   gpurun_out/prof/pmc_sq{1,2}_*    SQ issue / wait / LDS counters of k_demod (own passes, demod-only driver)
+#   gpurun_out/prof/drift_*          --kernel-trace --stats of bench.py's drift leg alone (tools/bench_channel.py)
 #   gpurun_out/prof/valu_rate.txt    tools/ubench/valu_rate.hip: issue cost of the instructions the Viterbi kernel is made of
 # The summaries are then copied into profiles/ by tools/collect_profiles.py <tag>.
 cd /tmp && export TMPDIR=/tmp
@@ -21,5 +22,7 @@ timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --kernel-include-regex k_demod --output-format csv -d $O -o pmc_sq1 -- python tools/prof_demod.py > $O/pmc_sq1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAVES GRBM_GUI_ACTIVE --kernel-include-regex k_demod --output-format csv -d $O -o pmc_sq2 -- python tools/prof_demod.py > $O/pmc_sq2.log 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o /tmp/valu_rate && timeout 120 /tmp/valu_rate > $O/valu_rate.txt 2>&1
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+# the drift leg (every ensemble its own sampling-clock offset: the find chain) under the kernel tracer, on its own
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o drift -- python tools/bench_channel.py drift > $O/drift.log 2>&1
+timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
 find $O -name "*.csv" | xargs ls -la
