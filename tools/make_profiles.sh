@@ -25,4 +25,8 @@ hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o /tmp/valu_rate && 
 # the drift leg (every ensemble its own sampling-clock offset: the find chain) under the kernel tracer, on its own
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o drift -- python tools/bench_channel.py drift > $O/drift.log 2>&1
 timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
+# (gpurun copies at most 64 MiB back: the per-dispatch traces of the long passes stay on the box, the statistics are what is kept)
+find $O -name "*kernel_trace.csv" -size +4M -delete; find $O -name "*.db" -delete; find $O -name "*.pftrace" -delete
+tail -n 2 $O/*.log | cut -c1-300
+du -sh $O gpurun_out
 find $O -name "*.csv" | xargs ls -la
