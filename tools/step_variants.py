@@ -24,7 +24,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 ALL = {"base": dict(sync_early=1, deferred=False, split=False), "early": dict(sync_early=0, deferred=False, split=False),
        "deferred": dict(sync_early=1, deferred=True, split=False), "both": dict(sync_early=0, deferred=True, split=False),
-       "both+split": dict(sync_early=0, deferred=True, split=True)}
+       "both+split": dict(sync_early=0, deferred=True, split=True), "front-wait": dict(sync_early=3, deferred=False, split=False)}
 names = sys.argv[3:] or ["base", "early", "deferred", "both"]
 lib = os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so"))
 iq, cfo, base, txs = workload.make_batch(B, rec_frames=workload.rec_frames_for(F))

@@ -68,7 +68,7 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name, prop.gcnArchName);
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
-    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 3 || h->cfg.sync_early < 0 || h->cfg.sync_early > 2) return fail(DABPHY_ERR_INVALID);
+    if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 3 || h->cfg.sync_early < 0 || h->cfg.sync_early > 3) return fail(DABPHY_ERR_INVALID);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
@@ -194,6 +194,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->drain_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
     if (h->tb_stream) { e = hipStreamSynchronize(h->tb_stream); e = hipStreamDestroy(h->tb_stream); }
     if (h->ev_rs_done) e = hipEventDestroy(h->ev_rs_done);
+    if (h->ev_wide_front) e = hipEventDestroy(h->ev_wide_front);
     if (h->h_tb_gave_up) e = hipHostFree(h->h_tb_gave_up);
     if (h->ev_tb_fork) e = hipEventDestroy(h->ev_tb_fork);
     if (h->ev_tb_join) e = hipEventDestroy(h->ev_tb_join);

@@ -148,6 +148,7 @@ struct dabphy_handle {
     int32_t* h_any_redo = nullptr;
     bool drift_seen = false;          // the last resolved pass settled frames through the find chain (ensembles whose PRS window moves): cfg.sync_early == 0 then queues the next batch's synchroniser in FRONT of the decoder
     hipEvent_t ev_wide_done[N_DESC]{};
+    hipEvent_t ev_wide_front = nullptr; bool wide_front_recorded = false;   // behind the wide pass proper of the chain queued last (cfg.sync_early == 3: the decoder's launch waits for it)
     bool wide_pending[N_DESC]{};      // the wide pass of this descriptor buffer has been queued, its verdict not yet read
     uint64_t chain_valid[N_DESC]{}; uint32_t chain_frames[N_DESC]{};   // n_valid and n_frames the chain of this buffer was queued with
     uint64_t n_wide_passes = 0, n_wide_fallbacks = 0;

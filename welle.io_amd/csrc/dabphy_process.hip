@@ -189,12 +189,17 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     // rounds, verdicts -- no longer waits for the decoder's persistent waves to retire, and what drifting ensembles need: their window
     // searches run one after the other, a millisecond of latency-bound work for one work-group per ensemble); behind it (1); or in front
     // only while the last pass met ensembles whose window moves (2))
-    const bool early = h->chain_early || (h->cfg.pipeline_sync != 2 && (h->cfg.sync_early == 0 || (h->cfg.sync_early == 2 && h->drift_seen)));
+    const bool early = h->chain_early || (h->cfg.pipeline_sync != 2 && (h->cfg.sync_early == 0 || h->cfg.sync_early == 3 || (h->cfg.sync_early == 2 && h->drift_seen)));
     if (!replay && depth && early) {
         // the next batch's synchroniser is handed to the device BEFORE this batch's decoder (whose persistent waves would otherwise hold
         // every wave slot until the end of the step: the synchroniser then runs in the step's tail)
         if (h->cfg.pipeline_sync != 2) HIPCHK(h, hipStreamWaitEvent(h->sync_stream, h->ev_chain_gate, 0));
+        h->wide_front_recorded = false;
         for (; h->ahead < 1 + depth; h->ahead++) if ((r = queue_chain(h, (cur + h->ahead) % ND, F))) return r;
+        // (sync_early 3: which of the two launches that become ready with the demod kernel's end gets the wave slots is the hardware's
+        // choice -- the decoder's persistent waves, once resident, give none back --: the decoder's launch waits for the wide pass
+        // proper, ~0.8 ms of throughput work that then has the device to itself; the find chain's rounds run beside the decoder)
+        if (h->cfg.sync_early == 3 && h->wide_front_recorded) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_wide_front, 0));
     }
     // dabphy_set_auto_superframes(2): the PREVIOUS batch's superframe filter pass, beside this batch's FFT stage; this batch's decoders
     // wait for it on the device before they overwrite the class outputs it reads

@@ -57,7 +57,8 @@ int queue_chain(dabphy_handle* h, int sel, uint32_t F)
         // transfer on the DMA engines); the host clears it here: the buffer's previous pass has been resolved
         h->h_any_redo[sel] = 0; h->h_any_redo[N_DESC_ + sel] = 0;
         sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel; sa.any_chain = h->d_any_redo + N_DESC_ + sel;
-        launch_sync_wide(sa, h->sync_stream);
+        if (!h->ev_wide_front) HIPCHK(h, hipEventCreateWithFlags(&h->ev_wide_front, hipEventDisableTiming));
+        launch_sync_wide(sa, h->sync_stream, h->ev_wide_front); h->wide_front_recorded = true;
         HIPCHK(h, hipEventRecord(h->ev_wide_done[sel], h->sync_stream));
         h->wide_pending[sel] = true; h->n_wide_passes++;
     } else {

@@ -946,11 +946,12 @@ void launch_slevel_catchup(const SyncArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_slevel_catchup, dim3(a.n_ens), dim3(256), 0, s, a);
 }
 
-void launch_sync_wide(const SyncArgs& a, hipStream_t s)
+void launch_sync_wide(const SyncArgs& a, hipStream_t s, hipEvent_t front)
 {
     hipLaunchKernelGGL(k_sync_find_wide, dim3(a.n_frames, a.n_ens), dim3(FFT_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_sync_validate, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+    if (front) { hipError_t e = hipEventRecord(front, s); (void)e; }
     // what the judge did not accept: the find chain, the sums of its frames, its judge (work-groups with nothing to do return at once).
     // A fine corrector that moves ends an ensemble's round (its later searches were made with the old one): the next round starts from
     // there.  SYNC_CHAIN_ROUNDS rounds are queued whatever happens; what is left after the last one goes to the serial chain.
