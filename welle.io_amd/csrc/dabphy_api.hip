@@ -69,7 +69,6 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     int r = 0;
     auto fail = [&](int code) { dabphy_destroy(h); return code; };
     if (h->cfg.fft_placement < 0 || h->cfg.fft_placement > 2 || h->cfg.freqsync_method < 0 || h->cfg.freqsync_method > 2 || h->cfg.pipeline_sync < 0 || h->cfg.pipeline_sync > 3 || h->cfg.decode_shape < 0 || h->cfg.decode_shape > 3 || h->cfg.sync_early < 0 || h->cfg.sync_early > 3) return fail(DABPHY_ERR_INVALID);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     const HostTables& T = host_tables();
     if ((r = upload_const(h, &h->d_tw, T.tw))) return fail(r);
     if ((r = upload_const(h, &h->d_ref, T.ref))) return fail(r);
@@ -95,6 +94,23 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     if (hipMalloc(&ds, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_NOMEM);
     h->owned.push_back(ds); h->d_dec = reinterpret_cast<DecState*>(ds);
     if (hipMemset(ds, 0, sizeof(DecState) * cfg->n_ensembles) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    {
+        // Stream placement.  Measured in round 6 (tools/probe_handle_order.py, profiles/r06_step_variants.txt): the SECOND handle a process
+        // opens decodes the benchmark batch 3 % faster than the first (decoder 6.0 against 6.6-6.7 ms, step 10.1 against 10.4) -- also
+        // behind a one-ensemble handle that never decodes anything, not behind a 12 GB dummy allocation or five torch streams: what
+        // matters is which hardware queues the runtime gives the handle's streams (it multiplexes streams onto a few queues in creation
+        // order), i.e. who wins the wave slots when the decoder and the next batch's synchroniser become ready together.  A handle
+        // therefore first creates the five streams such a predecessor would have created -- same order, same priorities, never used --
+        // and keeps them until it is destroyed.
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        for (int i = 0; i < 5; i++) {
+            hipStream_t ps = nullptr;
+            if ((i == 1 ? hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&ps, hipStreamNonBlocking)) != hipSuccess) return fail(DABPHY_ERR_HIP);
+            h->placeholder_streams.push_back(ps);
+        }
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     {   // the frame chain is short serial work: give its queue the highest dispatch priority
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
@@ -191,6 +207,7 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
     if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }
     if (h->fic_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
+    for (hipStream_t ps : h->placeholder_streams) if (ps) e = hipStreamDestroy(ps);
     if (h->drain_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
     if (h->tb_stream) { e = hipStreamSynchronize(h->tb_stream); e = hipStreamDestroy(h->tb_stream); }
     if (h->ev_rs_done) e = hipEventDestroy(h->ev_rs_done);
