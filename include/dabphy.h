@@ -101,11 +101,11 @@ typedef struct {
                                        (k_viterbi_fused: the throughput shape).  1: always lane-per-code-word; 2: always k_viterbi_sp2;
                                        3: always k_viterbi_sp.  Same bytes whichever runs. */
     int32_t sync_early;             /* pipelined schedules 1 and 3: where the NEXT batch's synchroniser is queued relative to this batch's decoder.
-                                       0 (default): in front of it -- its kernels take their wave slots first and the decoder's persistent waves
-                                       fill the rest: the synchroniser's last kernels no longer wait for the decoder to retire (3 % on the
-                                       256 x 32 benchmark), and ensembles whose PRS window moves (a sampling-clock offset) have their window
-                                       searches run one after the other in the find chain, latency-bound work that belongs BESIDE the decoder.
-                                       1: behind it (rounds 1-5).  2: in front only while the last pass met such ensembles.  Same bytes. */
+                                       0 (default): in front of it -- neutral on a batch of receivers in lock, 2 % on one whose ensembles'
+                                       PRS windows move (a sampling-clock offset: their window searches run one after the other in the find
+                                       chain, latency-bound work that belongs BESIDE the decoder, not behind it).  1: behind it (rounds 1-5).
+                                       2: in front only while the last pass met such ensembles.  3 (experiment, a measured loss): in front,
+                                       and the decoder's launch waits for the wide pass proper.  Same bytes. */
 } dabphy_config;
 #define DABPHY_CONFIG_INIT { (uint32_t)sizeof(dabphy_config) }      /* dabphy_config cfg = DABPHY_CONFIG_INIT;  -- sized, every option at its default */
 

@@ -185,10 +185,9 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     tick(2);
     mark(dabphy_handle::ST_DEMOD, true);
     if (!replay && (h->cfg.pipeline_sync == 1 || h->cfg.pipeline_sync == 3)) HIPCHK(h, hipEventRecord(h->ev_chain_gate, h->stream));
-    // (cfg.sync_early: in front of the decoder (0, the default: measured 3 % on the headline since the synchroniser's tail -- find chain
-    // rounds, verdicts -- no longer waits for the decoder's persistent waves to retire, and what drifting ensembles need: their window
-    // searches run one after the other, a millisecond of latency-bound work for one work-group per ensemble); behind it (1); or in front
-    // only while the last pass met ensembles whose window moves (2))
+    // (cfg.sync_early: in front of the decoder (0, the default: neutral on the headline, 0.2 ms on a batch of drifting ensembles, whose
+    // window searches run one after the other in the find chain -- latency-bound work for one work-group per ensemble that belongs beside the
+    // decoder); behind it (1); in front only while the last pass met ensembles whose window moves (2); 3: an experiment, see below)
     const bool early = h->chain_early || (h->cfg.pipeline_sync != 2 && (h->cfg.sync_early == 0 || h->cfg.sync_early == 3 || (h->cfg.sync_early == 2 && h->drift_seen)));
     if (!replay && depth && early) {
         // the next batch's synchroniser is handed to the device BEFORE this batch's decoder (whose persistent waves would otherwise hold
