@@ -840,7 +840,8 @@ def main():
                     line["extras"][kind] = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 torch.cuda.empty_cache()
             # the latency regime: ONE ensemble, 1 / 4 / 8 / 16 frames per call, both Viterbi kernels (the default picks the state-parallel one here)
-            line["extras"]["short_batches"] = _extra([os.path.join(ROOT, "tools", "sweep_decode_shape.py"), "--json"], {}, 300)
+            if os.environ.get("DABPHY_BENCH_QUICK") != "1":      # (tests/test_gpu_bench_entry.py skips this sweep: tests/test_gpu_stream.py covers the kernels it times)
+                line["extras"]["short_batches"] = _extra([os.path.join(ROOT, "tools", "sweep_decode_shape.py"), "--json"], {}, 300)
             line["facade"] = _extra([os.path.join(ROOT, "tools", "bench_facade.py"), "--json"], {}, 420)
             line["host_u8"] = _extra([os.path.join(ROOT, "tools", "bench_host_u8.py")], {"HOSTU8_B": str(B), "HOSTU8_F": str(F), "HOSTU8_STEPS": "3"}, 300)
         print(json.dumps(line), flush=True)

@@ -39,19 +39,12 @@ def test_impaired_stream_low_snr(gpu, channel, placement):
     P.check_impaired_stream(factory, channel, 4, 1, placement, snr_db=7, nf=22)
 
 
-def test_benchmark_geometry_with_drifting_ensembles(gpu):
-    """64 ensembles x 32 frames per call (the 256 x 32 geometry: the next test), the bench handle: recordings through +60 / -100 / +40 ppm (with fading and an echo) / -30 ppm,
-    so the window index moves in every frame and the fine correctors are still converging: the wide pass's prediction fails, the find
-    chain stops at every frame whose fine corrector moved, the serial chain takes those"""
-    P.check_bench_config(capi, GPU_LIB, 64, 32, 1, check_ens=[0, 1, 2, 63], n_steps=2,
-                         channels=[dict(ppm=60.0), dict(ppm=-100.0), dict(ppm=40.0, fade=(0.3, 7.0), echoes=[(150, 0.5j)]), dict(ppm=-30.0)],
-                         min_wide_fallbacks=1)
-
-
 def test_find_chain_follows_drifting_windows_at_the_benchmark_geometry(gpu):
-    """the same drifting recordings with carrier offsets small enough for the fine correctors to stand still: the window searches of every
+    """256 ensembles x 32 frames per call, the bench handle: recordings through +60 / -100 / +40 ppm (with fading and an echo) / -30 ppm,
+    so the window index moves in every frame, with carrier offsets small enough for the fine correctors to stand still (correctors that
+    are still converging under drift: test_impaired_stream's ppm cases): the window searches of every
     batch run in the find chain (k_sync_find_chain: each from the position the previous one really found; all cyclic-prefix sums at once);
     every FIB, corrector, soft bit, MSC byte and superframe total of the checked ensembles equals the oracle's"""
     P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 1, 2, 3, 254, 255], n_steps=2,
-                         channels=[dict(ppm=60.0), dict(ppm=-100.0), dict(ppm=3.0), dict(ppm=-30.0)],
-                         min_chain_frames=256 * 32, cfo_max_hz=4.0)
+                         channels=[dict(ppm=60.0), dict(ppm=-100.0), dict(ppm=40.0, fade=(0.3, 7.0), echoes=[(150, 0.5j)]), dict(ppm=-30.0)],
+                         min_wide_fallbacks=1, min_chain_frames=256 * 28, cfo_max_hz=4.0)

@@ -335,7 +335,7 @@ def test_service_changes_with_deep_batches(gpu):
     P.check_service_changes_in_mid_stream(factory_lane_per_codeword, F=8, nf=58, add_step=2, remove_step=4)
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("shape", [0, 2])          # (lane per code word: the 256 x 32 twin in test_gpu_bench_config.py)
 def test_independent_ensembles_in_one_batch(gpu, shape):
     """ten ensembles, five multiplexes, five selections (all / all / all / every other service / none), four frames per call, with
     either Viterbi kernel: every selected sub-channel of every ensemble, FIBs and superframe totals against the oracle"""

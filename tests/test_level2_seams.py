@@ -51,7 +51,7 @@ def test_seam_builds_on_the_device(gpu, variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["a", "b"])
+@pytest.mark.parametrize("variant", ["b"])         # (l2a: test_seam_builds_on_the_device[a] and bench.py's facade.level2)
 def test_welle_cli_with_one_seam_on_the_device(gpu, variant, tmp_path):
     """welle-cli -f <RAW u8 IQ file> -D built from the reference's sources with one file replaced by the seam binding: dump.fic and every
     service's .msc dump equal the reference build's"""
