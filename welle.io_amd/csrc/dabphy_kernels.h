@@ -85,7 +85,8 @@ struct SyncArgs {
     float level_max;                                     // upper bound of OFDMProcessor::sLevel for this stream (3e38: unknown): where the bracketing replay starts from above
     const int32_t* redo_from;                            // serial chain: [B] first frame slot the wide pass did not settle (nullptr: no wide pass ran)
     int32_t* redo_out; int32_t* any_redo;                // k_sync_validate: [B] and a flag (page-locked HOST memory, written by the last judge of the pass: no copy stands between the verdict and the host)
-    int32_t* any_chain;                                  // k_sync_validate_chain: raised (page-locked host memory) when the find chain settled frames of some ensemble in this pass
+    int32_t* any_chain;                                  // k_sync_validate_chain: raised (page-locked host memory) when some ensemble's window index moved within its last SYNC_CALM_MIN frames
+    int skip_wide;                                       // launch_sync_wide: no wide searches / sums / judge (every ensemble starts in the find chain: redo_out = 0)
     int last_round;                                      // k_sync_validate_chain: this is the pass's last judge (it raises any_redo for what is left)
 };
 

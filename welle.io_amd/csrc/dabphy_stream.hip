@@ -56,7 +56,7 @@ int queue_chain(dabphy_handle* h, int sel, uint32_t F)
         // the verdict lands in page-locked host memory straight from the last judge kernel (no copy that could queue behind a bulk
         // transfer on the DMA engines); the host clears it here: the buffer's previous pass has been resolved
         h->h_any_redo[sel] = 0; h->h_any_redo[N_DESC_ + sel] = 0;
-        sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel; sa.any_chain = h->d_any_redo + N_DESC_ + sel;
+        sa.redo_out = h->s_redo[sel].as<int32_t>(); sa.any_redo = h->d_any_redo + sel; sa.any_chain = h->d_any_redo + N_DESC_ + sel; sa.skip_wide = h->drift_seen ? 1 : 0;
         if (!h->ev_wide_front) HIPCHK(h, hipEventCreateWithFlags(&h->ev_wide_front, hipEventDisableTiming));
         launch_sync_wide(sa, h->sync_stream, h->ev_wide_front); h->wide_front_recorded = true;
         HIPCHK(h, hipEventRecord(h->ev_wide_done[sel], h->sync_stream));
@@ -73,7 +73,7 @@ int resolve_chain(dabphy_handle* h, int sel)
     if (!h->wide_pending[sel]) return DABPHY_OK;
     HIPCHK(h, hipEventSynchronize(h->ev_wide_done[sel]));
     h->wide_pending[sel] = false;
-    h->drift_seen = h->h_any_redo[N_DESC_ + sel] != 0;         // ensembles whose window moves: their searches ran in the find chain
+    h->drift_seen = h->h_any_redo[N_DESC_ + sel] != 0;         // ensembles whose window moves: the next pass starts in the find chain for everybody
     if (h->h_any_redo[sel]) {
         SyncArgs sa = sync_args(h, sel, h->chain_frames[sel], h->chain_valid[sel]);
         sa.redo_from = h->s_redo[sel].as<int32_t>();

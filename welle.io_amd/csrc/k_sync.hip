@@ -915,11 +915,12 @@ __device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
             if (g.first_lock_attempts < 0) g.first_lock_attempts = g.attempts;                  // ofdm-processor.cpp:351-355
             state_advance(A, b, g, d);
             g.n_wide_frames += 1;
-            if (CHAIN) { g.n_chain_frames += 1; if (A.any_chain) *A.any_chain = 1; }
+            if (CHAIN) g.n_chain_frames += 1;
         }
     }
     A.redo_out[b] = n;
     if (CHAIN && A.last_round && n < A.n_frames) *A.any_redo = 1;
+    if (CHAIN && A.last_round && A.any_chain && base.synced && g.calm_frames < SYNC_CALM_MIN) *A.any_chain = 1;      // this ensemble's window is moving
 }
 __global__ void __launch_bounds__(64) k_sync_validate(SyncArgs A) { sync_validate_body<false>(A); }
 __global__ void __launch_bounds__(64) k_sync_validate_chain(SyncArgs A) { sync_validate_body<true>(A); }
@@ -948,9 +949,16 @@ void launch_slevel_catchup(const SyncArgs& a, hipStream_t s)
 
 void launch_sync_wide(const SyncArgs& a, hipStream_t s, hipEvent_t front)
 {
-    hipLaunchKernelGGL(k_sync_find_wide, dim3(a.n_frames, a.n_ens), dim3(FFT_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_sync_validate, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+    if (a.skip_wide) {
+        // the last pass met ensembles whose window moves: the wide searches would only be skipped one by one -- by 8192 work-groups of a
+        // 196-register kernel that each have to find a wave slot beside the decoder first (4.5 ms of waiting in front of the find chain:
+        // profiles/r06_drift_kernel_stats.csv) -- so the pass starts in the find chain for everybody
+        hipError_t e = hipMemsetAsync(a.redo_out, 0, sizeof(int32_t) * (size_t)a.n_ens, s); (void)e;
+    } else {
+        hipLaunchKernelGGL(k_sync_find_wide, dim3(a.n_frames, a.n_ens), dim3(FFT_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_sync_finish_wide, dim3(a.n_frames, a.n_ens), dim3(FINISH_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_sync_validate, dim3((a.n_ens + 63) / 64), dim3(64), 0, s, a);
+    }
     if (front) { hipError_t e = hipEventRecord(front, s); (void)e; }
     // what the judge did not accept: the find chain, the sums of its frames, its judge (work-groups with nothing to do return at once).
     // A fine corrector that moves ends an ensemble's round (its later searches were made with the old one): the next round starts from
