@@ -45,6 +45,6 @@ def test_find_chain_follows_drifting_windows_at_the_benchmark_geometry(gpu):
     are still converging under drift: test_impaired_stream's ppm cases): the window searches of every
     batch run in the find chain (k_sync_find_chain: each from the position the previous one really found; all cyclic-prefix sums at once);
     every FIB, corrector, soft bit, MSC byte and superframe total of the checked ensembles equals the oracle's"""
-    P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 1, 2, 3, 254, 255], n_steps=2,
+    P.check_bench_config(capi, GPU_LIB, 256, 32, 1, check_ens=[0, 1, 2, 255], n_steps=2,
                          channels=[dict(ppm=60.0), dict(ppm=-100.0), dict(ppm=40.0, fade=(0.3, 7.0), echoes=[(150, 0.5j)]), dict(ppm=-30.0)],
                          min_wide_fallbacks=1, min_chain_frames=256 * 28, cfo_max_hz=4.0)

@@ -104,7 +104,11 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
         // and keeps them until it is destroyed.
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
-        for (int i = 0; i < 5; i++) {
+        int n_placeholders = 5;
+#ifdef DABPHY_EXPERIMENTS
+        if (const char* e = getenv("DABPHY_STREAM_LAYOUT")) { h->stream_layout = atoi(e); n_placeholders = (h->stream_layout & 1) ? 5 : 0; }      // (tools/probe_streams.py)
+#endif
+        for (int i = 0; i < n_placeholders; i++) {
             hipStream_t ps = nullptr;
             if ((i == 1 ? hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&ps, hipStreamNonBlocking)) != hipSuccess) return fail(DABPHY_ERR_HIP);
             h->placeholder_streams.push_back(ps);
@@ -119,7 +123,8 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
-    if (hipStreamCreateWithFlags(&h->fic_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
+    if (h->stream_layout & 2) h->fic_stream = h->aux_stream;      // (experiment: fewer streams)
+    else if (hipStreamCreateWithFlags(&h->fic_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_aux_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_ingest[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_chain_gate, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
@@ -206,9 +211,9 @@ void dabphy_destroy(dabphy_handle* h)
     if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
     if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
     if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }
-    if (h->fic_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
+    if (h->fic_stream && h->fic_stream != h->aux_stream) { e = hipStreamSynchronize(h->fic_stream); e = hipStreamDestroy(h->fic_stream); }
     for (hipStream_t ps : h->placeholder_streams) if (ps) e = hipStreamDestroy(ps);
-    if (h->drain_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
+    if (h->drain_stream && h->drain_stream != h->copy_stream) { e = hipStreamSynchronize(h->drain_stream); e = hipStreamDestroy(h->drain_stream); }
     if (h->tb_stream) { e = hipStreamSynchronize(h->tb_stream); e = hipStreamDestroy(h->tb_stream); }
     if (h->ev_rs_done) e = hipEventDestroy(h->ev_rs_done);
     if (h->ev_wide_front) e = hipEventDestroy(h->ev_wide_front);

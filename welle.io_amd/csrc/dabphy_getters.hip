@@ -241,7 +241,7 @@ int dabphy_msc_drain_begin(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t des
     int r;
     if ((r = drain_wait(h))) return r;                      // one drain at a time
     if (!h->drain_stream) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->drain_stream, hipStreamNonBlocking));
+        if (h->stream_layout & 4) h->drain_stream = h->copy_stream; else HIPCHK(h, hipStreamCreateWithFlags(&h->drain_stream, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_done, hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_staged, hipEventDisableTiming));
     }
