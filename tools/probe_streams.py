@@ -1,5 +1,5 @@
 """Not a test: the benchmark step and the overlapped bulk drain under different stream layouts of the handle (experiments build,
-DABPHY_STREAM_LAYOUT: bit 0 placeholder streams, bit 1 FIC work on the auxiliary stream, bit 2 the drain on the ingest stream), each layout in a
+DABPHY_STREAM_LAYOUT: bit 0 placeholder streams, bit 1 FIC work on the auxiliary stream, bit 3 the drain on a stream of its own), each layout in a
 process of its own.  usage: DABPHY_LIB=<experiments build> DABPHY_STREAM_LAYOUT=n python tools/probe_streams.py"""
 import os
 import sys

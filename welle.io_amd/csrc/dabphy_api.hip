@@ -123,7 +123,7 @@ int dabphy_create_v2(const dabphy_config* cfg_in, dabphy_handle** out)
     if (hipEventCreate(&h->ev_sync_done) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
-    if (h->stream_layout & 2) h->fic_stream = h->aux_stream;      // (experiment: fewer streams)
+    if (h->stream_layout & 2) h->fic_stream = h->aux_stream;      // (experiment: fewer streams -- measured slower, profiles/r06_step_variants.txt)
     else if (hipStreamCreateWithFlags(&h->fic_stream, hipStreamNonBlocking) != hipSuccess) return fail(DABPHY_ERR_HIP);
     if (hipEventCreateWithFlags(&h->ev_aux_done, hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&h->ev_ingest[i], hipEventDisableTiming) != hipSuccess) return fail(DABPHY_ERR_HIP);

@@ -241,7 +241,13 @@ int dabphy_msc_drain_begin(dabphy_handle* h, dabphy_msc_desc* desc, uint32_t des
     int r;
     if ((r = drain_wait(h))) return r;                      // one drain at a time
     if (!h->drain_stream) {
-        if (h->stream_layout & 4) h->drain_stream = h->copy_stream; else HIPCHK(h, hipStreamCreateWithFlags(&h->drain_stream, hipStreamNonBlocking));
+        // Which stream.  The runtime multiplexes a process's streams onto a few hardware queues, and a drain on a stream of its own -- the
+        // handle's sixth -- landed on the main stream's queue on some boxes: 13.0-13.8 ms per step with the drain against 10.0 without
+        // (tools/probe_streams.py, profiles/r06_step_variants.txt).  On the ingest stream, idle whenever the samples are resident in HBM,
+        // it overlaps completely (10.07 ms).  A handle that is fed through dabphy_stream_write_raw_async keeps that stream for its
+        // host-to-device transfers and drains on one of its own.
+        if (h->s_enqueued == 0 && !(h->stream_layout & 8)) h->drain_stream = h->copy_stream;
+        else HIPCHK(h, hipStreamCreateWithFlags(&h->drain_stream, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_done, hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_drain_staged, hipEventDisableTiming));
     }
