@@ -283,6 +283,7 @@ struct IngestArgs {
 };
 void launch_ingest(const IngestArgs& a, int n_ens, hipStream_t s);
 void launch_copy_f4(const void* src, void* dst, size_t n16, int blocks, hipStream_t s);
+void launch_copy_out(const void* src_device, void* dst_host, size_t bytes, hipStream_t s);      // a kernel's stores into page-locked host memory (hipHostMalloc: the same address on the device)
 
 // Reed-Solomon (k_rs.hip)
 struct RsArgs {            // contiguous superframes [n_sf][sf_stride], s = bitrate/8 codewords each

@@ -242,8 +242,8 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
             h->tii_ran = true;
         }
         // the host's copies of the descriptors and SNR reports leave here, beside the decoder, instead of behind the step's last kernel
-        HIPCHK(h, hipMemcpyAsync(h->h_desc, d_desc, (size_t)B * F * sizeof(FrameDesc), hipMemcpyDeviceToHost, fs));
-        HIPCHK(h, hipMemcpyAsync(h->h_snr, h->s_snr.p, (size_t)B * F * sizeof(float), hipMemcpyDeviceToHost, fs));
+        launch_copy_out(d_desc, h->h_desc, (size_t)B * F * sizeof(FrameDesc), fs);      // (kernel stores, not copy-engine packets: k_ingest.hip, launch_copy_out)
+        launch_copy_out(h->s_snr.p, h->h_snr, (size_t)B * F * sizeof(float), fs);
         HIPCHK(h, hipEventRecord(h->ev_aux_done, fs));
     }
     // pairs selected since the last batch learn the CIF count they start at (their time de-interleaver fills from here, dab-audio.cpp:146-149)
@@ -260,7 +260,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         mark(dabphy_handle::ST_MSC_VITERBI, true);
         if (fa.done) {
             if (!h->h_tb_gave_up) { void* p = nullptr; HIPCHK(h, hipHostMalloc(&p, sizeof(uint32_t), hipHostMallocDefault)); h->h_tb_gave_up = reinterpret_cast<uint32_t*>(p); }
-            HIPCHK(h, hipMemcpyAsync(h->h_tb_gave_up, fa.done + fa.n_work + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            launch_copy_out(fa.done + fa.n_work + 1, h->h_tb_gave_up, sizeof(uint32_t), h->stream);
         }
         if (fic_fused) HIPCHK(h, hipEventRecord(h->ev_fused_done, h->stream));
     }
@@ -273,10 +273,10 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
         launch_fib_crc(k, fs);
         k.any_effective = h->d_any_eff;
         if (!replay) launch_fic_ratio(k, fs);                    // (the second pass of exact batch mode has advanced the ratio frame by frame)
-        HIPCHK(h, hipMemcpyAsync(h->h_any_eff, h->d_any_eff, sizeof(int32_t), hipMemcpyDeviceToHost, fs));
+        launch_copy_out(h->d_any_eff, h->h_any_eff, sizeof(int32_t), fs);
         mark(dabphy_handle::ST_FIC, true, fs);
-        HIPCHK(h, hipMemcpyAsync(h->h_fib, h->s_fib.p, (size_t)B * F * 384, hipMemcpyDeviceToHost, fs));
-        HIPCHK(h, hipMemcpyAsync(h->h_ok, h->s_ok.p, (size_t)B * F * 12, hipMemcpyDeviceToHost, fs));
+        launch_copy_out(h->s_fib.p, h->h_fib, (size_t)B * F * 384, fs);
+        launch_copy_out(h->s_ok.p, h->h_ok, (size_t)B * F * 12, fs);
         HIPCHK(h, hipEventRecord(h->ev_fic_done, fs));
     }
     // classes the fused launch does not take (DABPHY_FUSED_MSC=0, a window schedule the kernel cannot follow, a span beyond 4 GiB): two
@@ -305,7 +305,7 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     if (h->sf_auto && !h->sf_deferred) {
         if ((r = launch_superframe_stats(h))) return r;
         h->sf_stats_ready = true;
-        HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->stream));
+        launch_copy_out(h->sf_stats.p, h->h_sf_stats, sizeof(int32_t) * 4 * B, h->stream);
         h->h_sf_stats_valid = true;
     }
     return DABPHY_OK;

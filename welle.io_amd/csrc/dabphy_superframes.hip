@@ -262,7 +262,7 @@ int launch_deferred_superframes(dabphy_handle* h)
     }
     int r;
     if ((r = launch_superframe_stats(h, h->rs_stream, h->sf_def_desc, h->sf_def_frames))) return r;
-    HIPCHK(h, hipMemcpyAsync(h->h_sf_stats, h->sf_stats.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, h->rs_stream));
+    launch_copy_out(h->sf_stats.p, h->h_sf_stats, sizeof(int32_t) * 4 * B, h->rs_stream);
     HIPCHK(h, hipEventRecord(h->ev_rs_done, h->rs_stream));
     h->sf_def_pending = false; h->sf_def_inflight = true; h->sf_def_unfetched = true;
     return DABPHY_OK;

@@ -73,6 +73,28 @@ void launch_copy_f4(const void* src, void* dst, size_t n16, int blocks, hipStrea
     hipLaunchKernelGGL(k_copy_f4, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n16);
 }
 
+// A batch's results -- descriptors, SNR reports, FIBs, CRC flags, verdict words: a few MB -- into the handle's page-locked host buffers by a
+// KERNEL (stores over the fabric), not by a copy-engine packet: a packet queues behind whatever the engine has in hand, e.g. the 100 MB of a
+// bulk MSC drain (dabphy_msc_drain_begin), and dabphy_process then waits for that.  Any size and alignment (dwords where both ends allow).
+__global__ void __launch_bounds__(256) k_copy_out(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes)
+{
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const float4* s4 = reinterpret_cast<const float4*>(src); float4* d4 = reinterpret_cast<float4*>(dst);
+        for (size_t i = i0; i < n16; i += stride) d4[i] = s4[i];
+        for (size_t i = n16 * 16 + i0; i < bytes; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = i0; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
+void launch_copy_out(const void* src_device, void* dst_host, size_t bytes, hipStream_t s)
+{
+    if (!bytes) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 256);
+    hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(src_device), reinterpret_cast<uint8_t*>(dst_host), bytes);
+}
+
 void launch_ingest(const IngestArgs& a, int n_ens, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::min<uint64_t>((a.n + 255) / 256, 4096);
