@@ -214,12 +214,16 @@ int dabphy_process(dabphy_handle* h, uint32_t n_frames)
     VitClass ficc = fic_c;
     ficc.sym = h->fsym.as<uint32_t>(); ficc.dec = h->fdec.as<uint2>(); ficc.out = h->s_fib.as<uint8_t>();
     {
+        const bool snr_main = (h->stream_layout & 16) != 0;
+        if (snr_main) { mark(dabphy_handle::ST_SNR, false); launch_snr(sn, h->stream); mark(dabphy_handle::ST_SNR, true); }
         HIPCHK(h, hipEventRecord(h->ev_demod_done, h->stream));
         HIPCHK(h, hipStreamWaitEvent(fs, h->ev_demod_done, 0));
         // the SNR estimate feeds nothing on the device: off the main stream, so that the MSC decode starts the moment the demod kernel ends
-        mark(dabphy_handle::ST_SNR, false, fs);
-        launch_snr(sn, fs);
-        mark(dabphy_handle::ST_SNR, true, fs);
+        if (!snr_main) {
+            mark(dabphy_handle::ST_SNR, false, fs);
+            launch_snr(sn, fs);
+            mark(dabphy_handle::ST_SNR, true, fs);
+        }
         if (!fic_fused) {
             FicGatherArgs g{}; g.soft = da.soft; g.soft_ring = ring_frames; g.frame_stride = SOFT_PER_FRAME; g.soft_ens_stride = ens_stride; g.desc = d_desc;
             g.n_ens = (int)B; g.n_frames = (int)F; g.map = h->d_fic_map; g.c = ficc;
