@@ -143,6 +143,7 @@ static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned 
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned long long wall_clock64() { static unsigned long long t = 0; return t += 100; }      // (bounded device waits time out quickly here)
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 #define __HIP_MEMORY_SCOPE_AGENT 4
 template <typename T> static inline T __hip_atomic_load(T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }

@@ -208,6 +208,9 @@ void dabphy_destroy(dabphy_handle* h)
     if (!h) return;
     hipError_t e;
     if (h->sync_stream) { e = hipStreamSynchronize(h->sync_stream); e = hipStreamDestroy(h->sync_stream); }
+#ifdef SYNC_CHAIN_TS
+    if (getenv("DABPHY_CHAIN_TS")) dump_chain_ts();
+#endif
     if (h->ev_sync_done) e = hipEventDestroy(h->ev_sync_done);
     if (h->aux_stream) { e = hipStreamSynchronize(h->aux_stream); e = hipStreamDestroy(h->aux_stream); }
     if (h->copy_stream) { e = hipStreamSynchronize(h->copy_stream); e = hipStreamDestroy(h->copy_stream); }

@@ -108,7 +108,7 @@ struct dabphy_handle {
     DevBuf sf_events, sf_count, sf_bytes, sf_stats, sf_gf, sf_accept; const FrameDesc* last_desc = nullptr;
     static constexpr int N_DESC = 3;    // descriptor buffers: the batch being decoded + up to two synchronised ahead
     DevBuf s_desc2[N_DESC], s_cir2[N_DESC], s_soft, s_con, s_mag, s_snr, s_fib, s_ok;
-    int stream_layout = 1;                          // experiments: bit 0 placeholder streams, bit 1 FIC work on the auxiliary stream, bit 3 the bulk drain on a stream of its own even when nothing is ingested asynchronously
+    int stream_layout = 1;                          // experiments: bit 0 placeholder streams, bit 1 FIC work on the auxiliary stream, bit 3 the bulk drain on a stream of its own even when nothing is ingested asynchronously, bit 4 the SNR kernels on the main stream in front of the decoder (no gain: profiles/r06_step_variants.txt)
     std::vector<hipStream_t> placeholder_streams;   // created in front of the handle's own, never used (dabphy_create_v2: stream placement)
     hipStream_t sync_stream = nullptr; hipEvent_t ev_sync_done = nullptr;
     hipStream_t aux_stream = nullptr; hipEvent_t ev_demod_done = nullptr, ev_fic_done = nullptr, ev_chain_gate = nullptr;

@@ -332,6 +332,9 @@ void launch_msc_gather(const MscGatherArgs& a, hipStream_t s);
 void launch_lin_gather(const LinGatherArgs& a, hipStream_t s);
 void launch_fib_crc(const CrcArgs& a, hipStream_t s);
 void launch_fic_ratio(const CrcArgs& a, hipStream_t s);
+#ifdef SYNC_CHAIN_TS
+void dump_chain_ts();
+#endif
 void launch_sync_find(const SyncArgs& a, hipStream_t s);
 void launch_sync_wide(const SyncArgs& a, hipStream_t s, hipEvent_t front = nullptr);      // front: recorded behind the wide pass proper (searches, sums, judge), in front of the find chain's rounds
 void launch_sync_finish(const SyncArgs& a, hipStream_t s);

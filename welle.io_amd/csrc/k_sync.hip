@@ -59,7 +59,8 @@ __device__ __forceinline__ int block_min_int(int x, int* red, int t)
 // OFDMProcessor::sLevel is advanced by every sample getSample(s) hands out (ofdm-processor.cpp:174,216) but only ever read by the
 // null-symbol search after a loss of lock (:284,:303).  While tracking, the synchroniser therefore just records what was pulled
 // (one descriptor per window search); k_acquire replays those samples through the recurrence when it is next needed.
-__device__ __forceinline__ void hist_append(const SyncArgs& A, int b, RxState& st, const FrameDesc& d)
+template <class State>
+__device__ __forceinline__ void hist_append(const SyncArgs& A, int b, State& st, const FrameDesc& d)
 {
     if (!A.hist) return;
     FrameDesc* h = A.hist + (size_t)b * A.hist_cap;
@@ -126,7 +127,8 @@ __device__ __forceinline__ bool fine_decided(int32_t fine_old, const double (*bl
 
 // What a window search starts from: the members of RxState the tracking loop reads and writes.
 struct SyncIn { int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced; };
-__device__ __forceinline__ SyncIn sync_in_of(const RxState& g)
+template <class State>
+__device__ __forceinline__ SyncIn sync_in_of(const State& g)
 {
     SyncIn s; s.pos = g.pos; s.frame_no = g.frame_no; s.local_phase = g.local_phase; s.coarse = g.coarse; s.fine = g.fine; s.synced = g.synced;
     return s;
@@ -167,7 +169,8 @@ __device__ __forceinline__ void finish_desc(FrameDesc& d, int32_t fine)
     d.fine_after = fine; d.coarse_after = coarse;                     // as RadioControllerInterface sees them after the frame
     d.valid = 1;
 }
-__device__ __forceinline__ void state_advance(const SyncArgs& A, const int b, RxState& st, const FrameDesc& d)
+template <class State>
+__device__ __forceinline__ void state_advance(const SyncArgs& A, const int b, State& st, const FrameDesc& d)
 {
     int32_t coarse = d.coarse_after, fine = d.fine_after;
     if (fine > 1000 / 2) { coarse += 1000; fine -= 1000; }            // :478-486
@@ -550,6 +553,14 @@ __global__ void __launch_bounds__(256) k_acquire(SyncArgs A)
 // move).  Returns true when the descriptor is left pending (valid = 2) for k_sync_finish.
 constexpr int SYNC_CALM_MIN = 8;
 constexpr int SYNC_CHAIN_ROUNDS = 3;
+#ifdef SYNC_CHAIN_TS
+// (timing experiment: where a window search of the find chain spends its time beside the decoder -- 100 MHz stamps of ensemble 0's searches,
+// printed when the handle is destroyed with DABPHY_CHAIN_TS set; build with EXTRA="-DDABPHY_EXPERIMENTS -DSYNC_CHAIN_TS")
+__device__ unsigned long long g_chain_ts[64][8];
+#define CHAIN_TS(k) do { if (MODE == 2 && b == 0 && threadIdx.x == 0) g_chain_ts[frame & 63][k] = wall_clock64(); } while (0)
+#else
+#define CHAIN_TS(k) do { } while (0)
+#endif
 template <int MODE>
 __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, const int frame, SyncIn& chain_st)
 {
@@ -588,11 +599,17 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
         return false;
     }
 
+    CHAIN_TS(0);
     FftTwiddles w; fft_load_twiddles(w, A.tab.tw, twB, t);
     cf32 v[16], u[16];
     // ---- PhaseReference::findIndex (phasereference.cpp:73-92): FFT, multiply by conj(refTable), IFFT (scaled by 1/N)
     load_mix2048(v, iq, A.ring, st.pos, 0, nco, d.L0, d.f_prs, 0, t);
+#ifdef SYNC_CHAIN_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CHAIN_TS(1);
     fft2048_wg<false>(v, tile, w, t);
+    CHAIN_TS(2);
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = cmul(v[j], cconj(A.tab.ref[t + 128 * j]));
 #pragma unroll
@@ -600,6 +617,7 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
 #pragma unroll
         for (int j = 0; j < 8; j++) u[8 * h + j] = v[h + 2 * j];          // bin t + 128 (h + 2j) = input t + 128h + 256j
     fft2048_wg<true>(u, tile, w, t);
+    CHAIN_TS(3);
     __syncthreads();                                                       // all round-C reads of the tile are done: it becomes lbuf / pa
     const float factor = 1.0f / (float)T_U;                                // fft.cpp:154
     float* cir = A.cir ? A.cir + ((size_t)b * A.n_frames + frame) * T_U : nullptr;
@@ -611,6 +629,7 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
     }
     if (t < 128) lbuf[T_U + t] = 0.0f;
     __syncthreads();
+    CHAIN_TS(4);
 
     int startIndex = -1;
     if (A.fft_placement == 0) {
@@ -712,6 +731,7 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
         startIndex = first < T_U ? first : -1;
     }
 
+    CHAIN_TS(5);
     if (startIndex < 0) {
         // ofdm-processor.cpp:347-350: SyncOnPhase failed -> notSynced (the 2048 samples are consumed)
         if (t == 0) {
@@ -838,6 +858,7 @@ __device__ __forceinline__ bool sync_find_body(const SyncArgs& A, const int b, c
         chain_st.local_phase = mod_rate64((int64_t)null_L - (int64_t)T_NULL * null_f);
         chain_st.coarse = coarse;
     }
+    CHAIN_TS(6);
     return true;
 }
 
@@ -886,17 +907,31 @@ __global__ void __launch_bounds__(FFT_THREADS, 1) k_sync_find_chain(SyncArgs A) 
 // CHAIN = true: behind the find chain (frames from redo_out[b] on, each computed from the state its descriptor names: position, frame
 // number, oscillator phase, coarse + fine -- and with the fine corrector this ensemble had in front of frame redo_out[b], which
 // k_sync_finish_wide used for all of them); *any_redo |= some ensemble still has slots for the serial chain.
+// (the judges walk 32 frames per lane: the members of RxState they touch live in registers meanwhile -- as members of the global struct
+// every frame cost a chain of dependent memory round trips, 93 us per pass on the step's critical path -- and the next descriptor is
+// fetched while the current one is judged)
+struct RxHot {
+    int64_t pos, frame_no; int32_t local_phase, coarse, fine, synced;
+    int32_t n_exact_sums, hist_count, hist_head, hist_dropped, attempts, first_lock_attempts, n_wide_frames, n_chain_frames, calm_frames;
+};
 template <bool CHAIN>
 __device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= A.n_ens) return;
-    RxState& g = A.state[b];
+    RxState& G = A.state[b];
+    RxHot g;
+    g.pos = G.pos; g.frame_no = G.frame_no; g.local_phase = G.local_phase; g.coarse = G.coarse; g.fine = G.fine; g.synced = G.synced;
+    g.n_exact_sums = G.n_exact_sums; g.hist_count = G.hist_count; g.hist_head = G.hist_head; g.hist_dropped = G.hist_dropped; g.attempts = G.attempts;
+    g.first_lock_attempts = G.first_lock_attempts; g.n_wide_frames = G.n_wide_frames; g.n_chain_frames = G.n_chain_frames; g.calm_frames = G.calm_frames;
     FrameDesc* const desc = A.desc + (size_t)b * A.n_frames;
     const SyncIn base = sync_in_of(g);
     int n = CHAIN ? A.redo_out[b] : 0;
-    if (base.synced) {
+    if (base.synced && n < A.n_frames) {
+        FrameDesc next = desc[n];
         for (; n < A.n_frames; n++) {
+            const FrameDesc d = next;
+            if (n + 1 < A.n_frames) next = desc[n + 1];
             if (!CHAIN) {
                 const SyncIn p = sync_predict(base, n);
                 if (g.pos != p.pos || g.frame_no != p.frame_no || g.local_phase != p.local_phase || g.coarse != p.coarse || g.fine != p.fine) break;
@@ -908,7 +943,6 @@ __device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
                 n = A.n_frames;
                 break;
             }
-            const FrameDesc d = desc[n];
             if (CHAIN && (g.pos != d.pos || g.frame_no != d.frame_no || g.local_phase != d.L0 || g.coarse + g.fine != d.f_prs || g.fine != base.fine)) break;
             if (d.valid != 1) break;                                   // failed window search: the serial chain takes it from here
             if (d.exact_sums) g.n_exact_sums += 1;
@@ -917,6 +951,9 @@ __device__ __forceinline__ void sync_validate_body(const SyncArgs& A)
             g.n_wide_frames += 1;
             if (CHAIN) g.n_chain_frames += 1;
         }
+        G.pos = g.pos; G.frame_no = g.frame_no; G.local_phase = g.local_phase; G.coarse = g.coarse; G.fine = g.fine;
+        G.n_exact_sums = g.n_exact_sums; G.hist_count = g.hist_count; G.hist_head = g.hist_head; G.hist_dropped = g.hist_dropped;
+        G.first_lock_attempts = g.first_lock_attempts; G.n_wide_frames = g.n_wide_frames; G.n_chain_frames = g.n_chain_frames; G.calm_frames = g.calm_frames;
     }
     A.redo_out[b] = n;
     if (CHAIN && A.last_round && n < A.n_frames) *A.any_redo = 1;
@@ -971,6 +1008,20 @@ void launch_sync_wide(const SyncArgs& a, hipStream_t s, hipEvent_t front)
         hipLaunchKernelGGL(k_sync_validate_chain, dim3((c.n_ens + 63) / 64), dim3(64), 0, s, c);
     }
 }
+#ifdef SYNC_CHAIN_TS
+void dump_chain_ts()
+{
+    unsigned long long ts[64][8];
+    if (hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_chain_ts), sizeof(ts)) != hipSuccess) return;
+    fprintf(stderr, "find chain, ensemble 0, last round that walked each frame [us]: frame: entry->samples  ->fft  ->ifft  ->cir  ->index  ->end | gap to the next frame\n");
+    for (int f = 0; f < 32; f++) {
+        fprintf(stderr, "chain_ts %2d:", f);
+        for (int k = 1; k <= 6; k++) fprintf(stderr, " %7.2f", (double)(long long)(ts[f][k] - ts[f][k - 1]) / 100.0);
+        if (f + 1 < 32) fprintf(stderr, " | %7.2f", (double)(long long)(ts[f + 1][0] - ts[f][6]) / 100.0);
+        fprintf(stderr, "   total %7.2f\n", (double)(long long)(ts[f][6] - ts[f][0]) / 100.0);
+    }
+}
+#endif
 void launch_sync_find(const SyncArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sync_find, dim3(a.n_ens), dim3(FFT_THREADS), 0, s, a);
