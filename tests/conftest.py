@@ -37,6 +37,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+# Cases of the execution-model suite whose IDENTICAL parametrisation also runs on the device (tests/test_gpu_stream.py, same function in
+# tests/parity_cases.py): on the GPU-less machine they are skipped unless DABPHY_FULL_CPU_SUITE=1 -- each function keeps at least two
+# parametrisations here, the execution model runs on one core and the whole CPU suite should stay a matter of minutes.
+CPU_QUICK_SKIP = {
+    "tests/test_emu_stream.py::test_low_snr_batches_with_coarse_corrector[2-40-4-9]",
+    "tests/test_emu_stream.py::test_low_snr_batches_with_coarse_corrector[3--1000-4-5]",
+    "tests/test_emu_stream.py::test_exact_batch_mode[4-17400-5-13-1-None]",
+    "tests/test_emu_stream.py::test_exact_batch_mode[3--1000-4-5-3-None]",
+    "tests/test_emu_stream.py::test_exact_batch_mode_with_different_ensembles[3]",
+    "tests/test_emu_stream.py::test_wide_synchroniser_pass[2]",
+    "tests/test_emu_stream.py::test_service_changes_while_the_synchroniser_runs_ahead[3]",
+    "tests/test_emu_stream.py::test_live_ring_in_batches[3-300-17-3]",
+    "tests/test_emu_stream.py::test_superframe_filter_where_the_damage_falls[2-damage_q0]",
+}
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("DABPHY_FULL_CPU_SUITE"):
+        return
+    skip = pytest.mark.skip(reason="the device twin runs the same parametrisation (-m gpu); DABPHY_FULL_CPU_SUITE=1 runs it here too")
+    for item in items:
+        if item.nodeid in CPU_QUICK_SKIP:
+            item.add_marker(skip)
+
+
 EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "libdabphy_emu.so")
 GPU_LIB = os.environ.get("DABPHY_LIB") or os.path.join(PKG_DIR, "libdabphy_hip.so")
 ORC_LIB = os.path.join(ROOT, "oracle", "libdabphy_oracle.so")
@@ -57,7 +82,7 @@ def oracle_built():
 @pytest.fixture(scope="session")
 def emu():
     """kernel sources compiled for the CPU execution model of tests/hipemu (logic check only, never timed)"""
-    _make(["emu"], os.path.join(PKG_DIR, "csrc"))
+    _make(["-j8", "emu"], os.path.join(PKG_DIR, "csrc"))
     from welle_io_amd import capi
     d = capi.DabPhy(lib_path=EMU_LIB)
     yield d

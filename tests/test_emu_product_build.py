@@ -15,7 +15,7 @@ LIB = os.path.join(ROOT, "tests", "hipemu", "libdabphy_emu_product.so")
 
 @pytest.fixture(scope="module")
 def emu_product():
-    subprocess.run(["make", "emu-product"], cwd=os.path.join(PKG_DIR, "csrc"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    subprocess.run(["make", "-j8", "emu-product"], cwd=os.path.join(PKG_DIR, "csrc"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     return LIB
 
 
