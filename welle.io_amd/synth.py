@@ -452,19 +452,31 @@ def _rs_genpoly():
 _RS_GEN = _rs_genpoly()
 
 
+def _rs_feedback_table():
+    """_RS_FB[fb][j] = fb x g[j + 1] in GF(256): what one step of the systematic encoder adds to the remainder"""
+    t = np.zeros((256, 10), np.uint8)
+    for fb in range(1, 256):
+        lf = _GF_LOG[fb]
+        for j in range(10):
+            c = _RS_GEN[j + 1]
+            if c:
+                t[fb, j] = _GF_EXP[lf + _GF_LOG[c]]
+    return t
+
+
+_RS_FB = _rs_feedback_table()
+
+
 def rs_parity(data110):
-    """systematic RS(120,110): 10 parity bytes for 110 data bytes"""
-    rem = [0] * 10
-    for d in data110:
-        fb = int(d) ^ rem[0]
-        rem = rem[1:] + [0]
-        if fb:
-            lf = _GF_LOG[fb]
-            for j in range(10):
-                c = _RS_GEN[j + 1]
-                if c:
-                    rem[j] ^= int(_GF_EXP[lf + _GF_LOG[c]])
-    return np.array(rem, np.uint8)
+    """systematic RS(120,110): 10 parity bytes for 110 data bytes -- or, for an array [110][n], the parity [10][n] of its n columns
+    (the codewords of a superframe in one pass: the encoder's steps are table look-ups over all columns at once)"""
+    d = np.asarray(data110, np.uint8)
+    cols = d.reshape(110, -1)
+    rem = np.zeros((cols.shape[1], 10), np.uint8)
+    for k in range(110):
+        fb = cols[k] ^ rem[:, 0]
+        rem = np.concatenate([rem[:, 1:], np.zeros((cols.shape[1], 1), np.uint8)], axis=1) ^ _RS_FB[fb]
+    return rem[0] if d.ndim == 1 else rem.T.copy()
 
 
 def crc16(data, initial_invert, final_invert, poly):
@@ -501,8 +513,7 @@ def make_superframe(bitrate, rng, header=True):
         data[0] = c >> 8; data[1] = c & 0xFF
     sf = np.zeros(120 * s, np.uint8)
     sf[:110 * s] = data
-    for i in range(s):
-        sf[110 * s + i::s] = rs_parity(data[i::s])
+    sf[110 * s:] = rs_parity(data.reshape(110, s)).reshape(-1)      # codeword i = bytes pos * s + i
     return sf
 
 
