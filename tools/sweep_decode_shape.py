@@ -3,7 +3,7 @@ frame): per (ensembles, frames per call) the whole dabphy_process call (host clo
 (dabphy_time_fused_msc) with dabphy_config.decode_shape = 1 (one LANE per code word, k_viterbi_fused), = 2 (state-parallel, two code words per
 wavefront, k_viterbi_sp2 + its traceback pass k_traceback_sp2) and = 3 (round 4's state-parallel kernel, one code word per wavefront, k_viterbi_sp).  Where the state-parallel kernel stops winning is what dabphy's default (decode_shape = 0) switches at.
   python tools/sweep_decode_shape.py            table (profiles/r04_viterbi_state_parallel.txt)
-  python tools/sweep_decode_shape.py --json     one JSON line with the single-ensemble rows (bench.py's extras.short_batches)"""
+  python tools/sweep_decode_shape.py --json     one JSON line with the single-ensemble rows and the 32 x 16 row (bench.py's extras.short_batches)"""
 import json
 import os
 import sys
@@ -21,7 +21,7 @@ from welle_io_amd import capi, workload  # noqa: E402
 
 lib = os.environ.get("DABPHY_LIB", os.path.join(PKG_DIR, "libdabphy_hip.so"))
 as_json = "--json" in sys.argv
-GEOM = [(1, 1), (1, 4), (1, 8), (1, 16)] if as_json else [(1, 1), (1, 4), (1, 8), (1, 16), (4, 4), (8, 8), (16, 8), (16, 16), (32, 16), (48, 16), (64, 16), (128, 16)]
+GEOM = [(1, 1), (1, 4), (1, 8), (1, 16), (32, 16)] if as_json else [(1, 1), (1, 4), (1, 8), (1, 16), (4, 4), (8, 8), (16, 8), (16, 16), (32, 16), (48, 16), (64, 16), (128, 16)]
 base = workload.make_base_streams(2, workload.REC_FRAMES, seed0=0)
 rows = []
 for B, F in GEOM:
@@ -48,4 +48,4 @@ for B, F in GEOM:
         print("%4d ensembles x %2d frames (%6d code words): lane-per-code-word %7.3f ms per call, decode alone %7.3f ms | state-parallel (2 code words per wave) %7.3f ms per call, decode alone %7.3f ms | round 4's (1 per wave) %7.3f / %7.3f | %s"
               % (B, F, rec["code_words"], a["ms_per_call"], a["decode_ms_alone"], b["ms_per_call"], b["decode_ms_alone"], c["ms_per_call"], c["decode_ms_alone"], "state-parallel wins" if b["decode_ms_alone"] < a["decode_ms_alone"] else "lane-per-code-word wins"), flush=True)
 if as_json:
-    print(json.dumps({"what": "one ensemble, F frames per dabphy_process call (serial synchroniser, FIBs copied out): per-call latency and x real-time with the lane-per-code-word kernel forced (decode_shape 1) and with the library's own choice (decode_shape 0: state-parallel -- k_viterbi_sp, above 1024 code words k_viterbi_sp2 + k_traceback_sp2)", "rows": rows}))
+    print(json.dumps({"what": "one ensemble (last row: 32 ensembles), F frames per dabphy_process call (serial synchroniser, FIBs copied out): per-call latency and x real-time with the lane-per-code-word kernel forced (decode_shape 1) and with the library's own choice (decode_shape 0: state-parallel -- k_viterbi_sp, above 1024 code words k_viterbi_sp2 + k_traceback_sp2)", "rows": rows}))
